@@ -1,0 +1,222 @@
+/*
+ * maskrcnn_hip.h — C ABI of libmaskrcnn_hip.so, the MI355X (gfx950) replacement for the hot path of
+ * edouardlp/Mask-RCNN-CoreML.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Every entry point cites the reference interface it replaces (paths relative to the reference
+ * repo).  All functions return an mrcnn_status (0 = OK) and never abort; the message of the last
+ * failure on the calling thread is available from mrcnn_last_error() (the reference throws Swift
+ * errors — `extension String: Error`, Sources/Mask-RCNN-CoreML/Utils.swift:13 — or crashes on a
+ * force-unwrap, ProposalLayer.swift:68).
+ *
+ * Threading: handles are not thread-safe; one in-flight call per handle; calls are synchronous
+ * (they return after the work on the handle's HIP stream has completed), like Core ML's
+ * `evaluate` (ProposalLayer.swift:103).  One model handle per GPU for multi-GPU use.
+ *
+ * Memory: the caller owns every buffer passed in; the callee never frees them and fully
+ * overwrites outputs including zero padding ("CoreML does not erase the memory between
+ * evaluations", ProposalLayer.swift:188) — except where the reference itself leaves rows
+ * unwritten (TimeDistributedMaskLayer, see below).
+ */
+#ifndef MASKRCNN_HIP_H
+#define MASKRCNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRCNN_API __attribute__((visibility("default")))
+
+typedef enum {
+    MRCNN_OK = 0,
+    MRCNN_ERR_INVALID = 1,      /* bad argument / unknown key / wrong dtype                        */
+    MRCNN_ERR_IO = 2,           /* file missing or malformed (anchors.bin, *.mrcw)                 */
+    MRCNN_ERR_HIP = 3,          /* HIP runtime failure, or no gfx950 device                        */
+    MRCNN_ERR_SHAPE = 4,        /* shape / stride mismatch                                          */
+    MRCNN_ERR_UNSUPPORTED = 5,
+    MRCNN_ERR_CONFIG = 6        /* MaskRCNNConfig URL not set before use                            */
+} mrcnn_status;
+
+MRCNN_API const char* mrcnn_last_error(void);
+MRCNN_API const char* mrcnn_version(void);
+/* Number of visible HIP devices (0 when none; never fails). */
+MRCNN_API int mrcnn_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * MLMultiArray mirror (CoreML): 5-D [sequence, batch, channel, height, width], row-major unless
+ * strides say otherwise; strides are in ELEMENTS.  The custom layers index with shape[0],
+ * strides[0] or strides[2] and the raw data pointer (e.g. ProposalLayer.swift:179,
+ * TimeDistributedClassifierLayer.swift:63, PyramidROIAlignLayer.swift:124).
+ * --------------------------------------------------------------------------------------------- */
+typedef enum { MRCNN_F32 = 0, MRCNN_F64 = 1, MRCNN_F16 = 2, MRCNN_U8 = 3, MRCNN_I32 = 4 } mrcnn_dtype;
+typedef enum { MRCNN_HOST = 0, MRCNN_DEVICE = 1 } mrcnn_memspace;
+
+typedef struct {
+    void*   data;
+    int32_t dtype;       /* mrcnn_dtype; the layers assert Float32 inputs (ProposalLayer.swift:108) */
+    int32_t memspace;    /* mrcnn_memspace: host buffers are staged over PCIe, device buffers used in place */
+    int64_t shape[5];
+    int64_t strides[5];  /* elements */
+} mrcnn_tensor;
+
+/* Custom-layer parameter dictionary entry: `parameters: [String : Any]`
+ * (ProposalLayer.swift:65).  Keys and types are fixed by the converter,
+ * Sources/maskrcnn/Python/Conversion/task.py:25-67 (intValue / doubleValue). */
+typedef enum { MRCNN_PARAM_INT = 0, MRCNN_PARAM_DOUBLE = 1, MRCNN_PARAM_STRING = 2 } mrcnn_param_type;
+typedef struct {
+    const char* key;
+    int32_t     type;    /* mrcnn_param_type */
+    int64_t     i;
+    double      d;
+    const char* s;
+} mrcnn_param;
+
+/* ---------------------------------------------------------------------------------------------
+ * MaskRCNNConfig.defaultConfig (Sources/Mask-RCNN-CoreML/MaskRCNNConfig.swift:10-18):
+ * process-global URLs read by the layers at init/evaluate (ProposalLayer.swift:68,
+ * TimeDistributedClassifierLayer.swift:41, TimeDistributedMaskLayer.swift:49).  Must be set before
+ * the main model / ProposalLayer is created (Example/Source/AppDelegate.swift:18-20).
+ * NULL clears.  Getters return NULL when unset; the pointer stays valid until the next set.
+ * --------------------------------------------------------------------------------------------- */
+MRCNN_API int mrcnn_config_set_anchors_path(const char* path);      /* anchorsURL                  */
+MRCNN_API int mrcnn_config_set_classifier_path(const char* path);   /* compiledClassifierModelURL  */
+MRCNN_API int mrcnn_config_set_mask_path(const char* path);         /* compiledMaskModelURL        */
+MRCNN_API const char* mrcnn_config_get_anchors_path(void);
+MRCNN_API const char* mrcnn_config_get_classifier_path(void);
+MRCNN_API const char* mrcnn_config_get_mask_path(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * The five MLCustomLayer plugins.  Core ML resolves them BY @objc CLASS NAME from the model spec
+ * (task.py:27,39,48,53,59) and drives four methods; mrcnn_layer_* mirror them one to one:
+ *
+ *   init(parameters:)                 → mrcnn_layer_create      (ProposalLayer.swift:65, PyramidROIAlignLayer.swift:48,
+ *                                                                DetectionLayer.swift:63, TimeDistributed*Layer.swift:18)
+ *   setWeightData(_:)                 → mrcnn_layer_set_weight_data   (no-op in all five: ProposalLayer.swift:93)
+ *   outputShapes(forInputShapes:)     → mrcnn_layer_output_shapes     (ProposalLayer.swift:97, PyramidROIAlignLayer.swift:65,
+ *                                                                DetectionLayer.swift:94, TimeDistributedClassifierLayer.swift:26,
+ *                                                                TimeDistributedMaskLayer.swift:26)
+ *   evaluate(inputs:outputs:)         → mrcnn_layer_evaluate          (ProposalLayer.swift:103, PyramidROIAlignLayer.swift:79,
+ *                                                                TimeDistributedClassifierLayer.swift:34, DetectionLayer.swift:107,
+ *                                                                TimeDistributedMaskLayer.swift:39)
+ *
+ * class_name ∈ { "ProposalLayer", "PyramidROIAlignLayer", "TimeDistributedClassifierLayer",
+ *                "DetectionLayer", "TimeDistributedMaskLayer" }.
+ *
+ * evaluate inputs/outputs per layer (all Float32):
+ *   ProposalLayer                  in : probs (A,·,2…) contiguous (A,2); deltas (A,4)          out: rois, maxProposals rows of 4, row stride strides[0]
+ *   PyramidROIAlignLayer           in : rois (n rows, stride strides[0]); 4 maps [·,·,C,H,W]   out: [n,1,C,pool,pool], row stride strides[0]
+ *   TimeDistributedClassifierLayer in : pooled [n,1,C,7,7]                                      out: [n,1,1,1,6] rows (dy,dx,dh,dw,classId,score), row stride strides[2]
+ *   DetectionLayer                 in : rois (n,4) row stride strides[0]; cls (n,6) contiguous  out: maxDetections rows of 6, row stride strides[0]
+ *   TimeDistributedMaskLayer       in : pooled [D,1,C,14,14]; detections (D rows, strides[0])   out: [1,1,D,28,28], row stride strides[2]; rows the
+ *                                        reference never writes (TimeDistributedMaskLayer.swift:58-89) are left untouched
+ * --------------------------------------------------------------------------------------------- */
+typedef struct mrcnn_layer mrcnn_layer;
+
+MRCNN_API int mrcnn_layer_create(const char* class_name, const mrcnn_param* params, int n_params,
+                                 mrcnn_layer** out_layer);
+MRCNN_API int mrcnn_layer_set_weight_data(mrcnn_layer* layer, const void* const* blobs,
+                                          const size_t* sizes, int n_blobs);
+MRCNN_API int mrcnn_layer_output_shapes(mrcnn_layer* layer, const int64_t (*in_shapes)[5], int n_in,
+                                        int64_t (*out_shapes)[5], int* n_out);
+MRCNN_API int mrcnn_layer_evaluate(mrcnn_layer* layer, const mrcnn_tensor* inputs, int n_in,
+                                   mrcnn_tensor* outputs, int n_out);
+MRCNN_API void mrcnn_layer_destroy(mrcnn_layer* layer);
+
+/* Stand-alone numerics helpers that are public in the reference:
+ *   IOU(_:_:)  Sources/Mask-RCNN-CoreML/Utils.swift:232  (boxes as (y1,x1,y2,x2) floats; Double arithmetic, Float result).
+ * Host-only (no GPU involved, as in the reference). */
+MRCNN_API float mrcnn_iou(const float a_yxyx[4], const float b_yxyx[4]);
+
+/* ---------------------------------------------------------------------------------------------
+ * The three-model surface.  Xcode generates `MaskRCNN`, `Classifier`, `Mask` classes from the
+ * .mlmodel files (Example/iOS Example.xcodeproj/project.pbxproj:25-28); the host uses
+ * `MaskRCNN().model` (Example/Source/ViewController.swift:37) and reads outputs "detections" and
+ * "mask" (task.py:70-72,87-89).  Here a model is a .mrcw artefact (see DESIGN.md "Artefacts").
+ * --------------------------------------------------------------------------------------------- */
+typedef enum { MRCNN_MODEL_MASKRCNN = 0, MRCNN_MODEL_CLASSIFIER = 1, MRCNN_MODEL_MASK = 2 } mrcnn_model_kind;
+typedef struct mrcnn_model mrcnn_model;
+
+/* Loads weights to the current HIP device, folds BatchNorm, repacks kernels, builds the static
+ * schedule.  For MRCNN_MODEL_MASKRCNN the anchors / Classifier / Mask artefacts are taken from the
+ * config singleton at load time (like ProposalLayer.init, ProposalLayer.swift:68), and loaded ONCE
+ * (the reference re-loads the sub-models on every evaluate, TimeDistributedClassifierLayer.swift:41 —
+ * deliberately not reproduced).  max_batch sizes the activation arena (images per predict call).
+ * compute_dtype: MRCNN_F32 (fp32 MFMA, fp32 activations).  */
+MRCNN_API int mrcnn_model_load(int kind, const char* path, int max_batch, int compute_dtype,
+                               mrcnn_model** out_model);
+MRCNN_API void mrcnn_model_destroy(mrcnn_model* model);
+/* Use an existing hipStream_t (e.g. torch's current stream) instead of the model's own. */
+MRCNN_API int mrcnn_model_set_stream(mrcnn_model* model, void* hip_stream);
+
+/* MaskRCNN.prediction(image:) — input `image` (task.py:70-75): RGB 8-bit, H×W = the model's
+ * input_image_shape, interleaved (B,H,W,3).  The per-channel mean is subtracted on the GPU.
+ * Outputs: `detections` (B, maxDetections, 6) rows (y1,x1,y2,x2,classId,score) normalized,
+ * zero-padded; `mask` (B, maxDetections, 28, 28).  Batched predict is an extension (the reference
+ * is batch 1).  memspace says where image/detections/masks live (host or device). */
+MRCNN_API int mrcnn_maskrcnn_predict(mrcnn_model* model, const uint8_t* rgb, int batch, int height,
+                                     int width, int memspace, float* detections, float* masks);
+/* Same, but only enqueues on the model's stream (no synchronisation); device buffers only. */
+MRCNN_API int mrcnn_maskrcnn_predict_async(mrcnn_model* model, const uint8_t* rgb, int batch, int height,
+                                           int width, float* detections, float* masks);
+
+/* Classifier.prediction(feature_map:) (task.py:106-113): feature_map (n,256,7,7) CHW →
+ * probabilities (n, numClasses), bounding_boxes (n, numClasses*4) class-major. */
+MRCNN_API int mrcnn_classifier_predict(mrcnn_model* model, const float* feature_map, int n, int memspace,
+                                       float* probabilities, float* bounding_boxes);
+/* Mask.prediction(feature_map:) (task.py:94-101): feature_map (n,256,14,14) CHW → masks (n,numClasses,28,28). */
+MRCNN_API int mrcnn_mask_predict(mrcnn_model* model, const float* feature_map, int n, int memspace,
+                                 float* masks);
+
+/* Introspection (integers from the artefact's metadata): "num_classes", "image_height",
+ * "image_width", "max_proposals", "max_detections", "num_anchors", "pre_nms_max_proposals". */
+MRCNN_API int mrcnn_model_get_int(mrcnn_model* model, const char* key, int64_t* value);
+
+/* Debug taps for parity tests: copies a named intermediate of the last predict (image b) to a host
+ * buffer of `capacity` floats and reports its element count.  Names: "rpn_probs" (A,2),
+ * "rpn_deltas" (A,4), "P2".."P5" (H,W,256 NHWC), "topk_idx" (int32 stored as float-exact values),
+ * "boxes_sorted" (n,4), "rois" (maxProposals,4), "pooled" (maxProposals,7,7,256 NHWC),
+ * "cls_probs" (maxProposals,nc), "cls_bbox" (maxProposals,nc*4), "cls6" (maxProposals,6),
+ * "detections" (maxDetections,6), "pooled_mask" (maxDetections,14,14,256 NHWC), "mask" (maxDetections,784). */
+MRCNN_API int mrcnn_model_read_tensor(mrcnn_model* model, const char* name, int image_index,
+                                      float* host_dst, int64_t capacity, int64_t* count);
+
+/* Per-stage GPU time of the last predict in milliseconds (HIP events on the model's stream).
+ * Stage names mirror the reference's os_signpost intervals (ProposalLayer.swift:105-194 etc.):
+ * "Trunk", "Proposal-Eval", "PyramidROIAlign-Eval", "TimeDistributedClassifierLayer-Eval",
+ * "Detection-Eval", "PyramidROIAlign-Eval-Mask", "TimeDistributedMask-Eval".
+ * Only collected after mrcnn_model_enable_timing(model, 1). */
+MRCNN_API int mrcnn_model_enable_timing(mrcnn_model* model, int on);
+MRCNN_API int mrcnn_model_stage_ms(mrcnn_model* model, const char* stage, float* ms);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolution micro-benchmark hook (bench.py roofline leg): runs one convolution of the trunk's
+ * kernel family on synthetic data resident in HBM and reports the average kernel time measured
+ * with HIP events on the launching stream.
+ * --------------------------------------------------------------------------------------------- */
+MRCNN_API int mrcnn_bench_conv(int batch, int h, int w, int cin, int cout, int ksize, int stride,
+                               int iters, float* avg_ms, double* flops);
+
+/* ---------------------------------------------------------------------------------------------
+ * Result decoding — Detection.detectionsFromFeatureValue (Sources/Mask-RCNN-CoreML/
+ * Detection.swift:23-62) and maskFromFeatureValue (:64-99).  Host-side, like the reference.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t index;        /* row in the detections array                       (Detection.swift:17) */
+    double  x, y, w, h;   /* boundingBox CGRect(x: x1, y: y1, width, height)   (Detection.swift:55) */
+    int64_t class_id;
+    double  score;
+} mrcnn_detection;
+
+/* Keeps rows with score > 0.7 (Detection.swift:38).  Writes at most `capacity` records; returns the
+ * number kept in *count. */
+MRCNN_API int mrcnn_detections_decode(const float* detections, int64_t n_rows, int64_t row_stride,
+                                      mrcnn_detection* out, int64_t capacity, int64_t* count);
+/* 28×28 mask → 8-bit: UInt8(255 - v/2*255) (Detection.swift:83-85). */
+MRCNN_API int mrcnn_mask_to_u8(const float* mask, int64_t n, uint8_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MASKRCNN_HIP_H */

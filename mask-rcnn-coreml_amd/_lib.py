@@ -1,0 +1,126 @@
+"""ctypes binding of libmaskrcnn_hip.so (C ABI: include/maskrcnn_hip.h).
+
+The library is the product; there is no CPU fallback.  ``lib()`` raises ``NativeLibraryMissing`` when
+the shared object has not been built (``python __graft_entry__.py`` / ``make -C csrc``), and every
+compute entry point returns ``MRCNN_ERR_HIP`` when no gfx950 device is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libmaskrcnn_hip.so")
+
+MRCNN_OK = 0
+F32, F64, F16, U8, I32 = 0, 1, 2, 3, 4
+HOST, DEVICE = 0, 1
+PARAM_INT, PARAM_DOUBLE, PARAM_STRING = 0, 1, 2
+MODEL_MASKRCNN, MODEL_CLASSIFIER, MODEL_MASK = 0, 1, 2
+
+EXPORTED_SYMBOLS = [
+    "mrcnn_last_error", "mrcnn_version", "mrcnn_device_count",
+    "mrcnn_config_set_anchors_path", "mrcnn_config_set_classifier_path", "mrcnn_config_set_mask_path",
+    "mrcnn_config_get_anchors_path", "mrcnn_config_get_classifier_path", "mrcnn_config_get_mask_path",
+    "mrcnn_layer_create", "mrcnn_layer_set_weight_data", "mrcnn_layer_output_shapes", "mrcnn_layer_evaluate",
+    "mrcnn_layer_destroy", "mrcnn_iou",
+    "mrcnn_model_load", "mrcnn_model_destroy", "mrcnn_model_set_stream", "mrcnn_maskrcnn_predict",
+    "mrcnn_maskrcnn_predict_async", "mrcnn_classifier_predict", "mrcnn_mask_predict", "mrcnn_model_get_int",
+    "mrcnn_model_read_tensor", "mrcnn_model_enable_timing", "mrcnn_model_stage_ms", "mrcnn_bench_conv",
+    "mrcnn_detections_decode", "mrcnn_mask_to_u8",
+]
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+class MrcnnError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[mrcnn status {code}] {msg}")
+        self.code = code
+
+
+class Tensor(C.Structure):          # mrcnn_tensor
+    _fields_ = [("data", C.c_void_p), ("dtype", C.c_int32), ("memspace", C.c_int32),
+                ("shape", C.c_int64 * 5), ("strides", C.c_int64 * 5)]
+
+
+class Param(C.Structure):           # mrcnn_param
+    _fields_ = [("key", C.c_char_p), ("type", C.c_int32), ("i", C.c_int64), ("d", C.c_double), ("s", C.c_char_p)]
+
+
+class DetectionRecord(C.Structure):  # mrcnn_detection
+    _fields_ = [("index", C.c_int64), ("x", C.c_double), ("y", C.c_double), ("w", C.c_double), ("h", C.c_double),
+                ("class_id", C.c_int64), ("score", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise NativeLibraryMissing(
+            f"{SO_PATH} not built. Run `python __graft_entry__.py` (or `make -C mask-rcnn-coreml_amd/csrc`). "
+            "There is no CPU fallback: the HIP library is the product.")
+    L = C.CDLL(SO_PATH)
+    vp, cp, i64p, f32p = C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_float)
+    L.mrcnn_last_error.restype = cp
+    L.mrcnn_version.restype = cp
+    L.mrcnn_device_count.restype = C.c_int
+    for n in ("anchors", "classifier", "mask"):
+        getattr(L, f"mrcnn_config_set_{n}_path").argtypes = [cp]
+        getattr(L, f"mrcnn_config_get_{n}_path").restype = cp
+    L.mrcnn_layer_create.argtypes = [cp, C.POINTER(Param), C.c_int, C.POINTER(vp)]
+    L.mrcnn_layer_set_weight_data.argtypes = [vp, vp, vp, C.c_int]
+    L.mrcnn_layer_output_shapes.argtypes = [vp, vp, C.c_int, vp, C.POINTER(C.c_int)]
+    L.mrcnn_layer_evaluate.argtypes = [vp, C.POINTER(Tensor), C.c_int, C.POINTER(Tensor), C.c_int]
+    L.mrcnn_layer_destroy.argtypes = [vp]
+    L.mrcnn_layer_destroy.restype = None
+    L.mrcnn_iou.argtypes = [f32p, f32p]
+    L.mrcnn_iou.restype = C.c_float
+    L.mrcnn_model_load.argtypes = [C.c_int, cp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.mrcnn_model_destroy.argtypes = [vp]
+    L.mrcnn_model_destroy.restype = None
+    L.mrcnn_model_set_stream.argtypes = [vp, vp]
+    L.mrcnn_maskrcnn_predict.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.mrcnn_maskrcnn_predict_async.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.mrcnn_classifier_predict.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
+    L.mrcnn_mask_predict.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    L.mrcnn_model_get_int.argtypes = [vp, cp, i64p]
+    L.mrcnn_model_read_tensor.argtypes = [vp, cp, C.c_int, vp, C.c_int64, i64p]
+    L.mrcnn_model_enable_timing.argtypes = [vp, C.c_int]
+    L.mrcnn_model_stage_ms.argtypes = [vp, cp, f32p]
+    L.mrcnn_bench_conv.argtypes = [C.c_int] * 8 + [f32p, C.POINTER(C.c_double)]
+    L.mrcnn_detections_decode.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(DetectionRecord), C.c_int64, i64p]
+    L.mrcnn_mask_to_u8.argtypes = [vp, C.c_int64, vp]
+    _lib = L
+    return L
+
+
+def check(status: int):
+    if status != MRCNN_OK:
+        raise MrcnnError(status, lib().mrcnn_last_error().decode(errors="replace"))
+
+
+def make_params(d: dict):
+    """dict → (Param array, n).  int → intValue, float → doubleValue, like task.py:25-67."""
+    arr = (Param * max(1, len(d)))()
+    keep = []
+    for i, (k, v) in enumerate(d.items()):
+        kb = str(k).encode()
+        keep.append(kb)
+        arr[i].key = kb
+        if isinstance(v, bool) or isinstance(v, int):
+            arr[i].type, arr[i].i = PARAM_INT, int(v)
+        elif isinstance(v, float):
+            arr[i].type, arr[i].d = PARAM_DOUBLE, float(v)
+        else:
+            sb = str(v).encode()
+            keep.append(sb)
+            arr[i].type, arr[i].s = PARAM_STRING, sb
+    arr._keepalive = keep
+    return arr, len(d)

@@ -1,0 +1,725 @@
+// api.hip — the C ABI of include/maskrcnn_hip.h: config singleton, the five custom-layer plugins,
+// the three-model surface, result decoding and the convolution micro-benchmark hook.
+#include <math.h>
+#include <string.h>
+
+#include <memory>
+#include <mutex>
+#include <random>
+
+#include "engine.h"
+
+using namespace mrcnn;
+
+// ================================================================================================
+// misc
+// ================================================================================================
+extern "C" const char* mrcnn_last_error(void) { return mrcnn::last_error(); }
+extern "C" const char* mrcnn_version(void) { return "maskrcnn_hip 0.1 (gfx950)"; }
+extern "C" int mrcnn_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ================================================================================================
+// MaskRCNNConfig.defaultConfig (MaskRCNNConfig.swift:10-18)
+// ================================================================================================
+namespace {
+std::mutex g_cfg_mu;
+struct OptStr { bool set = false; std::string v; };
+OptStr g_anchors, g_classifier, g_mask;
+int set_path(OptStr& o, const char* p)
+{
+    std::lock_guard<std::mutex> lk(g_cfg_mu);
+    o.set = p != nullptr;
+    o.v = p ? p : "";
+    return MRCNN_OK;
+}
+const char* get_path(OptStr& o)
+{
+    std::lock_guard<std::mutex> lk(g_cfg_mu);
+    return o.set ? o.v.c_str() : nullptr;
+}
+}  // namespace
+extern "C" int mrcnn_config_set_anchors_path(const char* p) { return set_path(g_anchors, p); }
+extern "C" int mrcnn_config_set_classifier_path(const char* p) { return set_path(g_classifier, p); }
+extern "C" int mrcnn_config_set_mask_path(const char* p) { return set_path(g_mask, p); }
+extern "C" const char* mrcnn_config_get_anchors_path(void) { return get_path(g_anchors); }
+extern "C" const char* mrcnn_config_get_classifier_path(void) { return get_path(g_classifier); }
+extern "C" const char* mrcnn_config_get_mask_path(void) { return get_path(g_mask); }
+
+// ================================================================================================
+// tensor staging helpers
+// ================================================================================================
+namespace {
+
+void check_f32(const mrcnn_tensor& t, const char* what)
+{
+    MRCNN_REQUIRE(t.data != nullptr, MRCNN_ERR_INVALID, "%s: null data pointer", what);
+    MRCNN_REQUIRE(t.dtype == MRCNN_F32, MRCNN_ERR_INVALID, "%s: dtype must be Float32 (the layers assert it, ProposalLayer.swift:108)", what);
+}
+
+// Copies n rows of `len` floats (source row stride `stride` elements) into a dense device buffer.
+const float* stage_rows(const void* src, int memspace, long n, long len, long stride, DevBuf& tmp)
+{
+    if (memspace == MRCNN_DEVICE && stride == len) return static_cast<const float*>(src);
+    tmp.alloc((size_t)(n > 0 ? n : 1) * len * 4);
+    if (n <= 0) return tmp.as<float>();
+    HIP_CHECK(hipMemcpy2D(tmp.p, (size_t)len * 4, src, (size_t)stride * 4, (size_t)len * 4, (size_t)n,
+                          memspace == MRCNN_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    return tmp.as<float>();
+}
+
+// Writes n dense device rows of `len` floats to a destination with row stride `stride`.
+void unstage_rows(const float* dev, void* dst, int memspace, long n, long len, long stride)
+{
+    if (n <= 0) return;
+    HIP_CHECK(hipMemcpy2D(dst, (size_t)stride * 4, dev, (size_t)len * 4, (size_t)len * 4, (size_t)n,
+                          memspace == MRCNN_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+}
+
+struct Params {
+    std::map<std::string, mrcnn_param> m;
+    Params(const mrcnn_param* p, int n)
+    {
+        for (int i = 0; i < n; ++i)
+            if (p[i].key) m[p[i].key] = p[i];
+    }
+    // `parameters["x"] as? Int` / `as? Double` (ProposalLayer.swift:70-90): wrong type → ignored.
+    bool get_int(const char* k, int64_t& v) const
+    {
+        auto it = m.find(k);
+        if (it == m.end() || it->second.type != MRCNN_PARAM_INT) return false;
+        v = it->second.i;
+        return true;
+    }
+    bool get_double(const char* k, double& v) const
+    {
+        auto it = m.find(k);
+        if (it == m.end() || it->second.type != MRCNN_PARAM_DOUBLE) return false;
+        v = it->second.d;
+        return true;
+    }
+    void std_dev(float out[4]) const   // ProposalLayer.swift:70-80 / DetectionLayer.swift:67-77
+    {
+        int64_t cnt;
+        if (!get_int("bboxStdDev_count", cnt) || cnt != 4) return;
+        float tmp[4];
+        for (int i = 0; i < 4; ++i) {
+            double d;
+            if (!get_double(("bboxStdDev_" + std::to_string(i)).c_str(), d)) return;
+            tmp[i] = (float)d;
+        }
+        memcpy(out, tmp, sizeof tmp);
+    }
+};
+
+struct Stream {
+    hipStream_t s = nullptr;
+    Stream() { require_gpu(); HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); }
+    ~Stream() { if (s) (void)hipStreamDestroy(s); }
+};
+
+// sub-model cache (deliberately NOT re-loading per evaluate, unlike TimeDistributedClassifierLayer.swift:41)
+std::mutex g_model_mu;
+std::map<std::string, std::shared_ptr<Model>> g_models;
+std::shared_ptr<Model> cached_model(int kind, const std::string& path, int min_cap)
+{
+    std::lock_guard<std::mutex> lk(g_model_mu);
+    const std::string key = std::to_string(kind) + ":" + path;
+    auto it = g_models.find(key);
+    if (it != g_models.end() && it->second->max_batch >= min_cap) return it->second;
+    auto m = std::make_shared<Model>();
+    m->load(kind, path, min_cap);
+    g_models[key] = m;
+    return m;
+}
+
+}  // namespace
+
+// ================================================================================================
+// custom layers
+// ================================================================================================
+struct mrcnn_layer {
+    virtual ~mrcnn_layer() {}
+    virtual void output_shapes(const int64_t (*in)[5], int n_in, int64_t (*out)[5], int* n_out) = 0;
+    virtual void evaluate(const mrcnn_tensor* in, int n_in, mrcnn_tensor* out, int n_out) = 0;
+};
+
+namespace {
+
+// ---- ProposalLayer (ProposalLayer.swift:52-197) ------------------------------------------------
+struct ProposalLayerImpl : mrcnn_layer {
+    float std4[4] = {0.1f, 0.1f, 0.2f, 0.2f};
+    int pre_nms = 6000, max_prop = 1000;
+    float nms_thr = 0.7f;
+    DevBuf anchors;
+    long n_anchors = 0;
+    DevBuf ws_buf, out_buf;
+    ProposalWorkspace ws;
+    Stream st;
+
+    explicit ProposalLayerImpl(const Params& p)
+    {
+        require_gpu();
+        const char* ap = mrcnn_config_get_anchors_path();   // ProposalLayer.swift:68 force-unwraps the URL
+        MRCNN_REQUIRE(ap, MRCNN_ERR_CONFIG, "MaskRCNNConfig.anchorsURL is not set (required by ProposalLayer.init)");
+        FILE* f = fopen(ap, "rb");
+        MRCNN_REQUIRE(f, MRCNN_ERR_IO, "cannot open anchors file '%s'", ap);
+        fseek(f, 0, SEEK_END);
+        const long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        if (sz <= 0 || sz % 16 != 0) { fclose(f); fail(MRCNN_ERR_IO, "anchors file '%s': size %ld is not a positive multiple of 16", ap, sz); }
+        std::vector<float> h((size_t)sz / 4);
+        const size_t got = fread(h.data(), 1, (size_t)sz, f);
+        fclose(f);
+        MRCNN_REQUIRE(got == (size_t)sz, MRCNN_ERR_IO, "short read on '%s'", ap);
+        n_anchors = sz / 16;
+        anchors.alloc((size_t)sz);
+        HIP_CHECK(hipMemcpy(anchors.p, h.data(), (size_t)sz, hipMemcpyHostToDevice));
+        p.std_dev(std4);
+        int64_t v;
+        double d;
+        if (p.get_int("preNMSMaxProposals", v)) pre_nms = (int)v;
+        if (p.get_int("maxProposals", v)) max_prop = (int)v;
+        if (p.get_double("nmsIOUThreshold", d)) nms_thr = (float)d;
+        MRCNN_REQUIRE(pre_nms >= 1 && max_prop >= 1, MRCNN_ERR_INVALID, "ProposalLayer: preNMSMaxProposals / maxProposals must be >= 1");
+    }
+    void output_shapes(const int64_t (*in)[5], int n_in, int64_t (*out)[5], int* n_out) override
+    {
+        MRCNN_REQUIRE(n_in >= 2, MRCNN_ERR_SHAPE, "ProposalLayer expects 2 inputs");
+        memcpy(out[0], in[1], sizeof(int64_t) * 5);       // :98-100
+        out[0][0] = max_prop;
+        *n_out = 1;
+    }
+    void evaluate(const mrcnn_tensor* in, int n_in, mrcnn_tensor* out, int n_out) override
+    {
+        MRCNN_REQUIRE(n_in >= 2 && n_out >= 1, MRCNN_ERR_SHAPE, "ProposalLayer expects 2 inputs and 1 output");
+        check_f32(in[0], "ProposalLayer probabilities");
+        check_f32(in[1], "ProposalLayer deltas");
+        check_f32(out[0], "ProposalLayer output");
+        const long A = in[0].shape[0];                    // :119
+        MRCNN_REQUIRE(A >= 1 && A <= n_anchors, MRCNN_ERR_SHAPE, "ProposalLayer: %ld regions but anchors.bin holds %ld", A, n_anchors);
+        MRCNN_REQUIRE(A < (1L << 24) / 4, MRCNN_ERR_UNSUPPORTED, "ProposalLayer: region count exceeds the reference's float-index range");
+        const int K = (int)(A < pre_nms ? A : pre_nms);   // :120
+        if (ws.A != (int)A || ws.K != K) {
+            ws_buf.alloc(ProposalWorkspace::bytes(1, (int)A, K, max_prop));
+            ws.bind(ws_buf.p, 1, (int)A, K, max_prop);
+        }
+        DevBuf t0, t1;
+        const float* probs = stage_rows(in[0].data, in[0].memspace, A, 2, 2, t0);
+        const float* deltas = stage_rows(in[1].data, in[1].memspace, A, 4, 4, t1);
+        const long ostride = out[0].strides[0];           // :179
+        MRCNN_REQUIRE(ostride >= 4, MRCNN_ERR_SHAPE, "ProposalLayer: output row stride %ld < 4", ostride);
+        if (out[0].memspace == MRCNN_DEVICE) {
+            proposal_forward(st.s, ws, probs, 0, deltas, 0, anchors.as<float>(), std4, nms_thr, (float*)out[0].data, 0, ostride);
+            HIP_CHECK(hipStreamSynchronize(st.s));
+        } else {
+            // kept rows receive 4 coordinates only; stage the caller's rows in so the rest is preserved
+            out_buf.alloc((size_t)max_prop * ostride * 4);
+            HIP_CHECK(hipMemcpy(out_buf.p, out[0].data, (size_t)max_prop * ostride * 4, hipMemcpyHostToDevice));
+            proposal_forward(st.s, ws, probs, 0, deltas, 0, anchors.as<float>(), std4, nms_thr, out_buf.as<float>(), 0, ostride);
+            HIP_CHECK(hipStreamSynchronize(st.s));
+            HIP_CHECK(hipMemcpy(out[0].data, out_buf.p, (size_t)max_prop * ostride * 4, hipMemcpyDeviceToHost));
+        }
+    }
+};
+
+// ---- PyramidROIAlignLayer (PyramidROIAlignLayer.swift:40-183) -----------------------------------
+struct PyramidLayerImpl : mrcnn_layer {
+    int pool = 7;
+    double img_w = 1024, img_h = 1024;
+    Stream st;
+    explicit PyramidLayerImpl(const Params& p)
+    {
+        require_gpu();
+        int64_t v, w, h;
+        if (p.get_int("poolSize", v)) pool = (int)v;
+        // :55-58 casts `as? CGFloat`; the converter writes intValue (task.py:41-42).  Accept both.
+        double dw, dh;
+        if (p.get_int("imageWidth", w) && p.get_int("imageHeight", h)) { img_w = (double)w; img_h = (double)h; }
+        else if (p.get_double("imageWidth", dw) && p.get_double("imageHeight", dh)) { img_w = dw; img_h = dh; }
+        MRCNN_REQUIRE(pool >= 1, MRCNN_ERR_INVALID, "PyramidROIAlignLayer: poolSize must be >= 1");
+    }
+    void output_shapes(const int64_t (*in)[5], int n_in, int64_t (*out)[5], int* n_out) override
+    {
+        MRCNN_REQUIRE(n_in >= 2, MRCNN_ERR_SHAPE, "PyramidROIAlignLayer expects rois + feature maps");
+        out[0][0] = in[0][0]; out[0][1] = in[0][1]; out[0][2] = in[1][2]; out[0][3] = pool; out[0][4] = pool;   // :67-76
+        *n_out = 1;
+    }
+    void evaluate(const mrcnn_tensor* in, int n_in, mrcnn_tensor* out, int n_out) override
+    {
+        MRCNN_REQUIRE(n_in == 5 && n_out >= 1, MRCNN_ERR_SHAPE, "PyramidROIAlignLayer expects rois + 4 feature maps");
+        for (int i = 0; i < 5; ++i) check_f32(in[i], "PyramidROIAlignLayer input");
+        check_f32(out[0], "PyramidROIAlignLayer output");
+        const long n = in[0].shape[0], rstride = in[0].strides[0];
+        const int C = (int)in[1].shape[2];
+        DevBuf tr, tm[4], to;
+        const float* rois = stage_rows(in[0].data, in[0].memspace, n, 4, rstride, tr);
+        const long roi_stride = (in[0].memspace == MRCNN_DEVICE && rstride == 4) ? 4 : 4;
+        PyramidMaps maps;
+        for (int l = 0; l < 4; ++l) {
+            const mrcnn_tensor& m = in[1 + l];
+            MRCNN_REQUIRE(m.shape[2] == C, MRCNN_ERR_SHAPE, "feature maps disagree on channel count");
+            maps.H[l] = (int)m.shape[3]; maps.W[l] = (int)m.shape[4];
+            const long len = (long)C * maps.H[l] * maps.W[l];
+            maps.data[l] = stage_rows(m.data, m.memspace, 1, len, len, tm[l]);
+            maps.sB[l] = len;
+        }
+        const long row = (long)C * pool * pool, ostride = out[0].strides[0];
+        MRCNN_REQUIRE(ostride >= row, MRCNN_ERR_SHAPE, "PyramidROIAlignLayer: output row stride too small");
+        if (out[0].memspace == MRCNN_DEVICE) {
+            roi_align_forward(st.s, maps, C, 0, rois, 0, roi_stride, (int)n, 1, pool, img_w, img_h, (float*)out[0].data, 0, ostride);
+            HIP_CHECK(hipStreamSynchronize(st.s));
+        } else {
+            to.alloc((size_t)(n > 0 ? n : 1) * row * 4);
+            roi_align_forward(st.s, maps, C, 0, rois, 0, roi_stride, (int)n, 1, pool, img_w, img_h, to.as<float>(), 0, row);
+            HIP_CHECK(hipStreamSynchronize(st.s));
+            unstage_rows(to.as<float>(), out[0].data, MRCNN_HOST, n, row, ostride);
+        }
+    }
+};
+
+// ---- TimeDistributedClassifierLayer (TimeDistributedClassifierLayer.swift:14-92) -----------------
+struct ClassifierLayerImpl : mrcnn_layer {
+    Stream st;
+    explicit ClassifierLayerImpl(const Params&) { require_gpu(); }
+    void output_shapes(const int64_t (*in)[5], int n_in, int64_t (*out)[5], int* n_out) override
+    {
+        MRCNN_REQUIRE(n_in >= 1, MRCNN_ERR_SHAPE, "TimeDistributedClassifierLayer expects 1 input");
+        out[0][0] = in[0][0]; out[0][1] = in[0][1]; out[0][2] = 1; out[0][3] = 1; out[0][4] = 6;   // :27-31
+        *n_out = 1;
+    }
+    void evaluate(const mrcnn_tensor* in, int n_in, mrcnn_tensor* out, int n_out) override
+    {
+        MRCNN_REQUIRE(n_in >= 1 && n_out >= 1, MRCNN_ERR_SHAPE, "TimeDistributedClassifierLayer expects 1 input and 1 output");
+        check_f32(in[0], "TimeDistributedClassifierLayer input");
+        check_f32(out[0], "TimeDistributedClassifierLayer output");
+        const char* cp = mrcnn_config_get_classifier_path();
+        MRCNN_REQUIRE(cp, MRCNN_ERR_CONFIG, "MaskRCNNConfig.compiledClassifierModelURL is not set");
+        const long n = in[0].shape[0];
+        auto model = cached_model(MRCNN_MODEL_CLASSIFIER, cp, (int)(n > 1000 ? n : 1000));
+        ClassifierHead& hd = model->cls_head;
+        const int C = (int)in[0].shape[2], ph = (int)in[0].shape[3], pw = (int)in[0].shape[4];
+        MRCNN_REQUIRE(C == hd.C && ph == hd.pool && pw == hd.pool, MRCNN_ERR_SHAPE, "feature_map is %dx%dx%d, Classifier expects %dx%dx%d", C, ph,
+                      pw, hd.C, hd.pool, hd.pool);
+        const long row = (long)C * ph * pw;
+        DevBuf ti;
+        const float* chw = stage_rows(in[0].data, in[0].memspace, n, row, in[0].strides[0], ti);
+        nchw_to_nhwc_forward(st.s, chw, n, C, ph, pw, hd.stage_in);
+        hd.forward(st.s, hd.stage_in, (int)n, hd.cls6, 6);
+        HIP_CHECK(hipStreamSynchronize(st.s));
+        const long ostride = out[0].strides[2];           // :63
+        MRCNN_REQUIRE(ostride >= 6, MRCNN_ERR_SHAPE, "TimeDistributedClassifierLayer: output stride %ld < 6", ostride);
+        unstage_rows(hd.cls6, out[0].data, out[0].memspace, n, 6, ostride);
+    }
+};
+
+// ---- DetectionLayer (DetectionLayer.swift:52-236) -----------------------------------------------
+struct DetectionLayerImpl : mrcnn_layer {
+    float std4[4] = {0.1f, 0.1f, 0.2f, 0.2f};
+    int max_det = 100;
+    float score_thr = 0.7f, nms_thr = 0.3f;
+    DevBuf ws_buf, out_buf;
+    DetectionWorkspace ws;
+    Stream st;
+    explicit DetectionLayerImpl(const Params& p)
+    {
+        require_gpu();
+        p.std_dev(std4);
+        int64_t v;
+        double d;
+        if (p.get_int("maxDetections", v)) max_det = (int)v;
+        if (p.get_double("scoreThreshold", d)) score_thr = (float)d;
+        if (p.get_double("nmsIOUThreshold", d)) nms_thr = (float)d;
+        MRCNN_REQUIRE(max_det >= 1, MRCNN_ERR_INVALID, "DetectionLayer: maxDetections must be >= 1");
+    }
+    void output_shapes(const int64_t (*in)[5], int n_in, int64_t (*out)[5], int* n_out) override
+    {
+        MRCNN_REQUIRE(n_in >= 1, MRCNN_ERR_SHAPE, "DetectionLayer expects 2 inputs");
+        out[0][0] = max_det; out[0][1] = in[0][1]; out[0][2] = 6; out[0][3] = 1; out[0][4] = 1;   // :96-104
+        *n_out = 1;
+    }
+    void evaluate(const mrcnn_tensor* in, int n_in, mrcnn_tensor* out, int n_out) override
+    {
+        MRCNN_REQUIRE(n_in >= 2 && n_out >= 1, MRCNN_ERR_SHAPE, "DetectionLayer expects 2 inputs and 1 output");
+        check_f32(in[0], "DetectionLayer rois");
+        check_f32(in[1], "DetectionLayer classifications");
+        check_f32(out[0], "DetectionLayer output");
+        const long n = in[0].shape[0];                    // :122
+        MRCNN_REQUIRE(n >= 1, MRCNN_ERR_SHAPE, "DetectionLayer: no regions");
+        if (ws.N != (int)n) {
+            ws_buf.alloc(DetectionWorkspace::bytes(1, (int)n, max_det));
+            ws.bind(ws_buf.p, 1, (int)n, max_det);
+        }
+        DevBuf t0, t1;
+        // rois are read through floatDataPointer + broadcast indices, i.e. as contiguous (n,4) (:144-145)
+        const float* rois = stage_rows(in[0].data, in[0].memspace, n, 4, 4, t0);
+        const float* cls = stage_rows(in[1].data, in[1].memspace, n, 6, 6, t1);     // stride 6 assumed (:125-128)
+        const long ostride = out[0].strides[0];           // :213
+        MRCNN_REQUIRE(ostride >= 6, MRCNN_ERR_SHAPE, "DetectionLayer: output row stride %ld < 6", ostride);
+        if (out[0].memspace == MRCNN_DEVICE) {
+            detection_forward(st.s, ws, rois, 0, 4, cls, 0, std4, score_thr, nms_thr, 0, (float*)out[0].data, 0, ostride);
+            HIP_CHECK(hipStreamSynchronize(st.s));
+        } else {
+            out_buf.alloc((size_t)max_det * ostride * 4);
+            HIP_CHECK(hipMemcpy(out_buf.p, out[0].data, (size_t)max_det * ostride * 4, hipMemcpyHostToDevice));
+            detection_forward(st.s, ws, rois, 0, 4, cls, 0, std4, score_thr, nms_thr, 0, out_buf.as<float>(), 0, ostride);
+            HIP_CHECK(hipStreamSynchronize(st.s));
+            HIP_CHECK(hipMemcpy(out[0].data, out_buf.p, (size_t)max_det * ostride * 4, hipMemcpyDeviceToHost));
+        }
+    }
+};
+
+// ---- TimeDistributedMaskLayer (TimeDistributedMaskLayer.swift:14-92) -----------------------------
+struct MaskLayerImpl : mrcnn_layer {
+    Stream st;
+    DevBuf ws_buf, nchw, out_buf;
+    explicit MaskLayerImpl(const Params&) { require_gpu(); }
+    void output_shapes(const int64_t (*in)[5], int n_in, int64_t (*out)[5], int* n_out) override
+    {
+        MRCNN_REQUIRE(n_in >= 1, MRCNN_ERR_SHAPE, "TimeDistributedMaskLayer expects 2 inputs");
+        out[0][0] = 1; out[0][1] = in[0][1]; out[0][2] = in[0][0]; out[0][3] = in[0][3] * 2; out[0][4] = in[0][4] * 2;   // :27-36
+        *n_out = 1;
+    }
+    void evaluate(const mrcnn_tensor* in, int n_in, mrcnn_tensor* out, int n_out) override
+    {
+        MRCNN_REQUIRE(n_in >= 2 && n_out >= 1, MRCNN_ERR_SHAPE, "TimeDistributedMaskLayer expects 2 inputs and 1 output");
+        check_f32(in[0], "TimeDistributedMaskLayer feature maps");
+        check_f32(in[1], "TimeDistributedMaskLayer detections");
+        check_f32(out[0], "TimeDistributedMaskLayer output");
+        const char* mp = mrcnn_config_get_mask_path();
+        MRCNN_REQUIRE(mp, MRCNN_ERR_CONFIG, "MaskRCNNConfig.compiledMaskModelURL is not set");
+        const long D = in[0].shape[0];
+        const long det_count = in[1].shape[0], det_stride = in[1].strides[0];     // :46-47
+        MRCNN_REQUIRE(D >= 1 && det_count >= D, MRCNN_ERR_SHAPE, "TimeDistributedMaskLayer: %ld feature rows, %ld detections", D, det_count);
+        auto model = cached_model(MRCNN_MODEL_MASK, mp, (int)(D > 100 ? D : 100));
+        MaskHead& hd = model->mask_head;
+        const int C = (int)in[0].shape[2], ph = (int)in[0].shape[3], pw = (int)in[0].shape[4];
+        MRCNN_REQUIRE(C == hd.C && ph == hd.pool && pw == hd.pool, MRCNN_ERR_SHAPE, "feature_map is %dx%dx%d, Mask expects %dx%dx%d", C, ph, pw,
+                      hd.C, hd.pool, hd.pool);
+        const long row = (long)C * ph * pw;
+        const int HW = 4 * ph * pw;
+        DevBuf ti, td;
+        const float* chw = stage_rows(in[0].data, in[0].memspace, D, row, in[0].strides[0], ti);
+        const float* det = stage_rows(in[1].data, in[1].memspace, det_count, det_stride, det_stride, td);
+        ws_buf.alloc((size_t)(2 * det_count + 1) * 4 + 1024);
+        MaskSelectWorkspace ws;
+        ws.flags = ws_buf.as<int32_t>();
+        ws.mapping = ws.flags + det_count;
+        ws.kept = ws.mapping + det_count;
+        mask_valid_rows_forward(st.s, chw, 0, row, row, (int)D, 1, ws);          // removeZeros:true (:52)
+        nchw_to_nhwc_forward(st.s, chw, D, C, ph, pw, hd.stage_in);
+        hd.forward_features(st.s, hd.stage_in, (int)D);
+        hd.forward_full(st.s, (int)D);
+        nchw.alloc((size_t)D * hd.nc * HW * 4);
+        nhwc_to_nchw_forward(st.s, hd.full, D, hd.nc, 2 * ph, 2 * pw, nchw.as<float>());
+        const long ostride = out[0].strides[2];           // :56
+        MRCNN_REQUIRE(ostride >= HW, MRCNN_ERR_SHAPE, "TimeDistributedMaskLayer: output stride %ld < %d", ostride, HW);
+        // `flags`/`mapping` are sized by D rows; padding (:87-89) runs to detectionCount rows.
+        float* o = (float*)out[0].data;
+        if (out[0].memspace != MRCNN_DEVICE) {
+            out_buf.alloc((size_t)det_count * ostride * 4);
+            HIP_CHECK(hipMemcpy(out_buf.p, out[0].data, (size_t)det_count * ostride * 4, hipMemcpyHostToDevice));
+            o = out_buf.as<float>();
+        }
+        mask_select_from_full_forward(st.s, nchw.as<float>(), 0, HW, hd.nc, det, 0, det_stride, (int)det_count, 1, ws, o, 0, ostride);
+        HIP_CHECK(hipStreamSynchronize(st.s));
+        if (out[0].memspace != MRCNN_DEVICE)
+            HIP_CHECK(hipMemcpy(out[0].data, out_buf.p, (size_t)det_count * ostride * 4, hipMemcpyDeviceToHost));
+    }
+};
+
+}  // namespace
+
+extern "C" int mrcnn_layer_create(const char* class_name, const mrcnn_param* params, int n_params, mrcnn_layer** out_layer)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(class_name && out_layer, MRCNN_ERR_INVALID, "null argument");
+        MRCNN_REQUIRE(n_params == 0 || params, MRCNN_ERR_INVALID, "null parameter array");
+        const Params p(params, n_params);
+        const std::string c = class_name;
+        if (c == "ProposalLayer") *out_layer = new ProposalLayerImpl(p);
+        else if (c == "PyramidROIAlignLayer") *out_layer = new PyramidLayerImpl(p);
+        else if (c == "TimeDistributedClassifierLayer") *out_layer = new ClassifierLayerImpl(p);
+        else if (c == "DetectionLayer") *out_layer = new DetectionLayerImpl(p);
+        else if (c == "TimeDistributedMaskLayer") *out_layer = new MaskLayerImpl(p);
+        else fail(MRCNN_ERR_INVALID, "unknown custom layer class '%s'", class_name);
+    });
+}
+extern "C" int mrcnn_layer_set_weight_data(mrcnn_layer* layer, const void* const*, const size_t*, int)
+{
+    return guarded([&] { MRCNN_REQUIRE(layer, MRCNN_ERR_INVALID, "null layer"); });   // no-op (ProposalLayer.swift:93-95)
+}
+extern "C" int mrcnn_layer_output_shapes(mrcnn_layer* layer, const int64_t (*in_shapes)[5], int n_in, int64_t (*out_shapes)[5], int* n_out)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(layer && in_shapes && out_shapes && n_out, MRCNN_ERR_INVALID, "null argument");
+        layer->output_shapes(in_shapes, n_in, out_shapes, n_out);
+    });
+}
+extern "C" int mrcnn_layer_evaluate(mrcnn_layer* layer, const mrcnn_tensor* inputs, int n_in, mrcnn_tensor* outputs, int n_out)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(layer && inputs && outputs, MRCNN_ERR_INVALID, "null argument");
+        layer->evaluate(inputs, n_in, outputs, n_out);
+    });
+}
+extern "C" void mrcnn_layer_destroy(mrcnn_layer* layer) { delete layer; }
+
+// IOU (Utils.swift:232-246) — host, as in the reference.
+extern "C" float mrcnn_iou(const float a[4], const float b[4])
+{
+    struct R { double x, y, w, h; };
+    auto mk = [](const float* d) { R r{(double)d[1], (double)d[0], (double)d[3] - (double)d[1], (double)d[2] - (double)d[0]}; return r; };
+    const R A = mk(a), B = mk(b);
+    const double areaA = fabs(A.w) * fabs(A.h);
+    if (areaA <= 0) return 0;
+    const double areaB = fabs(B.w) * fabs(B.h);
+    if (areaB <= 0) return 0;
+    auto minx = [](const R& r) { return r.w < 0 ? r.x + r.w : r.x; };
+    auto maxx = [](const R& r) { return r.w < 0 ? r.x : r.x + r.w; };
+    auto miny = [](const R& r) { return r.h < 0 ? r.y + r.h : r.y; };
+    auto maxy = [](const R& r) { return r.h < 0 ? r.y : r.y + r.h; };
+    const double ix0 = fmax(minx(A), minx(B)), iy0 = fmax(miny(A), miny(B));
+    const double ix1 = fmin(maxx(A), maxx(B)), iy1 = fmin(maxy(A), maxy(B));
+    const double inter = fmax(iy1 - iy0, 0.0) * fmax(ix1 - ix0, 0.0);
+    return (float)(inter / (areaA + areaB - inter));
+}
+
+// ================================================================================================
+// models
+// ================================================================================================
+struct mrcnn_model {
+    Model m;
+};
+
+extern "C" int mrcnn_model_load(int kind, const char* path, int max_batch, int compute_dtype, mrcnn_model** out_model)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(path && out_model, MRCNN_ERR_INVALID, "null argument");
+        MRCNN_REQUIRE(kind >= 0 && kind <= 2, MRCNN_ERR_INVALID, "unknown model kind %d", kind);
+        MRCNN_REQUIRE(compute_dtype == MRCNN_F32, MRCNN_ERR_UNSUPPORTED, "compute dtype %d not available (fp32 MFMA only in this build)", compute_dtype);
+        std::unique_ptr<mrcnn_model> h(new mrcnn_model);
+        h->m.load(kind, path, max_batch);
+        *out_model = h.release();
+    });
+}
+extern "C" void mrcnn_model_destroy(mrcnn_model* model) { delete model; }
+
+extern "C" int mrcnn_model_set_stream(mrcnn_model* model, void* hip_stream)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model, MRCNN_ERR_INVALID, "null model");
+        if (model->m.own_stream && model->m.stream) (void)hipStreamDestroy(model->m.stream);
+        model->m.stream = (hipStream_t)hip_stream;
+        model->m.own_stream = false;
+    });
+}
+
+extern "C" int mrcnn_maskrcnn_predict(mrcnn_model* model, const uint8_t* rgb, int batch, int height, int width, int memspace,
+                                      float* detections, float* masks)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model, MRCNN_ERR_INVALID, "null model");
+        model->m.predict(rgb, batch, height, width, memspace, detections, masks, true);
+    });
+}
+extern "C" int mrcnn_maskrcnn_predict_async(mrcnn_model* model, const uint8_t* rgb, int batch, int height, int width,
+                                            float* detections, float* masks)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model, MRCNN_ERR_INVALID, "null model");
+        model->m.predict(rgb, batch, height, width, MRCNN_DEVICE, detections, masks, false);
+    });
+}
+
+extern "C" int mrcnn_classifier_predict(mrcnn_model* model, const float* feature_map, int n, int memspace, float* probabilities,
+                                        float* bounding_boxes)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model && model->m.kind == MRCNN_MODEL_CLASSIFIER, MRCNN_ERR_INVALID, "not a Classifier model");
+        MRCNN_REQUIRE(feature_map && probabilities && bounding_boxes && n >= 0, MRCNN_ERR_INVALID, "bad argument");
+        ClassifierHead& hd = model->m.cls_head;
+        hipStream_t s = model->m.stream;
+        const long row = (long)hd.C * hd.pool * hd.pool;
+        const hipMemcpyKind back = memspace == MRCNN_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+        for (int i0 = 0; i0 < n; i0 += hd.cap) {
+            const int c = n - i0 < hd.cap ? n - i0 : hd.cap;
+            DevBuf ti;
+            const float* chw = stage_rows(feature_map + (size_t)i0 * row, memspace, c, row, row, ti);
+            nchw_to_nhwc_forward(s, chw, c, hd.C, hd.pool, hd.pool, hd.stage_in);
+            hd.forward(s, hd.stage_in, c, nullptr, 0);
+            HIP_CHECK(hipMemcpyAsync(probabilities + (size_t)i0 * hd.nc, hd.probs, (size_t)c * hd.nc * 4, back, s));
+            HIP_CHECK(hipMemcpyAsync(bounding_boxes + (size_t)i0 * hd.nc * 4, hd.bbox, (size_t)c * hd.nc * 16, back, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+        }
+    });
+}
+
+extern "C" int mrcnn_mask_predict(mrcnn_model* model, const float* feature_map, int n, int memspace, float* masks)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model && model->m.kind == MRCNN_MODEL_MASK, MRCNN_ERR_INVALID, "not a Mask model");
+        MRCNN_REQUIRE(feature_map && masks && n >= 0, MRCNN_ERR_INVALID, "bad argument");
+        MaskHead& hd = model->m.mask_head;
+        hipStream_t s = model->m.stream;
+        const long row = (long)hd.C * hd.pool * hd.pool;
+        const long orow = (long)hd.nc * 4 * hd.pool * hd.pool;
+        DevBuf tmp;
+        for (int i0 = 0; i0 < n; i0 += hd.cap) {
+            const int c = n - i0 < hd.cap ? n - i0 : hd.cap;
+            DevBuf ti;
+            const float* chw = stage_rows(feature_map + (size_t)i0 * row, memspace, c, row, row, ti);
+            nchw_to_nhwc_forward(s, chw, c, hd.C, hd.pool, hd.pool, hd.stage_in);
+            hd.forward_features(s, hd.stage_in, c);
+            hd.forward_full(s, c);
+            float* dst = masks + (size_t)i0 * orow;
+            if (memspace != MRCNN_DEVICE) { tmp.alloc((size_t)c * orow * 4); dst = tmp.as<float>(); }
+            nhwc_to_nchw_forward(s, hd.full, c, hd.nc, 2 * hd.pool, 2 * hd.pool, dst);
+            HIP_CHECK(hipStreamSynchronize(s));
+            if (memspace != MRCNN_DEVICE) HIP_CHECK(hipMemcpy(masks + (size_t)i0 * orow, tmp.p, (size_t)c * orow * 4, hipMemcpyDeviceToHost));
+        }
+    });
+}
+
+extern "C" int mrcnn_model_get_int(mrcnn_model* model, const char* key, int64_t* value)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model && key && value, MRCNN_ERR_INVALID, "null argument");
+        const Model& m = model->m;
+        const std::string k = key;
+        if (k == "num_classes") *value = m.nc;
+        else if (k == "max_batch") *value = m.max_batch;
+        else if (m.kind != MRCNN_MODEL_MASKRCNN) *value = m.file.get_int(k);
+        else if (k == "image_height") *value = m.H;
+        else if (k == "image_width") *value = m.W;
+        else if (k == "max_proposals") *value = m.max_prop;
+        else if (k == "max_detections") *value = m.max_det;
+        else if (k == "num_anchors") *value = m.A;
+        else if (k == "pre_nms_max_proposals") *value = m.pre_nms;
+        else if (k == "pre_nms_count") *value = m.K;
+        else if (k == "mask_size") *value = 2 * m.mask_pool;
+        else *value = m.file.get_int(k);
+    });
+}
+
+extern "C" int mrcnn_model_read_tensor(mrcnn_model* model, const char* name, int image_index, float* host_dst, int64_t capacity,
+                                       int64_t* count)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model && name, MRCNN_ERR_INVALID, "null argument");
+        model->m.read_tensor(name, image_index, host_dst, capacity, count);
+    });
+}
+
+extern "C" int mrcnn_model_enable_timing(mrcnn_model* model, int on)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model, MRCNN_ERR_INVALID, "null model");
+        model->m.timer.enabled = on != 0;
+    });
+}
+extern "C" int mrcnn_model_stage_ms(mrcnn_model* model, const char* stage, float* ms)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model && stage && ms, MRCNN_ERR_INVALID, "null argument");
+        auto it = model->m.timer.ms.find(stage);
+        MRCNN_REQUIRE(it != model->m.timer.ms.end(), MRCNN_ERR_INVALID, "no timing for stage '%s' (enable timing and run predict first)", stage);
+        *ms = it->second;
+    });
+}
+
+// ================================================================================================
+// convolution micro-benchmark (bench.py roofline leg)
+// ================================================================================================
+extern "C" int mrcnn_bench_conv(int batch, int h, int w, int cin, int cout, int ksize, int stride, int iters, float* avg_ms,
+                                double* flops)
+{
+    return guarded([&] {
+        require_gpu();
+        MRCNN_REQUIRE(avg_ms && flops && iters >= 1 && (ksize == 1 || ksize == 3) && cin % 32 == 0, MRCNN_ERR_INVALID, "bad bench_conv arguments");
+        const int pad = ksize / 2;
+        const int oh = (h + 2 * pad - ksize) / stride + 1, ow = (w + 2 * pad - ksize) / stride + 1;
+        const int bn = conv_n_tile(cout), npad = (cout + bn - 1) / bn * bn;
+        const size_t n_in = (size_t)batch * h * w * cin, n_w = (size_t)npad * ksize * ksize * cin, n_out = (size_t)batch * oh * ow * cout;
+        std::mt19937 rng(7);
+        std::uniform_real_distribution<float> U(-1.f, 1.f);
+        std::vector<float> hw(n_w), hs(npad, 1.f), hb(npad, 0.f);
+        for (auto& v : hw) v = U(rng) * 0.05f;
+        // the input is large: fill a 4 MiB random pattern and replicate it on the device
+        std::vector<float> hin(1 << 20);
+        for (auto& v : hin) v = U(rng);
+        DevBuf din(n_in * 4), dw(n_w * 4), ds(npad * 4), db(npad * 4), dout(n_out * 4);
+        for (size_t off = 0; off < n_in; off += hin.size()) {
+            const size_t c = n_in - off < hin.size() ? n_in - off : hin.size();
+            HIP_CHECK(hipMemcpy(din.as<float>() + off, hin.data(), c * 4, hipMemcpyHostToDevice));
+        }
+        HIP_CHECK(hipMemcpy(dw.p, hw.data(), n_w * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(ds.p, hs.data(), npad * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(db.p, hb.data(), npad * 4, hipMemcpyHostToDevice));
+        ConvDesc d;
+        d.in = din.as<float>(); d.B = batch; d.H = h; d.W = w; d.Cin = cin;
+        d.in_sW = cin; d.in_sH = (long)w * cin; d.in_sB = (long)h * w * cin;
+        d.wgt = dw.as<float>(); d.KH = d.KW = ksize; d.stride = stride; d.padH = d.padW = pad;
+        d.scale = ds.as<float>(); d.shift = db.as<float>();
+        d.OH = oh; d.OW = ow; d.Cout = cout; d.Npad = npad;
+        d.out = dout.as<float>(); d.out_sP = cout; d.out_sB = (long)oh * ow * cout; d.act = ACT_RELU;
+        Stream st;
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        for (int i = 0; i < 2; ++i) conv_forward(st.s, d);
+        HIP_CHECK(hipEventRecord(e0, st.s));
+        for (int i = 0; i < iters; ++i) conv_forward(st.s, d);
+        HIP_CHECK(hipEventRecord(e1, st.s));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *avg_ms = ms / iters;
+        *flops = 2.0 * (double)batch * oh * ow * (double)cout * ksize * ksize * cin;
+    });
+}
+
+// ================================================================================================
+// result decoding (Detection.swift:23-99) — host
+// ================================================================================================
+extern "C" int mrcnn_detections_decode(const float* det, int64_t n_rows, int64_t row_stride, mrcnn_detection* out, int64_t capacity,
+                                       int64_t* count)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(det && count && (out || capacity == 0) && row_stride >= 6, MRCNN_ERR_INVALID, "bad argument");
+        int64_t k = 0;
+        for (int64_t i = 0; i < n_rows; ++i) {
+            const float* r = det + i * row_stride;
+            const double score = (double)r[5];
+            if (score > 0.7) {                                                  // Detection.swift:38
+                if (k < capacity) {
+                    const double y1 = r[0], x1 = r[1], y2 = r[2], x2 = r[3];
+                    out[k].index = i;
+                    out[k].x = x1; out[k].y = y1; out[k].w = x2 - x1; out[k].h = y2 - y1;   // :45-55
+                    out[k].class_id = (int64_t)r[4];
+                    out[k].score = score;
+                }
+                ++k;
+            }
+        }
+        *count = k;
+    });
+}
+
+extern "C" int mrcnn_mask_to_u8(const float* mask, int64_t n, uint8_t* out)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(mask && out && n >= 0, MRCNN_ERR_INVALID, "bad argument");
+        for (int64_t i = 0; i < n; ++i) {
+            double v = 255.0 - ((double)mask[i] / 2.0 * 255.0);                 // Detection.swift:83-85
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            out[i] = (uint8_t)v;
+        }
+    });
+}

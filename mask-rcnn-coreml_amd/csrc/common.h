@@ -1,0 +1,88 @@
+// common.h — shared declarations of libmaskrcnn_hip.so (host + device).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/maskrcnn_hip.h"
+
+namespace mrcnn {
+
+// ---- error plumbing: every C entry point returns a status and records a thread-local message ----
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+const char* last_error();
+
+struct Error {
+    int code;
+    std::string msg;
+};
+[[noreturn]] void fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define HIP_CHECK(expr)                                                                              \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            ::mrcnn::fail(MRCNN_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                          __FILE__, __LINE__);                                                       \
+    } while (0)
+
+#define MRCNN_REQUIRE(cond, code, ...)                                                               \
+    do {                                                                                             \
+        if (!(cond)) ::mrcnn::fail((code), __VA_ARGS__);                                             \
+    } while (0)
+
+// Runs `body` (a lambda) and converts exceptions into a status code for the C ABI.
+template <class F>
+int guarded(F&& body)
+{
+    try {
+        body();
+        return MRCNN_OK;
+    } catch (const Error& e) {
+        set_error("%s", e.msg.c_str());
+        return e.code;
+    } catch (const std::exception& e) {
+        set_error("%s", e.what());
+        return MRCNN_ERR_INVALID;
+    } catch (...) {
+        set_error("unknown error");
+        return MRCNN_ERR_INVALID;
+    }
+}
+
+// Selects the current device and checks it is a gfx950 part; throws MRCNN_ERR_HIP otherwise.
+void require_gpu();
+
+// RAII device buffer.
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t n) { alloc(n); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept
+    {
+        if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t n)
+    {
+        release();
+        if (n == 0) n = 16;
+        HIP_CHECK(hipMalloc(&p, n));
+        bytes = n;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace mrcnn

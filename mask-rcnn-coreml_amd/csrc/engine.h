@@ -1,0 +1,150 @@
+// engine.h — model artefacts (.mrcw), weight packing and the static execution plans.
+#pragma once
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace mrcnn {
+
+// ---- .mrcw reader (format: mask-rcnn-coreml_amd/weights.py) --------------------------------------
+struct MrcwTensor {
+    int dtype = 0;                 // 0 = f32, 2 = f16
+    std::vector<uint32_t> dims;
+    const unsigned char* data = nullptr;
+    size_t nbytes = 0;
+    size_t count() const { size_t n = 1; for (auto d : dims) n *= d; return n; }
+};
+struct MrcwFile {
+    std::string path;
+    std::vector<unsigned char> buf;
+    std::map<std::string, int64_t> ints;
+    std::map<std::string, double> doubles;
+    std::map<std::string, std::string> strings;
+    std::map<std::string, MrcwTensor> tensors;
+    void load(const std::string& path);
+    int64_t get_int(const std::string& k) const;
+    int64_t get_int(const std::string& k, int64_t dflt) const;
+    double get_double(const std::string& k, double dflt) const;   // accepts ints too
+    std::string get_string(const std::string& k) const;
+    const MrcwTensor& tensor(const std::string& name) const;
+    std::vector<float> floats(const std::string& name) const;     // any dtype → fp32
+};
+
+// ---- packed convolution weights on the device ----------------------------------------------------
+struct PackedConv {
+    DevBuf wgt, scale, shift;
+    int Cin = 0, Cout = 0, KH = 1, KW = 1, Npad = 0;
+};
+
+struct Tensor4 {   // dense NHWC activation
+    float* p = nullptr;
+    int H = 0, W = 0, C = 0;
+    long sB() const { return (long)H * W * C; }
+};
+
+using Op = std::function<void(hipStream_t, int /*batch*/)>;
+
+struct Arena {
+    char* base = nullptr;
+    size_t off = 0;
+    float* alloc_f(size_t n_floats)
+    {
+        size_t bytes = (n_floats * 4 + 255) / 256 * 256;
+        char* r = base ? base + off : nullptr;
+        off += bytes;
+        return reinterpret_cast<float*>(r);
+    }
+    void* alloc_b(size_t bytes)
+    {
+        bytes = (bytes + 255) / 256 * 256;
+        char* r = base ? base + off : nullptr;
+        off += bytes;
+        return r;
+    }
+};
+
+// Box head: Classifier.mlmodel (task.py:106-116) + TimeDistributedClassifierLayer post-processing.
+struct ClassifierHead {
+    int nc = 0, pool = 7, C = 256, cap = 0;
+    PackedConv fc1, fc2, fc3;
+    DevBuf arena;
+    float *h1 = nullptr, *h2 = nullptr, *lb = nullptr, *probs = nullptr, *bbox = nullptr, *stage_in = nullptr, *cls6 = nullptr;
+    void load(const MrcwFile& f, int capacity_rows);
+    // pooled: n rows of pool*pool*C floats in (h,w,c) order, contiguous.
+    void forward(hipStream_t s, const float* pooled_nhwc, int n, float* cls6_out, long cls6_stride);
+};
+
+// Mask head: Mask.mlmodel (task.py:94-104).
+struct MaskHead {
+    int nc = 0, pool = 14, C = 256, cap = 0;
+    PackedConv conv[4], deconv, final_full;
+    DevBuf final_w, final_b;          // [nc][C], [nc] for the selected-class kernel
+    DevBuf arena;
+    float *t0 = nullptr, *t1 = nullptr, *feat = nullptr, *full = nullptr, *stage_in = nullptr;
+    void load(const MrcwFile& f, int capacity_rows);
+    // pooled: n rows of 14*14*C NHWC → feat (n, 28*28, C) = ReLU(deconv)
+    void forward_features(hipStream_t s, const float* pooled_nhwc, int n);
+    // feat → all-class sigmoid masks, NHWC (n, 784, nc) in `full`
+    void forward_full(hipStream_t s, int n);
+};
+
+struct StageTimer {
+    bool enabled = false;
+    std::vector<std::string> names;
+    std::vector<hipEvent_t> ev;       // names.size() + 1 events
+    std::map<std::string, float> ms;
+    void begin(hipStream_t s);
+    void mark(hipStream_t s, const char* name);
+    void finish();
+    ~StageTimer();
+};
+
+struct Model {
+    int kind = 0;
+    int max_batch = 1;
+    MrcwFile file;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // config
+    std::string arch;
+    int H = 0, W = 0, nc = 0, pre_nms = 0, max_prop = 0, max_det = 0, na = 3, A = 0, K = 0;
+    float mean[3] = {0, 0, 0};
+    float prop_std[4], det_std[4];
+    float prop_nms_thr = 0.7f, det_score_thr = 0.7f, det_nms_thr = 0.3f;
+    int cls_pool = 7, mask_pool = 14;
+    double roi_img_w = 0, roi_img_h = 0;
+    // weights
+    std::map<std::string, PackedConv> convs;
+    DevBuf anchors;
+    ClassifierHead cls_head;
+    MaskHead mask_head;
+    // activations
+    DevBuf arena;
+    std::vector<Op> trunk_ops;
+    std::map<std::string, std::pair<float*, long>> taps;    // name → (base, per-image elements)
+    uint8_t* d_rgb = nullptr;
+    float *rpn_logits = nullptr, *rpn_probs = nullptr, *rpn_deltas = nullptr, *rois = nullptr, *pooled = nullptr;
+    float *cls6 = nullptr, *detections = nullptr, *pooled_mask = nullptr, *mask_out = nullptr;
+    Tensor4 P[4];
+    ProposalWorkspace prop_ws;
+    DetectionWorkspace det_ws;
+    MaskSelectWorkspace msel_ws;
+    StageTimer timer;
+
+    ~Model();
+    void load(int kind, const std::string& path, int max_batch);
+    void build_maskrcnn();
+    void predict(const uint8_t* rgb, int batch, int h, int w, int memspace, float* det, float* masks, bool sync);
+    void read_tensor(const std::string& name, int image, float* dst, int64_t cap, int64_t* count);
+};
+
+// Helpers shared with api.hip
+PackedConv pack_conv_oihw(const MrcwFile& f, const std::string& conv, const std::string& bn);
+void run_conv_dense(hipStream_t s, const PackedConv& pc, const float* in, int B, int H, int W, float* out, int stride,
+                    int pad, int act, const float* res = nullptr);
+
+}  // namespace mrcnn

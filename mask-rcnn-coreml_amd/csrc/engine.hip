@@ -1,0 +1,827 @@
+// engine.hip — artefact loading, BatchNorm folding / weight packing, and the static schedules of the
+// three models.  Replaces the Core ML graph executors of MaskRCNN.mlmodel, Classifier.mlmodel and
+// Mask.mlmodel (reference: Sources/maskrcnn/Python/Conversion/task.py:69-116 emits the specs; the
+// layer list itself is the Matterport layout of the un-vendored `maskrcnn` package).
+//
+// HBM layout: all activations NHWC fp32 in one arena, one dense tensor per layer output (a batch of
+// 8 × 1024² images needs ≈9 GB of the 288 GB); weights are packed once at load as [cout][tap][cin]
+// fp32 with BatchNorm folded into a per-channel scale/shift; the pyramid P2..P5 stays resident for
+// both ROIAlign passes (the reference re-uploads 89 MB of textures per call,
+// PyramidROIAlignLayer.swift:110-118).
+#include "engine.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include <fstream>
+
+namespace mrcnn {
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+const char* last_error() { return g_last_error.c_str(); }
+
+void fail(int code, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    throw Error{code, buf};
+}
+
+void require_gpu()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        fail(MRCNN_ERR_HIP, "no HIP device visible (%s): libmaskrcnn_hip has no CPU fallback",
+             e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    HIP_CHECK(hipGetDeviceProperties(&p, dev));
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0)
+        fail(MRCNN_ERR_HIP, "device %d is %s; this library is built for gfx950 (MI355X) only", dev, p.gcnArchName);
+}
+
+// ------------------------------------------------------------------------------------------------
+// .mrcw
+// ------------------------------------------------------------------------------------------------
+static float half_to_float(uint16_t h)
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1Fu, man = h & 0x3FFu, f;
+    if (exp == 0) {
+        if (man == 0) f = sign;
+        else {
+            exp = 113;
+            while ((man & 0x400u) == 0) { man <<= 1; --exp; }
+            man &= 0x3FFu;
+            f = sign | (exp << 23) | (man << 13);
+        }
+    } else if (exp == 31) f = sign | 0x7F800000u | (man << 13);
+    else f = sign | ((exp + 112) << 23) | (man << 13);
+    float r;
+    memcpy(&r, &f, 4);
+    return r;
+}
+
+void MrcwFile::load(const std::string& p)
+{
+    path = p;
+    std::ifstream in(p, std::ios::binary | std::ios::ate);
+    MRCNN_REQUIRE(in.good(), MRCNN_ERR_IO, "cannot open model artefact '%s'", p.c_str());
+    const std::streamsize sz = in.tellg();
+    in.seekg(0);
+    buf.resize((size_t)sz);
+    in.read(reinterpret_cast<char*>(buf.data()), sz);
+    MRCNN_REQUIRE(in.good() && sz >= 16 && memcmp(buf.data(), "MRCW", 4) == 0, MRCNN_ERR_IO, "'%s' is not a .mrcw file", p.c_str());
+    size_t pos = 4;
+    auto need = [&](size_t n) { MRCNN_REQUIRE(pos + n <= buf.size(), MRCNN_ERR_IO, "'%s': truncated header", p.c_str()); };
+    auto rd = [&](void* dst, size_t n) { need(n); memcpy(dst, buf.data() + pos, n); pos += n; };
+    uint32_t ver, n_meta, n_t;
+    rd(&ver, 4); rd(&n_meta, 4); rd(&n_t, 4);
+    MRCNN_REQUIRE(ver == 1, MRCNN_ERR_IO, "'%s': unsupported .mrcw version %u", p.c_str(), ver);
+    for (uint32_t i = 0; i < n_meta; ++i) {
+        uint16_t kl; rd(&kl, 2);
+        need(kl);
+        std::string k((const char*)buf.data() + pos, kl); pos += kl;
+        uint8_t t; rd(&t, 1);
+        if (t == 0) { int64_t v; rd(&v, 8); ints[k] = v; }
+        else if (t == 1) { double v; rd(&v, 8); doubles[k] = v; }
+        else { uint32_t sl; rd(&sl, 4); need(sl); strings[k] = std::string((const char*)buf.data() + pos, sl); pos += sl; }
+    }
+    struct Ent { std::string name; MrcwTensor t; uint64_t off; };
+    std::vector<Ent> ents;
+    for (uint32_t i = 0; i < n_t; ++i) {
+        uint16_t nl; rd(&nl, 2);
+        need(nl);
+        Ent e;
+        e.name = std::string((const char*)buf.data() + pos, nl); pos += nl;
+        uint8_t dt, nd; rd(&dt, 1); rd(&nd, 1);
+        e.t.dtype = dt;
+        e.t.dims.resize(nd);
+        for (int d = 0; d < nd; ++d) rd(&e.t.dims[d], 4);
+        uint64_t nb; rd(&e.off, 8); rd(&nb, 8);
+        e.t.nbytes = (size_t)nb;
+        ents.push_back(std::move(e));
+    }
+    const size_t base = (pos + 63) / 64 * 64;
+    for (auto& e : ents) {
+        MRCNN_REQUIRE(base + e.off + e.t.nbytes <= buf.size(), MRCNN_ERR_IO, "'%s': tensor %s out of bounds", p.c_str(), e.name.c_str());
+        MRCNN_REQUIRE(e.t.dtype == 0 || e.t.dtype == 2, MRCNN_ERR_IO, "'%s': tensor %s has unsupported dtype", p.c_str(), e.name.c_str());
+        e.t.data = buf.data() + base + e.off;
+        tensors[e.name] = e.t;
+    }
+}
+int64_t MrcwFile::get_int(const std::string& k) const
+{
+    auto it = ints.find(k);
+    MRCNN_REQUIRE(it != ints.end(), MRCNN_ERR_IO, "'%s': missing integer metadata key '%s'", path.c_str(), k.c_str());
+    return it->second;
+}
+int64_t MrcwFile::get_int(const std::string& k, int64_t dflt) const
+{
+    auto it = ints.find(k);
+    return it == ints.end() ? dflt : it->second;
+}
+double MrcwFile::get_double(const std::string& k, double dflt) const
+{
+    auto it = doubles.find(k);
+    if (it != doubles.end()) return it->second;
+    auto ii = ints.find(k);
+    return ii == ints.end() ? dflt : (double)ii->second;
+}
+std::string MrcwFile::get_string(const std::string& k) const
+{
+    auto it = strings.find(k);
+    MRCNN_REQUIRE(it != strings.end(), MRCNN_ERR_IO, "'%s': missing string metadata key '%s'", path.c_str(), k.c_str());
+    return it->second;
+}
+const MrcwTensor& MrcwFile::tensor(const std::string& name) const
+{
+    auto it = tensors.find(name);
+    MRCNN_REQUIRE(it != tensors.end(), MRCNN_ERR_IO, "'%s': missing tensor '%s'", path.c_str(), name.c_str());
+    return it->second;
+}
+std::vector<float> MrcwFile::floats(const std::string& name) const
+{
+    const MrcwTensor& t = tensor(name);
+    std::vector<float> v(t.count());
+    if (t.dtype == 0) memcpy(v.data(), t.data, v.size() * 4);
+    else {
+        const uint16_t* h = reinterpret_cast<const uint16_t*>(t.data);
+        for (size_t i = 0; i < v.size(); ++i) v[i] = half_to_float(h[i]);
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------------
+static void upload(DevBuf& d, const std::vector<float>& h)
+{
+    d.alloc(h.size() * 4);
+    HIP_CHECK(hipMemcpy(d.p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+}
+
+// scale/shift of conv(+bias)(+BN):  y = acc*scale + shift
+static void fold_bn(const MrcwFile& f, const std::string& conv, const std::string& bn, int Cout, int Npad,
+                    std::vector<float>& scale, std::vector<float>& shift)
+{
+    const std::vector<float> bias = f.floats(conv + "/bias");
+    MRCNN_REQUIRE((int)bias.size() == Cout, MRCNN_ERR_IO, "%s/bias has %zu entries, expected %d", conv.c_str(), bias.size(), Cout);
+    scale.assign(Npad, 0.f);
+    shift.assign(Npad, 0.f);
+    if (bn.empty()) {
+        for (int o = 0; o < Cout; ++o) { scale[o] = 1.f; shift[o] = bias[o]; }
+        return;
+    }
+    const std::vector<float> g = f.floats(bn + "/gamma"), be = f.floats(bn + "/beta"), mu = f.floats(bn + "/mean"),
+                             var = f.floats(bn + "/variance");
+    const float eps = (float)f.get_double("bn_eps", 1e-3);
+    for (int o = 0; o < Cout; ++o) {
+        const float sc = g[o] / sqrtf(var[o] + eps);
+        scale[o] = sc;
+        shift[o] = (bias[o] - mu[o]) * sc + be[o];
+    }
+}
+
+// kernel [O][I][KH][KW] (Core ML layout) → [Npad][KH][KW][I]
+PackedConv pack_conv_oihw(const MrcwFile& f, const std::string& conv, const std::string& bn)
+{
+    const MrcwTensor& t = f.tensor(conv + "/kernel");
+    MRCNN_REQUIRE(t.dims.size() == 4, MRCNN_ERR_IO, "%s/kernel is not 4-D", conv.c_str());
+    const int O = t.dims[0], I = t.dims[1], KH = t.dims[2], KW = t.dims[3];
+    const std::vector<float> k = f.floats(conv + "/kernel");
+    PackedConv pc;
+    pc.Cin = I; pc.Cout = O; pc.KH = KH; pc.KW = KW;
+    const int bn_tile = conv_n_tile(O);
+    pc.Npad = (O + bn_tile - 1) / bn_tile * bn_tile;
+    std::vector<float> w((size_t)pc.Npad * KH * KW * I, 0.f);
+    for (int o = 0; o < O; ++o)
+        for (int i = 0; i < I; ++i)
+            for (int y = 0; y < KH; ++y)
+                for (int x = 0; x < KW; ++x)
+                    w[(((size_t)o * KH + y) * KW + x) * I + i] = k[(((size_t)o * I + i) * KH + y) * KW + x];
+    upload(pc.wgt, w);
+    std::vector<float> sc, sh;
+    fold_bn(f, conv, bn, O, pc.Npad, sc, sh);
+    upload(pc.scale, sc);
+    upload(pc.shift, sh);
+    return pc;
+}
+
+// conv1: 7×7 stride 2 on 3 channels.  The input is staged as zero-padded NHWC4, so one kernel row
+// (7 taps × 4 channels = 28 floats, padded to 32) is a contiguous 128-B run: taps = 7 (rows),
+// "Cin" = 32.  Packed [64][7][32] with k = kw*4 + ci.
+static PackedConv pack_conv1(const MrcwFile& f)
+{
+    const MrcwTensor& t = f.tensor("conv1/kernel");
+    MRCNN_REQUIRE(t.dims.size() == 4 && t.dims[1] == 3 && t.dims[2] == 7 && t.dims[3] == 7, MRCNN_ERR_IO, "conv1/kernel must be [O,3,7,7]");
+    const int O = t.dims[0];
+    const std::vector<float> k = f.floats("conv1/kernel");
+    PackedConv pc;
+    pc.Cin = 32; pc.Cout = O; pc.KH = 7; pc.KW = 1;
+    const int bn_tile = conv_n_tile(O);
+    pc.Npad = (O + bn_tile - 1) / bn_tile * bn_tile;
+    std::vector<float> w((size_t)pc.Npad * 7 * 32, 0.f);
+    for (int o = 0; o < O; ++o)
+        for (int ci = 0; ci < 3; ++ci)
+            for (int y = 0; y < 7; ++y)
+                for (int x = 0; x < 7; ++x)
+                    w[((size_t)o * 7 + y) * 32 + x * 4 + ci] = k[(((size_t)o * 3 + ci) * 7 + y) * 7 + x];
+    upload(pc.wgt, w);
+    std::vector<float> sc, sh;
+    fold_bn(f, "conv1", "bn_conv1", O, pc.Npad, sc, sh);
+    upload(pc.scale, sc);
+    upload(pc.shift, sh);
+    return pc;
+}
+
+// Several [O_i][I] inner-product / 1×1 kernels stacked along N (no BN).
+static PackedConv pack_stacked_1x1(const MrcwFile& f, const std::vector<std::string>& names)
+{
+    PackedConv pc;
+    int O = 0, I = -1;
+    for (auto& n : names) {
+        const MrcwTensor& t = f.tensor(n + "/kernel");
+        MRCNN_REQUIRE(t.dims.size() == 2 || (t.dims.size() == 4 && t.dims[2] == 1 && t.dims[3] == 1), MRCNN_ERR_IO,
+                      "%s/kernel is not an inner product / 1x1 kernel", n.c_str());
+        MRCNN_REQUIRE(I < 0 || I == (int)t.dims[1], MRCNN_ERR_IO, "%s: input size mismatch", n.c_str());
+        I = t.dims[1];
+        O += t.dims[0];
+    }
+    pc.Cin = I; pc.Cout = O; pc.KH = pc.KW = 1;
+    const int bn_tile = conv_n_tile(O);
+    pc.Npad = (O + bn_tile - 1) / bn_tile * bn_tile;
+    std::vector<float> w((size_t)pc.Npad * I, 0.f), sc(pc.Npad, 0.f), sh(pc.Npad, 0.f);
+    int o0 = 0;
+    for (auto& n : names) {
+        const std::vector<float> k = f.floats(n + "/kernel"), b = f.floats(n + "/bias");
+        memcpy(w.data() + (size_t)o0 * I, k.data(), k.size() * 4);
+        for (size_t o = 0; o < b.size(); ++o) { sc[o0 + o] = 1.f; sh[o0 + o] = b[o]; }
+        o0 += (int)b.size();
+    }
+    upload(pc.wgt, w);
+    upload(pc.scale, sc);
+    upload(pc.shift, sh);
+    return pc;
+}
+
+// ConvTranspose 2×2 stride 2, kernel [I][O][2][2] → GEMM rows n = (dy*2+dx)*O + co.
+static PackedConv pack_deconv2(const MrcwFile& f, const std::string& name)
+{
+    const MrcwTensor& t = f.tensor(name + "/kernel");
+    MRCNN_REQUIRE(t.dims.size() == 4 && t.dims[2] == 2 && t.dims[3] == 2, MRCNN_ERR_IO, "%s/kernel must be [I,O,2,2]", name.c_str());
+    const int I = t.dims[0], O = t.dims[1];
+    const std::vector<float> k = f.floats(name + "/kernel"), b = f.floats(name + "/bias");
+    PackedConv pc;
+    pc.Cin = I; pc.Cout = O; pc.KH = pc.KW = 1;
+    pc.Npad = 4 * O;
+    MRCNN_REQUIRE(pc.Npad % conv_n_tile(pc.Npad) == 0, MRCNN_ERR_SHAPE, "%s: 4*O must be a multiple of the N tile", name.c_str());
+    std::vector<float> w((size_t)pc.Npad * I), sc(pc.Npad, 1.f), sh(pc.Npad);
+    for (int qd = 0; qd < 4; ++qd)
+        for (int o = 0; o < O; ++o) {
+            for (int i = 0; i < I; ++i) w[((size_t)qd * O + o) * I + i] = k[(((size_t)i * O + o) * 2 + (qd >> 1)) * 2 + (qd & 1)];
+            sh[(size_t)qd * O + o] = b[o];
+        }
+    upload(pc.wgt, w);
+    upload(pc.scale, sc);
+    upload(pc.shift, sh);
+    return pc;
+}
+
+// Dense NHWC conv helper (in: B×H×W×Cin, out: B×OH×OW×Cout).
+void run_conv_dense(hipStream_t s, const PackedConv& pc, const float* in, int B, int H, int W, float* out, int stride,
+                    int pad, int act, const float* res)
+{
+    ConvDesc d;
+    d.in = in; d.B = B; d.H = H; d.W = W; d.Cin = pc.Cin;
+    d.in_sW = pc.Cin; d.in_sH = (long)W * pc.Cin; d.in_sB = (long)H * W * pc.Cin;
+    d.wgt = pc.wgt.as<float>(); d.KH = pc.KH; d.KW = pc.KW; d.stride = stride; d.padH = d.padW = pad;
+    d.scale = pc.scale.as<float>(); d.shift = pc.shift.as<float>();
+    d.OH = (H + 2 * pad - pc.KH) / stride + 1;
+    d.OW = (W + 2 * pad - pc.KW) / stride + 1;
+    d.Cout = pc.Cout; d.Npad = pc.Npad;
+    d.out = out; d.out_sP = pc.Cout; d.out_sB = (long)d.OH * d.OW * pc.Cout;
+    d.act = act;
+    if (res) { d.res = res; d.res_sB = d.out_sB; d.res_sW = pc.Cout; d.res_sH = (long)d.OW * pc.Cout; }
+    conv_forward(s, d);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Classifier head
+// ------------------------------------------------------------------------------------------------
+void ClassifierHead::load(const MrcwFile& f, int capacity_rows)
+{
+    nc = (int)f.get_int("num_classes");
+    cap = capacity_rows;
+    const MrcwTensor& k1 = f.tensor("mrcnn_class_conv1/kernel");
+    MRCNN_REQUIRE(k1.dims.size() == 4, MRCNN_ERR_IO, "mrcnn_class_conv1/kernel must be 4-D");
+    C = k1.dims[1]; pool = k1.dims[2];
+    fc1 = pack_conv_oihw(f, "mrcnn_class_conv1", "mrcnn_class_bn1");    // [1024][7][7][256] == rows of the NHWC pooled vector
+    fc1.Cin = fc1.Cin * fc1.KH * fc1.KW; fc1.KH = fc1.KW = 1;           // as an inner product over K = 12544
+    fc2 = pack_conv_oihw(f, "mrcnn_class_conv2", "mrcnn_class_bn2");
+    fc3 = pack_stacked_1x1(f, {"mrcnn_class_logits", "mrcnn_bbox_fc"});
+    MRCNN_REQUIRE(fc3.Cout == 5 * nc, MRCNN_ERR_IO, "classifier output size %d != 5*num_classes", fc3.Cout);
+    Arena ar;
+    for (int pass = 0; pass < 2; ++pass) {
+        ar.off = 0;
+        h1 = ar.alloc_f((size_t)cap * fc1.Cout);
+        h2 = ar.alloc_f((size_t)cap * fc2.Cout);
+        lb = ar.alloc_f((size_t)cap * fc3.Cout);
+        probs = ar.alloc_f((size_t)cap * nc);
+        bbox = ar.alloc_f((size_t)cap * nc * 4);
+        cls6 = ar.alloc_f((size_t)cap * 6);
+        stage_in = ar.alloc_f((size_t)cap * pool * pool * C);
+        if (pass == 0) { arena.alloc(ar.off); ar.base = arena.as<char>(); }
+    }
+}
+
+void ClassifierHead::forward(hipStream_t s, const float* pooled_nhwc, int n, float* cls6_out, long cls6_stride)
+{
+    MRCNN_REQUIRE(n <= cap, MRCNN_ERR_SHAPE, "classifier head: %d rows exceed capacity %d", n, cap);
+    if (n <= 0) return;
+    // rows are "pixels" of a 1×n image
+    run_conv_dense(s, fc1, pooled_nhwc, 1, 1, n, h1, 1, 0, ACT_RELU);
+    run_conv_dense(s, fc2, h1, 1, 1, n, h2, 1, 0, ACT_RELU);
+    run_conv_dense(s, fc3, h2, 1, 1, n, lb, 1, 0, ACT_NONE);
+    softmax_rows_forward(s, lb, fc3.Cout, nc, n, probs);
+    copy_columns_forward(s, lb, fc3.Cout, nc, 4 * nc, n, bbox);
+    if (cls6_out) classifier_postprocess_forward(s, probs, bbox, nc, n, cls6_out, cls6_stride);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mask head
+// ------------------------------------------------------------------------------------------------
+void MaskHead::load(const MrcwFile& f, int capacity_rows)
+{
+    nc = (int)f.get_int("num_classes");
+    cap = capacity_rows;
+    for (int i = 0; i < 4; ++i)
+        conv[i] = pack_conv_oihw(f, "mrcnn_mask_conv" + std::to_string(i + 1), "mrcnn_mask_bn" + std::to_string(i + 1));
+    C = conv[0].Cin;
+    deconv = pack_deconv2(f, "mrcnn_mask_deconv");
+    final_full = pack_conv_oihw(f, "mrcnn_mask", "");
+    upload(final_w, f.floats("mrcnn_mask/kernel"));
+    upload(final_b, f.floats("mrcnn_mask/bias"));
+    const size_t hw = (size_t)pool * pool;
+    Arena ar;
+    for (int pass = 0; pass < 2; ++pass) {
+        ar.off = 0;
+        t0 = ar.alloc_f((size_t)cap * hw * C);
+        t1 = ar.alloc_f((size_t)cap * hw * C);
+        feat = ar.alloc_f((size_t)cap * hw * 4 * deconv.Cout);
+        full = ar.alloc_f((size_t)cap * hw * 4 * nc);
+        stage_in = ar.alloc_f((size_t)cap * hw * C);
+        if (pass == 0) { arena.alloc(ar.off); ar.base = arena.as<char>(); }
+    }
+}
+
+void MaskHead::forward_features(hipStream_t s, const float* pooled_nhwc, int n)
+{
+    MRCNN_REQUIRE(n <= cap, MRCNN_ERR_SHAPE, "mask head: %d rows exceed capacity %d", n, cap);
+    if (n <= 0) return;
+    run_conv_dense(s, conv[0], pooled_nhwc, n, pool, pool, t0, 1, 1, ACT_RELU);
+    run_conv_dense(s, conv[1], t0, n, pool, pool, t1, 1, 1, ACT_RELU);
+    run_conv_dense(s, conv[2], t1, n, pool, pool, t0, 1, 1, ACT_RELU);
+    run_conv_dense(s, conv[3], t0, n, pool, pool, t1, 1, 1, ACT_RELU);
+    ConvDesc d;
+    const int Co = deconv.Cout;
+    d.in = t1; d.B = n; d.H = pool; d.W = pool; d.Cin = deconv.Cin;
+    d.in_sW = deconv.Cin; d.in_sH = (long)pool * deconv.Cin; d.in_sB = (long)pool * pool * deconv.Cin;
+    d.wgt = deconv.wgt.as<float>(); d.scale = deconv.scale.as<float>(); d.shift = deconv.shift.as<float>();
+    d.OH = pool; d.OW = pool; d.Cout = Co; d.Npad = deconv.Npad;
+    d.deconv2 = 1; d.act = ACT_RELU;
+    d.out = feat; d.out_sW = Co; d.out_sH = (long)2 * pool * Co; d.out_sB = (long)4 * pool * pool * Co;
+    d.out_sP = Co;
+    conv_forward(s, d);
+}
+
+void MaskHead::forward_full(hipStream_t s, int n)
+{
+    if (n <= 0) return;
+    ConvDesc d;
+    const int P2 = 2 * pool;
+    d.in = feat; d.B = n; d.H = P2; d.W = P2; d.Cin = final_full.Cin;
+    d.in_sW = d.Cin; d.in_sH = (long)P2 * d.Cin; d.in_sB = (long)P2 * P2 * d.Cin;
+    d.wgt = final_full.wgt.as<float>(); d.scale = final_full.scale.as<float>(); d.shift = final_full.shift.as<float>();
+    d.OH = P2; d.OW = P2; d.Cout = nc; d.Npad = final_full.Npad;
+    d.act = ACT_SIGMOID;
+    d.out = full; d.out_sP = nc; d.out_sB = (long)P2 * P2 * nc;
+    conv_forward(s, d);
+}
+
+// ------------------------------------------------------------------------------------------------
+// timers
+// ------------------------------------------------------------------------------------------------
+void StageTimer::begin(hipStream_t s)
+{
+    if (!enabled) return;
+    names.clear();
+    if (ev.empty()) {
+        ev.resize(16);
+        for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
+    }
+    HIP_CHECK(hipEventRecord(ev[0], s));
+}
+void StageTimer::mark(hipStream_t s, const char* name)
+{
+    if (!enabled) return;
+    names.push_back(name);
+    HIP_CHECK(hipEventRecord(ev[names.size()], s));
+}
+void StageTimer::finish()
+{
+    if (!enabled || names.empty()) return;
+    HIP_CHECK(hipEventSynchronize(ev[names.size()]));
+    ms.clear();
+    for (size_t i = 0; i < names.size(); ++i) {
+        float t = 0;
+        HIP_CHECK(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+        ms[names[i]] = t;
+    }
+}
+StageTimer::~StageTimer()
+{
+    for (auto& e : ev) (void)hipEventDestroy(e);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Model
+// ------------------------------------------------------------------------------------------------
+Model::~Model()
+{
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+}
+
+static void read_std(const MrcwFile& f, const std::string& prefix, float out[4])
+{
+    const float dflt[4] = {0.1f, 0.1f, 0.2f, 0.2f};
+    const int64_t cnt = f.get_int(prefix + "bboxStdDev_count", 0);
+    for (int i = 0; i < 4; ++i) out[i] = dflt[i];
+    if (cnt == 4)
+        for (int i = 0; i < 4; ++i) out[i] = (float)f.get_double(prefix + "bboxStdDev_" + std::to_string(i), dflt[i]);
+}
+
+void Model::load(int kind_, const std::string& path, int max_batch_)
+{
+    require_gpu();
+    kind = kind_;
+    max_batch = max_batch_ > 0 ? max_batch_ : 1;
+    file.load(path);
+    const char* want = kind == MRCNN_MODEL_MASKRCNN ? "MaskRCNN" : kind == MRCNN_MODEL_CLASSIFIER ? "Classifier" : "Mask";
+    MRCNN_REQUIRE(file.get_string("kind") == want, MRCNN_ERR_IO, "'%s' holds a %s model, expected %s", path.c_str(),
+                  file.get_string("kind").c_str(), want);
+    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    own_stream = true;
+    nc = (int)file.get_int("num_classes");
+    if (kind == MRCNN_MODEL_CLASSIFIER) { cls_head.load(file, max_batch); return; }
+    if (kind == MRCNN_MODEL_MASK) { mask_head.load(file, max_batch); return; }
+    build_maskrcnn();
+}
+
+void Model::build_maskrcnn()
+{
+    const MrcwFile& f = file;
+    arch = f.get_string("architecture");
+    MRCNN_REQUIRE(arch == "resnet101" || arch == "resnet50", MRCNN_ERR_UNSUPPORTED, "architecture '%s'", arch.c_str());
+    H = (int)f.get_int("image_height"); W = (int)f.get_int("image_width");
+    MRCNN_REQUIRE(H % 64 == 0 && W % 64 == 0 && H > 0 && W > 0, MRCNN_ERR_SHAPE, "input_image_shape %dx%d must be multiples of 64", H, W);
+    na = (int)f.get_int("num_anchors_per_location", 3);
+    mean[0] = (float)f.get_double("mean_r", 123.7); mean[1] = (float)f.get_double("mean_g", 116.8); mean[2] = (float)f.get_double("mean_b", 103.9);
+    pre_nms = (int)f.get_int("ProposalLayer.preNMSMaxProposals", 6000);
+    max_prop = (int)f.get_int("ProposalLayer.maxProposals", 1000);
+    prop_nms_thr = (float)f.get_double("ProposalLayer.nmsIOUThreshold", 0.7);
+    read_std(f, "ProposalLayer.", prop_std);
+    max_det = (int)f.get_int("DetectionLayer.maxDetections", 100);
+    det_score_thr = (float)f.get_double("DetectionLayer.scoreThreshold", 0.7);
+    det_nms_thr = (float)f.get_double("DetectionLayer.nmsIOUThreshold", 0.3);
+    read_std(f, "DetectionLayer.", det_std);
+    cls_pool = (int)f.get_int("PyramidROIAlignLayer.classifier.poolSize", 7);
+    mask_pool = (int)f.get_int("PyramidROIAlignLayer.mask.poolSize", 14);
+    roi_img_w = f.get_double("PyramidROIAlignLayer.classifier.imageWidth", (double)W);
+    roi_img_h = f.get_double("PyramidROIAlignLayer.classifier.imageHeight", (double)H);
+
+    // ---- sub-artefacts from the config singleton (ProposalLayer.swift:68, TimeDistributed*Layer.swift:41/49)
+    const char* ap = mrcnn_config_get_anchors_path();
+    const char* cp = mrcnn_config_get_classifier_path();
+    const char* mp = mrcnn_config_get_mask_path();
+    MRCNN_REQUIRE(ap, MRCNN_ERR_CONFIG, "MaskRCNNConfig.anchorsURL must be set before the MaskRCNN model is loaded");
+    MRCNN_REQUIRE(cp, MRCNN_ERR_CONFIG, "MaskRCNNConfig.compiledClassifierModelURL must be set before the MaskRCNN model is loaded");
+    MRCNN_REQUIRE(mp, MRCNN_ERR_CONFIG, "MaskRCNNConfig.compiledMaskModelURL must be set before the MaskRCNN model is loaded");
+
+    const int strides[5] = {4, 8, 16, 32, 64};
+    int fh[5], fw[5];
+    A = 0;
+    long lvl_off[5];
+    for (int l = 0; l < 5; ++l) {
+        fh[l] = (H + strides[l] - 1) / strides[l];
+        fw[l] = (W + strides[l] - 1) / strides[l];
+        lvl_off[l] = A;
+        A += fh[l] * fw[l] * na;
+    }
+    K = A < pre_nms ? A : pre_nms;
+    {   // anchors.bin: A×4 little-endian float32 (task.py:173-176)
+        std::ifstream in(ap, std::ios::binary | std::ios::ate);
+        MRCNN_REQUIRE(in.good(), MRCNN_ERR_IO, "cannot open anchors file '%s'", ap);
+        const std::streamsize sz = in.tellg();
+        MRCNN_REQUIRE(sz == (std::streamsize)A * 16, MRCNN_ERR_IO, "anchors file '%s' has %lld bytes, expected %lld (%d anchors x 4 float32)", ap,
+                      (long long)sz, (long long)A * 16, A);
+        std::vector<float> h((size_t)A * 4);
+        in.seekg(0);
+        in.read(reinterpret_cast<char*>(h.data()), sz);
+        upload(anchors, h);
+    }
+    {
+        MrcwFile cf; cf.load(cp);
+        MRCNN_REQUIRE(cf.get_string("kind") == "Classifier", MRCNN_ERR_IO, "'%s' is not a Classifier artefact", cp);
+        cls_head.load(cf, max_batch * max_prop);
+        MRCNN_REQUIRE(cls_head.nc == nc, MRCNN_ERR_IO, "Classifier num_classes %d != %d", cls_head.nc, nc);
+        MrcwFile mf; mf.load(mp);
+        MRCNN_REQUIRE(mf.get_string("kind") == "Mask", MRCNN_ERR_IO, "'%s' is not a Mask artefact", mp);
+        mask_head.load(mf, max_batch * max_det);
+        MRCNN_REQUIRE(mask_head.nc == nc, MRCNN_ERR_IO, "Mask num_classes %d != %d", mask_head.nc, nc);
+    }
+
+    // ---- trunk weights ----------------------------------------------------------------------------
+    convs["conv1"] = pack_conv1(f);
+    std::vector<std::vector<std::string>> blocks(6);
+    {
+        const int n4 = arch == "resnet101" ? 22 : 5;
+        blocks[2] = {"a", "b", "c"};
+        blocks[3] = {"a", "b", "c", "d"};
+        blocks[4] = {"a"};
+        for (int i = 0; i < n4; ++i) blocks[4].push_back(std::string(1, (char)('b' + i)));
+        blocks[5] = {"a", "b", "c"};
+    }
+    for (int st = 2; st <= 5; ++st)
+        for (auto& b : blocks[st]) {
+            const std::string p = std::to_string(st) + b;
+            for (const char* br : {"2a", "2b", "2c"}) convs["res" + p + "_branch" + br] = pack_conv_oihw(f, "res" + p + "_branch" + br, "bn" + p + "_branch" + br);
+            if (b == "a") convs["res" + p + "_branch1"] = pack_conv_oihw(f, "res" + p + "_branch1", "bn" + p + "_branch1");
+        }
+    for (const char* n : {"fpn_c5p5", "fpn_c4p4", "fpn_c3p3", "fpn_c2p2", "fpn_p2", "fpn_p3", "fpn_p4", "fpn_p5", "rpn_conv_shared"})
+        convs[n] = pack_conv_oihw(f, n, "");
+    convs["rpn_heads"] = pack_stacked_1x1(f, {"rpn_class_raw", "rpn_bbox_pred"});
+    MRCNN_REQUIRE(convs["rpn_heads"].Cout == 6 * na, MRCNN_ERR_IO, "RPN head width %d != 6*anchors_per_location", convs["rpn_heads"].Cout);
+
+    // ---- activation plan (pass 0 sizes the arena, pass 1 binds pointers and records the ops) ------
+    const int Bm = max_batch;
+    Arena ar;
+    for (int pass = 0; pass < 2; ++pass) {
+        ar.off = 0;
+        trunk_ops.clear();
+        taps.clear();
+        const bool real = pass == 1;
+        auto T = [&](int h, int w, int c) { Tensor4 t; t.H = h; t.W = w; t.C = c; t.p = ar.alloc_f((size_t)Bm * h * w * c); return t; };
+        auto add = [&](Op op) { if (real) trunk_ops.push_back(std::move(op)); };
+        auto conv_op = [&](const std::string& name, const Tensor4& in, const Tensor4& out, int stride, int pad, int act,
+                           const Tensor4* res, int res_shift) {
+            const PackedConv* pc = &convs.at(name);
+            ConvDesc d;
+            d.in = in.p; d.H = in.H; d.W = in.W; d.Cin = pc->Cin;
+            d.in_sW = in.C; d.in_sH = (long)in.W * in.C; d.in_sB = in.sB();
+            d.wgt = pc->wgt.as<float>(); d.KH = pc->KH; d.KW = pc->KW; d.stride = stride; d.padH = d.padW = pad;
+            d.scale = pc->scale.as<float>(); d.shift = pc->shift.as<float>();
+            d.OH = out.H; d.OW = out.W; d.Cout = pc->Cout; d.Npad = pc->Npad;
+            d.out = out.p; d.out_sP = out.C; d.out_sB = out.sB();
+            d.act = act;
+            if (res) { d.res = res->p; d.res_sB = res->sB(); d.res_sH = (long)res->W * res->C; d.res_sW = res->C; d.res_shift = res_shift; }
+            add([d](hipStream_t s, int batch) { ConvDesc x = d; x.B = batch; conv_forward(s, x); });
+        };
+
+        d_rgb = (uint8_t*)ar.alloc_b((size_t)Bm * H * W * 3);
+        // C1: zero-padded NHWC4 staging, 7×7/2 conv as 7 row-taps of 32 contiguous floats, 3×3/2 max pool
+        const int Hp = H + 6, Wp = W + 6;
+        float* x0 = ar.alloc_f((size_t)Bm * Hp * Wp * 4 + 64);
+        {
+            const float m3[3] = {mean[0], mean[1], mean[2]};
+            uint8_t* src = d_rgb;
+            const int h = H, w = W;
+            add([=](hipStream_t s, int batch) { preprocess_forward(s, src, batch, h, w, 3, m3, x0); });
+        }
+        Tensor4 c1 = T(H / 2, W / 2, 64);
+        {
+            const PackedConv* pc = &convs.at("conv1");
+            ConvDesc d;
+            d.in = x0; d.H = Hp; d.W = Wp; d.Cin = 32;
+            d.in_sW = 4; d.in_sH = (long)Wp * 4; d.in_sB = (long)Hp * Wp * 4;
+            d.wgt = pc->wgt.as<float>(); d.KH = 7; d.KW = 1; d.stride = 2; d.padH = d.padW = 0;
+            d.scale = pc->scale.as<float>(); d.shift = pc->shift.as<float>();
+            d.OH = c1.H; d.OW = c1.W; d.Cout = pc->Cout; d.Npad = pc->Npad;
+            d.out = c1.p; d.out_sP = c1.C; d.out_sB = c1.sB(); d.act = ACT_RELU;
+            add([d](hipStream_t s, int batch) { ConvDesc x = d; x.B = batch; conv_forward(s, x); });
+        }
+        Tensor4 x = T(H / 4, W / 4, 64);
+        {
+            const Tensor4 i = c1, o = x;
+            add([i, o](hipStream_t s, int batch) { maxpool3x3s2_forward(s, i.p, batch, i.H, i.W, i.C, o.p, o.H, o.W); });
+        }
+        Tensor4 Cf[6];
+        const int f1s[6] = {0, 0, 64, 128, 256, 512}, f3s[6] = {0, 0, 256, 512, 1024, 2048};
+        for (int st = 2; st <= 5; ++st) {
+            for (auto& b : blocks[st]) {
+                const std::string p = std::to_string(st) + b;
+                const bool first = b == "a";
+                const int stride = (first && st > 2) ? 2 : 1;
+                const int oh = x.H / stride, ow = x.W / stride;
+                Tensor4 ta = T(oh, ow, f1s[st]);
+                conv_op("res" + p + "_branch2a", x, ta, stride, 0, ACT_RELU, nullptr, 0);
+                Tensor4 tb = T(oh, ow, f1s[st]);
+                conv_op("res" + p + "_branch2b", ta, tb, 1, 1, ACT_RELU, nullptr, 0);
+                Tensor4 sc = x;
+                if (first) {
+                    sc = T(oh, ow, f3s[st]);
+                    conv_op("res" + p + "_branch1", x, sc, stride, 0, ACT_NONE, nullptr, 0);
+                }
+                Tensor4 to = T(oh, ow, f3s[st]);
+                conv_op("res" + p + "_branch2c", tb, to, 1, 0, ACT_RELU, &sc, 0);
+                x = to;
+            }
+            Cf[st] = x;
+        }
+        // FPN: lateral 1×1 (+ nearest 2× upsample of the level above, fused as a shifted residual), then 3×3
+        Tensor4 L5 = T(Cf[5].H, Cf[5].W, 256), L4 = T(Cf[4].H, Cf[4].W, 256), L3 = T(Cf[3].H, Cf[3].W, 256), L2 = T(Cf[2].H, Cf[2].W, 256);
+        conv_op("fpn_c5p5", Cf[5], L5, 1, 0, ACT_NONE, nullptr, 0);
+        conv_op("fpn_c4p4", Cf[4], L4, 1, 0, ACT_NONE, &L5, 1);
+        conv_op("fpn_c3p3", Cf[3], L3, 1, 0, ACT_NONE, &L4, 1);
+        conv_op("fpn_c2p2", Cf[2], L2, 1, 0, ACT_NONE, &L3, 1);
+        const Tensor4 Ls[4] = {L2, L3, L4, L5};
+        const char* pn[4] = {"fpn_p2", "fpn_p3", "fpn_p4", "fpn_p5"};
+        const char* tn[4] = {"P2", "P3", "P4", "P5"};
+        for (int l = 0; l < 4; ++l) {
+            P[l] = T(Ls[l].H, Ls[l].W, 256);
+            conv_op(pn[l], Ls[l], P[l], 1, 1, ACT_NONE, nullptr, 0);
+            taps[tn[l]] = {P[l].p, P[l].sB()};
+            MRCNN_REQUIRE(P[l].H == fh[l] && P[l].W == fw[l], MRCNN_ERR_SHAPE, "pyramid level %d shape mismatch", l + 2);
+        }
+        // RPN on P2..P6 (P6 = P5 sub-sampled by 2: read in place through doubled strides)
+        rpn_logits = ar.alloc_f((size_t)Bm * A * 2);
+        rpn_probs = ar.alloc_f((size_t)Bm * A * 2);
+        rpn_deltas = ar.alloc_f((size_t)Bm * A * 4);
+        taps["rpn_probs"] = {rpn_probs, (long)A * 2};
+        taps["rpn_deltas"] = {rpn_deltas, (long)A * 4};
+        float* rpn_feat = ar.alloc_f((size_t)Bm * P[0].H * P[0].W * 512);
+        for (int l = 0; l < 5; ++l) {
+            const Tensor4& src = P[l < 4 ? l : 3];
+            const int sub = l < 4 ? 1 : 2;
+            const PackedConv* pc = &convs.at("rpn_conv_shared");
+            ConvDesc d;
+            d.in = src.p; d.H = fh[l]; d.W = fw[l]; d.Cin = 256;
+            d.in_sW = (long)sub * src.C; d.in_sH = (long)sub * src.W * src.C; d.in_sB = src.sB();
+            d.wgt = pc->wgt.as<float>(); d.KH = 3; d.KW = 3; d.stride = 1; d.padH = d.padW = 1;
+            d.scale = pc->scale.as<float>(); d.shift = pc->shift.as<float>();
+            d.OH = fh[l]; d.OW = fw[l]; d.Cout = 512; d.Npad = pc->Npad;
+            d.out = rpn_feat; d.out_sP = 512; d.out_sB = (long)fh[l] * fw[l] * 512; d.act = ACT_RELU;
+            add([d](hipStream_t s, int batch) { ConvDesc x = d; x.B = batch; conv_forward(s, x); });
+            const PackedConv* hc = &convs.at("rpn_heads");
+            ConvDesc e;
+            e.in = rpn_feat; e.H = fh[l]; e.W = fw[l]; e.Cin = 512;
+            e.in_sW = 512; e.in_sH = (long)fw[l] * 512; e.in_sB = (long)fh[l] * fw[l] * 512;
+            e.wgt = hc->wgt.as<float>(); e.scale = hc->scale.as<float>(); e.shift = hc->shift.as<float>();
+            e.OH = fh[l]; e.OW = fw[l]; e.Cout = hc->Cout; e.Npad = hc->Npad;
+            e.out = rpn_logits + lvl_off[l] * 2; e.out_sP = 2 * na; e.out_sB = (long)A * 2;
+            e.out2 = rpn_deltas + lvl_off[l] * 4; e.out2_sP = 4 * na; e.out2_sB = (long)A * 4; e.n_split = 2 * na;
+            add([e](hipStream_t s, int batch) { ConvDesc x = e; x.B = batch; conv_forward(s, x); });
+        }
+        {
+            float* lg = rpn_logits; float* pr = rpn_probs; const long per = A;
+            add([=](hipStream_t s, int batch) { softmax_pairs_forward(s, lg, pr, per * batch); });
+        }
+        rois = ar.alloc_f((size_t)Bm * max_prop * 4);
+        pooled = ar.alloc_f((size_t)Bm * max_prop * cls_pool * cls_pool * 256);
+        cls6 = ar.alloc_f((size_t)Bm * max_prop * 6);
+        detections = ar.alloc_f((size_t)Bm * max_det * 6);
+        pooled_mask = ar.alloc_f((size_t)Bm * max_det * mask_pool * mask_pool * 256);
+        mask_out = ar.alloc_f((size_t)Bm * max_det * 4 * mask_pool * mask_pool);
+        taps["rois"] = {rois, (long)max_prop * 4};
+        taps["pooled"] = {pooled, (long)max_prop * cls_pool * cls_pool * 256};
+        taps["cls6"] = {cls6, (long)max_prop * 6};
+        taps["detections"] = {detections, (long)max_det * 6};
+        taps["pooled_mask"] = {pooled_mask, (long)max_det * mask_pool * mask_pool * 256};
+        taps["mask"] = {mask_out, (long)max_det * 4 * mask_pool * mask_pool};
+        void* pws = ar.alloc_b(ProposalWorkspace::bytes(Bm, A, K, max_prop));
+        void* dws = ar.alloc_b(DetectionWorkspace::bytes(Bm, max_prop, max_det));
+        msel_ws.flags = (int32_t*)ar.alloc_b((size_t)Bm * max_det * 4);
+        msel_ws.mapping = (int32_t*)ar.alloc_b((size_t)Bm * max_det * 4);
+        msel_ws.kept = (int32_t*)ar.alloc_b((size_t)Bm * 4);
+        if (real) {
+            prop_ws.bind(pws, Bm, A, K, max_prop);
+            det_ws.bind(dws, Bm, max_prop, max_det);
+        }
+        if (pass == 0) { arena.alloc(ar.off); ar.base = arena.as<char>(); }
+    }
+    taps["cls_probs"] = {cls_head.probs, (long)max_prop * nc};
+    taps["cls_bbox"] = {cls_head.bbox, (long)max_prop * nc * 4};
+}
+
+void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, float* det_out, float* masks_out, bool sync)
+{
+    MRCNN_REQUIRE(kind == MRCNN_MODEL_MASKRCNN, MRCNN_ERR_INVALID, "predict called on a non-MaskRCNN model");
+    MRCNN_REQUIRE(rgb && det_out && masks_out, MRCNN_ERR_INVALID, "null buffer");
+    MRCNN_REQUIRE(h == H && w == W, MRCNN_ERR_SHAPE, "image is %dx%d, the model expects %dx%d", h, w, H, W);
+    MRCNN_REQUIRE(batch >= 1 && batch <= max_batch, MRCNN_ERR_SHAPE, "batch %d outside 1..%d", batch, max_batch);
+    hipStream_t s = stream;
+    const size_t img_bytes = (size_t)batch * H * W * 3;
+    HIP_CHECK(hipMemcpyAsync(d_rgb, rgb, img_bytes, memspace == MRCNN_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    timer.begin(s);
+    for (auto& op : trunk_ops) op(s, batch);
+    timer.mark(s, "Trunk");
+    // ProposalLayer
+    ProposalWorkspace pw = prop_ws; pw.B = batch;
+    proposal_forward(s, pw, rpn_probs, (long)A * 2, rpn_deltas, (long)A * 4, anchors.as<float>(), prop_std, prop_nms_thr, rois,
+                     (long)max_prop * 4, 4);
+    timer.mark(s, "Proposal-Eval");
+    // PyramidROIAlign (classifier)
+    PyramidMaps maps;
+    for (int l = 0; l < 4; ++l) { maps.data[l] = P[l].p; maps.H[l] = P[l].H; maps.W[l] = P[l].W; maps.sB[l] = P[l].sB(); }
+    const long prow = (long)cls_pool * cls_pool * 256;
+    roi_align_forward(s, maps, 256, 1, rois, (long)max_prop * 4, 4, max_prop, batch, cls_pool, roi_img_w, roi_img_h, pooled,
+                      (long)max_prop * prow, prow);
+    timer.mark(s, "PyramidROIAlign-Eval");
+    // TimeDistributedClassifier
+    cls_head.forward(s, pooled, batch * max_prop, cls6, 6);
+    timer.mark(s, "TimeDistributedClassifierLayer-Eval");
+    // DetectionLayer
+    DetectionWorkspace dw = det_ws; dw.B = batch;
+    detection_forward(s, dw, rois, (long)max_prop * 4, 4, cls6, (long)max_prop * 6, det_std, det_score_thr, det_nms_thr, nc,
+                      detections, (long)max_det * 6, 6);
+    timer.mark(s, "Detection-Eval");
+    // PyramidROIAlign (mask) on the detections' boxes
+    const long mrow = (long)mask_pool * mask_pool * 256;
+    roi_align_forward(s, maps, 256, 1, detections, (long)max_det * 6, 6, max_det, batch, mask_pool, roi_img_w, roi_img_h, pooled_mask,
+                      (long)max_det * mrow, mrow);
+    timer.mark(s, "PyramidROIAlign-Eval-Mask");
+    // TimeDistributedMask
+    const int HW = 4 * mask_pool * mask_pool;
+    mask_valid_rows_forward(s, pooled_mask, (long)max_det * mrow, mrow, mrow, max_det, batch, msel_ws);
+    mask_head.forward_features(s, pooled_mask, batch * max_det);
+    mask_select_forward(s, mask_head.feat, (long)max_det * HW * mask_head.deconv.Cout, HW, mask_head.deconv.Cout,
+                        mask_head.final_w.as<float>(), mask_head.final_b.as<float>(), nc, detections, (long)max_det * 6, 6, max_det,
+                        batch, msel_ws, mask_out, (long)max_det * HW, HW);
+    timer.mark(s, "TimeDistributedMask-Eval");
+    const hipMemcpyKind back = memspace == MRCNN_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    HIP_CHECK(hipMemcpyAsync(det_out, detections, (size_t)batch * max_det * 6 * 4, back, s));
+    HIP_CHECK(hipMemcpyAsync(masks_out, mask_out, (size_t)batch * max_det * HW * 4, back, s));
+    if (sync) {
+        HIP_CHECK(hipStreamSynchronize(s));
+        timer.finish();
+    }
+}
+
+void Model::read_tensor(const std::string& name, int image, float* dst, int64_t cap, int64_t* count)
+{
+    MRCNN_REQUIRE(kind == MRCNN_MODEL_MASKRCNN, MRCNN_ERR_INVALID, "taps exist on the MaskRCNN model only");
+    MRCNN_REQUIRE(image >= 0 && image < max_batch, MRCNN_ERR_INVALID, "image index %d out of range", image);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (name == "topk_idx" || name == "keep_idx") {
+        const bool tk = name == "topk_idx";
+        const long n = tk ? K : max_prop;
+        if (count) *count = n;
+        MRCNN_REQUIRE(dst && cap >= n, MRCNN_ERR_SHAPE, "tensor '%s' needs %ld floats", name.c_str(), n);
+        std::vector<int32_t> tmp((size_t)n);
+        HIP_CHECK(hipMemcpy(tmp.data(), (tk ? prop_ws.topk_idx : prop_ws.keep_idx) + (size_t)image * n, (size_t)n * 4, hipMemcpyDeviceToHost));
+        for (long i = 0; i < n; ++i) dst[i] = (float)tmp[(size_t)i];
+        return;
+    }
+    if (name == "boxes_sorted") {
+        const long n = (long)K * 4;
+        if (count) *count = n;
+        MRCNN_REQUIRE(dst && cap >= n, MRCNN_ERR_SHAPE, "tensor '%s' needs %ld floats", name.c_str(), n);
+        HIP_CHECK(hipMemcpy(dst, prop_ws.boxes + (size_t)image * n, (size_t)n * 4, hipMemcpyDeviceToHost));
+        return;
+    }
+    if (name == "keep_count") {
+        if (count) *count = 1;
+        MRCNN_REQUIRE(dst && cap >= 1, MRCNN_ERR_SHAPE, "tensor '%s' needs 1 float", name.c_str());
+        int32_t v = 0;
+        HIP_CHECK(hipMemcpy(&v, prop_ws.keep_count + image, 4, hipMemcpyDeviceToHost));
+        dst[0] = (float)v;
+        return;
+    }
+    auto it = taps.find(name);
+    MRCNN_REQUIRE(it != taps.end(), MRCNN_ERR_INVALID, "unknown tensor '%s'", name.c_str());
+    const long n = it->second.second;
+    if (count) *count = n;
+    MRCNN_REQUIRE(dst && cap >= n, MRCNN_ERR_SHAPE, "tensor '%s' needs %ld floats, buffer holds %lld", name.c_str(), n, (long long)cap);
+    HIP_CHECK(hipMemcpy(dst, it->second.first + (size_t)image * n, (size_t)n * 4, hipMemcpyDeviceToHost));
+}
+
+}  // namespace mrcnn

@@ -1,0 +1,145 @@
+// kernels.h — host-side launchers of the gfx950 kernels (one namespace, no torch, no templates in the API).
+#pragma once
+#include "common.h"
+
+namespace mrcnn {
+
+// ================================================================================================
+// Box path (kernels_boxes.hip): top-k → decode → NMS, detection filtering.  -ffp-contract=off.
+// ================================================================================================
+
+// Workspace of the proposal path for a batch of images; all pointers are device memory.
+struct ProposalWorkspace {
+    int B = 0, A = 0, K = 0, Kpad = 0, max_keep = 0, nblk = 0, W = 0;
+    uint32_t* keys = nullptr;        // [B][A]      order keys of the foreground scores
+    uint32_t* hist = nullptr;        // [B][3][4096] radix-select histograms (12+12+8 bits)
+    uint32_t* blockhist = nullptr;   // [B][nblk][256] per-block histogram of the last 8 bits
+    uint32_t* state = nullptr;       // [B][8]      {prefix, k_remaining, threshold key, need_ties, n_gt, slot counter}
+    uint64_t* cand = nullptr;        // [B][Kpad]   (~key << 32 | index), sorted ascending
+    int32_t* topk_idx = nullptr;     // [B][K]      anchor index of the i-th best score
+    float* boxes = nullptr;          // [B][K][4]   decoded + clipped boxes in score order
+    uint64_t* nms_mask = nullptr;    // [B][K][W]   bit j of word w of row i: box 64w+j (> i) is suppressed by i
+    int32_t* keep_idx = nullptr;     // [B][max_keep]
+    int32_t* keep_count = nullptr;   // [B]
+    static size_t bytes(int B, int A, int K, int max_keep);
+    void bind(void* base, int B, int A, int K, int max_keep);
+};
+
+// ProposalLayer.evaluate for B images.  probs (B, A, 2) / deltas (B, A, 4) with batch strides in
+// elements; anchors (A,4); rois out: B × max_proposals rows of `row_stride` floats (first 4 written,
+// whole rows zeroed beyond the kept count — ProposalLayer.swift:181-192).
+void proposal_forward(hipStream_t s, const ProposalWorkspace& ws, const float* probs, long probs_sB,
+                      const float* deltas, long deltas_sB, const float* anchors, const float std4[4],
+                      float nms_thr, float* rois, long rois_sB, long row_stride);
+
+struct DetectionWorkspace {
+    int B = 0, N = 0, max_det = 0, W = 0, Npad = 0;
+    int32_t* count = nullptr;        // [B]        rows surviving the score/background filter
+    int32_t* src = nullptr;          // [B][N]     original ROI index of filtered row k
+    float* boxes = nullptr;          // [B][N][4]  refined, clipped
+    float* score = nullptr;          // [B][N]
+    int32_t* cls = nullptr;          // [B][N]
+    uint64_t* nms_mask = nullptr;    // [B][N][W]
+    int32_t* keep_idx = nullptr;     // [B][N]
+    int32_t* keep_count = nullptr;   // [B]
+    static size_t bytes(int B, int N, int max_det);
+    void bind(void* base, int B, int N, int max_det);
+};
+
+// DetectionLayer.evaluate for B images: rois (B, N, 4) rows of roi_stride, cls6 (B, N, 6) contiguous
+// rows, out: B × max_det rows of row_stride floats.
+void detection_forward(hipStream_t s, const DetectionWorkspace& ws, const float* rois, long rois_sB,
+                       long roi_stride, const float* cls6, long cls_sB, const float std4[4],
+                       float score_thr, float nms_thr, int num_classes_hint, float* out, long out_sB,
+                       long row_stride);
+
+// ================================================================================================
+// ROIAlign (kernels_roialign.hip).  -ffp-contract=off.
+// ================================================================================================
+struct PyramidMaps {
+    const float* data[4];
+    int H[4], W[4];
+    long sB[4];          // batch stride in elements
+};
+// layout_nhwc = 1: maps are (B,H,W,C) and out is (B,n,P,P,C); 0: maps (B,C,H,W), out (B,n,C,P,P).
+void roi_align_forward(hipStream_t s, const PyramidMaps& maps, int C, int layout_nhwc, const float* rois,
+                       long rois_sB, long roi_stride, int n_rois, int B, int pool, double image_w,
+                       double image_h, float* out, long out_sB, long out_row_stride);
+
+// ================================================================================================
+// Convolution family + element-wise helpers (kernels_conv.hip)
+// ================================================================================================
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
+
+struct ConvDesc {
+    // input NHWC (channel stride 1), arbitrary outer strides in elements
+    const float* in = nullptr;
+    int B = 0, H = 0, W = 0, Cin = 0;
+    long in_sB = 0, in_sH = 0, in_sW = 0;
+    // filter: packed [Npad][KH*KW*Cin], k contiguous (tap-major, channel-minor)
+    const float* wgt = nullptr;
+    int KH = 1, KW = 1, stride = 1, padH = 0, padW = 0;
+    // epilogue: y = act(acc*scale[n] + shift[n] + residual)
+    const float* scale = nullptr;
+    const float* shift = nullptr;
+    const float* res = nullptr;
+    long res_sB = 0, res_sH = 0, res_sW = 0;
+    int res_shift = 0;           // residual read at (oh >> res_shift, ow >> res_shift): nearest 2× upsample when 1
+    int act = ACT_NONE;
+    // output NHWC: address = b*out_sB + (oh*OW+ow)*out_sP + n  (rows of the image contiguous)
+    float* out = nullptr;
+    int OH = 0, OW = 0, Cout = 0, Npad = 0;
+    long out_sB = 0, out_sP = 0;
+    // optional second output: columns >= n_split go to out2 (column n - n_split)
+    float* out2 = nullptr;
+    int n_split = 0;
+    long out2_sB = 0, out2_sP = 0;
+    // transposed-conv 2x2 stride 2 scatter: column n = q*Cout + co, q = dy*2+dx → pixel (2oh+dy, 2ow+dx)
+    int deconv2 = 0;
+    long out_sH = 0, out_sW = 0;  // only used when deconv2
+};
+// Picks the tile shape from Cout; returns the N tile it will use so that callers can pad weights.
+int conv_n_tile(int Cout);
+void conv_forward(hipStream_t s, const ConvDesc& d);
+
+// uint8 RGB (B,H,W,3) → fp32 (B, H+2*pad, W+2*pad, 4) minus mean, zero border, channel 3 = 0.
+void preprocess_forward(hipStream_t s, const uint8_t* rgb, int B, int H, int W, int pad, const float mean[3],
+                        float* out);
+// 3×3 stride-2 max pool, Keras 'same' (window clipped at the bottom/right edge). NHWC, C % 4 == 0.
+void maxpool3x3s2_forward(hipStream_t s, const float* in, int B, int H, int W, int C, float* out, int OH, int OW);
+// softmax over consecutive pairs: logits (n,2) → probs (n,2)
+void softmax_pairs_forward(hipStream_t s, const float* logits, float* probs, long n_pairs);
+// row softmax: logits rows of ld floats, first nc columns → probs (n, nc) contiguous
+void softmax_rows_forward(hipStream_t s, const float* logits, long ld, int nc, long n, float* probs);
+// copy bbox columns: src rows of ld floats starting at column c0, ncols columns → dst (n, ncols)
+void copy_columns_forward(hipStream_t s, const float* src, long ld, int c0, int ncols, long n, float* dst);
+// TimeDistributedClassifierLayer post-processing: probs (n,nc), bbox (n,nc*4) → rows (dy,dx,dh,dw,id,score)
+void classifier_postprocess_forward(hipStream_t s, const float* probs, const float* bbox, int nc, long n,
+                                    float* out, long out_row_stride);
+// layout changes between Core ML's CHW and the engine's HWC
+void nchw_to_nhwc_forward(hipStream_t s, const float* in, long n, int C, int H, int W, float* out);
+void nhwc_to_nchw_forward(hipStream_t s, const float* in, long n, int C, int H, int W, float* out);
+// strided row gather: dst[i][0..len) = src[i*src_stride .. +len)
+void copy_rows_forward(hipStream_t s, const float* src, long src_stride, long n, long len, float* dst, long dst_stride);
+
+// TimeDistributedMaskLayer pieces -----------------------------------------------------------------
+struct MaskSelectWorkspace {
+    int32_t* flags = nullptr;      // [B][D] row is all-nonzero
+    int32_t* mapping = nullptr;    // [B][D] compact index → row
+    int32_t* kept = nullptr;       // [B]
+};
+// flags/mapping of MultiArrayBatchProvider(removeZeros:true): pooled (B, D, row_len) contiguous rows.
+void mask_valid_rows_forward(hipStream_t s, const float* pooled, long pooled_sB, long row_stride, long row_len,
+                             int D, int B, const MaskSelectWorkspace& ws);
+// feat (B, D, HW, C) = ReLU(deconv) NHWC; w (nc, C), bias (nc); detections rows det_stride;
+// out rows out_stride (>= HW).  Writes exactly what TimeDistributedMaskLayer.swift:58-89 writes.
+void mask_select_forward(hipStream_t s, const float* feat, long feat_sB, int HW, int C, const float* w,
+                         const float* bias, int nc, const float* det, long det_sB, long det_stride, int D, int B,
+                         const MaskSelectWorkspace& ws, float* out, long out_sB, long out_stride);
+// Variant for precomputed per-class masks (n_kept-compacted or in-place), used by the stand-alone layer:
+// masks (B, D, nc, HW) in place (row r of the batch = detection r).
+void mask_select_from_full_forward(hipStream_t s, const float* masks, long masks_sB, int HW, int nc,
+                                   const float* det, long det_sB, long det_stride, int D, int B,
+                                   const MaskSelectWorkspace& ws, float* out, long out_sB, long out_stride);
+
+}  // namespace mrcnn

@@ -1,0 +1,614 @@
+// kernels_boxes.hip — the proposal path and the detection path on gfx950.
+//
+// Replaces (reference, Sources/Mask-RCNN-CoreML/):
+//   ProposalLayer.evaluate              ProposalLayer.swift:103-195
+//   sortedIndices / indexed / broadcastedIndices / elementWiseMultiply   Utils.swift:28-38,56-66,112-148,173-180
+//   applyBoxDeltas / clip               BoxUtils.swift:32-80
+//   nonMaxSupression / IOU              Utils.swift:185-246
+//   DetectionLayer.evaluate             DetectionLayer.swift:107-276
+//
+// Design (HBM-bound integer/byte work — no MFMA here):
+//   * top-k = 3-pass radix select (12+12+8 bits) over monotone uint32 keys, coalesced 16-B loads,
+//     LDS histograms, then an order-preserving tie compaction (ties → lowest anchor index, the
+//     total order the parity tests pin) and one in-LDS bitonic sort of the K survivors per image;
+//   * gather of the K anchors / deltas as 16-B rows, decode + clip in registers;
+//   * NMS = all-pairs suppression bit-matrix (64×64 tiles, one wave per tile, IoU in fp64 exactly
+//     like the CGRect code) + a chunked greedy scan: a wave resolves 64 candidates at a time from
+//     the diagonal word with ballot/readlane, then the block ORs the kept rows into the removed
+//     set.  Early exit at maxProposals kept.
+// Compiled with -ffp-contract=off (see device_math.h).
+#include "device_math.h"
+#include "kernels.h"
+
+namespace mrcnn {
+
+static constexpr int CHUNK = 1024;   // scores per block in the select passes (256 threads × 4)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+// ------------------------------------------------------------------------------------------------
+// workspace carving
+// ------------------------------------------------------------------------------------------------
+size_t ProposalWorkspace::bytes(int B, int A, int K, int max_keep)
+{
+    const int nblk = (A + CHUNK - 1) / CHUNK, W = (K + 63) / 64, Kpad = next_pow2(K);
+    size_t n = 0;
+    n += align_up((size_t)B * (size_t)(nblk * CHUNK) * 4, 256);   // keys (padded to whole chunks)
+    n += align_up((size_t)B * 3 * 4096 * 4, 256);                  // hist
+    n += align_up((size_t)B * nblk * 256 * 4, 256);                // blockhist
+    n += align_up((size_t)B * 8 * 4, 256);                         // state
+    n += align_up((size_t)B * Kpad * 8, 256);                      // cand
+    n += align_up((size_t)B * K * 4, 256);                         // topk_idx
+    n += align_up((size_t)B * K * 16, 256);                        // boxes
+    n += align_up((size_t)B * K * W * 8, 256);                     // nms_mask
+    n += align_up((size_t)B * max_keep * 4, 256);                  // keep_idx
+    n += align_up((size_t)B * 4, 256);                             // keep_count
+    return n;
+}
+
+void ProposalWorkspace::bind(void* base, int B_, int A_, int K_, int max_keep_)
+{
+    B = B_; A = A_; K = K_; max_keep = max_keep_;
+    nblk = (A + CHUNK - 1) / CHUNK; W = (K + 63) / 64; Kpad = next_pow2(K);
+    char* p = (char*)base;
+    auto take = [&](size_t n) { char* r = p; p += align_up(n, 256); return r; };
+    keys = (uint32_t*)take((size_t)B * (size_t)(nblk * CHUNK) * 4);
+    hist = (uint32_t*)take((size_t)B * 3 * 4096 * 4);
+    blockhist = (uint32_t*)take((size_t)B * nblk * 256 * 4);
+    state = (uint32_t*)take((size_t)B * 8 * 4);
+    cand = (uint64_t*)take((size_t)B * Kpad * 8);
+    topk_idx = (int32_t*)take((size_t)B * K * 4);
+    boxes = (float*)take((size_t)B * K * 16);
+    nms_mask = (uint64_t*)take((size_t)B * K * W * 8);
+    keep_idx = (int32_t*)take((size_t)B * max_keep * 4);
+    keep_count = (int32_t*)take((size_t)B * 4);
+}
+
+// state words
+enum { ST_PREFIX = 0, ST_KREM = 1, ST_T = 2, ST_NEED = 3, ST_NGT = 4, ST_SLOT = 5, ST_TIEBIN = 6 };
+
+// ------------------------------------------------------------------------------------------------
+// pass 0: foreground score → key, histogram of the top 12 bits
+// probs are (A,2) pairs; the object probability is the odd element (ProposalLayer.swift:124).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_keys_hist0(const float* __restrict__ probs, long probs_sB, int A,
+                                                    uint32_t* __restrict__ keys, long keys_sB,
+                                                    uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t lh[4096];
+    const int b = blockIdx.y, t = threadIdx.x;
+    for (int i = t; i < 4096; i += 256) lh[i] = 0;
+    __syncthreads();
+    const float* p = probs + (size_t)b * probs_sB;
+    const int i0 = blockIdx.x * CHUNK + t * 4;
+    uint32_t k[4];
+    if (i0 + 3 < A && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+        const float4 v0 = *reinterpret_cast<const float4*>(p + (size_t)i0 * 2);
+        const float4 v1 = *reinterpret_cast<const float4*>(p + (size_t)i0 * 2 + 4);
+        k[0] = order_key(v0.y); k[1] = order_key(v0.w); k[2] = order_key(v1.y); k[3] = order_key(v1.w);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) k[j] = (i0 + j < A) ? order_key(p[(size_t)(i0 + j) * 2 + 1]) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (i0 + j < A) atomicAdd(&lh[k[j] >> 20], 1u);
+    *reinterpret_cast<uint4*>(keys + (size_t)b * keys_sB + i0) = make_uint4(k[0], k[1], k[2], k[3]);
+    __syncthreads();
+    uint32_t* gh = hist + (size_t)b * 3 * 4096;
+    for (int i = t; i < 4096; i += 256)
+        if (lh[i]) atomicAdd(&gh[i], lh[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// scan of a pass histogram from the top: finds the bin holding the k-th largest key
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_select_scan(uint32_t* __restrict__ hist, uint32_t* __restrict__ state,
+                                                     int pass, int K)
+{
+    __shared__ uint32_t part[256];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int nbins = pass == 2 ? 256 : 4096, per = nbins / 256, bits = pass == 2 ? 8 : 12;
+    const uint32_t* h = hist + ((size_t)b * 3 + pass) * 4096;
+    uint32_t* st = state + (size_t)b * 8;
+    uint32_t s = 0;
+    for (int i = 0; i < per; ++i) s += h[t * per + i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        const uint32_t k = pass == 0 ? (uint32_t)K : st[ST_KREM];
+        uint32_t above = 0;
+        int g = 255;
+        for (; g > 0; --g) {
+            if (above + part[g] >= k) break;
+            above += part[g];
+        }
+        int bin = (g + 1) * per - 1;
+        for (; bin > g * per; --bin) {
+            if (above + h[bin] >= k) break;
+            above += h[bin];
+        }
+        const uint32_t prefix = pass == 0 ? 0u : st[ST_PREFIX];
+        st[ST_PREFIX] = (prefix << bits) | (uint32_t)bin;
+        st[ST_KREM] = k - above;
+        if (pass == 2) {
+            st[ST_T] = (prefix << bits) | (uint32_t)bin;
+            st[ST_NEED] = k - above;                  // how many keys equal to T are taken (lowest indices)
+            st[ST_NGT] = (uint32_t)K - (k - above);   // keys strictly greater than T
+            st[ST_TIEBIN] = (uint32_t)bin;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// passes 1/2: histogram of the next digit among keys matching the prefix found so far
+// ------------------------------------------------------------------------------------------------
+template <int PASS>
+__global__ __launch_bounds__(256) void k_hist_pass(const uint32_t* __restrict__ keys, long keys_sB, int A,
+                                                   const uint32_t* __restrict__ state, uint32_t* __restrict__ hist,
+                                                   uint32_t* __restrict__ blockhist, int nblk)
+{
+    constexpr int NB = PASS == 1 ? 4096 : 256;
+    __shared__ uint32_t lh[NB];
+    const int b = blockIdx.y, t = threadIdx.x;
+    for (int i = t; i < NB; i += 256) lh[i] = 0;
+    __syncthreads();
+    const uint32_t prefix = state[(size_t)b * 8 + ST_PREFIX];
+    const int i0 = blockIdx.x * CHUNK + t * 4;
+    const uint4 kv = *reinterpret_cast<const uint4*>(keys + (size_t)b * keys_sB + i0);
+    const uint32_t k[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (i0 + j >= A) continue;
+        if (PASS == 1) {
+            if ((k[j] >> 20) == prefix) atomicAdd(&lh[(k[j] >> 8) & 0xFFFu], 1u);
+        } else {
+            if ((k[j] >> 8) == prefix) atomicAdd(&lh[k[j] & 0xFFu], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* gh = hist + ((size_t)b * 3 + PASS) * 4096;
+    for (int i = t; i < NB; i += 256)
+        if (lh[i]) atomicAdd(&gh[i], lh[i]);
+    if (PASS == 2) blockhist[((size_t)b * nblk + blockIdx.x) * 256 + t] = lh[t];
+}
+
+// ------------------------------------------------------------------------------------------------
+// compaction: keys > T in any order, keys == T in index order (first `need` of them)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_compact(const uint32_t* __restrict__ keys, long keys_sB, int A,
+                                                 uint32_t* __restrict__ state, const uint32_t* __restrict__ blockhist,
+                                                 int nblk, uint64_t* __restrict__ cand, int Kpad)
+{
+    __shared__ uint32_t red[256];
+    __shared__ uint32_t wsum[4];
+    const int b = blockIdx.y, t = threadIdx.x, blk = blockIdx.x;
+    uint32_t* st = state + (size_t)b * 8;
+    const uint32_t T = st[ST_T], need = st[ST_NEED], ngt = st[ST_NGT], tiebin = st[ST_TIEBIN];
+    // ties in the blocks before this one
+    uint32_t s = 0;
+    for (int i = t; i < blk; i += 256) s += blockhist[((size_t)b * nblk + i) * 256 + tiebin];
+    red[t] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) red[t] += red[t + o];
+        __syncthreads();
+    }
+    const uint32_t tie_base = red[0];
+    const int i0 = blk * CHUNK + t * 4;
+    const uint4 kv = *reinterpret_cast<const uint4*>(keys + (size_t)b * keys_sB + i0);
+    const uint32_t k[4] = {kv.x, kv.y, kv.z, kv.w};
+    uint32_t nt = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) nt += (i0 + j < A && k[j] == T) ? 1u : 0u;
+    // exclusive scan of nt over the 256 threads (wave scan + 4 wave totals)
+    const int lane = t & 63, wv = t >> 6;
+    uint32_t inc = nt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int i = 0; i < wv; ++i) wbase += wsum[i];
+    uint32_t rank = tie_base + wbase + inc - nt;
+    uint64_t* c = cand + (size_t)b * Kpad;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (i0 + j >= A) continue;
+        const uint64_t v = ((uint64_t)(~k[j]) << 32) | (uint32_t)(i0 + j);
+        if (k[j] > T) {
+            const uint32_t slot = atomicAdd(&st[ST_SLOT], 1u);
+            c[slot] = v;
+        } else if (k[j] == T) {
+            if (rank < need) c[ngt + rank] = v;
+            ++rank;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// in-LDS bitonic sort of the K candidates, then gather + decode + clip
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_sort_decode(const uint64_t* __restrict__ cand, int K, int Kpad,
+                                                      const float* __restrict__ deltas, long deltas_sB,
+                                                      const float* __restrict__ anchors, float4 stdv,
+                                                      int32_t* __restrict__ topk_idx, float* __restrict__ boxes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* a = reinterpret_cast<uint64_t*>(smem);
+    const int b = blockIdx.x, t = threadIdx.x;
+    const uint64_t* c = cand + (size_t)b * Kpad;
+    for (int i = t; i < Kpad; i += 1024) a[i] = i < K ? c[i] : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= Kpad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < Kpad; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t x = a[i], y = a[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { a[i] = y; a[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const float* dl = deltas + (size_t)b * deltas_sB;
+    for (int i = t; i < K; i += 1024) {
+        const uint32_t idx = (uint32_t)(a[i] & 0xFFFFFFFFull);
+        topk_idx[(size_t)b * K + i] = (int32_t)idx;
+        float4 d = *reinterpret_cast<const float4*>(dl + (size_t)idx * 4);
+        const float4 an = *reinterpret_cast<const float4*>(anchors + (size_t)idx * 4);
+        d.x = d.x * stdv.x; d.y = d.y * stdv.y; d.z = d.z * stdv.z; d.w = d.w * stdv.w;   // Utils.swift:173-180
+        *reinterpret_cast<float4*>(boxes + ((size_t)b * K + i) * 4) = decode_clip_box(an, d);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// NMS part 1: suppression bit-matrix.  Block = one wave = rows rb*64.., columns cb*64..; only
+// cb >= rb is computed.  Bit j of mask[i][cb] ⇔ column box (cb*64+j) > i, same class, IoU > thr.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes, long boxes_sB,
+                                                 const int32_t* __restrict__ cls, long cls_sB,
+                                                 const int32_t* __restrict__ n_dev, int n_const, float thr,
+                                                 uint64_t* __restrict__ mask, long mask_sB, int W)
+{
+    const int cb = blockIdx.x, rb = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+    if (cb < rb) return;
+    const int n = n_dev ? n_dev[b] : n_const;
+    if (rb * 64 >= n) return;
+    __shared__ float4 cbox[64];
+    __shared__ int32_t ccls[64];
+    const float* bx = boxes + (size_t)b * boxes_sB;
+    const int cj = cb * 64 + lane;
+    cbox[lane] = cj < n ? *reinterpret_cast<const float4*>(bx + (size_t)cj * 4) : make_float4(0, 0, 0, 0);
+    ccls[lane] = (cls && cj < n) ? cls[(size_t)b * cls_sB + cj] : 0;
+    __syncthreads();
+    const int i = rb * 64 + lane;
+    if (i >= n) return;
+    const float4 me = *reinterpret_cast<const float4*>(bx + (size_t)i * 4);
+    const int mycls = cls ? cls[(size_t)b * cls_sB + i] : 0;
+    uint64_t bits = 0;
+    for (int j = 0; j < 64; ++j) {
+        const int gj = cb * 64 + j;
+        if (gj <= i || gj >= n) continue;
+        if (cls && ccls[j] != mycls) continue;
+        if (iou_yxyx(cbox[j], me) > thr) bits |= 1ull << j;     // IOU(anchorA = candidate, anchorB = selected)
+    }
+    mask[(size_t)b * mask_sB + (size_t)i * W + cb] = bits;
+}
+
+// ------------------------------------------------------------------------------------------------
+// NMS part 2: greedy scan (nonMaxSupression, Utils.swift:185-218).  One 256-thread block per image.
+// Wave 0 resolves each 64-candidate chunk; all waves then OR the kept rows into `removed`.
+// per_class_max > 0: candidates carry classes; a class stops selecting after per_class_max keeps
+// (each class is its own nonMaxSupression call in DetectionLayer.swift:170-183).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_nms_scan(const float* __restrict__ boxes, long boxes_sB,
+                                                  const int32_t* __restrict__ cls, long cls_sB,
+                                                  const int32_t* __restrict__ n_dev, int n_const,
+                                                  const uint64_t* __restrict__ mask, long mask_sB, int W,
+                                                  int max_keep, int per_class_max,
+                                                  int32_t* __restrict__ keep_idx, long keep_sB,
+                                                  int32_t* __restrict__ keep_count)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* removed = reinterpret_cast<uint64_t*>(smem);                 // [W]
+    int32_t* kept_cls = reinterpret_cast<int32_t*>(smem + (size_t)W * 8);   // [max_keep] (per-class mode)
+    __shared__ uint64_t s_keptmask;
+    __shared__ int s_kc;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int n = n_dev ? n_dev[b] : n_const;
+    const int nW = (n + 63) / 64;
+    for (int i = t; i < W; i += 256) removed[i] = 0;
+    if (t == 0) s_kc = 0;
+    __syncthreads();
+    const float* bx = boxes + (size_t)b * boxes_sB;
+    const uint64_t* mk = mask + (size_t)b * mask_sB;
+    int32_t* kidx = keep_idx + (size_t)b * keep_sB;
+    for (int c = 0; c < nW; ++c) {
+        if (wv == 0) {
+            const int row = c * 64 + lane;
+            const bool inr = row < n;
+            const uint64_t diag = inr ? mk[(size_t)row * W + c] : 0ull;
+            const bool ok = inr && rect_selectable(*reinterpret_cast<const float4*>(bx + (size_t)(inr ? row : 0) * 4));
+            const int mycls = (cls && inr) ? cls[(size_t)b * cls_sB + row] : 0;
+            uint64_t m = __ballot(ok) & ~removed[c];
+            uint64_t keptmask = 0;
+            int kc = s_kc;
+            while (m != 0ull && kc < max_keep) {
+                const int i = __ffsll((unsigned long long)m) - 1;
+                m &= ~(1ull << i);
+                bool take = true;
+                int ci = 0;
+                if (per_class_max > 0) {
+                    ci = __shfl(mycls, i);
+                    int cnt = 0;
+                    for (int base = 0; base < kc; base += 64) {
+                        const bool eq = (base + lane < kc) && kept_cls[base + lane] == ci;
+                        cnt += __popcll(__ballot(eq));
+                    }
+                    take = cnt < per_class_max;
+                }
+                if (take) {
+                    keptmask |= 1ull << i;
+                    if (lane == 0) {
+                        kidx[kc] = c * 64 + i;
+                        if (per_class_max > 0) kept_cls[kc] = ci;
+                    }
+                    ++kc;
+                    const uint32_t lo = __shfl((uint32_t)(diag & 0xFFFFFFFFull), i);
+                    const uint32_t hi = __shfl((uint32_t)(diag >> 32), i);
+                    m &= ~(((uint64_t)hi << 32) | lo);
+                }
+            }
+            if (lane == 0) { s_keptmask = keptmask; s_kc = kc; }
+        }
+        __syncthreads();
+        const uint64_t km = s_keptmask;
+        const int kc_now = s_kc;
+        if (km != 0ull) {
+            for (int w = c + 1 + t; w < nW; w += 256) {
+                uint64_t acc = 0;
+                uint64_t mm = km;
+                while (mm) {
+                    const int i = __ffsll((unsigned long long)mm) - 1;
+                    mm &= mm - 1;
+                    acc |= mk[(size_t)(c * 64 + i) * W + w];
+                }
+                removed[w] |= acc;
+            }
+        }
+        __syncthreads();
+        if (kc_now >= max_keep) break;
+    }
+    if (t == 0) keep_count[b] = s_kc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ProposalLayer output copy + zero padding (ProposalLayer.swift:178-192)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_write_rois(const float* __restrict__ boxes, long boxes_sB,
+                                                    const int32_t* __restrict__ keep_idx, long keep_sB,
+                                                    const int32_t* __restrict__ keep_count, int max_keep,
+                                                    float* __restrict__ rois, long rois_sB, long row_stride)
+{
+    const int b = blockIdx.x;
+    const int nk = keep_count[b];
+    float* o = rois + (size_t)b * rois_sB;
+    const float* bx = boxes + (size_t)b * boxes_sB;
+    for (long e = threadIdx.x; e < (long)max_keep * row_stride; e += 256) {
+        const long i = e / row_stride, j = e % row_stride;
+        float v = 0.0f;
+        if (i < nk) {
+            if (j < 4) v = bx[(size_t)keep_idx[(size_t)b * keep_sB + i] * 4 + j];
+            else continue;    // the reference writes only the 4 coordinates of kept rows
+        }
+        o[e] = v;
+    }
+}
+
+void proposal_forward(hipStream_t s, const ProposalWorkspace& ws, const float* probs, long probs_sB,
+                      const float* deltas, long deltas_sB, const float* anchors, const float std4[4],
+                      float nms_thr, float* rois, long rois_sB, long row_stride)
+{
+    const int B = ws.B, A = ws.A, K = ws.K;
+    const long keys_sB = (long)ws.nblk * CHUNK;
+    HIP_CHECK(hipMemsetAsync(ws.hist, 0, (size_t)B * 3 * 4096 * 4, s));
+    HIP_CHECK(hipMemsetAsync(ws.state, 0, (size_t)B * 8 * 4, s));
+    dim3 g(ws.nblk, B);
+    hipLaunchKernelGGL(k_keys_hist0, g, dim3(256), 0, s, probs, probs_sB, A, ws.keys, keys_sB, ws.hist);
+    hipLaunchKernelGGL(k_select_scan, dim3(B), dim3(256), 0, s, ws.hist, ws.state, 0, K);
+    hipLaunchKernelGGL(k_hist_pass<1>, g, dim3(256), 0, s, ws.keys, keys_sB, A, ws.state, ws.hist, ws.blockhist, ws.nblk);
+    hipLaunchKernelGGL(k_select_scan, dim3(B), dim3(256), 0, s, ws.hist, ws.state, 1, K);
+    hipLaunchKernelGGL(k_hist_pass<2>, g, dim3(256), 0, s, ws.keys, keys_sB, A, ws.state, ws.hist, ws.blockhist, ws.nblk);
+    hipLaunchKernelGGL(k_select_scan, dim3(B), dim3(256), 0, s, ws.hist, ws.state, 2, K);
+    hipLaunchKernelGGL(k_compact, g, dim3(256), 0, s, ws.keys, keys_sB, A, ws.state, ws.blockhist, ws.nblk, ws.cand, ws.Kpad);
+    const size_t sort_lds = (size_t)ws.Kpad * 8;
+    MRCNN_REQUIRE(sort_lds <= 160 * 1024 - 1024, MRCNN_ERR_UNSUPPORTED,
+                  "preNMSMaxProposals %d exceeds the in-LDS sort capacity (max 16384)", K);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_decode, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_nms_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr_set = true;
+    }
+    const float4 stdv = make_float4(std4[0], std4[1], std4[2], std4[3]);
+    hipLaunchKernelGGL(k_sort_decode, dim3(B), dim3(1024), sort_lds, s, ws.cand, K, ws.Kpad, deltas, deltas_sB, anchors,
+                       stdv, ws.topk_idx, ws.boxes);
+    const long boxes_sB = (long)K * 4, mask_sB = (long)K * ws.W;
+    hipLaunchKernelGGL(k_nms_mask, dim3(ws.W, ws.W, B), dim3(64), 0, s, ws.boxes, boxes_sB, (const int32_t*)nullptr, 0L,
+                       (const int32_t*)nullptr, K, nms_thr, ws.nms_mask, mask_sB, ws.W);
+    hipLaunchKernelGGL(k_nms_scan, dim3(B), dim3(256), (size_t)ws.W * 8, s, ws.boxes, boxes_sB, (const int32_t*)nullptr, 0L,
+                       (const int32_t*)nullptr, K, ws.nms_mask, mask_sB, ws.W, ws.max_keep, 0, ws.keep_idx,
+                       (long)ws.max_keep, ws.keep_count);
+    hipLaunchKernelGGL(k_write_rois, dim3(B), dim3(256), 0, s, ws.boxes, boxes_sB, ws.keep_idx, (long)ws.max_keep,
+                       ws.keep_count, ws.max_keep, rois, rois_sB, row_stride);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ================================================================================================
+// DetectionLayer
+// ================================================================================================
+size_t DetectionWorkspace::bytes(int B, int N, int /*max_det*/)
+{
+    const int W = (N + 63) / 64;
+    size_t n = 0;
+    n += align_up((size_t)B * 4, 256) * 2;              // count, keep_count
+    n += align_up((size_t)B * N * 4, 256) * 4;          // src, score, cls, keep_idx
+    n += align_up((size_t)B * N * 16, 256);             // boxes
+    n += align_up((size_t)B * N * W * 8, 256);          // nms_mask
+    return n;
+}
+
+void DetectionWorkspace::bind(void* base, int B_, int N_, int max_det_)
+{
+    B = B_; N = N_; max_det = max_det_; W = (N + 63) / 64; Npad = next_pow2(N);
+    char* p = (char*)base;
+    auto take = [&](size_t n) { char* r = p; p += align_up(n, 256); return r; };
+    count = (int32_t*)take((size_t)B * 4);
+    keep_count = (int32_t*)take((size_t)B * 4);
+    src = (int32_t*)take((size_t)B * N * 4);
+    score = (float*)take((size_t)B * N * 4);
+    cls = (int32_t*)take((size_t)B * N * 4);
+    keep_idx = (int32_t*)take((size_t)B * N * 4);
+    boxes = (float*)take((size_t)B * N * 16);
+    nms_mask = (uint64_t*)take((size_t)B * N * W * 8);
+}
+
+// score >= threshold (vDSP_vthres + vDSP_vcmprs, DetectionLayer.swift:238-276), classId > 0 (:136-140),
+// order-preserving compaction, then ×std, applyBoxDeltas, clip (:156-164).
+__global__ __launch_bounds__(1024) void k_det_filter_decode(const float* __restrict__ rois, long rois_sB, long roi_stride,
+                                                            const float* __restrict__ cls6, long cls_sB, int N,
+                                                            float4 stdv, float score_thr, int32_t* __restrict__ count,
+                                                            int32_t* __restrict__ src, float* __restrict__ boxes,
+                                                            float* __restrict__ score, int32_t* __restrict__ cls)
+{
+    __shared__ int wsum[16];
+    __shared__ int s_base;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const float* r = rois + (size_t)b * rois_sB;
+    const float* c = cls6 + (size_t)b * cls_sB;
+    if (t == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < N; i0 += 1024) {
+        const int i = i0 + t;
+        bool keep = false;
+        float sc = 0.0f, cid = 0.0f;
+        if (i < N) {
+            cid = c[(size_t)i * 6 + 4];
+            sc = c[(size_t)i * 6 + 5];
+            const float gated = sc >= score_thr ? sc : 0.0f;
+            keep = gated != 0.0f && cid > 0.0f;
+        }
+        const uint64_t bal = __ballot(keep);
+        const int wpre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wv] = __popcll(bal);
+        __syncthreads();
+        int base = s_base;
+        for (int w = 0; w < wv; ++w) base += wsum[w];
+        if (keep) {
+            const int k = base + wpre;
+            float4 box = make_float4(r[(size_t)i * roi_stride], r[(size_t)i * roi_stride + 1], r[(size_t)i * roi_stride + 2],
+                                     r[(size_t)i * roi_stride + 3]);
+            float4 d = make_float4(c[(size_t)i * 6], c[(size_t)i * 6 + 1], c[(size_t)i * 6 + 2], c[(size_t)i * 6 + 3]);
+            d.x = d.x * stdv.x; d.y = d.y * stdv.y; d.z = d.z * stdv.z; d.w = d.w * stdv.w;
+            *reinterpret_cast<float4*>(boxes + ((size_t)b * N + k) * 4) = decode_clip_box(box, d);
+            src[(size_t)b * N + k] = i;
+            score[(size_t)b * N + k] = sc;
+            cls[(size_t)b * N + k] = (int32_t)cid;
+        }
+        __syncthreads();
+        if (t == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wsum[w];
+            s_base += tot;
+        }
+        __syncthreads();
+    }
+    if (t == 0) count[b] = s_base;
+}
+
+// Top maxDetections of the NMS survivors by score (DetectionLayer.swift:186-209; ties keep the
+// nmsBoxIds order = class ascending, then ROI order), row write-out and zero padding (:211-231).
+__global__ __launch_bounds__(1024) void k_det_finalize(const float* __restrict__ boxes, const float* __restrict__ score,
+                                                       const int32_t* __restrict__ cls, const int32_t* __restrict__ keep_idx,
+                                                       const int32_t* __restrict__ keep_count, int N, int Npad, int max_det,
+                                                       float* __restrict__ out, long out_sB, long row_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* a = reinterpret_cast<uint64_t*>(smem);
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int nk = keep_count[b];
+    for (int i = t; i < Npad; i += 1024) {
+        uint64_t v = ~0ull;
+        if (i < nk) {
+            const int k = keep_idx[(size_t)b * N + i];
+            const uint32_t sk = ~order_key(score[(size_t)b * N + k]);
+            v = ((uint64_t)sk << 32) | ((uint64_t)((uint32_t)cls[(size_t)b * N + k] & 0xFFFFu) << 16) | (uint32_t)(k & 0xFFFF);
+        }
+        a[i] = v;
+    }
+    __syncthreads();
+    for (int k = 2; k <= Npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < Npad; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t x = a[i], y = a[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { a[i] = y; a[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int nd = nk < max_det ? nk : max_det;
+    float* o = out + (size_t)b * out_sB;
+    for (long e = t; e < (long)max_det * row_stride; e += 1024) {
+        const long i = e / row_stride, j = e % row_stride;
+        float v = 0.0f;
+        if (i < nd) {
+            if (j >= 6) continue;
+            const int k = (int)(a[i] & 0xFFFFull);
+            if (j < 4) v = boxes[((size_t)b * N + k) * 4 + j];
+            else if (j == 4) v = (float)cls[(size_t)b * N + k];
+            else v = score[(size_t)b * N + k];
+        }
+        o[e] = v;
+    }
+}
+
+void detection_forward(hipStream_t s, const DetectionWorkspace& ws, const float* rois, long rois_sB,
+                       long roi_stride, const float* cls6, long cls_sB, const float std4[4],
+                       float score_thr, float nms_thr, int /*num_classes_hint*/, float* out, long out_sB,
+                       long row_stride)
+{
+    const int B = ws.B, N = ws.N;
+    MRCNN_REQUIRE(N <= 65535, MRCNN_ERR_UNSUPPORTED, "DetectionLayer: more than 65535 regions (%d)", N);
+    const float4 stdv = make_float4(std4[0], std4[1], std4[2], std4[3]);
+    hipLaunchKernelGGL(k_det_filter_decode, dim3(B), dim3(1024), 0, s, rois, rois_sB, roi_stride, cls6, cls_sB, N, stdv,
+                       score_thr, ws.count, ws.src, ws.boxes, ws.score, ws.cls);
+    const long boxes_sB = (long)N * 4, mask_sB = (long)N * ws.W;
+    hipLaunchKernelGGL(k_nms_mask, dim3(ws.W, ws.W, B), dim3(64), 0, s, ws.boxes, boxes_sB, ws.cls, (long)N, ws.count, 0,
+                       nms_thr, ws.nms_mask, mask_sB, ws.W);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_nms_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_det_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        attr_set = true;
+    }
+    const size_t scan_lds = (size_t)ws.W * 8 + (size_t)N * 4;
+    MRCNN_REQUIRE(scan_lds <= 64 * 1024, MRCNN_ERR_UNSUPPORTED, "DetectionLayer: too many regions (%d)", N);
+    hipLaunchKernelGGL(k_nms_scan, dim3(B), dim3(256), scan_lds, s, ws.boxes, boxes_sB, ws.cls, (long)N, ws.count, 0,
+                       ws.nms_mask, mask_sB, ws.W, N, ws.max_det, ws.keep_idx, (long)N, ws.keep_count);
+    hipLaunchKernelGGL(k_det_finalize, dim3(B), dim3(1024), (size_t)ws.Npad * 8, s, ws.boxes, ws.score, ws.cls, ws.keep_idx,
+                       ws.keep_count, N, ws.Npad, ws.max_det, out, out_sB, row_stride);
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace mrcnn

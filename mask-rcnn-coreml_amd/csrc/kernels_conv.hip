@@ -1,0 +1,564 @@
+// kernels_conv.hip — the convolution family of the trunk and heads on gfx950 matrix cores, plus
+// the small element-wise kernels around it.
+//
+// Replaces the built-in Core ML layers of MaskRCNN.mlmodel / Classifier.mlmodel / Mask.mlmodel
+// (spec emitted by Sources/maskrcnn/Python/Conversion/task.py:69-116 of the reference): 7×7/3×3/1×1
+// convolutions with folded BatchNorm, ReLU, residual adds, FPN nearest-neighbour upsample+add, the
+// RPN / box / mask heads (inner products as 1×1 convolutions, the 2×2 stride-2 transposed
+// convolution as a scatter GEMM), soft-max and sigmoid.
+//
+// Kernel design (fp32, exact f32 MFMA `v_mfma_f32_32x32x2_f32`, 157.3 TFLOP/s peak):
+//   implicit GEMM  out[m][n] = Σ_k A[m][k]·Wt[n][k],  m = (image, oh, ow), k = (tap, cin), n = cout
+//   * activations NHWC and filters packed [cout][tap][cin], so BOTH operands are "rows of K":
+//     every global load is a 16-B piece of a 128-B contiguous run (32 channels of one tap);
+//   * 128×BN×32 block tile, 4 waves (wave64), each wave a (TM×32)×(TN×32) sub-tile of 32×32 MFMA
+//     accumulators; K is permuted inside the tile (lane kk∈{0,1} owns k = 8t+4kk+{0..3}) so a lane
+//     fetches its operands for four MFMA steps with ONE ds_read_b128 — identical permutation on
+//     both operands, so the sum is unchanged;
+//   * LDS rows padded to 36 floats (144 B): the 16-lane groups of ds_read_b128 hit 16 distinct
+//     16-B bank slots (36·r mod 64 is a permutation of the multiples of 4 for r = 0..15), and the
+//     8-lane groups of ds_write_b128 write 128 contiguous bytes — conflict-free both ways;
+//   * double-buffered LDS + register prefetch: the global loads of tile k+1 are issued before the
+//     MFMAs of tile k and written to the other buffer after them; one barrier per K step;
+//   * fused epilogue: per-channel scale/shift (folded BN + bias), residual (optionally read at
+//     (oh>>1, ow>>1): FPN top-down upsample+add), ReLU / sigmoid, optional column split into two
+//     outputs (RPN class + bbox from one GEMM) or 2×2 scatter (transposed conv);
+//   * XCD-aware block→tile map: the 8 XCDs get contiguous runs of tiles, N-tiles of one M-tile
+//     adjacent, so an A tile is fetched into one XCD's L2 once.
+#include "kernels.h"
+
+namespace mrcnn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+    const float* in; const float* wgt; const float* scale; const float* shift; const float* res;
+    float* out; float* out2;
+    long in_sB, in_sH, in_sW;
+    long res_sB, res_sH, res_sW;
+    long out_sB, out_sP, out_sH, out_sW;
+    long out2_sB, out2_sP;
+    int B, H, W, Cin, KH, KW, stride, padH, padW;
+    int OH, OW, Cout, ncols, Ktot, M;
+    int res_shift, act, n_split, deconv2;
+    int tiles_m, tiles_n;
+};
+
+static constexpr int BM = 128;
+static constexpr int BK = 32;
+static constexpr int LDS_ROW = 36;
+
+template <int BN, int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256) void k_conv_mfma_f32(const ConvArgs a)
+{
+    static_assert(WM * TM * 32 == BM && WN * TN * 32 == BN && WM * WN == 4, "tile shape");
+    constexpr int AP = BM / 32;     // A rows per thread
+    constexpr int BP = BN / 32;     // B rows per thread
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_ROW];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_ROW];
+
+    // ---- XCD-aware tile assignment (bijective for any block count) ------------------------------
+    const int nblocks = a.tiles_m * a.tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nblocks >> 3, r8 = nblocks & 7;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + local;
+    const int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int t = threadIdx.x;
+    const int kq = t & 7, r0 = t >> 3;
+
+    // ---- per-thread A rows: output pixel → input window origin ----------------------------------
+    long a_off[AP];
+    int ih0[AP], iw0[AP];
+    bool a_ok[AP];
+    const int ohw = a.OH * a.OW;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+        const int m = m0 + r0 + 32 * p;
+        a_ok[p] = m < a.M;
+        const int mm = a_ok[p] ? m : 0;
+        const int b = mm / ohw, rem = mm - b * ohw;
+        const int oh = rem / a.OW, ow = rem - oh * a.OW;
+        ih0[p] = oh * a.stride - a.padH;
+        iw0[p] = ow * a.stride - a.padW;
+        a_off[p] = (long)b * a.in_sB + (long)ih0[p] * a.in_sH + (long)iw0[p] * a.in_sW + kq * 4;
+    }
+    const float* wrow[BP];
+#pragma unroll
+    for (int p = 0; p < BP; ++p) wrow[p] = a.wgt + (size_t)(n0 + r0 + 32 * p) * a.Ktot + kq * 4;
+
+    const int cin_tiles = a.Cin / BK;
+    const int KT = a.KH * a.KW * cin_tiles;
+
+    float4 ra[AP], rb[BP];
+    int kh = 0, kw = 0, ct = 0;      // position of the NEXT tile to load
+    auto load_tile = [&](int kt) {
+        const long tap_off = (long)kh * a.in_sH + (long)kw * a.in_sW + ct * BK;
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            const int ih = ih0[p] + kh, iw = iw0[p] + kw;
+            const bool ok = a_ok[p] && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            ra[p] = ok ? *reinterpret_cast<const float4*>(a.in + a_off[p] + tap_off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int p = 0; p < BP; ++p) rb[p] = *reinterpret_cast<const float4*>(wrow[p] + (size_t)kt * BK);
+        if (++ct == cin_tiles) { ct = 0; if (++kw == a.KW) { kw = 0; ++kh; } }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < AP; ++p) *reinterpret_cast<float4*>(&As[buf][(r0 + 32 * p) * LDS_ROW + kq * 4]) = ra[p];
+#pragma unroll
+        for (int p = 0; p < BP; ++p) *reinterpret_cast<float4*>(&Bs[buf][(r0 + 32 * p) * LDS_ROW + kq * 4]) = rb[p];
+    };
+
+    const int wave = t >> 6, lane = t & 63;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int l31 = lane & 31, kk = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) load_tile(kt + 1);
+        const float* as = &As[buf][(wm * TM * 32 + l31) * LDS_ROW + kk * 4];
+        const float* bs = &Bs[buf][(wn * TN * 32 + l31) * LDS_ROW + kk * 4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDS_ROW + t4 * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_ROW + t4 * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < KT) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------------
+    const bool dense_out = a.out_sB == (long)ohw * a.out_sP;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+            const int m = m0 + row;
+            if (m >= a.M) continue;
+            int b = 0, pix = m, oh = 0, ow = 0;
+            const bool need_bp = !dense_out || a.out2 != nullptr || a.deconv2 || (a.res && a.res_shift);
+            if (need_bp || a.res) { b = m / ohw; pix = m - b * ohw; }
+            if (a.deconv2 || (a.res && a.res_shift)) { oh = pix / a.OW; ow = pix - oh * a.OW; }
+            const long o1 = dense_out ? (long)m * a.out_sP : (long)b * a.out_sB + (long)pix * a.out_sP;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * TN * 32 + j * 32 + l31;
+                if (n >= a.ncols) continue;
+                float v = acc[i][j][e];
+                v = v * (a.scale ? a.scale[n] : 1.0f) + (a.shift ? a.shift[n] : 0.0f);
+                if (a.res) {
+                    long ro;
+                    if (a.res_shift) ro = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
+                    else ro = (long)b * a.res_sB + (long)pix * a.res_sW;
+                    v += a.res[ro + n];
+                }
+                if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
+                else if (a.act == ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                if (a.deconv2) {
+                    const int qd = n / a.Cout, co = n - qd * a.Cout;
+                    a.out[(long)b * a.out_sB + (long)(2 * oh + (qd >> 1)) * a.out_sH + (long)(2 * ow + (qd & 1)) * a.out_sW + co] = v;
+                } else if (a.out2 && n >= a.n_split) {
+                    a.out2[(long)b * a.out2_sB + (long)pix * a.out2_sP + (n - a.n_split)] = v;
+                } else {
+                    a.out[o1 + n] = v;
+                }
+            }
+        }
+    }
+}
+
+int conv_n_tile(int Cout)
+{
+    if (Cout > 64) return 128;
+    if (Cout > 32) return 64;
+    return 32;
+}
+
+void conv_forward(hipStream_t s, const ConvDesc& d)
+{
+    MRCNN_REQUIRE(d.Cin % BK == 0, MRCNN_ERR_SHAPE, "conv: Cin %d not a multiple of %d", d.Cin, BK);
+    ConvArgs a;
+    a.in = d.in; a.wgt = d.wgt; a.scale = d.scale; a.shift = d.shift; a.res = d.res; a.out = d.out; a.out2 = d.out2;
+    a.in_sB = d.in_sB; a.in_sH = d.in_sH; a.in_sW = d.in_sW;
+    a.res_sB = d.res_sB; a.res_sH = d.res_sH; a.res_sW = d.res_sW;
+    a.out_sB = d.out_sB; a.out_sP = d.out_sP; a.out_sH = d.out_sH; a.out_sW = d.out_sW;
+    a.out2_sB = d.out2_sB; a.out2_sP = d.out2_sP;
+    a.B = d.B; a.H = d.H; a.W = d.W; a.Cin = d.Cin; a.KH = d.KH; a.KW = d.KW; a.stride = d.stride; a.padH = d.padH; a.padW = d.padW;
+    a.OH = d.OH; a.OW = d.OW; a.Cout = d.Cout;
+    a.ncols = d.deconv2 ? 4 * d.Cout : d.Cout;
+    a.Ktot = d.KH * d.KW * d.Cin;
+    const long M = (long)d.B * d.OH * d.OW;
+    MRCNN_REQUIRE(M > 0 && M < (1L << 31) - BM, MRCNN_ERR_SHAPE, "conv: M out of range");
+    a.M = (int)M;
+    a.res_shift = d.res_shift; a.act = d.act; a.n_split = d.n_split; a.deconv2 = d.deconv2;
+    const int bn = conv_n_tile(a.ncols);
+    MRCNN_REQUIRE(d.Npad % bn == 0 && d.Npad >= a.ncols, MRCNN_ERR_SHAPE, "conv: Npad %d incompatible with tile %d", d.Npad, bn);
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = d.Npad / bn;
+    const dim3 grid(a.tiles_m * a.tiles_n), block(256);
+    if (bn == 128) hipLaunchKernelGGL((k_conv_mfma_f32<128, 2, 2, 2, 2>), grid, block, 0, s, a);
+    else if (bn == 64) hipLaunchKernelGGL((k_conv_mfma_f32<64, 2, 1, 2, 2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_conv_mfma_f32<32, 1, 1, 4, 1>), grid, block, 0, s, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ================================================================================================
+// element-wise helpers
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_preprocess(const uint8_t* __restrict__ rgb, int B, int H, int W, int pad,
+                                                    float mr, float mg, float mb, float* __restrict__ out)
+{
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const long total = (long)B * Hp * Wp;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int x = (int)(e % Wp);
+        const int y = (int)((e / Wp) % Hp);
+        const int b = (int)(e / ((long)Wp * Hp));
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int sy = y - pad, sx = x - pad;
+        if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) {
+            const uint8_t* p = rgb + (((long)b * H + sy) * W + sx) * 3;
+            v.x = (float)p[0] - mr; v.y = (float)p[1] - mg; v.z = (float)p[2] - mb;
+        }
+        reinterpret_cast<float4*>(out)[e] = v;
+    }
+}
+
+void preprocess_forward(hipStream_t s, const uint8_t* rgb, int B, int H, int W, int pad, const float mean[3], float* out)
+{
+    const long total = (long)B * (H + 2 * pad) * (W + 2 * pad);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_preprocess, dim3(grid), dim3(256), 0, s, rgb, B, H, W, pad, mean[0], mean[1], mean[2], out);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_maxpool3x3s2(const float* __restrict__ in, int B, int H, int W, int C4,
+                                                      float* __restrict__ out, int OH, int OW)
+{
+    const long total = (long)B * OH * OW * C4;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C4);
+        const int ox = (int)((e / C4) % OW);
+        const int oy = (int)((e / ((long)C4 * OW)) % OH);
+        const int b = (int)(e / ((long)C4 * OW * OH));
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        for (int dy = 0; dy < 3; ++dy) {
+            const int y = 2 * oy + dy;
+            if (y >= H) break;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int x = 2 * ox + dx;
+                if (x >= W) break;
+                const float4 v = reinterpret_cast<const float4*>(in)[(((long)b * H + y) * W + x) * C4 + c];
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        reinterpret_cast<float4*>(out)[e] = m;
+    }
+}
+
+void maxpool3x3s2_forward(hipStream_t s, const float* in, int B, int H, int W, int C, float* out, int OH, int OW)
+{
+    MRCNN_REQUIRE(C % 4 == 0, MRCNN_ERR_SHAPE, "maxpool: C %% 4 != 0");
+    const long total = (long)B * OH * OW * (C / 4);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(k_maxpool3x3s2, dim3(grid), dim3(256), 0, s, in, B, H, W, C / 4, out, OH, OW);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_softmax_pairs(const float2* __restrict__ logits, float2* __restrict__ probs, long n)
+{
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const float2 l = logits[e];
+        const float m = fmaxf(l.x, l.y);
+        const float e0 = expf(l.x - m), e1 = expf(l.y - m);
+        const float inv = 1.0f / (e0 + e1);
+        probs[e] = make_float2(e0 * inv, e1 * inv);
+    }
+}
+
+void softmax_pairs_forward(hipStream_t s, const float* logits, float* probs, long n_pairs)
+{
+    const int grid = (int)((n_pairs + 255) / 256 < 8192 ? (n_pairs + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_softmax_pairs, dim3(grid), dim3(256), 0, s, (const float2*)logits, (float2*)probs, n_pairs);
+    HIP_CHECK(hipGetLastError());
+}
+
+// one wave per row
+__global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ logits, long ld, int nc, long n,
+                                                      float* __restrict__ probs)
+{
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const float* l = logits + row * ld;
+    float m = -INFINITY;
+    for (int c = lane; c < nc; c += 64) m = fmaxf(m, l[c]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float sum = 0.f;
+    for (int c = lane; c < nc; c += 64) sum += expf(l[c] - m);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+    for (int c = lane; c < nc; c += 64) probs[row * nc + c] = expf(l[c] - m) * inv;
+}
+
+void softmax_rows_forward(hipStream_t s, const float* logits, long ld, int nc, long n, float* probs)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, logits, ld, nc, n, probs);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_copy_columns(const float* __restrict__ src, long ld, int c0, int ncols, long n,
+                                                      float* __restrict__ dst)
+{
+    const long total = n * ncols;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / ncols;
+        const int c = (int)(e - r * ncols);
+        dst[e] = src[r * ld + c0 + c];
+    }
+}
+
+void copy_columns_forward(hipStream_t s, const float* src, long ld, int c0, int ncols, long n, float* dst)
+{
+    if (n <= 0) return;
+    const long total = n * ncols;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_copy_columns, dim3(grid), dim3(256), 0, s, src, ld, c0, ncols, n, dst);
+    HIP_CHECK(hipGetLastError());
+}
+
+// TimeDistributedClassifierLayer.swift:65-86: argmax over all classes (ties → lowest index), score,
+// the four deltas of the arg-max class.  One wave per ROI.
+__global__ __launch_bounds__(256) void k_classifier_post(const float* __restrict__ probs, const float* __restrict__ bbox,
+                                                         int nc, long n, float* __restrict__ out, long out_row_stride)
+{
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const float* p = probs + row * nc;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < nc; c += 64) {
+        const float v = p[c];
+        if (v > bv || (v == bv && c < bi)) { bv = v; bi = c; }
+    }
+    if (bi == 0x7fffffff) { bv = -INFINITY; }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    float* o = out + row * out_row_stride;
+    if (lane < 4) o[lane] = bbox[row * nc * 4 + (long)bi * 4 + lane];
+    else if (lane == 4) o[4] = (float)bi;
+    else if (lane == 5) o[5] = bv;
+}
+
+void classifier_postprocess_forward(hipStream_t s, const float* probs, const float* bbox, int nc, long n, float* out,
+                                    long out_row_stride)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_classifier_post, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, probs, bbox, nc, n, out, out_row_stride);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float* __restrict__ in, long n, int C, int HW, float* __restrict__ out)
+{
+    const long total = n * C * HW;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const int p = (int)((e / C) % HW);
+        const long i = e / ((long)C * HW);
+        out[e] = in[(i * C + c) * HW + p];
+    }
+}
+__global__ __launch_bounds__(256) void k_nhwc_to_nchw(const float* __restrict__ in, long n, int C, int HW, float* __restrict__ out)
+{
+    const long total = n * C * HW;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int p = (int)(e % HW);
+        const int c = (int)((e / HW) % C);
+        const long i = e / ((long)C * HW);
+        out[e] = in[(i * HW + p) * C + c];
+    }
+}
+void nchw_to_nhwc_forward(hipStream_t s, const float* in, long n, int C, int H, int W, float* out)
+{
+    const long total = n * C * H * W;
+    if (total <= 0) return;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(grid), dim3(256), 0, s, in, n, C, H * W, out);
+    HIP_CHECK(hipGetLastError());
+}
+void nhwc_to_nchw_forward(hipStream_t s, const float* in, long n, int C, int H, int W, float* out)
+{
+    const long total = n * C * H * W;
+    if (total <= 0) return;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(grid), dim3(256), 0, s, in, n, C, H * W, out);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_copy_rows(const float* __restrict__ src, long src_stride, long n, long len,
+                                                   float* __restrict__ dst, long dst_stride)
+{
+    const long total = n * len;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / len, c = e - r * len;
+        dst[r * dst_stride + c] = src[r * src_stride + c];
+    }
+}
+void copy_rows_forward(hipStream_t s, const float* src, long src_stride, long n, long len, float* dst, long dst_stride)
+{
+    const long total = n * len;
+    if (total <= 0) return;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(k_copy_rows, dim3(grid), dim3(256), 0, s, src, src_stride, n, len, dst, dst_stride);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ================================================================================================
+// TimeDistributedMaskLayer
+// ================================================================================================
+// MultiArrayBatchProvider(removeZeros:true) (TimeDistributedClassifierLayer.swift:116-127): a row is
+// kept iff every element is != 0.
+__global__ __launch_bounds__(256) void k_mask_row_flags(const float* __restrict__ pooled, long pooled_sB, long row_stride,
+                                                        long row_len, int D, int32_t* __restrict__ flags)
+{
+    const int d = blockIdx.x, b = blockIdx.y;
+    const float* r = pooled + (size_t)b * pooled_sB + (size_t)d * row_stride;
+    int ok = 1;
+    for (long e = threadIdx.x; e < row_len; e += 256) ok &= (r[e] != 0.0f) ? 1 : 0;
+    ok = __syncthreads_and(ok);
+    if (threadIdx.x == 0) flags[(size_t)b * D + d] = ok;
+}
+__global__ void k_mask_row_compact(const int32_t* __restrict__ flags, int D, int32_t* __restrict__ mapping,
+                                   int32_t* __restrict__ kept)
+{
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    int k = 0;
+    for (int d = 0; d < D; ++d)
+        if (flags[(size_t)b * D + d]) mapping[(size_t)b * D + k++] = d;
+    kept[b] = k;
+}
+
+void mask_valid_rows_forward(hipStream_t s, const float* pooled, long pooled_sB, long row_stride, long row_len, int D,
+                             int B, const MaskSelectWorkspace& ws)
+{
+    if (D <= 0 || B <= 0) return;
+    hipLaunchKernelGGL(k_mask_row_flags, dim3(D, B), dim3(256), 0, s, pooled, pooled_sB, row_stride, row_len, D, ws.flags);
+    hipLaunchKernelGGL(k_mask_row_compact, dim3(B), dim3(64), 0, s, ws.flags, D, ws.mapping, ws.kept);
+    HIP_CHECK(hipGetLastError());
+}
+
+// TimeDistributedMaskLayer.swift:58-89 with the Mask model's last layer (1×1 conv to numClasses +
+// sigmoid, of which the reference keeps one channel) evaluated for the selected class only.
+// Compact index i = blockIdx.y: row actual = mapping[i] is written with class detections[i][4]
+// (:71 reads the compact index); rows i >= kept are zero padding (:87-89).
+__global__ __launch_bounds__(256) void k_mask_select(const float* __restrict__ feat, long feat_sB, int HW, int C,
+                                                     const float* __restrict__ w, const float* __restrict__ bias, int nc,
+                                                     const float* __restrict__ det, long det_sB, long det_stride, int D,
+                                                     const int32_t* __restrict__ mapping, const int32_t* __restrict__ kept,
+                                                     float* __restrict__ out, long out_sB, long out_stride)
+{
+    const int i = blockIdx.y, b = blockIdx.z;
+    const int nk = kept[b];
+    float* ob = out + (size_t)b * out_sB;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (i >= nk) {
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < out_stride; e += (long)gridDim.x * 256) ob[(size_t)i * out_stride + e] = 0.0f;
+        return;
+    }
+    const int actual = mapping[(size_t)b * D + i];
+    if (actual >= nk) return;                       // would be overwritten by the zero padding
+    int cid = (int)det[(size_t)b * det_sB + (size_t)i * det_stride + 4];
+    cid = cid < 0 ? 0 : (cid >= nc ? nc - 1 : cid);
+    const float* wr = w + (size_t)cid * C;
+    const float* f = feat + (size_t)b * feat_sB + (size_t)actual * HW * C;
+    for (int p = blockIdx.x * 4 + wave; p < HW; p += gridDim.x * 4) {
+        float sum = 0.f;
+        for (int c = lane * 4; c < C; c += 256) {
+            const float4 x = *reinterpret_cast<const float4*>(f + (size_t)p * C + c);
+            const float4 y = *reinterpret_cast<const float4*>(wr + c);
+            sum += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (lane == 0) ob[(size_t)actual * out_stride + p] = 1.0f / (1.0f + expf(-(sum + bias[cid])));
+    }
+    // the reference copies `stride` elements per row (:83); HW == stride for the 28×28 output
+}
+
+void mask_select_forward(hipStream_t s, const float* feat, long feat_sB, int HW, int C, const float* w,
+                         const float* bias, int nc, const float* det, long det_sB, long det_stride, int D, int B,
+                         const MaskSelectWorkspace& ws, float* out, long out_sB, long out_stride)
+{
+    if (D <= 0 || B <= 0) return;
+    MRCNN_REQUIRE(C % 4 == 0, MRCNN_ERR_SHAPE, "mask head: C %% 4 != 0");
+    hipLaunchKernelGGL(k_mask_select, dim3(49, D, B), dim3(256), 0, s, feat, feat_sB, HW, C, w, bias, nc, det, det_sB,
+                       det_stride, D, ws.mapping, ws.kept, out, out_sB, out_stride);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_mask_select_full(const float* __restrict__ masks, long masks_sB, int HW, int nc,
+                                                          const float* __restrict__ det, long det_sB, long det_stride,
+                                                          int D, const int32_t* __restrict__ mapping,
+                                                          const int32_t* __restrict__ kept, float* __restrict__ out,
+                                                          long out_sB, long out_stride)
+{
+    const int i = blockIdx.x, b = blockIdx.y;
+    const int nk = kept[b];
+    float* ob = out + (size_t)b * out_sB;
+    if (i >= nk) {
+        for (long e = threadIdx.x; e < out_stride; e += 256) ob[(size_t)i * out_stride + e] = 0.0f;
+        return;
+    }
+    const int actual = mapping[(size_t)b * D + i];
+    if (actual >= nk) return;
+    int cid = (int)det[(size_t)b * det_sB + (size_t)i * det_stride + 4];
+    cid = cid < 0 ? 0 : (cid >= nc ? nc - 1 : cid);
+    const float* src = masks + (size_t)b * masks_sB + ((size_t)actual * nc + cid) * HW;
+    for (int e = threadIdx.x; e < HW; e += 256) ob[(size_t)actual * out_stride + e] = src[e];
+}
+
+void mask_select_from_full_forward(hipStream_t s, const float* masks, long masks_sB, int HW, int nc, const float* det,
+                                   long det_sB, long det_stride, int D, int B, const MaskSelectWorkspace& ws, float* out,
+                                   long out_sB, long out_stride)
+{
+    if (D <= 0 || B <= 0) return;
+    hipLaunchKernelGGL(k_mask_select_full, dim3(D, B), dim3(256), 0, s, masks, masks_sB, HW, nc, det, det_sB, det_stride,
+                       D, ws.mapping, ws.kept, out, out_sB, out_stride);
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace mrcnn

@@ -1,0 +1,153 @@
+// kernels_roialign.hip — PyramidROIAlignLayer on gfx950.
+//
+// Replaces (reference, Sources/Mask-RCNN-CoreML/PyramidROIAlignLayer.swift):
+//   roisToInputItems        :351-396   FPN level selection in Double, validity
+//   evaluate / performBatch / copyOutput :79-274   (89 MB texture upload per call, 64
+//                           MPSNNCropAndResizeBilinear encodes per ROI, per-ROI read-back)
+//   groupInputItemsByContent / batchInputGroups :399-498 are Metal scheduling artefacts and have
+//                           no counterpart: one launch covers every ROI of every image.
+//
+// The sampler follows TensorFlow's crop_and_resize (bilinear, extrapolation value 0): the MPS
+// kernel is closed source, its documented behaviour is that convention (unpinned).
+// HBM-bound gather: with the engine's NHWC maps one wave reads 64 × 16 B = 1 KiB of consecutive
+// channels per corner, so every access is a full-line coalesced load; the pyramid stays resident
+// in HBM (no staging copy at all).  Compiled with -ffp-contract=off.
+#include "device_math.h"
+#include "kernels.h"
+
+namespace mrcnn {
+
+struct RoiGeom {
+    int level;      // 0..3, -1 = padding ROI
+    float y1, x1, y2, x2;
+};
+
+// roisToInputItems (:351-396).  ratio = 224 / sqrt(imageW*imageH), all in Double.
+__device__ __forceinline__ RoiGeom roi_geom(const float* r, double ratio)
+{
+    RoiGeom g;
+    g.y1 = r[0]; g.x1 = r[1]; g.y2 = r[2]; g.x2 = r[3];
+    const double width = (double)g.x2 - (double)g.x1;
+    const double height = (double)g.y2 - (double)g.y1;
+    const double lf = log2(sqrt(width * height) / ratio) + 4.0;
+    const bool valid = !isnan(lf) && !isinf(lf);
+    int level = 2;
+    if (valid) {
+        double rr = round(lf);                       // Swift round(): half away from zero
+        rr = rr < 2.0 ? 2.0 : (rr > 5.0 ? 5.0 : rr);
+        level = (int)rr;
+    }
+    g.level = valid ? level - 2 : -1;
+    return g;
+}
+
+struct Sample {
+    bool ok;
+    int t, b, l, r;
+    float ly, lx;
+};
+
+__device__ __forceinline__ Sample make_sample(const RoiGeom& g, int H, int W, int P, int py, int px)
+{
+    Sample s;
+    const float hs = (P > 1) ? (g.y2 - g.y1) * (float)(H - 1) / (float)(P - 1) : 0.0f;
+    const float ws = (P > 1) ? (g.x2 - g.x1) * (float)(W - 1) / (float)(P - 1) : 0.0f;
+    const float in_y = (P > 1) ? g.y1 * (float)(H - 1) + (float)py * hs : 0.5f * (g.y1 + g.y2) * (float)(H - 1);
+    const float in_x = (P > 1) ? g.x1 * (float)(W - 1) + (float)px * ws : 0.5f * (g.x1 + g.x2) * (float)(W - 1);
+    s.ok = !(in_y < 0 || in_y > (float)(H - 1)) && !(in_x < 0 || in_x > (float)(W - 1));
+    const float fy = floorf(in_y), cy = ceilf(in_y), fx = floorf(in_x), cx = ceilf(in_x);
+    s.ly = in_y - fy;
+    s.lx = in_x - fx;
+    s.t = (int)fy; s.b = (int)cy; s.l = (int)fx; s.r = (int)cx;
+    return s;
+}
+
+__device__ __forceinline__ float bilerp(float tl, float tr, float bl, float br, float lx, float ly)
+{
+    const float top = tl + (tr - tl) * lx;
+    const float bot = bl + (br - bl) * lx;
+    return top + (bot - top) * ly;
+}
+
+// NHWC: block = one ROI; thread = (channel quad, point group).
+__global__ __launch_bounds__(256) void k_roi_align_nhwc(PyramidMaps maps, int C, const float* __restrict__ rois,
+                                                        long rois_sB, long roi_stride, int P, double ratio,
+                                                        float* __restrict__ out, long out_sB, long out_row_stride)
+{
+    const int roi = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const RoiGeom g = roi_geom(rois + (size_t)b * rois_sB + (size_t)roi * roi_stride, ratio);
+    float* o = out + (size_t)b * out_sB + (size_t)roi * out_row_stride;
+    const int C4 = C >> 2;
+    const int total = P * P * C4;
+    if (g.level < 0) {
+        for (int e = t; e < total; e += 256) reinterpret_cast<float4*>(o)[e] = make_float4(0, 0, 0, 0);
+        return;
+    }
+    const int H = maps.H[g.level], W = maps.W[g.level];
+    const float* m = maps.data[g.level] + (size_t)b * maps.sB[g.level];
+    for (int e = t; e < total; e += 256) {
+        const int cq = e % C4, pt = e / C4;
+        const int py = pt / P, px = pt % P;
+        const Sample s = make_sample(g, H, W, P, py, px);
+        float4 v = make_float4(0, 0, 0, 0);
+        if (s.ok) {
+            const float4 tl = reinterpret_cast<const float4*>(m + ((size_t)s.t * W + s.l) * C)[cq];
+            const float4 tr = reinterpret_cast<const float4*>(m + ((size_t)s.t * W + s.r) * C)[cq];
+            const float4 bl = reinterpret_cast<const float4*>(m + ((size_t)s.b * W + s.l) * C)[cq];
+            const float4 br = reinterpret_cast<const float4*>(m + ((size_t)s.b * W + s.r) * C)[cq];
+            v.x = bilerp(tl.x, tr.x, bl.x, br.x, s.lx, s.ly);
+            v.y = bilerp(tl.y, tr.y, bl.y, br.y, s.lx, s.ly);
+            v.z = bilerp(tl.z, tr.z, bl.z, br.z, s.lx, s.ly);
+            v.w = bilerp(tl.w, tr.w, bl.w, br.w, s.lx, s.ly);
+        }
+        reinterpret_cast<float4*>(o)[(size_t)pt * C4 + cq] = v;
+    }
+}
+
+// NCHW (Core ML layout, used by the stand-alone custom layer): thread = one output element,
+// px fastest so that stores are coalesced.
+__global__ __launch_bounds__(256) void k_roi_align_nchw(PyramidMaps maps, int C, const float* __restrict__ rois,
+                                                        long rois_sB, long roi_stride, int P, double ratio,
+                                                        float* __restrict__ out, long out_sB, long out_row_stride)
+{
+    const int roi = blockIdx.x, b = blockIdx.y;
+    const RoiGeom g = roi_geom(rois + (size_t)b * rois_sB + (size_t)roi * roi_stride, ratio);
+    float* o = out + (size_t)b * out_sB + (size_t)roi * out_row_stride;
+    const int total = C * P * P;
+    if (g.level < 0) {
+        for (int e = threadIdx.x; e < total; e += 256) o[e] = 0.0f;
+        return;
+    }
+    const int H = maps.H[g.level], W = maps.W[g.level];
+    const float* m = maps.data[g.level] + (size_t)b * maps.sB[g.level];
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int px = e % P, py = (e / P) % P, c = e / (P * P);
+        const Sample s = make_sample(g, H, W, P, py, px);
+        float v = 0.0f;
+        if (s.ok) {
+            const float* mc = m + (size_t)c * H * W;
+            v = bilerp(mc[(size_t)s.t * W + s.l], mc[(size_t)s.t * W + s.r], mc[(size_t)s.b * W + s.l],
+                       mc[(size_t)s.b * W + s.r], s.lx, s.ly);
+        }
+        o[e] = v;
+    }
+}
+
+void roi_align_forward(hipStream_t s, const PyramidMaps& maps, int C, int layout_nhwc, const float* rois,
+                       long rois_sB, long roi_stride, int n_rois, int B, int pool, double image_w,
+                       double image_h, float* out, long out_sB, long out_row_stride)
+{
+    if (n_rois <= 0 || B <= 0) return;
+    const double ratio = 224.0 / sqrt(image_w * image_h);    // PyramidROIAlignLayer.swift:98,357
+    if (layout_nhwc) {
+        MRCNN_REQUIRE(C % 4 == 0, MRCNN_ERR_SHAPE, "ROIAlign: channel count %d not a multiple of 4", C);
+        hipLaunchKernelGGL(k_roi_align_nhwc, dim3(n_rois, B), dim3(256), 0, s, maps, C, rois, rois_sB, roi_stride, pool,
+                           ratio, out, out_sB, out_row_stride);
+    } else {
+        hipLaunchKernelGGL(k_roi_align_nchw, dim3(n_rois, B), dim3(256), 0, s, maps, C, rois, rois_sB, roi_stride, pool,
+                           ratio, out, out_sB, out_row_stride);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace mrcnn

@@ -1,0 +1,179 @@
+"""The three-model surface: ``MaskRCNN``, ``Classifier``, ``Mask``.
+
+Mirrors the classes Xcode generates from the reference's three ``.mlmodel`` artefacts
+(``Example/iOS Example.xcodeproj/project.pbxproj:25-28``; specs emitted by
+``Sources/maskrcnn/Python/Conversion/task.py:69-116``): ``MaskRCNN().prediction(image:)`` →
+``detections`` (100,6) + ``mask`` (100,28,28); ``Classifier.prediction(feature_map:)`` →
+``probabilities``, ``bounding_boxes``; ``Mask.prediction(feature_map:)`` → ``masks``.
+``MaskRCNN.predict`` is the batched extension used by the bench / multi-GPU driver.
+Nothing here computes: all work is ``mrcnn_*`` calls into libmaskrcnn_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib
+from .config import MaskRCNNConfig
+
+STAGES = ["Trunk", "Proposal-Eval", "PyramidROIAlign-Eval", "TimeDistributedClassifierLayer-Eval", "Detection-Eval",
+          "PyramidROIAlign-Eval-Mask", "TimeDistributedMask-Eval"]
+
+
+class _Model:
+    KIND = -1
+
+    def __init__(self, path: str, max_batch: int, compute_dtype: int = _lib.F32):
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().mrcnn_model_load(self.KIND, os.fspath(path).encode(), int(max_batch), compute_dtype,
+                                               C.byref(self._h)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().mrcnn_model_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def get_int(self, key: str) -> int:
+        v = C.c_int64(0)
+        _lib.check(_lib.lib().mrcnn_model_get_int(self._h, key.encode(), C.byref(v)))
+        return int(v.value)
+
+    def set_stream(self, hip_stream: int):
+        _lib.check(_lib.lib().mrcnn_model_set_stream(self._h, C.c_void_p(hip_stream)))
+
+
+class MaskRCNN(_Model):
+    """``MaskRCNN(path)``: loads MaskRCNN.mrcw; anchors / Classifier / Mask come from
+    ``MaskRCNNConfig.defaultConfig()`` which must be set first (AppDelegate.swift:18-20)."""
+    KIND = _lib.MODEL_MASKRCNN
+
+    def __init__(self, path: str, max_batch: int = 1):
+        cfg = MaskRCNNConfig.defaultConfig()
+        for name in ("anchorsURL", "compiledClassifierModelURL", "compiledMaskModelURL"):
+            if getattr(cfg, name) is None:
+                # the reference force-unwraps and crashes (ProposalLayer.swift:68); we raise
+                raise _lib.MrcnnError(6, f"MaskRCNNConfig.defaultConfig().{name} must be set before loading MaskRCNN")
+        super().__init__(path, max_batch)
+        self.max_batch = max_batch
+        self.image_height = self.get_int("image_height")
+        self.image_width = self.get_int("image_width")
+        self.max_detections = self.get_int("max_detections")
+        self.max_proposals = self.get_int("max_proposals")
+        self.num_classes = self.get_int("num_classes")
+        self.mask_size = self.get_int("mask_size")
+
+    # -- reference-shaped single-image call ---------------------------------------------------------
+    def prediction(self, image: np.ndarray) -> Dict[str, np.ndarray]:
+        """image (H,W,3) uint8 RGB → {"detections": (maxDet,6), "mask": (maxDet,28,28)}."""
+        det, mask = self.predict(image[None])
+        return {"detections": det[0], "mask": mask[0]}
+
+    # -- batched extension --------------------------------------------------------------------------
+    def predict(self, images):
+        """images (B,H,W,3) uint8 — numpy (host) or torch CUDA tensor (device, results stay on the GPU)."""
+        if isinstance(images, np.ndarray):
+            imgs = np.ascontiguousarray(images, dtype=np.uint8)
+            B, H, W, _ = imgs.shape
+            det = np.empty((B, self.max_detections, 6), dtype=np.float32)
+            mask = np.empty((B, self.max_detections, self.mask_size, self.mask_size), dtype=np.float32)
+            _lib.check(_lib.lib().mrcnn_maskrcnn_predict(self._h, imgs.ctypes.data, B, H, W, _lib.HOST, det.ctypes.data,
+                                                         mask.ctypes.data))
+            return det, mask
+        import torch
+        assert images.is_cuda and images.dtype == torch.uint8 and images.is_contiguous()
+        B, H, W, _ = images.shape
+        det = torch.empty((B, self.max_detections, 6), dtype=torch.float32, device=images.device)
+        mask = torch.empty((B, self.max_detections, self.mask_size, self.mask_size), dtype=torch.float32, device=images.device)
+        _lib.check(_lib.lib().mrcnn_maskrcnn_predict(self._h, images.data_ptr(), B, H, W, _lib.DEVICE, det.data_ptr(),
+                                                     mask.data_ptr()))
+        return det, mask
+
+    def predict_into(self, images, det, mask, sync: bool = True):
+        """Device tensors in, pre-allocated device tensors out (bench loop: no allocation, optional no sync)."""
+        B, H, W, _ = images.shape
+        fn = _lib.lib().mrcnn_maskrcnn_predict if sync else None
+        if sync:
+            _lib.check(fn(self._h, images.data_ptr(), B, H, W, _lib.DEVICE, det.data_ptr(), mask.data_ptr()))
+        else:
+            _lib.check(_lib.lib().mrcnn_maskrcnn_predict_async(self._h, images.data_ptr(), B, H, W, det.data_ptr(), mask.data_ptr()))
+
+    # -- parity / profiling hooks -------------------------------------------------------------------
+    def read_tensor(self, name: str, image_index: int = 0) -> np.ndarray:
+        cnt = C.c_int64(0)
+        L = _lib.lib()
+        st = L.mrcnn_model_read_tensor(self._h, name.encode(), image_index, None, 0, C.byref(cnt))
+        if cnt.value <= 0:
+            _lib.check(st)
+        buf = np.empty(cnt.value, dtype=np.float32)
+        _lib.check(L.mrcnn_model_read_tensor(self._h, name.encode(), image_index, buf.ctypes.data, buf.size, C.byref(cnt)))
+        return buf
+
+    def enable_timing(self, on: bool = True):
+        _lib.check(_lib.lib().mrcnn_model_enable_timing(self._h, int(on)))
+
+    def stage_ms(self) -> Dict[str, float]:
+        out = {}
+        for s in STAGES:
+            v = C.c_float(0)
+            _lib.check(_lib.lib().mrcnn_model_stage_ms(self._h, s.encode(), C.byref(v)))
+            out[s] = float(v.value)
+        return out
+
+
+class Classifier(_Model):
+    KIND = _lib.MODEL_CLASSIFIER
+
+    def __init__(self, path: str, max_rows: int = 1000):
+        super().__init__(path, max_rows)
+        self.num_classes = self.get_int("num_classes")
+
+    def prediction(self, feature_map: np.ndarray) -> Dict[str, np.ndarray]:
+        """feature_map (256,7,7) or (n,256,7,7) float32 CHW → probabilities (n,nc), bounding_boxes (n,nc*4)."""
+        fm = np.ascontiguousarray(feature_map, dtype=np.float32)
+        single = fm.ndim == 3
+        if single:
+            fm = fm[None]
+        n = fm.shape[0]
+        probs = np.empty((n, self.num_classes), dtype=np.float32)
+        bbox = np.empty((n, self.num_classes * 4), dtype=np.float32)
+        _lib.check(_lib.lib().mrcnn_classifier_predict(self._h, fm.ctypes.data, n, _lib.HOST, probs.ctypes.data, bbox.ctypes.data))
+        if single:
+            return {"probabilities": probs[0], "bounding_boxes": bbox[0]}
+        return {"probabilities": probs, "bounding_boxes": bbox}
+
+
+class Mask(_Model):
+    KIND = _lib.MODEL_MASK
+
+    def __init__(self, path: str, max_rows: int = 100):
+        super().__init__(path, max_rows)
+        self.num_classes = self.get_int("num_classes")
+
+    def prediction(self, feature_map: np.ndarray) -> Dict[str, np.ndarray]:
+        """feature_map (256,14,14) or (n,256,14,14) float32 CHW → masks (n,nc,28,28)."""
+        fm = np.ascontiguousarray(feature_map, dtype=np.float32)
+        single = fm.ndim == 3
+        if single:
+            fm = fm[None]
+        n = fm.shape[0]
+        masks = np.empty((n, self.num_classes, 2 * fm.shape[2], 2 * fm.shape[3]), dtype=np.float32)
+        _lib.check(_lib.lib().mrcnn_mask_predict(self._h, fm.ctypes.data, n, _lib.HOST, masks.ctypes.data))
+        return {"masks": masks[0] if single else masks}
+
+
+def load_maskrcnn(model_dir: str, max_batch: int = 1) -> MaskRCNN:
+    """Sets MaskRCNNConfig from a directory holding MaskRCNN.mrcw / Classifier.mrcw / Mask.mrcw /
+    anchors.bin (the four artefacts of DownloadCommand.swift:10-32) and loads the main model —
+    the sequence of EvaluateCommand.swift:144-153."""
+    cfg = MaskRCNNConfig.defaultConfig()
+    cfg.anchorsURL = os.path.join(model_dir, "anchors.bin")
+    cfg.compiledClassifierModelURL = os.path.join(model_dir, "Classifier.mrcw")
+    cfg.compiledMaskModelURL = os.path.join(model_dir, "Mask.mrcw")
+    return MaskRCNN(os.path.join(model_dir, "MaskRCNN.mrcw"), max_batch=max_batch)

@@ -1,0 +1,188 @@
+"""GPU parity of the fused engine (MaskRCNN.predict) against the CPU oracle, stage by stage.
+
+The trunk (fp32 MFMA convolutions) is compared with the torch-CPU fp32 network within a stated
+tolerance; every later stage is fed THE GPU'S OWN tap of its input and must then agree with the
+oracle bit-exactly where it is index/box arithmetic (top-k order, proposals, ROIAlign samples,
+class ids, detections) and within tolerance where convolutions are involved (box head, mask head).
+This is how "bit-exact for top-k indices and class labels, fp32 tolerance elsewhere" is pinned
+without requiring two different summation orders to round identically through 100+ layers.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rand_images, make_model_dir
+
+pytestmark = pytest.mark.gpu
+
+TRUNK_RTOL = 5e-4   # max |gpu - cpu| / max |cpu| per tensor, fp32 vs fp32 with different summation order
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
+
+
+def _nhwc_to_chw(x, h, w, c):
+    return np.ascontiguousarray(x.reshape(h, w, c).transpose(2, 0, 1))
+
+
+def _check_stages(pkg, orc, om, m, cfg, images, b, check_trunk=True, trunk=None):
+    H, W = cfg.image_height, cfg.image_width
+    shapes = cfg.feature_shapes()
+    A = cfg.num_anchors()
+    # ---- trunk ---------------------------------------------------------------------------------
+    P = [_nhwc_to_chw(m.read_tensor(f"P{l + 2}", b), shapes[l][0], shapes[l][1], 256) for l in range(4)]
+    probs = m.read_tensor("rpn_probs", b).reshape(A, 2)
+    deltas = m.read_tensor("rpn_deltas", b).reshape(A, 4)
+    if check_trunk:
+        pyr, oprobs, odeltas = trunk
+        for l in range(4):
+            assert _rel(P[l], pyr[l][b]) < TRUNK_RTOL, f"P{l + 2}"
+        assert _rel(deltas, odeltas[b]) < TRUNK_RTOL
+        assert np.abs(probs - oprobs[b]).max() < 5e-4
+    # ---- ProposalLayer on the GPU's RPN outputs: bit-exact ---------------------------------------
+    K = min(A, cfg.pre_nms_max_proposals)
+    want_rois, dbg = om.proposals(probs, deltas, debug=True)
+    np.testing.assert_array_equal(m.read_tensor("topk_idx", b).astype(np.int64), dbg["topk_idx"].astype(np.int64))
+    np.testing.assert_array_equal(m.read_tensor("boxes_sorted", b).reshape(K, 4), dbg["boxes"])
+    rois = m.read_tensor("rois", b).reshape(cfg.max_proposals, 4)
+    np.testing.assert_array_equal(rois, want_rois)
+    assert int(m.read_tensor("keep_count", b)[0]) == dbg["count"]
+    # ---- PyramidROIAlign (7×7) on the GPU's pyramid + rois: bit-exact -----------------------------
+    ps = cfg.classifier_pool_size
+    pooled = m.read_tensor("pooled", b).reshape(cfg.max_proposals, ps, ps, 256).transpose(0, 3, 1, 2)
+    np.testing.assert_array_equal(pooled, om.roi_align(rois, P, ps))
+    # ---- box head: tolerance; post-processing bit-exact on the GPU's probabilities ---------------
+    gp = m.read_tensor("cls_probs", b).reshape(cfg.max_proposals, cfg.num_classes)
+    gb = m.read_tensor("cls_bbox", b).reshape(cfg.max_proposals, cfg.num_classes * 4)
+    _, op, ob = om.classify(np.ascontiguousarray(pooled))
+    assert np.abs(gp - op).max() < 5e-4
+    assert _rel(gb, ob) < TRUNK_RTOL
+    cls6 = m.read_tensor("cls6", b).reshape(cfg.max_proposals, 6)
+    np.testing.assert_array_equal(cls6, orc.classifier_postprocess(gp, gb))
+    # ---- DetectionLayer on the GPU's rois + cls6: bit-exact ---------------------------------------
+    det = m.read_tensor("detections", b).reshape(cfg.max_detections, 6)
+    np.testing.assert_array_equal(det, om.detect(rois, cls6))
+    # ---- PyramidROIAlign (14×14) on the detections: bit-exact -------------------------------------
+    pm = cfg.mask_pool_size
+    pooled_m = m.read_tensor("pooled_mask", b).reshape(cfg.max_detections, pm, pm, 256).transpose(0, 3, 1, 2)
+    np.testing.assert_array_equal(pooled_m, om.roi_align(det, P, pm))
+    # ---- mask head: same write set, values within 3e-4 --------------------------------------------
+    mask = m.read_tensor("mask", b).reshape(cfg.max_detections, 4 * pm * pm)
+    want = om.masks(np.ascontiguousarray(pooled_m), det)
+    np.testing.assert_array_equal(mask == 0, want == 0)
+    assert np.abs(mask - want).max() < 3e-4
+    return det, mask
+
+
+def test_engine_small_staged(pkg, orc, small_model):
+    from oracle.network import load_oracle_model
+    models = __import__("importlib").import_module("mask-rcnn-coreml_amd.models")
+    d, cfg = small_model
+    om = load_oracle_model(d)
+    B = 3
+    m = models.load_maskrcnn(d, max_batch=B)
+    images = rand_images(B, cfg.image_height, cfg.image_width, seed=1)
+    det, mask = m.predict(images)
+    assert det.shape == (B, cfg.max_detections, 6) and mask.shape == (B, cfg.max_detections, 28, 28)
+    trunk = om.trunk(images)
+    n_det = []
+    for b in range(B):
+        d_b, m_b = _check_stages(pkg, orc, om, m, cfg, images, b, True, trunk)
+        np.testing.assert_array_equal(det[b], d_b)
+        np.testing.assert_array_equal(mask[b].reshape(cfg.max_detections, -1), m_b)
+        n_det.append(int((d_b[:, 5] > 0).sum()))
+    assert max(n_det) > 0, "synthetic weights produced no detections: the heads were not exercised"
+
+
+def test_engine_batch_independence(pkg, small_model):
+    """Per-image results do not depend on the batch they ride in (the multi-GPU sharding contract)."""
+    models = __import__("importlib").import_module("mask-rcnn-coreml_amd.models")
+    d, cfg = small_model
+    m = models.load_maskrcnn(d, max_batch=4)
+    images = rand_images(4, cfg.image_height, cfg.image_width, seed=3)
+    det, mask = m.predict(images)
+    for b in range(4):
+        d1, m1 = m.predict(images[b:b + 1])
+        np.testing.assert_array_equal(d1[0], det[b])
+        np.testing.assert_array_equal(m1[0], mask[b])
+    # reference-shaped single-image call and the decoder
+    r = m.prediction(images[0])
+    np.testing.assert_array_equal(r["detections"], det[0])
+    dets = pkg.Detection.detectionsFromFeatureValue(r["detections"], r["mask"])
+    assert len(dets) == int((det[0][:, 5] > 0.7).sum())
+    for dd in dets:
+        assert dd.mask.shape == (28, 28) and dd.mask.dtype == np.uint8
+
+
+def test_engine_device_tensors(pkg, small_model):
+    import torch
+    models = __import__("importlib").import_module("mask-rcnn-coreml_amd.models")
+    d, cfg = small_model
+    m = models.load_maskrcnn(d, max_batch=2)
+    images = rand_images(2, cfg.image_height, cfg.image_width, seed=5)
+    det_h, mask_h = m.predict(images)
+    det_d, mask_d = m.predict(torch.from_numpy(images).cuda())
+    np.testing.assert_array_equal(det_d.cpu().numpy(), det_h)
+    np.testing.assert_array_equal(mask_d.cpu().numpy(), mask_h)
+    m.enable_timing(True)
+    m.predict(images)
+    ms = m.stage_ms()
+    assert all(v >= 0 for v in ms.values()) and ms["Trunk"] > 0
+
+
+def test_engine_errors(pkg, small_model, tmp_path):
+    models = __import__("importlib").import_module("mask-rcnn-coreml_amd.models")
+    d, cfg = small_model
+    m = models.load_maskrcnn(d, max_batch=1)
+    with pytest.raises(Exception) as e:
+        m.predict(rand_images(1, 64, 64))
+    assert "expects" in str(e.value)
+    with pytest.raises(Exception):
+        m.predict(rand_images(2, cfg.image_height, cfg.image_width))       # batch > max_batch
+    with pytest.raises(Exception) as e:
+        models.MaskRCNN(os.path.join(d, "Classifier.mrcw"))                 # wrong artefact kind
+    assert "expected MaskRCNN" in str(e.value)
+    bad = tmp_path / "bad.mrcw"
+    bad.write_bytes(b"nope")
+    with pytest.raises(Exception):
+        models.Classifier(str(bad))
+    pkg.MaskRCNNConfig.defaultConfig().anchorsURL = str(tmp_path / "missing.bin")
+    with pytest.raises(Exception) as e:
+        models.MaskRCNN(os.path.join(d, "MaskRCNN.mrcw"))
+    assert "anchors" in str(e.value)
+
+
+def test_engine_resnet101_256(pkg, orc, tmp_path_factory, weights_mod):
+    """ResNet-101 (23 C4 blocks) at 256² with the default 81 classes, batch 2."""
+    from oracle.network import load_oracle_model
+    models = __import__("importlib").import_module("mask-rcnn-coreml_amd.models")
+    d, cfg = make_model_dir(tmp_path_factory, pkg, weights_mod, "r101", architecture="resnet101",
+                            input_image_shape=(256, 256, 3), pre_nms_max_proposals=1000, max_proposals=128,
+                            max_detections=32)
+    om = load_oracle_model(d)
+    m = models.load_maskrcnn(d, max_batch=2)
+    images = rand_images(2, 256, 256, seed=7)
+    m.predict(images)
+    trunk = om.trunk(images)
+    for b in range(2):
+        _check_stages(pkg, orc, om, m, cfg, images, b, True, trunk)
+
+
+def test_engine_full_size_one_image(pkg, orc, tmp_path_factory, weights_mod):
+    """BASELINE config: ResNet-101 + FPN, 1024², 81 classes, preNMS 6000, 1000 proposals, 100
+    detections — one image, every stage after the trunk bit-exact on the GPU's taps; the trunk
+    itself against torch-CPU fp32."""
+    from oracle.network import load_oracle_model
+    models = __import__("importlib").import_module("mask-rcnn-coreml_amd.models")
+    d, cfg = make_model_dir(tmp_path_factory, pkg, weights_mod, "full", architecture="resnet101")
+    om = load_oracle_model(d)
+    m = models.load_maskrcnn(d, max_batch=1)
+    images = rand_images(1, 1024, 1024, seed=1)
+    det, mask = m.predict(images)
+    trunk = om.trunk(images)
+    d0, _ = _check_stages(pkg, orc, om, m, cfg, images, 0, True, trunk)
+    # the synthetic "forced full load" weights must actually load the data-dependent stages
+    assert int(m.read_tensor("keep_count", 0)[0]) == cfg.max_proposals
+    assert int((d0[:, 5] > 0).sum()) == cfg.max_detections

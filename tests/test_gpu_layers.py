@@ -1,0 +1,300 @@
+"""GPU parity: each of the five custom layers, through the C ABI (mrcnn_layer_*), against the CPU
+oracle on the same seeded inputs.  Integer / index / box outputs must be BIT-EXACT (the box
+arithmetic is all-IEEE and compiled without FMA contraction on both sides); the two sub-model
+layers (which run convolutions) are compared within the fp32 tolerances stated in each test.
+"""
+import numpy as np
+import pytest
+
+from conftest import rand_images  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _anchors_for(pkg, anchors_mod, size, tmp_path):
+    cfg = pkg.ModelConfig(input_image_shape=(size, size, 3))
+    p = str(tmp_path / f"anchors_{size}.bin")
+    a = anchors_mod.write_anchors_bin(p, cfg)
+    pkg.MaskRCNNConfig.defaultConfig().anchorsURL = p
+    return cfg, a
+
+
+def _run_proposal(pkg, probs, deltas, params, out_stride=4, prefill=np.nan):
+    layer = pkg.ProposalLayer(params)
+    maxp = params.get("maxProposals", 1000)
+    out = np.full((maxp, out_stride), np.float32(prefill), dtype=np.float32)
+    ML = pkg.MLMultiArray
+    layer.evaluate([ML(probs), ML(deltas)], [ML(out, shape=(maxp, 1, out_stride, 1, 1))])
+    return out
+
+
+@pytest.mark.parametrize("size,pre,maxp", [(128, 300, 64), (256, 1000, 200)])
+def test_proposal_layer_random(pkg, anchors_mod, orc, tmp_path, size, pre, maxp):
+    cfg, anchors = _anchors_for(pkg, anchors_mod, size, tmp_path)
+    A = anchors.shape[0]
+    rng = np.random.default_rng(2)
+    fg = rng.random(A, dtype=np.float32)
+    probs = np.stack([1 - fg, fg], axis=1).astype(np.float32)
+    deltas = rng.standard_normal((A, 4)).astype(np.float32)
+    params = dict(cfg.proposal_layer_params(), preNMSMaxProposals=pre, maxProposals=maxp)
+    got = _run_proposal(pkg, probs, deltas, params)
+    want = orc.proposal_layer(probs, deltas, anchors, pre, maxp, 0.7)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_proposal_layer_ties_and_padding(pkg, anchors_mod, orc, tmp_path):
+    """Saturated scores (many exact ties → lowest anchor index wins), far fewer survivors than
+    maxProposals (zero padding), wider output rows (only 4 floats of kept rows are written)."""
+    cfg, anchors = _anchors_for(pkg, anchors_mod, 128, tmp_path)
+    A = anchors.shape[0]
+    rng = np.random.default_rng(3)
+    fg = np.round(rng.random(A) * 8) / 8          # 9 distinct values → massive ties
+    fg = fg.astype(np.float32)
+    probs = np.stack([1 - fg, fg], axis=1).astype(np.float32)
+    deltas = (rng.standard_normal((A, 4)) * 0.1).astype(np.float32)   # near-anchor boxes → heavy suppression
+    params = dict(cfg.proposal_layer_params(), preNMSMaxProposals=500, maxProposals=400)
+    got = _run_proposal(pkg, probs, deltas, params, out_stride=6, prefill=7.0)
+    want = np.full((400, 6), np.float32(7.0), dtype=np.float32)
+    want = orc.proposal_layer(probs, deltas, anchors, 500, 400, 0.7, out_stride=6, out=want)
+    np.testing.assert_array_equal(got, want)
+    assert (got[-1] == 0).all()                   # padded tail
+    n_kept = int((np.abs(got[:, :4]).sum(1) > 0).sum())
+    assert n_kept < 400
+    assert (got[:n_kept, 4:] == 7.0).all()        # columns 4,5 of kept rows untouched, like the reference
+
+
+def test_proposal_layer_all_equal_scores(pkg, anchors_mod, orc, tmp_path):
+    cfg, anchors = _anchors_for(pkg, anchors_mod, 128, tmp_path)
+    A = anchors.shape[0]
+    probs = np.full((A, 2), 0.5, dtype=np.float32)
+    deltas = np.zeros((A, 4), dtype=np.float32)
+    params = dict(cfg.proposal_layer_params(), preNMSMaxProposals=100, maxProposals=50)
+    got = _run_proposal(pkg, probs, deltas, params)
+    want = orc.proposal_layer(probs, deltas, anchors, 100, 50, 0.7)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_proposal_layer_pre_nms_exceeds_anchor_count(pkg, anchors_mod, orc, tmp_path):
+    cfg, anchors = _anchors_for(pkg, anchors_mod, 64, tmp_path)
+    A = anchors.shape[0]
+    rng = np.random.default_rng(4)
+    fg = rng.random(A, dtype=np.float32)
+    probs = np.stack([1 - fg, fg], axis=1).astype(np.float32)
+    deltas = rng.standard_normal((A, 4)).astype(np.float32)
+    params = dict(cfg.proposal_layer_params(), preNMSMaxProposals=6000, maxProposals=100)
+    got = _run_proposal(pkg, probs, deltas, params)
+    want = orc.proposal_layer(probs, deltas, anchors, 6000, 100, 0.7)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_proposal_layer_full_size(pkg, anchors_mod, orc, tmp_path):
+    """BASELINE config 2 sizes: A = 261 888, preNMS 6000, 1000 proposals."""
+    cfg, anchors = _anchors_for(pkg, anchors_mod, 1024, tmp_path)
+    A = anchors.shape[0]
+    assert A == 261888
+    rng = np.random.default_rng(2)
+    fg = rng.random(A, dtype=np.float32)
+    probs = np.stack([1 - fg, fg], axis=1).astype(np.float32)
+    deltas = rng.standard_normal((A, 4)).astype(np.float32)
+    params = cfg.proposal_layer_params()
+    got = _run_proposal(pkg, probs, deltas, params)
+    want, dbg = orc.proposal_layer(probs, deltas, anchors, 6000, 1000, 0.7, debug=True)
+    np.testing.assert_array_equal(got, want)
+    # size-independent properties: rows inside [0,1], y2>=y1, x2>=x1, kept rows pairwise IoU <= 0.7
+    assert got.min() >= 0 and got.max() <= 1
+    assert (got[:, 2] >= got[:, 0]).all() and (got[:, 3] >= got[:, 1]).all()
+    k = dbg["count"]
+    sub = got[: min(k, 200)]
+    for i in range(1, len(sub)):
+        for j in range(i):
+            assert orc.iou(sub[i], sub[j]) <= 0.7
+
+
+def test_proposal_layer_stress_12000(pkg, anchors_mod, orc, tmp_path):
+    """BASELINE config 5: 1536², 589 248 anchors, preNMS 12000."""
+    cfg, anchors = _anchors_for(pkg, anchors_mod, 1536, tmp_path)
+    A = anchors.shape[0]
+    assert A == 589248
+    rng = np.random.default_rng(5)
+    fg = rng.random(A, dtype=np.float32)
+    probs = np.stack([1 - fg, fg], axis=1).astype(np.float32)
+    deltas = (rng.standard_normal((A, 4)) * 0.5).astype(np.float32)
+    params = dict(cfg.proposal_layer_params(), preNMSMaxProposals=12000)
+    got = _run_proposal(pkg, probs, deltas, params)
+    want = orc.proposal_layer(probs, deltas, anchors, 12000, 1000, 0.7)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_proposal_layer_missing_config(pkg):
+    pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None
+    with pytest.raises(Exception) as e:
+        pkg.ProposalLayer({})
+    assert "anchorsURL" in str(e.value)
+
+
+def _pyramid(rng, C, sizes):
+    return [rng.standard_normal((C, s, s)).astype(np.float32) for s in sizes]
+
+
+@pytest.mark.parametrize("pool", [7, 14])
+def test_pyramid_roi_align(pkg, orc, pool):
+    rng = np.random.default_rng(6)
+    C, sizes, n = 32, (64, 32, 16, 8), 200
+    fm = _pyramid(rng, C, sizes)
+    y1 = rng.random(n) * 0.7; x1 = rng.random(n) * 0.7
+    hh = rng.random(n) ** 2 * (1 - y1); ww = rng.random(n) ** 2 * (1 - x1)
+    rois = np.stack([y1, x1, y1 + hh, x1 + ww], 1).astype(np.float32)
+    rois[5] = 0                                   # padding ROI → zero row
+    rois[6] = [0.2, 0.3, 0.2, 0.9]                # zero height → padding
+    rois[7] = [0.0, 0.0, 1.0, 1.0]                # whole image, touches the border
+    rois[8] = [0.5, 0.5, 0.4, 0.6]                # negative height → NaN level → padding
+    layer = pkg.PyramidROIAlignLayer({"poolSize": pool, "imageWidth": 256, "imageHeight": 256})
+    ML = pkg.MLMultiArray
+    out = np.full((n, 1, C, pool, pool), np.float32(np.nan), dtype=np.float32)
+    ins = [ML(rois)] + [ML(f) for f in fm]
+    assert layer.outputShapes([a.shape for a in ins]) == [[n, 1, C, pool, pool]]
+    layer.evaluate(ins, [ML(out)])
+    want = orc.pyramid_roi_align(rois, fm, pool, 256, 256)
+    np.testing.assert_array_equal(out.reshape(want.shape), want)
+    assert (out[5] == 0).all() and (out[6] == 0).all() and (out[8] == 0).all()
+    lv = orc.roi_levels(rois, 256, 256)
+    assert set(np.unique(lv)) >= {-1, 0, 1, 2, 3}   # every level exercised
+
+
+def _cls6(rng, n, nc, frac_pass=0.6):
+    c = np.zeros((n, 6), dtype=np.float32)
+    c[:, :4] = rng.standard_normal((n, 4)).astype(np.float32)
+    c[:, 4] = rng.integers(0, nc, n).astype(np.float32)
+    s = rng.random(n).astype(np.float32)
+    c[:, 5] = np.where(rng.random(n) < frac_pass, 0.7 + 0.3 * s, 0.7 * s).astype(np.float32)
+    return c
+
+
+@pytest.mark.parametrize("n,nc,maxd,seed", [(1000, 81, 100, 7), (300, 5, 100, 8), (64, 3, 8, 9)])
+def test_detection_layer(pkg, orc, n, nc, maxd, seed):
+    rng = np.random.default_rng(seed)
+    y1 = rng.random(n) * 0.8; x1 = rng.random(n) * 0.8
+    rois = np.stack([y1, x1, y1 + rng.random(n) * 0.2, x1 + rng.random(n) * 0.2], 1).astype(np.float32)
+    cls = _cls6(rng, n, nc)
+    cls[3, 5] = 0.7                               # exactly at the threshold: kept (>=)
+    cls[4, 5] = np.nextafter(np.float32(0.7), np.float32(0))   # just below: dropped
+    rois[10] = 0                                  # zero-area ROI never survives NMS
+    cls[20:40, 5] = cls[20, 5]                    # equal scores → stable order
+    params = {"bboxStdDev_count": 4, "bboxStdDev_0": 0.1, "bboxStdDev_1": 0.1, "bboxStdDev_2": 0.2, "bboxStdDev_3": 0.2,
+              "maxDetections": maxd, "scoreThreshold": 0.7, "nmsIOUThreshold": 0.3}
+    layer = pkg.DetectionLayer(params)
+    ML = pkg.MLMultiArray
+    out = np.full((maxd, 6), np.float32(np.nan), dtype=np.float32)
+    assert layer.outputShapes([[n, 1, 4, 1, 1], [n, 1, 6, 1, 1]]) == [[maxd, 1, 6, 1, 1]]
+    layer.evaluate([ML(rois), ML(cls)], [ML(out)])
+    want = orc.detection_layer(rois, cls, maxd, 0.7, 0.3)
+    np.testing.assert_array_equal(out, want)
+
+
+def test_detection_layer_nothing_passes(pkg, orc):
+    rng = np.random.default_rng(10)
+    n = 100
+    rois = rng.random((n, 4)).astype(np.float32)
+    cls = _cls6(rng, n, 10, frac_pass=0.0)
+    layer = pkg.DetectionLayer({"maxDetections": 10})
+    ML = pkg.MLMultiArray
+    out = np.full((10, 6), np.float32(np.nan), dtype=np.float32)
+    layer.evaluate([ML(rois), ML(cls)], [ML(out)])
+    assert (out == 0).all()
+
+
+def test_detection_layer_per_class_limit(pkg, orc):
+    """One class with far more than maxDetections non-overlapping survivors: the per-class NMS call
+    stops at maxDetections selections in ROI order (Utils.swift:191), before the score sort."""
+    n, maxd = 400, 16
+    g = np.arange(n)
+    y1 = (g // 20) / 20.0; x1 = (g % 20) / 20.0
+    rois = np.stack([y1, x1, y1 + 0.04, x1 + 0.04], 1).astype(np.float32)
+    rng = np.random.default_rng(11)
+    cls = np.zeros((n, 6), dtype=np.float32)
+    cls[:, 4] = 1 + (g % 2)
+    cls[:, 5] = (0.7 + 0.3 * rng.random(n)).astype(np.float32)
+    layer = pkg.DetectionLayer({"maxDetections": maxd})
+    ML = pkg.MLMultiArray
+    out = np.full((maxd, 6), np.float32(np.nan), dtype=np.float32)
+    layer.evaluate([ML(rois), ML(cls)], [ML(out)])
+    want = orc.detection_layer(rois, cls, maxd, 0.7, 0.3)
+    np.testing.assert_array_equal(out, want)
+
+
+def test_classifier_layer(pkg, orc, small_model):
+    """TimeDistributedClassifierLayer: sub-model in fp32 MFMA vs torch fp32 (tolerance: 2e-4
+    relative to the largest |value| per tensor), then class id bit-exact on the GPU's own probs."""
+    from oracle.network import load_oracle_model
+    d, cfg = small_model
+    om = load_oracle_model(d)
+    import os
+    pkg.MaskRCNNConfig.defaultConfig().compiledClassifierModelURL = os.path.join(d, "Classifier.mrcw")
+    rng = np.random.default_rng(12)
+    n = 50
+    pooled = rng.standard_normal((n, 1, 256, 7, 7)).astype(np.float32)
+    layer = pkg.TimeDistributedClassifierLayer({})
+    ML = pkg.MLMultiArray
+    out = np.full((n, 1, 1, 1, 6), np.float32(np.nan), dtype=np.float32)
+    assert layer.outputShapes([[n, 1, 256, 7, 7]]) == [[n, 1, 1, 1, 6]]
+    layer.evaluate([ML(pooled)], [ML(out)])
+    got = out.reshape(n, 6)
+    want, probs, bbox = om.classify(pooled.reshape(n, 256, 7, 7))
+    # stand-alone Classifier model gives the GPU probs/bbox → the post-processing must match bit-exactly on them
+    cm = pkg.Classifier(os.path.join(d, "Classifier.mrcw"))
+    r = cm.prediction(pooled.reshape(n, 256, 7, 7))
+    np.testing.assert_allclose(r["probabilities"], probs, atol=2e-4 * max(1.0, float(np.abs(probs).max())))
+    np.testing.assert_allclose(r["bounding_boxes"], bbox, atol=2e-4 * float(np.abs(bbox).max()))
+    np.testing.assert_array_equal(got, orc.classifier_postprocess(r["probabilities"], r["bounding_boxes"]))
+    agree = (got[:, 4] == want[:, 4]).mean()
+    assert agree >= 0.95                          # against the CPU model end to end (near-ties may flip)
+
+
+def test_mask_layer(pkg, orc, small_model):
+    """TimeDistributedMaskLayer incl. the removeZeros / compact-index quirks: detections prefix,
+    a zero row in the middle (reference writes row `mapping[i]` with class of row i, then zero-pads
+    from the kept count).  Tolerance on mask values: 2e-4 absolute (sigmoid outputs)."""
+    from oracle.network import load_oracle_model
+    import os
+    d, cfg = small_model
+    om = load_oracle_model(d)
+    pkg.MaskRCNNConfig.defaultConfig().compiledMaskModelURL = os.path.join(d, "Mask.mrcw")
+    rng = np.random.default_rng(13)
+    D = 12
+    pooled = rng.standard_normal((D, 1, 256, 14, 14)).astype(np.float32)
+    pooled[4] = 0                                 # invalid row in the middle
+    pooled[9:] = 0                                # padding tail
+    pooled[7, 0, 3, 2, 1] = 0                     # a single exact zero also drops the row
+    det = np.zeros((D, 6), dtype=np.float32)
+    det[:, 4] = rng.integers(1, cfg.num_classes, D)
+    det[:, 5] = 0.9
+    layer = pkg.TimeDistributedMaskLayer({})
+    ML = pkg.MLMultiArray
+    out = np.full((1, 1, D, 28, 28), np.float32(5.0), dtype=np.float32)
+    assert layer.outputShapes([[D, 1, 256, 14, 14], [D, 1, 6, 1, 1]]) == [[1, 1, D, 28, 28]]
+    layer.evaluate([ML(pooled), ML(det)], [ML(out)])
+    want = np.full((D, 784), np.float32(5.0), dtype=np.float32)
+    want = om.masks(pooled.reshape(D, 256, 14, 14), det, out=want)
+    got = out.reshape(D, 784)
+    written = want != 5.0
+    np.testing.assert_array_equal(got == 5.0, want == 5.0)     # identical write set
+    np.testing.assert_allclose(got[written], want[written], atol=2e-4)
+    # stand-alone Mask model
+    mm = pkg.Mask(os.path.join(d, "Mask.mrcw"))
+    r = mm.prediction(pooled[:3].reshape(3, 256, 14, 14))
+    np.testing.assert_allclose(r["masks"], om.mask_model(pooled[:3].reshape(3, 256, 14, 14)), atol=2e-4)
+
+
+def test_layer_errors(pkg):
+    with pytest.raises(Exception) as e:
+        from importlib import import_module
+        L = import_module("mask-rcnn-coreml_amd.layers")
+
+        class Bogus(L._Layer):
+            CLASS_NAME = "NoSuchLayer"
+        Bogus({})
+    assert "unknown custom layer" in str(e.value)
+    layer = pkg.DetectionLayer({})
+    ML = pkg.MLMultiArray
+    with pytest.raises(Exception):
+        layer.evaluate([ML(np.zeros((4, 4), np.float32))], [ML(np.zeros((100, 6), np.float32))])   # missing input
