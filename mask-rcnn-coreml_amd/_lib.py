@@ -66,6 +66,15 @@ def lib():
         raise NativeLibraryMissing(
             f"{SO_PATH} not built. Run `python __graft_entry__.py` (or `make -C mask-rcnn-coreml_amd/csrc`). "
             "There is no CPU fallback: the HIP library is the product.")
+    # torch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7).
+    # Two HIP runtimes in one process cannot both own the GPU, so when torch is importable it is
+    # imported FIRST: the loader then resolves this library's DT_NEEDED libamdhip64.so.7 to the copy
+    # torch already mapped, and torch tensors / streams and this library share one runtime.  A host
+    # without torch (the Swift host) simply gets /opt/rocm's runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(SO_PATH)
     vp, cp, i64p, f32p = C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_float)
     L.mrcnn_last_error.restype = cp

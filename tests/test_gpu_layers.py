@@ -148,16 +148,16 @@ def test_pyramid_roi_align(pkg, orc, pool):
     rois[6] = [0.2, 0.3, 0.2, 0.9]                # zero height → padding
     rois[7] = [0.0, 0.0, 1.0, 1.0]                # whole image, touches the border
     rois[8] = [0.5, 0.5, 0.4, 0.6]                # negative height → NaN level → padding
-    layer = pkg.PyramidROIAlignLayer({"poolSize": pool, "imageWidth": 256, "imageHeight": 256})
+    layer = pkg.PyramidROIAlignLayer({"poolSize": pool, "imageWidth": 1024, "imageHeight": 1024})
     ML = pkg.MLMultiArray
     out = np.full((n, 1, C, pool, pool), np.float32(np.nan), dtype=np.float32)
     ins = [ML(rois)] + [ML(f) for f in fm]
     assert layer.outputShapes([a.shape for a in ins]) == [[n, 1, C, pool, pool]]
     layer.evaluate(ins, [ML(out)])
-    want = orc.pyramid_roi_align(rois, fm, pool, 256, 256)
+    want = orc.pyramid_roi_align(rois, fm, pool, 1024, 1024)
     np.testing.assert_array_equal(out.reshape(want.shape), want)
     assert (out[5] == 0).all() and (out[6] == 0).all() and (out[8] == 0).all()
-    lv = orc.roi_levels(rois, 256, 256)
+    lv = orc.roi_levels(rois, 1024, 1024)
     assert set(np.unique(lv)) >= {-1, 0, 1, 2, 3}   # every level exercised
 
 
