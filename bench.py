@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""bench.py — images/s of the Mask-RCNN hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one pass of MaskRCNN.predict over a batch of 8 synthetic 1024×1024×3 uint8 images that are
+already resident in HBM (BASELINE.json configs[1]: ResNet101+FPN, 1024², batch 8 per GPU, pre_nms 6000,
+max_proposals 1000), followed — when N > 1 — by the one collective the path has: an RCCL all-gather of
+the fixed-size detection records.  Weak scaling: every GPU processes its own 8 images.
+Weights are seeded synthetic weights of the exact architecture ("forced full load": 1000 proposals and
+100 detections per image, so no data-dependent stage idles); there is no network for checkpoints.
+
+Rank 0 prints ONE JSON line with, besides the contract fields:
+  roofline     — dominant kernel k_conv_mfma_f32<128,2,2,2,2> (fp32 MFMA implicit-GEMM conv): its
+                 ALGORITHMIC flops per launch ÷ its average launch duration, both measured live with HIP
+                 events on the launching stream over the timed region; peak = 157.3 TFLOP/s (dense fp32 MFMA)
+  cpu_baseline — the oracle (torch-CPU fp32 network + the C restatement of the custom layers) timed on this
+                 box's host cores on a bounded sample of the same workload (rank 0, N = 1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+GFLOP_PER_IMAGE_SURVEY = 777.3         # SURVEY.md §8(d), R101 1024² 81 classes
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--arch", default="resnet101")
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=3)
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    n_gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = importlib.import_module("mask-rcnn-coreml_amd")
+    models = importlib.import_module("mask-rcnn-coreml_amd.models")
+    weights = importlib.import_module("mask-rcnn-coreml_amd.weights")
+    dmod = importlib.import_module("mask-rcnn-coreml_amd.dist")
+
+    cfg = pkg.ModelConfig(architecture=args.arch, input_image_shape=(args.size, args.size, 3))
+    model_dir = tempfile.mkdtemp(prefix=f"mrcnn_bench_r{rank}_")
+    weights.save_synthetic_models(model_dir, cfg, seed=0, forced_load=True)
+    m = models.load_maskrcnn(model_dir, max_batch=args.batch)
+    B = args.batch
+    # synthetic batch, uint8 uniform[0,255], seed 1; a different slice of the stream per rank
+    rng = np.random.default_rng(1)
+    rng.bit_generator.advance(rank * B * args.size * args.size * 3)
+    images = torch.from_numpy(rng.integers(0, 256, (B, args.size, args.size, 3), dtype=np.uint8)).to(dev)
+    det = torch.empty((B, m.max_detections, 6), dtype=torch.float32, device=dev)
+    mask = torch.empty((B, m.max_detections, m.mask_size, m.mask_size), dtype=torch.float32, device=dev)
+    gather = dmod.DetectionGather(B, m.max_detections, m.mask_size, world, dev) if world > 1 else None
+
+    def step():
+        m.predict_into(images, det, mask, sync=True)       # returns after the model's stream has drained
+        if gather is not None:
+            gather.all_gather(det, mask)
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_kernel_events:
+        m.conv_profile_enable(True)
+    m.enable_timing(True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    prof = m.conv_profile() if not args.no_kernel_events else None
+    stages = m.stage_ms()
+    n_prop = int(m.read_tensor("keep_count", 0)[0])
+    n_det = int((det[0, :, 5] > 0).sum().item())
+
+    if rank == 0:
+        total_images = n_gpus * B * args.steps
+        value = total_images / elapsed
+        out = {
+            "metric": "images/sec (1024x1024, COCO-80)", "value": round(value, 3), "unit": "images/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {args.arch}+FPN {args.size}x{args.size}, batch {B} per GPU, "
+                                   f"81 classes, pre_nms 6000, max_proposals 1000, max_detections 100; "
+                                   f"synthetic seeded weights (forced full load)",
+                       "global_batch": n_gpus * B, "parallelism": f"dp{n_gpus}" if n_gpus > 1 else "single",
+                       "proposals_kept_image0": n_prop, "detections_image0": n_det},
+            "stage_ms_last_step": {k: round(v, 3) for k, v in stages.items()},
+        }
+        if prof is not None:
+            launches, ms, flops = prof["128x128"]
+            all_ms = sum(v[1] for v in prof.values())
+            all_fl = sum(v[2] for v in prof.values())
+            if launches:
+                achieved = flops / (ms * 1e-3) / 1e12
+                out["roofline"] = {
+                    "kernel": "k_conv_mfma_f32<128,2,2,2,2>", "bound": "mfma", "achieved": round(achieved, 2),
+                    "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "traffic": None,
+                    "launches_per_step": launches // args.steps,
+                    "avg_launch_ms": round(ms / launches, 4),
+                    "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
+                    "share_of_step_time": round(ms / (1e3 * elapsed), 4),
+                    "all_conv_kernels": {"tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2),
+                                         "gflop_per_image": round(all_fl / (B * args.steps) / 1e9, 2),
+                                         "survey_gflop_per_image": GFLOP_PER_IMAGE_SURVEY,
+                                         "share_of_step_time": round(all_ms / (1e3 * elapsed), 4)},
+                }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model_dir, cfg, args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(model_dir, cfg, args):
+    """The oracle on host cores: 1 warm-up image, then `cpu_images` images, wall clock around predict
+    only, model load excluded (EvaluateCommand.swift:146-179); median ms/image → images/s."""
+    import numpy as np
+    import torch
+    from oracle.network import load_oracle_model
+    om = load_oracle_model(model_dir, cfg)
+    rng = np.random.default_rng(1)
+    imgs = rng.integers(0, 256, (1 + args.cpu_images, args.size, args.size, 3), dtype=np.uint8)
+    om.predict(imgs[:1])
+    ts = []
+    for i in range(args.cpu_images):
+        t0 = time.perf_counter()
+        om.predict(imgs[1 + i:2 + i])
+        ts.append(time.perf_counter() - t0)
+    med = float(np.median(ts))
+    return {"value": round(1.0 / med, 4), "unit": "images/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{args.cpu_images} images of the same workload after 1 warm-up, batch 1, median "
+                      f"{round(med * 1e3, 1)} ms/image; torch-CPU fp32 network (oneDNN) + C restatement of the custom layers"}
+
+
+if __name__ == "__main__":
+    main()

@@ -190,6 +190,14 @@ MRCNN_API int mrcnn_model_read_tensor(mrcnn_model* model, const char* name, int 
 MRCNN_API int mrcnn_model_enable_timing(mrcnn_model* model, int on);
 MRCNN_API int mrcnn_model_stage_ms(mrcnn_model* model, const char* stage, float* ms);
 
+/* Live per-kernel profile of the convolution family during predict (bench.py roofline leg): when
+ * enabled every conv launch is bracketed by HIP events on the model's stream.  tile: 0 = the
+ * 128x128 kernel (dominant), 1 = 128x64, 2 = 128x32.  Totals accumulate since enable/reset;
+ * total_flops is ALGORITHMIC work (2*M*N*K of the convolution, padding excluded). */
+MRCNN_API int mrcnn_model_conv_profile_enable(mrcnn_model* model, int on);
+MRCNN_API int mrcnn_model_conv_profile_get(mrcnn_model* model, int tile, int64_t* launches, double* total_ms,
+                                           double* total_flops);
+
 /* ---------------------------------------------------------------------------------------------
  * Convolution micro-benchmark hook (bench.py roofline leg): runs one convolution of the trunk's
  * kernel family on synthetic data resident in HBM and reports the average kernel time measured

@@ -632,6 +632,25 @@ extern "C" int mrcnn_model_stage_ms(mrcnn_model* model, const char* stage, float
     });
 }
 
+extern "C" int mrcnn_model_conv_profile_enable(mrcnn_model* model, int on)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model, MRCNN_ERR_INVALID, "null model");
+        model->m.conv_profile.active = on != 0;
+        model->m.conv_profile.reset();
+    });
+}
+extern "C" int mrcnn_model_conv_profile_get(mrcnn_model* model, int tile, int64_t* launches, double* total_ms, double* total_flops)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model && launches && total_ms && total_flops && tile >= 0 && tile < 3, MRCNN_ERR_INVALID, "bad argument");
+        HIP_CHECK(hipStreamSynchronize(model->m.stream));
+        model->m.conv_profile.collect();
+        const auto& sl = model->m.conv_profile.by_tile[tile];
+        *launches = sl.launches; *total_ms = sl.ms; *total_flops = sl.flops;
+    });
+}
+
 // ================================================================================================
 // convolution micro-benchmark (bench.py roofline leg)
 // ================================================================================================

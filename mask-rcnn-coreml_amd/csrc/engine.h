@@ -134,6 +134,7 @@ struct Model {
     DetectionWorkspace det_ws;
     MaskSelectWorkspace msel_ws;
     StageTimer timer;
+    ConvProfile conv_profile;
 
     ~Model();
     void load(int kind, const std::string& path, int max_batch);

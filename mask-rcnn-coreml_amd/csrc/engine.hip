@@ -627,6 +627,7 @@ void Model::build_maskrcnn()
             d.scale = pc->scale.as<float>(); d.shift = pc->shift.as<float>();
             d.OH = c1.H; d.OW = c1.W; d.Cout = pc->Cout; d.Npad = pc->Npad;
             d.out = c1.p; d.out_sP = c1.C; d.out_sB = c1.sB(); d.act = ACT_RELU;
+            d.algo_k = 147;   // 7*7*3 real taps (the packed row is padded to 7*32)
             add([d](hipStream_t s, int batch) { ConvDesc x = d; x.B = batch; conv_forward(s, x); });
         }
         Tensor4 x = T(H / 4, W / 4, 64);
@@ -742,6 +743,7 @@ void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, f
     const size_t img_bytes = (size_t)batch * H * W * 3;
     HIP_CHECK(hipMemcpyAsync(d_rgb, rgb, img_bytes, memspace == MRCNN_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     timer.begin(s);
+    conv_set_profiler(conv_profile.active ? &conv_profile : nullptr);
     for (auto& op : trunk_ops) op(s, batch);
     timer.mark(s, "Trunk");
     // ProposalLayer
@@ -780,9 +782,11 @@ void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, f
     const hipMemcpyKind back = memspace == MRCNN_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     HIP_CHECK(hipMemcpyAsync(det_out, detections, (size_t)batch * max_det * 6 * 4, back, s));
     HIP_CHECK(hipMemcpyAsync(masks_out, mask_out, (size_t)batch * max_det * HW * 4, back, s));
+    conv_set_profiler(nullptr);
     if (sync) {
         HIP_CHECK(hipStreamSynchronize(s));
         timer.finish();
+        if (conv_profile.active) conv_profile.collect();
     }
 }
 

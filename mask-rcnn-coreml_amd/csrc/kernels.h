@@ -1,5 +1,7 @@
 // kernels.h — host-side launchers of the gfx950 kernels (one namespace, no torch, no templates in the API).
 #pragma once
+#include <vector>
+
 #include "common.h"
 
 namespace mrcnn {
@@ -97,7 +99,26 @@ struct ConvDesc {
     // transposed-conv 2x2 stride 2 scatter: column n = q*Cout + co, q = dy*2+dx → pixel (2oh+dy, 2ow+dx)
     int deconv2 = 0;
     long out_sH = 0, out_sW = 0;  // only used when deconv2
+    // algorithmic reduction length per output (defaults to KH*KW*Cin; conv1 pads 147 → 224)
+    int algo_k = 0;
 };
+
+// Live per-kernel profile of the conv family: when a profiler is active on the calling thread every
+// conv_forward launch is bracketed by HIP events on its own stream; collect() (after the stream
+// has been synchronised) folds the elapsed times into per-tile-shape totals.
+struct ConvProfile {
+    struct Slot { long launches = 0; double ms = 0, flops = 0; };
+    Slot by_tile[3];                 // 0: 128x128, 1: 128x64, 2: 128x32
+    std::vector<hipEvent_t> pool;
+    struct Pending { int tile; double flops; int e0, e1; };
+    std::vector<Pending> pending;
+    int used = 0;
+    bool active = false;
+    void reset();
+    void collect();
+    ~ConvProfile();
+};
+void conv_set_profiler(ConvProfile* p);   // thread-local; nullptr disables
 // Picks the tile shape from Cout; returns the N tile it will use so that callers can pad weights.
 int conv_n_tile(int Cout);
 void conv_forward(hipStream_t s, const ConvDesc& d);

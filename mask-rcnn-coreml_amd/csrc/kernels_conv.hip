@@ -196,6 +196,41 @@ __global__ __launch_bounds__(256) void k_conv_mfma_f32(const ConvArgs a)
     }
 }
 
+static thread_local ConvProfile* g_prof = nullptr;
+void conv_set_profiler(ConvProfile* p) { g_prof = p; }
+void ConvProfile::reset()
+{
+    for (auto& s : by_tile) s = Slot();
+    pending.clear();
+    used = 0;
+}
+void ConvProfile::collect()
+{
+    for (auto& pd : pending) {
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, pool[pd.e0], pool[pd.e1]));
+        by_tile[pd.tile].launches += 1;
+        by_tile[pd.tile].ms += ms;
+        by_tile[pd.tile].flops += pd.flops;
+    }
+    pending.clear();
+    used = 0;
+}
+ConvProfile::~ConvProfile()
+{
+    for (auto e : pool) (void)hipEventDestroy(e);
+}
+static int prof_event(ConvProfile* p, hipStream_t s)
+{
+    if (p->used == (int)p->pool.size()) {
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreate(&e));
+        p->pool.push_back(e);
+    }
+    HIP_CHECK(hipEventRecord(p->pool[p->used], s));
+    return p->used++;
+}
+
 int conv_n_tile(int Cout)
 {
     if (Cout > 64) return 128;
@@ -225,9 +260,16 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = d.Npad / bn;
     const dim3 grid(a.tiles_m * a.tiles_n), block(256);
+    ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
+    const int e0 = prof ? prof_event(prof, s) : 0;
     if (bn == 128) hipLaunchKernelGGL((k_conv_mfma_f32<128, 2, 2, 2, 2>), grid, block, 0, s, a);
     else if (bn == 64) hipLaunchKernelGGL((k_conv_mfma_f32<64, 2, 1, 2, 2>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_conv_mfma_f32<32, 1, 1, 4, 1>), grid, block, 0, s, a);
+    if (prof) {
+        const int e1 = prof_event(prof, s);
+        const double k = d.algo_k > 0 ? d.algo_k : a.Ktot;
+        prof->pending.push_back({bn == 128 ? 0 : (bn == 64 ? 1 : 2), 2.0 * (double)a.M * (double)a.ncols * k, e0, e1});
+    }
     HIP_CHECK(hipGetLastError());
 }
 

@@ -1,0 +1,88 @@
+"""Multi-GPU: shard a batch of images over the ranks of one node, one all-gather of the results.
+
+New functionality asked for by the north star (the reference is single image / single device,
+SURVEY.md §8e).  Each image's pipeline is independent, so the batch is split into contiguous blocks
+(image b → rank b // ceil(B/G)), weights and anchors are replicated, there is NO collective on the
+data path, and the only exchange is one all-gather of fixed-size, zero-padded records per image:
+
+    record = detections (maxDet × 6 f32) ‖ masks (maxDet × S × S f32)      316 000 B at the defaults
+
+over RCCL/xGMI (``torch.distributed`` backend "nccl"); the same code runs on gloo/CPU tensors, which
+is how the N > 1 path is tested without GPUs.  Results are identical for any G because the per-image
+computation does not depend on the batch it rides in (tests/test_gpu_engine.py::test_engine_batch_independence).
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(global_batch: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block of image indices [lo, hi) owned by `rank` (blocks differ by at most one image)."""
+    base, rem = divmod(global_batch, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_records(det: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """(b, D, 6) + (b, D, S, S) → (b, D*6 + D*S*S) contiguous."""
+    b = det.shape[0]
+    return torch.cat([det.reshape(b, -1), mask.reshape(b, -1)], dim=1).contiguous()
+
+
+def unpack_records(rec: torch.Tensor, max_det: int, mask_size: int):
+    n = rec.shape[0]
+    d = rec[:, : max_det * 6].reshape(n, max_det, 6)
+    m = rec[:, max_det * 6:].reshape(n, max_det, mask_size, mask_size)
+    return d, m
+
+
+class DetectionGather:
+    """Pre-allocated all-gather of the per-image records (equal shards: the bench's weak-scaling case)."""
+
+    def __init__(self, per_rank_batch: int, max_det: int, mask_size: int, world: int, device):
+        self.b, self.D, self.S, self.world = per_rank_batch, max_det, mask_size, world
+        self.rec_len = max_det * 6 + max_det * mask_size * mask_size
+        self.send = torch.empty((per_rank_batch, self.rec_len), dtype=torch.float32, device=device)
+        self.recv = torch.empty((world * per_rank_batch, self.rec_len), dtype=torch.float32, device=device)
+
+    def all_gather(self, det: torch.Tensor, mask: torch.Tensor):
+        self.send[:, : self.D * 6].copy_(det.reshape(self.b, -1))
+        self.send[:, self.D * 6:].copy_(mask.reshape(self.b, -1))
+        if self.world == 1:
+            self.recv.copy_(self.send)
+        elif self.send.is_cuda:
+            dist.all_gather_into_tensor(self.recv, self.send)
+        else:
+            parts = list(self.recv.chunk(self.world, dim=0))
+            dist.all_gather(parts, self.send)
+        return unpack_records(self.recv, self.D, self.S)
+
+
+def gather_uneven(rec: torch.Tensor, global_batch: int) -> torch.Tensor:
+    """All-gather for shards that differ by one image: pad to the largest shard, gather, drop padding."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = [shard_bounds(global_batch, world, r) for r in range(world)]
+    mx = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((mx, rec.shape[1]), dtype=rec.dtype, device=rec.device)
+    pad[: rec.shape[0]] = rec
+    parts: List[torch.Tensor] = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)
+
+
+def predict_sharded(predict_fn, images, max_det: int, mask_size: int):
+    """images: the GLOBAL batch (same on every rank).  `predict_fn(images_shard) -> (det, mask)` runs the
+    local model.  Returns the detections and masks of the whole batch, in order, on every rank."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    lo, hi = shard_bounds(images.shape[0], world, rank)
+    det, mask = predict_fn(images[lo:hi])
+    det = torch.as_tensor(det)
+    mask = torch.as_tensor(mask)
+    rec = pack_records(det, mask)
+    if world > 1:
+        rec = gather_uneven(rec, images.shape[0])
+    return unpack_records(rec, max_det, mask_size)

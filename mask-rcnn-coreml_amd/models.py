@@ -115,6 +115,18 @@ class MaskRCNN(_Model):
         _lib.check(L.mrcnn_model_read_tensor(self._h, name.encode(), image_index, buf.ctypes.data, buf.size, C.byref(cnt)))
         return buf
 
+    def conv_profile_enable(self, on: bool = True):
+        _lib.check(_lib.lib().mrcnn_model_conv_profile_enable(self._h, int(on)))
+
+    def conv_profile(self):
+        """{tile: (launches, total_ms, total_algorithmic_flops)} since conv_profile_enable()."""
+        out = {}
+        for tile, name in enumerate(("128x128", "128x64", "128x32")):
+            n, ms, fl = C.c_int64(0), C.c_double(0), C.c_double(0)
+            _lib.check(_lib.lib().mrcnn_model_conv_profile_get(self._h, tile, C.byref(n), C.byref(ms), C.byref(fl)))
+            out[name] = (int(n.value), float(ms.value), float(fl.value))
+        return out
+
     def enable_timing(self, on: bool = True):
         _lib.check(_lib.lib().mrcnn_model_enable_timing(self._h, int(on)))
 
