@@ -42,6 +42,7 @@ struct ConvArgs {
     int OH, OW, Cout, ncols, Ktot, M;
     int res_shift, act, n_split, deconv2;
     int tiles_m, tiles_n;
+    int vec_ok;          // epilogue may use 16-B stores / residual loads
 };
 
 static constexpr int BM = 128;
@@ -54,8 +55,13 @@ __global__ __launch_bounds__(256) void k_conv_mfma_f32(const ConvArgs a)
     static_assert(WM * TM * 32 == BM && WN * TN * 32 == BN && WM * WN == 4, "tile shape");
     constexpr int AP = BM / 32;     // A rows per thread
     constexpr int BP = BN / 32;     // B rows per thread
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_ROW];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_ROW];
+    constexpr int A_STAGE = BM * LDS_ROW, B_STAGE = BN * LDS_ROW;
+    constexpr int SMEM = 2 * (A_STAGE + B_STAGE);
+    constexpr int C_ROW = BN + 4;   // epilogue staging tile, rows padded by one float4
+    static_assert(BM * C_ROW <= SMEM, "the C tile re-uses the operand buffers");
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    float* const As = smem;                 // [2][BM][LDS_ROW]
+    float* const Bs = smem + 2 * A_STAGE;   // [2][BN][LDS_ROW]
 
     // ---- XCD-aware tile assignment (bijective for any block count) ------------------------------
     const int nblocks = a.tiles_m * a.tiles_n;
@@ -108,9 +114,9 @@ __global__ __launch_bounds__(256) void k_conv_mfma_f32(const ConvArgs a)
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < AP; ++p) *reinterpret_cast<float4*>(&As[buf][(r0 + 32 * p) * LDS_ROW + kq * 4]) = ra[p];
+        for (int p = 0; p < AP; ++p) *reinterpret_cast<float4*>(&As[buf * A_STAGE + (r0 + 32 * p) * LDS_ROW + kq * 4]) = ra[p];
 #pragma unroll
-        for (int p = 0; p < BP; ++p) *reinterpret_cast<float4*>(&Bs[buf][(r0 + 32 * p) * LDS_ROW + kq * 4]) = rb[p];
+        for (int p = 0; p < BP; ++p) *reinterpret_cast<float4*>(&Bs[buf * B_STAGE + (r0 + 32 * p) * LDS_ROW + kq * 4]) = rb[p];
     };
 
     const int wave = t >> 6, lane = t & 63;
@@ -132,64 +138,115 @@ __global__ __launch_bounds__(256) void k_conv_mfma_f32(const ConvArgs a)
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < KT) load_tile(kt + 1);
-        const float* as = &As[buf][(wm * TM * 32 + l31) * LDS_ROW + kk * 4];
-        const float* bs = &Bs[buf][(wn * TN * 32 + l31) * LDS_ROW + kk * 4];
+        const float* as = &As[buf * A_STAGE + (wm * TM * 32 + l31) * LDS_ROW + kk * 4];
+        const float* bs = &Bs[buf * B_STAGE + (wn * TN * 32 + l31) * LDS_ROW + kk * 4];
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
-            float4 af[TM], bf[TN];
+            float af[TM][4], bf[TN][4];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDS_ROW + t4 * 8);
+            for (int i = 0; i < TM; ++i) {
+                const float4 v = *reinterpret_cast<const float4*>(as + i * 32 * LDS_ROW + t4 * 8);
+                af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+            }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_ROW + t4 * 8);
+            for (int j = 0; j < TN; ++j) {
+                const float4 v = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_ROW + t4 * 8);
+                bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
+            }
+            // consecutive MFMAs go to different accumulators (no back-to-back dependent issue)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                }
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][c], bf[j][c], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < KT) store_tile(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue -------------------------------------------------------------------------------
+    // ---- epilogue: accumulators → LDS → full-row 16-B stores ------------------------------------
+    // (the loop's final barrier guarantees nobody still reads the operand buffers)
+    float* const Cs = smem;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+                Cs[row * C_ROW + wn * TN * 32 + j * 32 + l31] = acc[i][j][e];
+            }
+    __syncthreads();
+
+    constexpr int TPR = BN / 4;       // threads per output row (one float4 each)
+    constexpr int RPP = 256 / TPR;    // rows per pass
+    const int c4 = t % TPR, rr = t / TPR;
+    const int n = n0 + c4 * 4;
+    if (n >= a.ncols) return;
     const bool dense_out = a.out_sB == (long)ohw * a.out_sP;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
-            const int m = m0 + row;
-            if (m >= a.M) continue;
+    const bool dense_res = a.res_sB == (long)ohw * a.res_sW && a.res_shift == 0;
+    const bool need_bp = !dense_out || a.out2 != nullptr || a.deconv2 || (a.res && !dense_res);
+    const bool need_yx = a.deconv2 || (a.res && a.res_shift);
+    if (a.vec_ok) {
+        const float4 sc = a.scale ? *reinterpret_cast<const float4*>(a.scale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 sh = a.shift ? *reinterpret_cast<const float4*>(a.shift + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int qd = a.deconv2 ? n / a.Cout : 0;
+        const int co = a.deconv2 ? n - qd * a.Cout : n;
+        for (int r = rr; r < BM; r += RPP) {
+            const int m = m0 + r;
+            if (m >= a.M) break;
             int b = 0, pix = m, oh = 0, ow = 0;
-            const bool need_bp = !dense_out || a.out2 != nullptr || a.deconv2 || (a.res && a.res_shift);
-            if (need_bp || a.res) { b = m / ohw; pix = m - b * ohw; }
-            if (a.deconv2 || (a.res && a.res_shift)) { oh = pix / a.OW; ow = pix - oh * a.OW; }
-            const long o1 = dense_out ? (long)m * a.out_sP : (long)b * a.out_sB + (long)pix * a.out_sP;
+            if (need_bp) { b = m / ohw; pix = m - b * ohw; }
+            if (need_yx) { oh = pix / a.OW; ow = pix - oh * a.OW; }
+            float4 v = *reinterpret_cast<const float4*>(&Cs[r * C_ROW + c4 * 4]);
+            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+            if (a.res) {
+                long ro;
+                if (dense_res) ro = (long)m * a.res_sW;
+                else if (a.res_shift) ro = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
+                else ro = (long)b * a.res_sB + (long)pix * a.res_sW;
+                const float4 rv = *reinterpret_cast<const float4*>(a.res + ro + n);
+                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            }
+            if (a.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            else if (a.act == ACT_SIGMOID) {
+                v.x = 1.0f / (1.0f + expf(-v.x)); v.y = 1.0f / (1.0f + expf(-v.y));
+                v.z = 1.0f / (1.0f + expf(-v.z)); v.w = 1.0f / (1.0f + expf(-v.w));
+            }
+            long o;
+            if (a.deconv2) o = (long)b * a.out_sB + (long)(2 * oh + (qd >> 1)) * a.out_sH + (long)(2 * ow + (qd & 1)) * a.out_sW + co;
+            else o = (dense_out ? (long)m * a.out_sP : (long)b * a.out_sB + (long)pix * a.out_sP) + n;
+            *reinterpret_cast<float4*>(a.out + o) = v;
+        }
+    } else {
+        for (int r = rr; r < BM; r += RPP) {
+            const int m = m0 + r;
+            if (m >= a.M) break;
+            const int b = m / ohw, pix = m - b * ohw;
+            const int oh = pix / a.OW, ow = pix - oh * a.OW;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * TN * 32 + j * 32 + l31;
-                if (n >= a.ncols) continue;
-                float v = acc[i][j][e];
-                v = v * (a.scale ? a.scale[n] : 1.0f) + (a.shift ? a.shift[n] : 0.0f);
+            for (int c = 0; c < 4; ++c) {
+                const int nn = n + c;
+                if (nn >= a.ncols) break;
+                float v = Cs[r * C_ROW + c4 * 4 + c];
+                v = v * (a.scale ? a.scale[nn] : 1.0f) + (a.shift ? a.shift[nn] : 0.0f);
                 if (a.res) {
                     long ro;
                     if (a.res_shift) ro = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
                     else ro = (long)b * a.res_sB + (long)pix * a.res_sW;
-                    v += a.res[ro + n];
+                    v += a.res[ro + nn];
                 }
                 if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
                 else if (a.act == ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
                 if (a.deconv2) {
-                    const int qd = n / a.Cout, co = n - qd * a.Cout;
+                    const int qd = nn / a.Cout, co = nn - qd * a.Cout;
                     a.out[(long)b * a.out_sB + (long)(2 * oh + (qd >> 1)) * a.out_sH + (long)(2 * ow + (qd & 1)) * a.out_sW + co] = v;
-                } else if (a.out2 && n >= a.n_split) {
-                    a.out2[(long)b * a.out2_sB + (long)pix * a.out2_sP + (n - a.n_split)] = v;
+                } else if (a.out2 && nn >= a.n_split) {
+                    a.out2[(long)b * a.out2_sB + (long)pix * a.out2_sP + (nn - a.n_split)] = v;
                 } else {
-                    a.out[o1 + n] = v;
+                    a.out[(long)b * a.out_sB + (long)pix * a.out_sP + nn] = v;
                 }
             }
         }
@@ -257,6 +314,11 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     a.res_shift = d.res_shift; a.act = d.act; a.n_split = d.n_split; a.deconv2 = d.deconv2;
     const int bn = conv_n_tile(a.ncols);
     MRCNN_REQUIRE(d.Npad % bn == 0 && d.Npad >= a.ncols, MRCNN_ERR_SHAPE, "conv: Npad %d incompatible with tile %d", d.Npad, bn);
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    a.vec_ok = a.ncols % 4 == 0 && d.out2 == nullptr && d.out_sP % 4 == 0 && d.out_sB % 4 == 0 && al16(d.out) &&
+               (!d.scale || al16(d.scale)) && (!d.shift || al16(d.shift)) &&
+               (!d.res || (d.res_sW % 4 == 0 && d.res_sH % 4 == 0 && d.res_sB % 4 == 0 && al16(d.res))) &&
+               (!d.deconv2 || (d.Cout % 4 == 0 && d.out_sH % 4 == 0 && d.out_sW % 4 == 0));
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = d.Npad / bn;
     const dim3 grid(a.tiles_m * a.tiles_n), block(256);
