@@ -91,33 +91,44 @@ __global__ __launch_bounds__(256) void k_conv_mfma_f32(const ConvArgs a)
         iw0[p] = ow * a.stride - a.padW;
         a_off[p] = (long)b * a.in_sB + (long)ih0[p] * a.in_sH + (long)iw0[p] * a.in_sW + kq * 4;
     }
-    const float* wrow[BP];
-#pragma unroll
-    for (int p = 0; p < BP; ++p) wrow[p] = a.wgt + (size_t)(n0 + r0 + 32 * p) * a.Ktot + kq * 4;
+    const float* const wbase = a.wgt + (size_t)(n0 + r0) * a.Ktot + kq * 4;
 
     const int cin_tiles = a.Cin / BK;
     const int KT = a.KH * a.KW * cin_tiles;
 
-    float4 ra[AP], rb[BP];
+    // Register staging of the next K tile, in NAMED registers: with `float4 rb[BP]` (lambda or
+    // not) hipcc (ROCm 7.2) left the array in scratch memory for the 128-wide variant, which put a
+    // vmcnt(0) + scratch round trip between the global loads and the MFMAs and serialised the
+    // pipeline (MFMA pipe busy 64 %).
+    static_assert(AP == 4 && BP <= 4, "staging registers are spelled out for 4 A rows / <= 4 B rows per thread");
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
     int kh = 0, kw = 0, ct = 0;      // position of the NEXT tile to load
-    auto load_tile = [&](int kt) {
-        const long tap_off = (long)kh * a.in_sH + (long)kw * a.in_sW + ct * BK;
-#pragma unroll
-        for (int p = 0; p < AP; ++p) {
-            const int ih = ih0[p] + kh, iw = iw0[p] + kw;
-            const bool ok = a_ok[p] && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-            ra[p] = ok ? *reinterpret_cast<const float4*>(a.in + a_off[p] + tap_off) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int p = 0; p < BP; ++p) rb[p] = *reinterpret_cast<const float4*>(wrow[p] + (size_t)kt * BK);
-        if (++ct == cin_tiles) { ct = 0; if (++kw == a.KW) { kw = 0; ++kh; } }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < AP; ++p) *reinterpret_cast<float4*>(&As[buf * A_STAGE + (r0 + 32 * p) * LDS_ROW + kq * 4]) = ra[p];
-#pragma unroll
-        for (int p = 0; p < BP; ++p) *reinterpret_cast<float4*>(&Bs[buf * B_STAGE + (r0 + 32 * p) * LDS_ROW + kq * 4]) = rb[p];
-    };
+#define MRCNN_LD_A(P)                                                                                          \
+    {                                                                                                          \
+        const int ih = ih0[P] + kh, iw = iw0[P] + kw;                                                          \
+        const bool ok = a_ok[P] && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;               \
+        ra##P = ok ? *reinterpret_cast<const float4*>(a.in + a_off[P] + tap_off) : make_float4(0.f, 0.f, 0.f, 0.f); \
+    }
+#define MRCNN_LD_B(P) \
+    if constexpr (BP > P) rb##P = *reinterpret_cast<const float4*>(wbase + (size_t)(32 * P) * a.Ktot + (size_t)kt_next * BK);
+#define MRCNN_LOAD_TILE(KT_)                                                                                   \
+    {                                                                                                          \
+        const long tap_off = (long)kh * a.in_sH + (long)kw * a.in_sW + ct * BK;                                \
+        const int kt_next = (KT_);                                                                             \
+        MRCNN_LD_A(0) MRCNN_LD_A(1) MRCNN_LD_A(2) MRCNN_LD_A(3)                                                \
+        MRCNN_LD_B(0) MRCNN_LD_B(1) MRCNN_LD_B(2) MRCNN_LD_B(3)                                                \
+        if (++ct == cin_tiles) { ct = 0; if (++kw == a.KW) { kw = 0; ++kh; } }                                 \
+    }
+#define MRCNN_ST_A(P) *reinterpret_cast<float4*>(sa + (32 * P) * LDS_ROW) = ra##P;
+#define MRCNN_ST_B(P) if constexpr (BP > P) *reinterpret_cast<float4*>(sb + (32 * P) * LDS_ROW) = rb##P;
+#define MRCNN_STORE_TILE(BUF_)                                                                                 \
+    {                                                                                                          \
+        float* const sa = &As[(BUF_) * A_STAGE + r0 * LDS_ROW + kq * 4];                                       \
+        float* const sb = &Bs[(BUF_) * B_STAGE + r0 * LDS_ROW + kq * 4];                                       \
+        MRCNN_ST_A(0) MRCNN_ST_A(1) MRCNN_ST_A(2) MRCNN_ST_A(3)                                                \
+        MRCNN_ST_B(0) MRCNN_ST_B(1) MRCNN_ST_B(2) MRCNN_ST_B(3)                                                \
+    }
 
     const int wave = t >> 6, lane = t & 63;
     const int wm = wave / WN, wn = wave - wm * WN;
@@ -131,13 +142,13 @@ __global__ __launch_bounds__(256) void k_conv_mfma_f32(const ConvArgs a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    load_tile(0);
-    store_tile(0);
+    MRCNN_LOAD_TILE(0)
+    MRCNN_STORE_TILE(0)
     __syncthreads();
 
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < KT) load_tile(kt + 1);
+        if (kt + 1 < KT) MRCNN_LOAD_TILE(kt + 1)
         const float* as = &As[buf * A_STAGE + (wm * TM * 32 + l31) * LDS_ROW + kk * 4];
         const float* bs = &Bs[buf * B_STAGE + (wn * TN * 32 + l31) * LDS_ROW + kk * 4];
 #pragma unroll
@@ -162,10 +173,16 @@ __global__ __launch_bounds__(256) void k_conv_mfma_f32(const ConvArgs a)
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][c], bf[j][c], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < KT) store_tile(buf ^ 1);
+        if (kt + 1 < KT) MRCNN_STORE_TILE(buf ^ 1)
         __syncthreads();
     }
 
+#undef MRCNN_LOAD_TILE
+#undef MRCNN_STORE_TILE
+#undef MRCNN_LD_A
+#undef MRCNN_LD_B
+#undef MRCNN_ST_A
+#undef MRCNN_ST_B
     // ---- epilogue: accumulators → LDS → full-row 16-B stores ------------------------------------
     // (the loop's final barrier guarantees nobody still reads the operand buffers)
     float* const Cs = smem;
