@@ -1,0 +1,194 @@
+"""Host-side logic and the C-ABI surface, without a GPU: config / artefact tooling, the MLMultiArray
+mirror, symbol export of libmaskrcnn_hip.so versus include/maskrcnn_hip.h, loud failure when no GPU
+is present, and the N > 1 sharding + all-gather path on gloo (world_size 2 and 3)."""
+import importlib
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config_and_layer_params(pkg):
+    cfg = pkg.ModelConfig()
+    assert cfg.num_anchors() == 261888                       # A at 1024²
+    assert pkg.ModelConfig(input_image_shape=(1536, 1536, 3)).num_anchors() == 589248
+    p = cfg.proposal_layer_params()                          # keys of Conversion/task.py:25-35
+    assert p == {"bboxStdDev_count": 4, "bboxStdDev_0": 0.1, "bboxStdDev_1": 0.1, "bboxStdDev_2": 0.2,
+                 "bboxStdDev_3": 0.2, "preNMSMaxProposals": 6000, "maxProposals": 1000, "nmsIOUThreshold": 0.7}
+    d = cfg.detection_layer_params()                         # task.py:57-67
+    assert d["maxDetections"] == 100 and d["scoreThreshold"] == 0.7 and d["nmsIOUThreshold"] == 0.3
+    assert cfg.pyramid_params(7) == {"poolSize": 7, "imageWidth": 1024, "imageHeight": 1024}
+    c2 = pkg.ModelConfig.from_dict({"architecture": "resnet50", "input_image_shape": [512, 512, 3], "num_classes": 2,
+                                    "pre_nms_max_proposals": 12000, "max_proposals": 500, "ignored_key": 1})
+    assert (c2.architecture, c2.image_height, c2.num_classes, c2.pre_nms_max_proposals, c2.max_proposals) == \
+        ("resnet50", 512, 2, 12000, 500)
+
+
+def test_anchors_bin_layout(pkg, anchors_mod, tmp_path):
+    cfg = pkg.ModelConfig(input_image_shape=(128, 128, 3))
+    p = str(tmp_path / "anchors.bin")
+    a = anchors_mod.write_anchors_bin(p, cfg)
+    assert os.path.getsize(p) == a.shape[0] * 16             # A×4 float32 (task.py:176)
+    b = anchors_mod.read_anchors_bin(p, cfg.num_anchors())
+    np.testing.assert_array_equal(a, b)
+    # first P2 anchor: centre (0,0), scale 32, ratio 0.5 → h = 32/sqrt(.5), w = 32*sqrt(.5); normalised by (127)
+    h, w = 32 / np.sqrt(0.5), 32 * np.sqrt(0.5)
+    want = (np.array([-h / 2, -w / 2, h / 2, w / 2]) - [0, 0, 1, 1]) / 127.0
+    np.testing.assert_allclose(a[0], want.astype(np.float32), rtol=0, atol=1e-7)
+    # level-major: the last anchors belong to P6 (scale 512)
+    assert (a[-1, 2] - a[-1, 0]) > (a[0, 2] - a[0, 0]) * 8
+    with open(p, "ab") as f:
+        f.write(b"\0\0\0")
+    with pytest.raises(ValueError):
+        anchors_mod.read_anchors_bin(p)
+
+
+def test_mrcw_roundtrip_and_synthetic_models(pkg, weights_mod, tmp_path):
+    cfg = pkg.ModelConfig(architecture="resnet50", input_image_shape=(64, 64, 3), num_classes=5)
+    paths = weights_mod.save_synthetic_models(str(tmp_path), cfg, seed=3)
+    meta, t = weights_mod.read_mrcw(paths["MaskRCNN"])
+    assert meta["kind"] == "MaskRCNN" and meta["architecture"] == "resnet50" and meta["num_classes"] == 5
+    assert meta["ProposalLayer.preNMSMaxProposals"] == 6000 and meta["DetectionLayer.scoreThreshold"] == 0.7
+    assert t["conv1/kernel"].shape == (64, 3, 7, 7) and t["conv1/kernel"].dtype == np.float16
+    assert t["res4f_branch2b/kernel"].shape == (256, 256, 3, 3) and "res4g_branch2a/kernel" not in t
+    assert t["rpn_class_raw/kernel"].shape == (6, 512, 1, 1) and t["rpn_bbox_pred/kernel"].shape == (12, 512, 1, 1)
+    _, c = weights_mod.read_mrcw(paths["Classifier"])
+    assert c["mrcnn_class_conv1/kernel"].shape == (1024, 256, 7, 7) and c["mrcnn_bbox_fc/kernel"].shape == (20, 1024)
+    _, m = weights_mod.read_mrcw(paths["Mask"])
+    assert m["mrcnn_mask_deconv/kernel"].shape == (256, 256, 2, 2) and m["mrcnn_mask/kernel"].shape == (5, 256, 1, 1)
+    # determinism
+    meta2, t2 = weights_mod.synthetic_models(cfg, seed=3)["MaskRCNN"]
+    np.testing.assert_array_equal(t2["fpn_p2/kernel"], t["fpn_p2/kernel"])
+    n101 = len(weights_mod.trunk_layers(pkg.ModelConfig(architecture="resnet101")))
+    n50 = len(weights_mod.trunk_layers(cfg))
+    assert n101 - n50 == 17 * 3
+
+
+def test_mlmultiarray_shapes(pkg):
+    ML = pkg.MLMultiArray
+    a = ML(np.zeros((10, 4), np.float32))
+    assert a.shape == (10, 1, 4, 1, 1) and a.strides == (4, 4, 1, 1, 1)
+    b = ML(np.zeros((256, 8, 8), np.float32))
+    assert b.shape == (1, 1, 256, 8, 8) and b.strides[2] == 64
+    c = ML(np.zeros((3, 1, 256, 7, 7), np.float32))
+    assert c.strides[0] == 256 * 49
+    with pytest.raises(TypeError):
+        ML(np.zeros((4, 4), np.float64))
+
+
+def test_c_abi_exports_every_declared_symbol(pkg):
+    lib_mod = importlib.import_module("mask-rcnn-coreml_amd._lib")
+    if not os.path.exists(lib_mod.SO_PATH):
+        pytest.skip("libmaskrcnn_hip.so not built (run python __graft_entry__.py)")
+    hdr = open(os.path.join(ROOT, "include", "maskrcnn_hip.h")).read()
+    declared = sorted(set(re.findall(r"MRCNN_API\s+[\w\s\*]+?\b(mrcnn_\w+)\s*\(", hdr)))
+    assert len(declared) >= 25
+    L = lib_mod.lib()
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert sorted(lib_mod.EXPORTED_SYMBOLS) == declared
+    assert L.mrcnn_version().startswith(b"maskrcnn_hip")
+
+
+def test_no_cpu_fallback_without_gpu(pkg, tmp_path):
+    """On a box without a GPU every compute entry point fails loudly with MRCNN_ERR_HIP."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib_mod = importlib.import_module("mask-rcnn-coreml_amd._lib")
+    if not os.path.exists(lib_mod.SO_PATH):
+        pytest.skip("library not built")
+    with pytest.raises(lib_mod.MrcnnError) as e:
+        pkg.DetectionLayer({})
+    assert e.value.code == 3 and "no CPU fallback" in str(e.value)
+    models = importlib.import_module("mask-rcnn-coreml_amd.models")
+    with pytest.raises(lib_mod.MrcnnError) as e:
+        models.Classifier(str(tmp_path / "x.mrcw"))
+    assert e.value.code == 3
+    # host-only entry points work without a GPU
+    det = np.array([[0.1, 0.2, 0.5, 0.8, 3, 0.9], [0, 0, 0, 0, 0, 0]], np.float32)
+    d = pkg.Detection.detectionsFromFeatureValue(det, np.full((2, 28, 28), 0.5, np.float32))
+    assert len(d) == 1 and d[0].classId == 3 and d[0].mask[0, 0] == 191
+    assert abs(pkg.IOU((0, 0, 1, 1), (0.5, 0, 1, 1)) - 1 / 3) < 1e-6
+
+
+def test_oracle_and_product_do_not_mix():
+    """The product package never imports the oracle."""
+    pkg_dir = os.path.join(ROOT, "mask-rcnn-coreml_amd")
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "from oracle" not in txt and "import oracle" not in txt and "mrcnn_oracle" not in txt, f
+
+
+# ---------------------------------------------------------------------------------------------------
+# multi-rank path on gloo
+# ---------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_predict(images):
+    """Deterministic per-image function standing in for the GPU model (independent of the batch)."""
+    import torch
+    x = torch.as_tensor(images).to(torch.float32)
+    s = x.reshape(x.shape[0], -1).sum(1)
+    det = torch.stack([s + k for k in range(4 * 6)], 1).reshape(-1, 4, 6)
+    mask = torch.stack([s * 0.5 + k for k in range(4 * 9)], 1).reshape(-1, 4, 3, 3)
+    return det, mask
+
+
+def _rank_main(rank, world, port, global_batch, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    dmod = importlib.import_module("mask-rcnn-coreml_amd.dist")
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    imgs = torch.arange(global_batch * 2 * 2 * 3, dtype=torch.float32).reshape(global_batch, 2, 2, 3)
+    det, mask = dmod.predict_sharded(_fake_predict, imgs, 4, 3)
+    # equal-shard pre-allocated path (the bench's)
+    lo, hi = dmod.shard_bounds(world * 2, world, rank)
+    g = dmod.DetectionGather(2, 4, 3, world, "cpu")
+    d2, m2 = _fake_predict(imgs[:world * 2][lo:hi])
+    gd, gm = g.all_gather(d2, m2)
+    q.put((rank, det.numpy(), mask.numpy(), gd.numpy().copy(), gm.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,global_batch", [(2, 8), (3, 7)])
+def test_sharded_predict_gloo(world, global_batch):
+    import torch
+    import torch.multiprocessing as mp
+    dmod = importlib.import_module("mask-rcnn-coreml_amd.dist")
+    bounds = [dmod.shard_bounds(global_batch, world, r) for r in range(world)]
+    assert bounds[0][0] == 0 and bounds[-1][1] == global_batch
+    assert all(bounds[i][1] == bounds[i + 1][0] for i in range(world - 1))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, global_batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    imgs = torch.arange(global_batch * 2 * 2 * 3, dtype=torch.float32).reshape(global_batch, 2, 2, 3)
+    want_d, want_m = _fake_predict(imgs)
+    for rank, det, mask, gd, gm in res:
+        np.testing.assert_array_equal(det, want_d.numpy())          # every rank holds the whole batch, in order
+        np.testing.assert_array_equal(mask, want_m.numpy())
+        wd, wm = _fake_predict(imgs[:world * 2])
+        np.testing.assert_array_equal(gd, wd.numpy())
+        np.testing.assert_array_equal(gm, wm.numpy())
