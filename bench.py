@@ -140,7 +140,7 @@ def main():
                 out["roofline"] = {
                     "kernel": "k_conv_mfma_f32<128,2,2,2,2>", "bound": "mfma", "achieved": round(achieved, 2),
                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "traffic": None,
+                    "traffic": pmc_traffic(),
                     "launches_per_step": launches // args.steps,
                     "avg_launch_ms": round(ms / launches, 4),
                     "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
@@ -156,6 +156,18 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command
+    (profiles/r01_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md §HBM).  PMC collection cannot run inside the timed process, hence a committed value."""
+    p = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return round(float(json.load(f)["hbm_bytes_per_launch_corrected"]))
+    except Exception:
+        return None
 
 
 def cpu_baseline(model_dir, cfg, args):
