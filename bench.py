@@ -13,7 +13,7 @@ Weights are seeded synthetic weights of the exact architecture ("forced full loa
 100 detections per image, so no data-dependent stage idles); there is no network for checkpoints.
 
 Rank 0 prints ONE JSON line with, besides the contract fields:
-  roofline     — dominant kernel k_conv_mfma_f32<128,2,2,2,2> (fp32 MFMA implicit-GEMM conv): its
+  roofline     — dominant kernel k_conv_mfma_f32<128,1,2,4,2> (fp32 MFMA implicit-GEMM conv): its
                  ALGORITHMIC flops per launch ÷ its average launch duration, both measured live with HIP
                  events on the launching stream over the timed region; peak = 157.3 TFLOP/s (dense fp32 MFMA)
   cpu_baseline — the oracle (torch-CPU fp32 network + the C restatement of the custom layers) timed on this
@@ -138,7 +138,7 @@ def main():
             if launches:
                 achieved = flops / (ms * 1e-3) / 1e12
                 out["roofline"] = {
-                    "kernel": "k_conv_mfma_f32<128,2,2,2,2>", "bound": "mfma", "achieved": round(achieved, 2),
+                    "kernel": "k_conv_mfma_f32<128,1,2,4,2>", "bound": "mfma", "achieved": round(achieved, 2),
                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                     "traffic": pmc_traffic(),
                     "launches_per_step": launches // args.steps,

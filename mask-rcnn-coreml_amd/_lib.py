@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libmaskrcnn_hip.so")
+SO_PATH = os.environ.get("MRCNN_HIP_LIB") or os.path.join(_HERE, "libmaskrcnn_hip.so")   # override: A/B builds
 
 MRCNN_OK = 0
 F32, F64, F16, U8, I32 = 0, 1, 2, 3, 4

@@ -50,11 +50,14 @@ static constexpr int BK = 32;
 static constexpr int LDS_ROW = 36;
 
 template <int BN, int TM, int TN, int WM, int WN>
-__global__ __launch_bounds__(256) void k_conv_mfma_f32(const ConvArgs a)
+__global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_f32(const ConvArgs a)
 {
-    static_assert(WM * TM * 32 == BM && WN * TN * 32 == BN && WM * WN == 4, "tile shape");
-    constexpr int AP = BM / 32;     // A rows per thread
-    constexpr int BP = BN / 32;     // B rows per thread
+    static_assert(WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
+    constexpr int NT = WM * WN * 64;   // threads per block
+    constexpr int RPT = NT / 8;        // tile rows covered by one staging pass (8 threads × 16 B per row)
+    constexpr int AP = BM / RPT;       // A rows per thread
+    constexpr int BP = BN / RPT;       // B rows per thread
+    static_assert(AP >= 1 && BP >= 1, "tile too small for the thread count");
     constexpr int A_STAGE = BM * LDS_ROW, B_STAGE = BN * LDS_ROW;
     constexpr int SMEM = 2 * (A_STAGE + B_STAGE);
     constexpr int C_ROW = BN + 4;   // epilogue staging tile, rows padded by one float4
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma_f32(const ConvArgs a)
     const int ohw = a.OH * a.OW;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-        const int m = m0 + r0 + 32 * p;
+        const int m = m0 + r0 + RPT * p;
         a_ok[p] = m < a.M;
         const int mm = a_ok[p] ? m : 0;
         const int b = mm / ohw, rem = mm - b * ohw;
@@ -100,18 +103,18 @@ __global__ __launch_bounds__(256) void k_conv_mfma_f32(const ConvArgs a)
     // not) hipcc (ROCm 7.2) left the array in scratch memory for the 128-wide variant, which put a
     // vmcnt(0) + scratch round trip between the global loads and the MFMAs and serialised the
     // pipeline (MFMA pipe busy 64 %).
-    static_assert(AP == 4 && BP <= 4, "staging registers are spelled out for 4 A rows / <= 4 B rows per thread");
+    static_assert(AP <= 4 && BP <= 4, "staging registers are spelled out for <= 4 A rows / <= 4 B rows per thread");
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
     int kh = 0, kw = 0, ct = 0;      // position of the NEXT tile to load
 #define MRCNN_LD_A(P)                                                                                          \
-    {                                                                                                          \
+    if constexpr (AP > P) {                                                                                    \
         const int ih = ih0[P] + kh, iw = iw0[P] + kw;                                                          \
         const bool ok = a_ok[P] && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;               \
         ra##P = ok ? *reinterpret_cast<const float4*>(a.in + a_off[P] + tap_off) : make_float4(0.f, 0.f, 0.f, 0.f); \
     }
 #define MRCNN_LD_B(P) \
-    if constexpr (BP > P) rb##P = *reinterpret_cast<const float4*>(wbase + (size_t)(32 * P) * a.Ktot + (size_t)kt_next * BK);
+    if constexpr (BP > P) rb##P = *reinterpret_cast<const float4*>(wbase + (size_t)(RPT * P) * a.Ktot + (size_t)kt_next * BK);
 #define MRCNN_LOAD_TILE(KT_)                                                                                   \
     {                                                                                                          \
         const long tap_off = (long)kh * a.in_sH + (long)kw * a.in_sW + ct * BK;                                \
@@ -120,8 +123,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma_f32(const ConvArgs a)
         MRCNN_LD_B(0) MRCNN_LD_B(1) MRCNN_LD_B(2) MRCNN_LD_B(3)                                                \
         if (++ct == cin_tiles) { ct = 0; if (++kw == a.KW) { kw = 0; ++kh; } }                                 \
     }
-#define MRCNN_ST_A(P) *reinterpret_cast<float4*>(sa + (32 * P) * LDS_ROW) = ra##P;
-#define MRCNN_ST_B(P) if constexpr (BP > P) *reinterpret_cast<float4*>(sb + (32 * P) * LDS_ROW) = rb##P;
+#define MRCNN_ST_A(P) if constexpr (AP > P) *reinterpret_cast<float4*>(sa + (RPT * P) * LDS_ROW) = ra##P;
+#define MRCNN_ST_B(P) if constexpr (BP > P) *reinterpret_cast<float4*>(sb + (RPT * P) * LDS_ROW) = rb##P;
 #define MRCNN_STORE_TILE(BUF_)                                                                                 \
     {                                                                                                          \
         float* const sa = &As[(BUF_) * A_STAGE + r0 * LDS_ROW + kq * 4];                                       \
@@ -142,15 +145,37 @@ __global__ __launch_bounds__(256) void k_conv_mfma_f32(const ConvArgs a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+#ifndef MRCNN_EARLY_STORE
+#define MRCNN_EARLY_STORE 1
+#endif
+#ifndef MRCNN_SETPRIO
+#define MRCNN_SETPRIO 0
+#endif
+    // Pipeline: tile k+1 sits in registers while tile k is computed from LDS.  With EARLY_STORE the
+    // registers are written to the other LDS buffer at the TOP of step k (that buffer was last read in
+    // step k-1, which every wave left through the barrier) and immediately re-used for the global
+    // loads of tile k+2, so neither the vmcnt wait nor the ds_writes sit between the last MFMA of a
+    // step and its barrier.
     MRCNN_LOAD_TILE(0)
     MRCNN_STORE_TILE(0)
+#if MRCNN_EARLY_STORE
+    if (KT > 1) MRCNN_LOAD_TILE(1)
+#endif
     __syncthreads();
 
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
+#if MRCNN_EARLY_STORE
+        if (kt + 1 < KT) MRCNN_STORE_TILE(buf ^ 1)
+        if (kt + 2 < KT) MRCNN_LOAD_TILE(kt + 2)
+#else
         if (kt + 1 < KT) MRCNN_LOAD_TILE(kt + 1)
+#endif
         const float* as = &As[buf * A_STAGE + (wm * TM * 32 + l31) * LDS_ROW + kk * 4];
         const float* bs = &Bs[buf * B_STAGE + (wn * TN * 32 + l31) * LDS_ROW + kk * 4];
+#if MRCNN_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
             float af[TM][4], bf[TN][4];
@@ -173,7 +198,12 @@ __global__ __launch_bounds__(256) void k_conv_mfma_f32(const ConvArgs a)
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][c], bf[j][c], acc[i][j], 0, 0, 0);
         }
+#if MRCNN_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+#if !MRCNN_EARLY_STORE
         if (kt + 1 < KT) MRCNN_STORE_TILE(buf ^ 1)
+#endif
         __syncthreads();
     }
 
@@ -185,6 +215,46 @@ __global__ __launch_bounds__(256) void k_conv_mfma_f32(const ConvArgs a)
 #undef MRCNN_ST_B
     // ---- epilogue: accumulators → LDS → full-row 16-B stores ------------------------------------
     // (the loop's final barrier guarantees nobody still reads the operand buffers)
+    constexpr int TPR = BN / 4;       // threads per output row (one float4 each)
+    constexpr int RPP = NT / TPR;     // rows per pass
+    constexpr int NPASS = BM / RPP;
+    const int c4 = t % TPR, rr = t / TPR;
+    const int n = n0 + c4 * 4;
+    const bool col_ok = n < a.ncols;
+    const bool dense_out = a.out_sB == (long)ohw * a.out_sP;
+    const bool dense_res = a.res_sB == (long)ohw * a.res_sW && a.res_shift == 0;
+    const bool need_bp = !dense_out || a.out2 != nullptr || a.deconv2 || (a.res && !dense_res);
+    const bool need_yx = a.deconv2 || (a.res && a.res_shift);
+
+    // Residual / scale / shift are fetched BEFORE the accumulators are staged through LDS: `res` and
+    // `out` may alias as far as the compiler knows, so inside the store loop every residual load would
+    // wait behind the previous store (16 serialized HBM round trips per thread on the branch2c layers).
+    float4 rv[NPASS];
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.vec_ok && col_ok) {
+        if (a.scale) sc = *reinterpret_cast<const float4*>(a.scale + n);
+        if (a.shift) sh = *reinterpret_cast<const float4*>(a.shift + n);
+        if (a.res) {
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int m = m0 + rr + ps * RPP;
+                rv[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < a.M) {
+                    long ro;
+                    if (dense_res) ro = (long)m * a.res_sW;
+                    else {
+                        const int b = m / ohw, pix = m - b * ohw;
+                        if (a.res_shift) {
+                            const int oh = pix / a.OW, ow = pix - oh * a.OW;
+                            ro = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
+                        } else ro = (long)b * a.res_sB + (long)pix * a.res_sW;
+                    }
+                    rv[ps] = *reinterpret_cast<const float4*>(a.res + ro + n);
+                }
+            }
+        }
+    }
+
     float* const Cs = smem;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -197,21 +267,13 @@ __global__ __launch_bounds__(256) void k_conv_mfma_f32(const ConvArgs a)
             }
     __syncthreads();
 
-    constexpr int TPR = BN / 4;       // threads per output row (one float4 each)
-    constexpr int RPP = 256 / TPR;    // rows per pass
-    const int c4 = t % TPR, rr = t / TPR;
-    const int n = n0 + c4 * 4;
-    if (n >= a.ncols) return;
-    const bool dense_out = a.out_sB == (long)ohw * a.out_sP;
-    const bool dense_res = a.res_sB == (long)ohw * a.res_sW && a.res_shift == 0;
-    const bool need_bp = !dense_out || a.out2 != nullptr || a.deconv2 || (a.res && !dense_res);
-    const bool need_yx = a.deconv2 || (a.res && a.res_shift);
+    if (!col_ok) return;
     if (a.vec_ok) {
-        const float4 sc = a.scale ? *reinterpret_cast<const float4*>(a.scale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
-        const float4 sh = a.shift ? *reinterpret_cast<const float4*>(a.shift + n) : make_float4(0.f, 0.f, 0.f, 0.f);
         const int qd = a.deconv2 ? n / a.Cout : 0;
         const int co = a.deconv2 ? n - qd * a.Cout : n;
-        for (int r = rr; r < BM; r += RPP) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int r = rr + ps * RPP;
             const int m = m0 + r;
             if (m >= a.M) break;
             int b = 0, pix = m, oh = 0, ow = 0;
@@ -219,14 +281,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma_f32(const ConvArgs a)
             if (need_yx) { oh = pix / a.OW; ow = pix - oh * a.OW; }
             float4 v = *reinterpret_cast<const float4*>(&Cs[r * C_ROW + c4 * 4]);
             v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-            if (a.res) {
-                long ro;
-                if (dense_res) ro = (long)m * a.res_sW;
-                else if (a.res_shift) ro = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
-                else ro = (long)b * a.res_sB + (long)pix * a.res_sW;
-                const float4 rv = *reinterpret_cast<const float4*>(a.res + ro + n);
-                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-            }
+            if (a.res) { v.x += rv[ps].x; v.y += rv[ps].y; v.z += rv[ps].z; v.w += rv[ps].w; }
             if (a.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             else if (a.act == ACT_SIGMOID) {
                 v.x = 1.0f / (1.0f + expf(-v.x)); v.y = 1.0f / (1.0f + expf(-v.y));
@@ -329,21 +384,25 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     MRCNN_REQUIRE(M > 0 && M < (1L << 31) - BM, MRCNN_ERR_SHAPE, "conv: M out of range");
     a.M = (int)M;
     a.res_shift = d.res_shift; a.act = d.act; a.n_split = d.n_split; a.deconv2 = d.deconv2;
-    const int bn = conv_n_tile(a.ncols);
-    MRCNN_REQUIRE(d.Npad % bn == 0 && d.Npad >= a.ncols, MRCNN_ERR_SHAPE, "conv: Npad %d incompatible with tile %d", d.Npad, bn);
+    // Tile choice: the widest N tile the packed weights allow, narrowed while the grid would leave
+    // the chip under-filled (< 2 blocks per CU) — C5, the top FPN levels and the small RPN levels.
+    const int bn_max = conv_n_tile(a.ncols);
+    MRCNN_REQUIRE(d.Npad % bn_max == 0 && d.Npad >= a.ncols, MRCNN_ERR_SHAPE, "conv: Npad %d incompatible with tile %d", d.Npad, bn_max);
+    a.tiles_m = (a.M + BM - 1) / BM;
+    int bn = bn_max;
+    while (bn > 32 && (long)a.tiles_m * (d.Npad / bn) < 512) bn >>= 1;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     a.vec_ok = a.ncols % 4 == 0 && d.out2 == nullptr && d.out_sP % 4 == 0 && d.out_sB % 4 == 0 && al16(d.out) &&
                (!d.scale || al16(d.scale)) && (!d.shift || al16(d.shift)) &&
                (!d.res || (d.res_sW % 4 == 0 && d.res_sH % 4 == 0 && d.res_sB % 4 == 0 && al16(d.res))) &&
                (!d.deconv2 || (d.Cout % 4 == 0 && d.out_sH % 4 == 0 && d.out_sW % 4 == 0));
-    a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = d.Npad / bn;
-    const dim3 grid(a.tiles_m * a.tiles_n), block(256);
+    const dim3 grid(a.tiles_m * a.tiles_n);
     ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
     const int e0 = prof ? prof_event(prof, s) : 0;
-    if (bn == 128) hipLaunchKernelGGL((k_conv_mfma_f32<128, 2, 2, 2, 2>), grid, block, 0, s, a);
-    else if (bn == 64) hipLaunchKernelGGL((k_conv_mfma_f32<64, 2, 1, 2, 2>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_conv_mfma_f32<32, 1, 1, 4, 1>), grid, block, 0, s, a);
+    if (bn == 128) hipLaunchKernelGGL((k_conv_mfma_f32<128, 1, 2, 4, 2>), grid, dim3(512), 0, s, a);
+    else if (bn == 64) hipLaunchKernelGGL((k_conv_mfma_f32<64, 1, 1, 4, 2>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((k_conv_mfma_f32<32, 1, 1, 4, 1>), grid, dim3(256), 0, s, a);
     if (prof) {
         const int e1 = prof_event(prof, s);
         const double k = d.algo_k > 0 ? d.algo_k : a.Ktot;
