@@ -143,7 +143,9 @@ typedef struct mrcnn_model mrcnn_model;
  * config singleton at load time (like ProposalLayer.init, ProposalLayer.swift:68), and loaded ONCE
  * (the reference re-loads the sub-models on every evaluate, TimeDistributedClassifierLayer.swift:41 —
  * deliberately not reproduced).  max_batch sizes the activation arena (images per predict call).
- * compute_dtype: MRCNN_F32 (fp32 MFMA, fp32 activations).  */
+ * compute_dtype: MRCNN_F32 (exact-fp32 MFMA, fp32 activations — the default and the parity
+ * baseline) or MRCNN_F16 (fp16 activations and filters, fp32 accumulate, fp32 box path and outputs:
+ * BASELINE configs[3]). */
 MRCNN_API int mrcnn_model_load(int kind, const char* path, int max_batch, int compute_dtype,
                                mrcnn_model** out_model);
 MRCNN_API void mrcnn_model_destroy(mrcnn_model* model);
@@ -205,6 +207,9 @@ MRCNN_API int mrcnn_model_conv_profile_get(mrcnn_model* model, int tile, int64_t
  * --------------------------------------------------------------------------------------------- */
 MRCNN_API int mrcnn_bench_conv(int batch, int h, int w, int cin, int cout, int ksize, int stride,
                                int iters, float* avg_ms, double* flops);
+/* Same with an explicit element type (MRCNN_F32 | MRCNN_F16, fp32 accumulate). */
+MRCNN_API int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout, int ksize, int stride,
+                                     int iters, int dtype, float* avg_ms, double* flops);
 
 /* ---------------------------------------------------------------------------------------------
  * Result decoding — Detection.detectionsFromFeatureValue (Sources/Mask-RCNN-CoreML/

@@ -132,7 +132,7 @@ std::shared_ptr<Model> cached_model(int kind, const std::string& path, int min_c
     auto it = g_models.find(key);
     if (it != g_models.end() && it->second->max_batch >= min_cap) return it->second;
     auto m = std::make_shared<Model>();
-    m->load(kind, path, min_cap);
+    m->load(kind, path, min_cap, MRCNN_F32);
     g_models[key] = m;
     return m;
 }
@@ -271,11 +271,11 @@ struct PyramidLayerImpl : mrcnn_layer {
         const long row = (long)C * pool * pool, ostride = out[0].strides[0];
         MRCNN_REQUIRE(ostride >= row, MRCNN_ERR_SHAPE, "PyramidROIAlignLayer: output row stride too small");
         if (out[0].memspace == MRCNN_DEVICE) {
-            roi_align_forward(st.s, maps, C, 0, rois, 0, roi_stride, (int)n, 1, pool, img_w, img_h, (float*)out[0].data, 0, ostride);
+            roi_align_forward(st.s, maps, C, 0, rois, 0, roi_stride, (int)n, 1, pool, img_w, img_h, (float*)out[0].data, 0, ostride, MRCNN_F32);
             HIP_CHECK(hipStreamSynchronize(st.s));
         } else {
             to.alloc((size_t)(n > 0 ? n : 1) * row * 4);
-            roi_align_forward(st.s, maps, C, 0, rois, 0, roi_stride, (int)n, 1, pool, img_w, img_h, to.as<float>(), 0, row);
+            roi_align_forward(st.s, maps, C, 0, rois, 0, roi_stride, (int)n, 1, pool, img_w, img_h, to.as<float>(), 0, row, MRCNN_F32);
             HIP_CHECK(hipStreamSynchronize(st.s));
             unstage_rows(to.as<float>(), out[0].data, MRCNN_HOST, n, row, ostride);
         }
@@ -308,7 +308,7 @@ struct ClassifierLayerImpl : mrcnn_layer {
         const long row = (long)C * ph * pw;
         DevBuf ti;
         const float* chw = stage_rows(in[0].data, in[0].memspace, n, row, in[0].strides[0], ti);
-        nchw_to_nhwc_forward(st.s, chw, n, C, ph, pw, hd.stage_in);
+        nchw_to_nhwc_forward(st.s, chw, n, C, ph, pw, hd.stage_in, hd.dtype);
         hd.forward(st.s, hd.stage_in, (int)n, hd.cls6, 6);
         HIP_CHECK(hipStreamSynchronize(st.s));
         const long ostride = out[0].strides[2];           // :63
@@ -410,8 +410,8 @@ struct MaskLayerImpl : mrcnn_layer {
         ws.flags = ws_buf.as<int32_t>();
         ws.mapping = ws.flags + det_count;
         ws.kept = ws.mapping + det_count;
-        mask_valid_rows_forward(st.s, chw, 0, row, row, (int)D, 1, ws);          // removeZeros:true (:52)
-        nchw_to_nhwc_forward(st.s, chw, D, C, ph, pw, hd.stage_in);
+        mask_valid_rows_forward(st.s, chw, 0, row, row, (int)D, 1, ws, MRCNN_F32);          // removeZeros:true (:52)
+        nchw_to_nhwc_forward(st.s, chw, D, C, ph, pw, hd.stage_in, hd.dtype);
         hd.forward_features(st.s, hd.stage_in, (int)D);
         hd.forward_full(st.s, (int)D);
         nchw.alloc((size_t)D * hd.nc * HW * 4);
@@ -501,9 +501,9 @@ extern "C" int mrcnn_model_load(int kind, const char* path, int max_batch, int c
     return guarded([&] {
         MRCNN_REQUIRE(path && out_model, MRCNN_ERR_INVALID, "null argument");
         MRCNN_REQUIRE(kind >= 0 && kind <= 2, MRCNN_ERR_INVALID, "unknown model kind %d", kind);
-        MRCNN_REQUIRE(compute_dtype == MRCNN_F32, MRCNN_ERR_UNSUPPORTED, "compute dtype %d not available (fp32 MFMA only in this build)", compute_dtype);
+        MRCNN_REQUIRE(compute_dtype == MRCNN_F32 || compute_dtype == MRCNN_F16, MRCNN_ERR_UNSUPPORTED, "compute dtype %d not available (MRCNN_F32 or MRCNN_F16)", compute_dtype);
         std::unique_ptr<mrcnn_model> h(new mrcnn_model);
-        h->m.load(kind, path, max_batch);
+        h->m.load(kind, path, max_batch, compute_dtype);
         *out_model = h.release();
     });
 }
@@ -550,7 +550,7 @@ extern "C" int mrcnn_classifier_predict(mrcnn_model* model, const float* feature
             const int c = n - i0 < hd.cap ? n - i0 : hd.cap;
             DevBuf ti;
             const float* chw = stage_rows(feature_map + (size_t)i0 * row, memspace, c, row, row, ti);
-            nchw_to_nhwc_forward(s, chw, c, hd.C, hd.pool, hd.pool, hd.stage_in);
+            nchw_to_nhwc_forward(s, chw, c, hd.C, hd.pool, hd.pool, hd.stage_in, hd.dtype);
             hd.forward(s, hd.stage_in, c, nullptr, 0);
             HIP_CHECK(hipMemcpyAsync(probabilities + (size_t)i0 * hd.nc, hd.probs, (size_t)c * hd.nc * 4, back, s));
             HIP_CHECK(hipMemcpyAsync(bounding_boxes + (size_t)i0 * hd.nc * 4, hd.bbox, (size_t)c * hd.nc * 16, back, s));
@@ -573,7 +573,7 @@ extern "C" int mrcnn_mask_predict(mrcnn_model* model, const float* feature_map, 
             const int c = n - i0 < hd.cap ? n - i0 : hd.cap;
             DevBuf ti;
             const float* chw = stage_rows(feature_map + (size_t)i0 * row, memspace, c, row, row, ti);
-            nchw_to_nhwc_forward(s, chw, c, hd.C, hd.pool, hd.pool, hd.stage_in);
+            nchw_to_nhwc_forward(s, chw, c, hd.C, hd.pool, hd.pool, hd.stage_in, hd.dtype);
             hd.forward_features(s, hd.stage_in, c);
             hd.forward_full(s, c);
             float* dst = masks + (size_t)i0 * orow;
@@ -593,6 +593,7 @@ extern "C" int mrcnn_model_get_int(mrcnn_model* model, const char* key, int64_t*
         const std::string k = key;
         if (k == "num_classes") *value = m.nc;
         else if (k == "max_batch") *value = m.max_batch;
+        else if (k == "compute_dtype") *value = m.dtype;
         else if (m.kind != MRCNN_MODEL_MASKRCNN) *value = m.file.get_int(k);
         else if (k == "image_height") *value = m.H;
         else if (k == "image_width") *value = m.W;
@@ -657,35 +658,51 @@ extern "C" int mrcnn_model_conv_profile_get(mrcnn_model* model, int tile, int64_
 extern "C" int mrcnn_bench_conv(int batch, int h, int w, int cin, int cout, int ksize, int stride, int iters, float* avg_ms,
                                 double* flops)
 {
+    return mrcnn_bench_conv_dtype(batch, h, w, cin, cout, ksize, stride, iters, MRCNN_F32, avg_ms, flops);
+}
+
+extern "C" int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout, int ksize, int stride, int iters, int dtype,
+                                      float* avg_ms, double* flops)
+{
     return guarded([&] {
         require_gpu();
-        MRCNN_REQUIRE(avg_ms && flops && iters >= 1 && (ksize == 1 || ksize == 3) && cin % 32 == 0, MRCNN_ERR_INVALID, "bad bench_conv arguments");
+        MRCNN_REQUIRE(avg_ms && flops && iters >= 1 && (ksize == 1 || ksize == 3) && cin % 64 == 0, MRCNN_ERR_INVALID, "bad bench_conv arguments");
+        const size_t es = dtype == MRCNN_F16 ? 2 : 4;
         const int pad = ksize / 2;
         const int oh = (h + 2 * pad - ksize) / stride + 1, ow = (w + 2 * pad - ksize) / stride + 1;
         const int bn = conv_n_tile(cout), npad = (cout + bn - 1) / bn * bn;
         const size_t n_in = (size_t)batch * h * w * cin, n_w = (size_t)npad * ksize * ksize * cin, n_out = (size_t)batch * oh * ow * cout;
         std::mt19937 rng(7);
         std::uniform_real_distribution<float> U(-1.f, 1.f);
-        std::vector<float> hw(n_w), hs(npad, 1.f), hb(npad, 0.f);
-        for (auto& v : hw) v = U(rng) * 0.05f;
-        // the input is large: fill a 4 MiB random pattern and replicate it on the device
-        std::vector<float> hin(1 << 20);
-        for (auto& v : hin) v = U(rng);
-        DevBuf din(n_in * 4), dw(n_w * 4), ds(npad * 4), db(npad * 4), dout(n_out * 4);
-        for (size_t off = 0; off < n_in; off += hin.size()) {
-            const size_t c = n_in - off < hin.size() ? n_in - off : hin.size();
-            HIP_CHECK(hipMemcpy(din.as<float>() + off, hin.data(), c * 4, hipMemcpyHostToDevice));
+        std::vector<float> hs(npad, 1.f), hb(npad, 0.f);
+        // random operands in [-1,1) (weights scaled); for fp16 the bit patterns are generated directly
+        const size_t pat = 1 << 20;
+        std::vector<unsigned char> hin(pat * es), hw(n_w * es);
+        auto fill = [&](unsigned char* dst, size_t n, float scale) {
+            for (size_t i = 0; i < n; ++i) {
+                const float v = U(rng) * scale;
+                if (es == 4) memcpy(dst + i * 4, &v, 4);
+                else { const _Float16 hv = (_Float16)v; memcpy(dst + i * 2, &hv, 2); }
+            }
+        };
+        fill(hin.data(), pat, 1.f);
+        fill(hw.data(), n_w, 0.05f);
+        DevBuf din(n_in * es), dw(n_w * es), ds(npad * 4), db(npad * 4), dout(n_out * es);
+        for (size_t off = 0; off < n_in; off += pat) {
+            const size_t c = n_in - off < pat ? n_in - off : pat;
+            HIP_CHECK(hipMemcpy((char*)din.p + off * es, hin.data(), c * es, hipMemcpyHostToDevice));
         }
-        HIP_CHECK(hipMemcpy(dw.p, hw.data(), n_w * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dw.p, hw.data(), n_w * es, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(ds.p, hs.data(), npad * 4, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(db.p, hb.data(), npad * 4, hipMemcpyHostToDevice));
         ConvDesc d;
-        d.in = din.as<float>(); d.B = batch; d.H = h; d.W = w; d.Cin = cin;
+        d.dtype = dtype;
+        d.in = din.p; d.B = batch; d.H = h; d.W = w; d.Cin = cin;
         d.in_sW = cin; d.in_sH = (long)w * cin; d.in_sB = (long)h * w * cin;
-        d.wgt = dw.as<float>(); d.KH = d.KW = ksize; d.stride = stride; d.padH = d.padW = pad;
+        d.wgt = dw.p; d.KH = d.KW = ksize; d.stride = stride; d.padH = d.padW = pad;
         d.scale = ds.as<float>(); d.shift = db.as<float>();
         d.OH = oh; d.OW = ow; d.Cout = cout; d.Npad = npad;
-        d.out = dout.as<float>(); d.out_sP = cout; d.out_sB = (long)oh * ow * cout; d.act = ACT_RELU;
+        d.out = dout.p; d.out_sP = cout; d.out_sB = (long)oh * ow * cout; d.act = ACT_RELU;
         Stream st;
         hipEvent_t e0, e1;
         HIP_CHECK(hipEventCreate(&e0));

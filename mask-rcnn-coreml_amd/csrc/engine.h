@@ -36,12 +36,13 @@ struct MrcwFile {
 
 // ---- packed convolution weights on the device ----------------------------------------------------
 struct PackedConv {
-    DevBuf wgt, scale, shift;
+    DevBuf wgt, scale, shift;     // wgt in the compute dtype; scale/shift always fp32
     int Cin = 0, Cout = 0, KH = 1, KW = 1, Npad = 0;
+    int dtype = MRCNN_F32;
 };
 
-struct Tensor4 {   // dense NHWC activation
-    float* p = nullptr;
+struct Tensor4 {   // dense NHWC activation (element type = the model's compute dtype)
+    void* p = nullptr;
     int H = 0, W = 0, C = 0;
     long sB() const { return (long)H * W * C; }
 };
@@ -51,6 +52,7 @@ using Op = std::function<void(hipStream_t, int /*batch*/)>;
 struct Arena {
     char* base = nullptr;
     size_t off = 0;
+    void* alloc_e(size_t n_elems, int dtype) { return alloc_b(n_elems * (dtype == MRCNN_F16 ? 2 : 4)); }
     float* alloc_f(size_t n_floats)
     {
         size_t bytes = (n_floats * 4 + 255) / 256 * 256;
@@ -69,25 +71,27 @@ struct Arena {
 
 // Box head: Classifier.mlmodel (task.py:106-116) + TimeDistributedClassifierLayer post-processing.
 struct ClassifierHead {
-    int nc = 0, pool = 7, C = 256, cap = 0;
+    int nc = 0, pool = 7, C = 256, cap = 0, dtype = MRCNN_F32;
     PackedConv fc1, fc2, fc3;
     DevBuf arena;
-    float *h1 = nullptr, *h2 = nullptr, *lb = nullptr, *probs = nullptr, *bbox = nullptr, *stage_in = nullptr, *cls6 = nullptr;
-    void load(const MrcwFile& f, int capacity_rows);
-    // pooled: n rows of pool*pool*C floats in (h,w,c) order, contiguous.
-    void forward(hipStream_t s, const float* pooled_nhwc, int n, float* cls6_out, long cls6_stride);
+    void *h1 = nullptr, *h2 = nullptr, *stage_in = nullptr;           // compute dtype
+    float *lb = nullptr, *probs = nullptr, *bbox = nullptr, *cls6 = nullptr;
+    void load(const MrcwFile& f, int capacity_rows, int dtype);
+    // pooled: n rows of pool*pool*C elements in (h,w,c) order, contiguous, compute dtype.
+    void forward(hipStream_t s, const void* pooled_nhwc, int n, float* cls6_out, long cls6_stride);
 };
 
 // Mask head: Mask.mlmodel (task.py:94-104).
 struct MaskHead {
-    int nc = 0, pool = 14, C = 256, cap = 0;
+    int nc = 0, pool = 14, C = 256, cap = 0, dtype = MRCNN_F32;
     PackedConv conv[4], deconv, final_full;
-    DevBuf final_w, final_b;          // [nc][C], [nc] for the selected-class kernel
+    DevBuf final_w, final_b;          // [nc][C], [nc] fp32 for the selected-class kernel
     DevBuf arena;
-    float *t0 = nullptr, *t1 = nullptr, *feat = nullptr, *full = nullptr, *stage_in = nullptr;
-    void load(const MrcwFile& f, int capacity_rows);
+    void *t0 = nullptr, *t1 = nullptr, *feat = nullptr, *stage_in = nullptr;   // compute dtype
+    float* full = nullptr;
+    void load(const MrcwFile& f, int capacity_rows, int dtype);
     // pooled: n rows of 14*14*C NHWC → feat (n, 28*28, C) = ReLU(deconv)
-    void forward_features(hipStream_t s, const float* pooled_nhwc, int n);
+    void forward_features(hipStream_t s, const void* pooled_nhwc, int n);
     // feat → all-class sigmoid masks, NHWC (n, 784, nc) in `full`
     void forward_full(hipStream_t s, int n);
 };
@@ -106,6 +110,7 @@ struct StageTimer {
 struct Model {
     int kind = 0;
     int max_batch = 1;
+    int dtype = MRCNN_F32;      // compute dtype of activations / filters
     MrcwFile file;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -125,10 +130,12 @@ struct Model {
     // activations
     DevBuf arena;
     std::vector<Op> trunk_ops;
-    std::map<std::string, std::pair<float*, long>> taps;    // name → (base, per-image elements)
+    struct Tap { void* base; long per_image; int dtype; };
+    std::map<std::string, Tap> taps;    // name → (base, per-image elements, element type)
     uint8_t* d_rgb = nullptr;
-    float *rpn_logits = nullptr, *rpn_probs = nullptr, *rpn_deltas = nullptr, *rois = nullptr, *pooled = nullptr;
-    float *cls6 = nullptr, *detections = nullptr, *pooled_mask = nullptr, *mask_out = nullptr;
+    float *rpn_logits = nullptr, *rpn_probs = nullptr, *rpn_deltas = nullptr, *rois = nullptr;
+    float *cls6 = nullptr, *detections = nullptr, *mask_out = nullptr;
+    void *pooled = nullptr, *pooled_mask = nullptr;     // compute dtype
     Tensor4 P[4];
     ProposalWorkspace prop_ws;
     DetectionWorkspace det_ws;
@@ -137,15 +144,15 @@ struct Model {
     ConvProfile conv_profile;
 
     ~Model();
-    void load(int kind, const std::string& path, int max_batch);
+    void load(int kind, const std::string& path, int max_batch, int dtype);
     void build_maskrcnn();
     void predict(const uint8_t* rgb, int batch, int h, int w, int memspace, float* det, float* masks, bool sync);
     void read_tensor(const std::string& name, int image, float* dst, int64_t cap, int64_t* count);
 };
 
 // Helpers shared with api.hip
-PackedConv pack_conv_oihw(const MrcwFile& f, const std::string& conv, const std::string& bn);
-void run_conv_dense(hipStream_t s, const PackedConv& pc, const float* in, int B, int H, int W, float* out, int stride,
-                    int pad, int act, const float* res = nullptr);
+PackedConv pack_conv_oihw(const MrcwFile& f, const std::string& conv, const std::string& bn, int dtype);
+void run_conv_dense(hipStream_t s, const PackedConv& pc, const void* in, int B, int H, int W, void* out, int stride,
+                    int pad, int act, const void* res = nullptr, int out_f32 = 0);
 
 }  // namespace mrcnn

@@ -180,6 +180,40 @@ static void upload(DevBuf& d, const std::vector<float>& h)
     HIP_CHECK(hipMemcpy(d.p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
 }
 
+static uint16_t float_to_half(float f)   // round to nearest even
+{
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7FFFFFFFu;
+    if (x >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | (x > 0x7F800000u ? 0x200u : 0));
+    if (x >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);            // overflow → inf
+    if (x < 0x38800000u) {                                              // subnormal half / zero
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const int e = (int)(x >> 23);
+        uint32_t m = (x & 0x7FFFFFu) | 0x800000u;
+        const int shift = 126 - e;                                      // 14..24
+        const uint32_t half_m = m >> shift, rem = m & ((1u << shift) - 1), mid = 1u << (shift - 1);
+        uint32_t r = half_m;
+        if (rem > mid || (rem == mid && (half_m & 1))) ++r;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = ((x - 0x38000000u) >> 13);
+    const uint32_t rem = x & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1))) ++r;
+    return (uint16_t)(sign | r);
+}
+
+// filter weights in the compute dtype (the artefact stores fp16, so the fp16 path is lossless)
+static void upload_w(DevBuf& d, const std::vector<float>& h, int dtype)
+{
+    if (dtype != MRCNN_F16) { upload(d, h); return; }
+    std::vector<uint16_t> hh(h.size());
+    for (size_t i = 0; i < h.size(); ++i) hh[i] = float_to_half(h[i]);
+    d.alloc(hh.size() * 2);
+    HIP_CHECK(hipMemcpy(d.p, hh.data(), hh.size() * 2, hipMemcpyHostToDevice));
+}
+
 // scale/shift of conv(+bias)(+BN):  y = acc*scale + shift
 static void fold_bn(const MrcwFile& f, const std::string& conv, const std::string& bn, int Cout, int Npad,
                     std::vector<float>& scale, std::vector<float>& shift)
@@ -203,13 +237,14 @@ static void fold_bn(const MrcwFile& f, const std::string& conv, const std::strin
 }
 
 // kernel [O][I][KH][KW] (Core ML layout) → [Npad][KH][KW][I]
-PackedConv pack_conv_oihw(const MrcwFile& f, const std::string& conv, const std::string& bn)
+PackedConv pack_conv_oihw(const MrcwFile& f, const std::string& conv, const std::string& bn, int dtype)
 {
     const MrcwTensor& t = f.tensor(conv + "/kernel");
     MRCNN_REQUIRE(t.dims.size() == 4, MRCNN_ERR_IO, "%s/kernel is not 4-D", conv.c_str());
     const int O = t.dims[0], I = t.dims[1], KH = t.dims[2], KW = t.dims[3];
     const std::vector<float> k = f.floats(conv + "/kernel");
     PackedConv pc;
+    pc.dtype = dtype;
     pc.Cin = I; pc.Cout = O; pc.KH = KH; pc.KW = KW;
     const int bn_tile = conv_n_tile(O);
     pc.Npad = (O + bn_tile - 1) / bn_tile * bn_tile;
@@ -219,7 +254,7 @@ PackedConv pack_conv_oihw(const MrcwFile& f, const std::string& conv, const std:
             for (int y = 0; y < KH; ++y)
                 for (int x = 0; x < KW; ++x)
                     w[(((size_t)o * KH + y) * KW + x) * I + i] = k[(((size_t)o * I + i) * KH + y) * KW + x];
-    upload(pc.wgt, w);
+    upload_w(pc.wgt, w, dtype);
     std::vector<float> sc, sh;
     fold_bn(f, conv, bn, O, pc.Npad, sc, sh);
     upload(pc.scale, sc);
@@ -230,23 +265,26 @@ PackedConv pack_conv_oihw(const MrcwFile& f, const std::string& conv, const std:
 // conv1: 7×7 stride 2 on 3 channels.  The input is staged as zero-padded NHWC4, so one kernel row
 // (7 taps × 4 channels = 28 floats, padded to 32) is a contiguous 128-B run: taps = 7 (rows),
 // "Cin" = 32.  Packed [64][7][32] with k = kw*4 + ci.
-static PackedConv pack_conv1(const MrcwFile& f)
+static PackedConv pack_conv1(const MrcwFile& f, int dtype)
 {
     const MrcwTensor& t = f.tensor("conv1/kernel");
     MRCNN_REQUIRE(t.dims.size() == 4 && t.dims[1] == 3 && t.dims[2] == 7 && t.dims[3] == 7, MRCNN_ERR_IO, "conv1/kernel must be [O,3,7,7]");
     const int O = t.dims[0];
     const std::vector<float> k = f.floats("conv1/kernel");
     PackedConv pc;
-    pc.Cin = 32; pc.Cout = O; pc.KH = 7; pc.KW = 1;
+    pc.dtype = dtype;
+    const int px = dtype == MRCNN_F16 ? 8 : 4;      // channels per staged pixel (NHWC8 / NHWC4): 16 B either way
+    const int row = 8 * px;                         // one kernel row = 7 taps padded to 8 pixels = 128 B
+    pc.Cin = row; pc.Cout = O; pc.KH = 7; pc.KW = 1;
     const int bn_tile = conv_n_tile(O);
     pc.Npad = (O + bn_tile - 1) / bn_tile * bn_tile;
-    std::vector<float> w((size_t)pc.Npad * 7 * 32, 0.f);
+    std::vector<float> w((size_t)pc.Npad * 7 * row, 0.f);
     for (int o = 0; o < O; ++o)
         for (int ci = 0; ci < 3; ++ci)
             for (int y = 0; y < 7; ++y)
                 for (int x = 0; x < 7; ++x)
-                    w[((size_t)o * 7 + y) * 32 + x * 4 + ci] = k[(((size_t)o * 3 + ci) * 7 + y) * 7 + x];
-    upload(pc.wgt, w);
+                    w[((size_t)o * 7 + y) * row + x * px + ci] = k[(((size_t)o * 3 + ci) * 7 + y) * 7 + x];
+    upload_w(pc.wgt, w, dtype);
     std::vector<float> sc, sh;
     fold_bn(f, "conv1", "bn_conv1", O, pc.Npad, sc, sh);
     upload(pc.scale, sc);
@@ -255,9 +293,10 @@ static PackedConv pack_conv1(const MrcwFile& f)
 }
 
 // Several [O_i][I] inner-product / 1×1 kernels stacked along N (no BN).
-static PackedConv pack_stacked_1x1(const MrcwFile& f, const std::vector<std::string>& names)
+static PackedConv pack_stacked_1x1(const MrcwFile& f, const std::vector<std::string>& names, int dtype)
 {
     PackedConv pc;
+    pc.dtype = dtype;
     int O = 0, I = -1;
     for (auto& n : names) {
         const MrcwTensor& t = f.tensor(n + "/kernel");
@@ -278,20 +317,21 @@ static PackedConv pack_stacked_1x1(const MrcwFile& f, const std::vector<std::str
         for (size_t o = 0; o < b.size(); ++o) { sc[o0 + o] = 1.f; sh[o0 + o] = b[o]; }
         o0 += (int)b.size();
     }
-    upload(pc.wgt, w);
+    upload_w(pc.wgt, w, dtype);
     upload(pc.scale, sc);
     upload(pc.shift, sh);
     return pc;
 }
 
 // ConvTranspose 2×2 stride 2, kernel [I][O][2][2] → GEMM rows n = (dy*2+dx)*O + co.
-static PackedConv pack_deconv2(const MrcwFile& f, const std::string& name)
+static PackedConv pack_deconv2(const MrcwFile& f, const std::string& name, int dtype)
 {
     const MrcwTensor& t = f.tensor(name + "/kernel");
     MRCNN_REQUIRE(t.dims.size() == 4 && t.dims[2] == 2 && t.dims[3] == 2, MRCNN_ERR_IO, "%s/kernel must be [I,O,2,2]", name.c_str());
     const int I = t.dims[0], O = t.dims[1];
     const std::vector<float> k = f.floats(name + "/kernel"), b = f.floats(name + "/bias");
     PackedConv pc;
+    pc.dtype = dtype;
     pc.Cin = I; pc.Cout = O; pc.KH = pc.KW = 1;
     pc.Npad = 4 * O;
     MRCNN_REQUIRE(pc.Npad % conv_n_tile(pc.Npad) == 0, MRCNN_ERR_SHAPE, "%s: 4*O must be a multiple of the N tile", name.c_str());
@@ -301,20 +341,21 @@ static PackedConv pack_deconv2(const MrcwFile& f, const std::string& name)
             for (int i = 0; i < I; ++i) w[((size_t)qd * O + o) * I + i] = k[(((size_t)i * O + o) * 2 + (qd >> 1)) * 2 + (qd & 1)];
             sh[(size_t)qd * O + o] = b[o];
         }
-    upload(pc.wgt, w);
+    upload_w(pc.wgt, w, dtype);
     upload(pc.scale, sc);
     upload(pc.shift, sh);
     return pc;
 }
 
 // Dense NHWC conv helper (in: B×H×W×Cin, out: B×OH×OW×Cout).
-void run_conv_dense(hipStream_t s, const PackedConv& pc, const float* in, int B, int H, int W, float* out, int stride,
-                    int pad, int act, const float* res)
+void run_conv_dense(hipStream_t s, const PackedConv& pc, const void* in, int B, int H, int W, void* out, int stride,
+                    int pad, int act, const void* res, int out_f32)
 {
     ConvDesc d;
+    d.dtype = pc.dtype; d.out_f32 = out_f32;
     d.in = in; d.B = B; d.H = H; d.W = W; d.Cin = pc.Cin;
     d.in_sW = pc.Cin; d.in_sH = (long)W * pc.Cin; d.in_sB = (long)H * W * pc.Cin;
-    d.wgt = pc.wgt.as<float>(); d.KH = pc.KH; d.KW = pc.KW; d.stride = stride; d.padH = d.padW = pad;
+    d.wgt = pc.wgt.p; d.KH = pc.KH; d.KW = pc.KW; d.stride = stride; d.padH = d.padW = pad;
     d.scale = pc.scale.as<float>(); d.shift = pc.shift.as<float>();
     d.OH = (H + 2 * pad - pc.KH) / stride + 1;
     d.OW = (W + 2 * pad - pc.KW) / stride + 1;
@@ -328,40 +369,41 @@ void run_conv_dense(hipStream_t s, const PackedConv& pc, const float* in, int B,
 // ------------------------------------------------------------------------------------------------
 // Classifier head
 // ------------------------------------------------------------------------------------------------
-void ClassifierHead::load(const MrcwFile& f, int capacity_rows)
+void ClassifierHead::load(const MrcwFile& f, int capacity_rows, int dtype_)
 {
     nc = (int)f.get_int("num_classes");
     cap = capacity_rows;
+    dtype = dtype_;
     const MrcwTensor& k1 = f.tensor("mrcnn_class_conv1/kernel");
     MRCNN_REQUIRE(k1.dims.size() == 4, MRCNN_ERR_IO, "mrcnn_class_conv1/kernel must be 4-D");
     C = k1.dims[1]; pool = k1.dims[2];
-    fc1 = pack_conv_oihw(f, "mrcnn_class_conv1", "mrcnn_class_bn1");    // [1024][7][7][256] == rows of the NHWC pooled vector
+    fc1 = pack_conv_oihw(f, "mrcnn_class_conv1", "mrcnn_class_bn1", dtype);    // [1024][7][7][256] == rows of the NHWC pooled vector
     fc1.Cin = fc1.Cin * fc1.KH * fc1.KW; fc1.KH = fc1.KW = 1;           // as an inner product over K = 12544
-    fc2 = pack_conv_oihw(f, "mrcnn_class_conv2", "mrcnn_class_bn2");
-    fc3 = pack_stacked_1x1(f, {"mrcnn_class_logits", "mrcnn_bbox_fc"});
+    fc2 = pack_conv_oihw(f, "mrcnn_class_conv2", "mrcnn_class_bn2", dtype);
+    fc3 = pack_stacked_1x1(f, {"mrcnn_class_logits", "mrcnn_bbox_fc"}, dtype);
     MRCNN_REQUIRE(fc3.Cout == 5 * nc, MRCNN_ERR_IO, "classifier output size %d != 5*num_classes", fc3.Cout);
     Arena ar;
     for (int pass = 0; pass < 2; ++pass) {
         ar.off = 0;
-        h1 = ar.alloc_f((size_t)cap * fc1.Cout);
-        h2 = ar.alloc_f((size_t)cap * fc2.Cout);
+        h1 = ar.alloc_e((size_t)cap * fc1.Cout, dtype);
+        h2 = ar.alloc_e((size_t)cap * fc2.Cout, dtype);
         lb = ar.alloc_f((size_t)cap * fc3.Cout);
         probs = ar.alloc_f((size_t)cap * nc);
         bbox = ar.alloc_f((size_t)cap * nc * 4);
         cls6 = ar.alloc_f((size_t)cap * 6);
-        stage_in = ar.alloc_f((size_t)cap * pool * pool * C);
+        stage_in = ar.alloc_e((size_t)cap * pool * pool * C, dtype);
         if (pass == 0) { arena.alloc(ar.off); ar.base = arena.as<char>(); }
     }
 }
 
-void ClassifierHead::forward(hipStream_t s, const float* pooled_nhwc, int n, float* cls6_out, long cls6_stride)
+void ClassifierHead::forward(hipStream_t s, const void* pooled_nhwc, int n, float* cls6_out, long cls6_stride)
 {
     MRCNN_REQUIRE(n <= cap, MRCNN_ERR_SHAPE, "classifier head: %d rows exceed capacity %d", n, cap);
     if (n <= 0) return;
     // rows are "pixels" of a 1×n image
     run_conv_dense(s, fc1, pooled_nhwc, 1, 1, n, h1, 1, 0, ACT_RELU);
     run_conv_dense(s, fc2, h1, 1, 1, n, h2, 1, 0, ACT_RELU);
-    run_conv_dense(s, fc3, h2, 1, 1, n, lb, 1, 0, ACT_NONE);
+    run_conv_dense(s, fc3, h2, 1, 1, n, lb, 1, 0, ACT_NONE, nullptr, 1);
     softmax_rows_forward(s, lb, fc3.Cout, nc, n, probs);
     copy_columns_forward(s, lb, fc3.Cout, nc, 4 * nc, n, bbox);
     if (cls6_out) classifier_postprocess_forward(s, probs, bbox, nc, n, cls6_out, cls6_stride);
@@ -370,31 +412,32 @@ void ClassifierHead::forward(hipStream_t s, const float* pooled_nhwc, int n, flo
 // ------------------------------------------------------------------------------------------------
 // Mask head
 // ------------------------------------------------------------------------------------------------
-void MaskHead::load(const MrcwFile& f, int capacity_rows)
+void MaskHead::load(const MrcwFile& f, int capacity_rows, int dtype_)
 {
     nc = (int)f.get_int("num_classes");
     cap = capacity_rows;
+    dtype = dtype_;
     for (int i = 0; i < 4; ++i)
-        conv[i] = pack_conv_oihw(f, "mrcnn_mask_conv" + std::to_string(i + 1), "mrcnn_mask_bn" + std::to_string(i + 1));
+        conv[i] = pack_conv_oihw(f, "mrcnn_mask_conv" + std::to_string(i + 1), "mrcnn_mask_bn" + std::to_string(i + 1), dtype);
     C = conv[0].Cin;
-    deconv = pack_deconv2(f, "mrcnn_mask_deconv");
-    final_full = pack_conv_oihw(f, "mrcnn_mask", "");
+    deconv = pack_deconv2(f, "mrcnn_mask_deconv", dtype);
+    final_full = pack_conv_oihw(f, "mrcnn_mask", "", dtype);
     upload(final_w, f.floats("mrcnn_mask/kernel"));
     upload(final_b, f.floats("mrcnn_mask/bias"));
     const size_t hw = (size_t)pool * pool;
     Arena ar;
     for (int pass = 0; pass < 2; ++pass) {
         ar.off = 0;
-        t0 = ar.alloc_f((size_t)cap * hw * C);
-        t1 = ar.alloc_f((size_t)cap * hw * C);
-        feat = ar.alloc_f((size_t)cap * hw * 4 * deconv.Cout);
+        t0 = ar.alloc_e((size_t)cap * hw * C, dtype);
+        t1 = ar.alloc_e((size_t)cap * hw * C, dtype);
+        feat = ar.alloc_e((size_t)cap * hw * 4 * deconv.Cout, dtype);
         full = ar.alloc_f((size_t)cap * hw * 4 * nc);
-        stage_in = ar.alloc_f((size_t)cap * hw * C);
+        stage_in = ar.alloc_e((size_t)cap * hw * C, dtype);
         if (pass == 0) { arena.alloc(ar.off); ar.base = arena.as<char>(); }
     }
 }
 
-void MaskHead::forward_features(hipStream_t s, const float* pooled_nhwc, int n)
+void MaskHead::forward_features(hipStream_t s, const void* pooled_nhwc, int n)
 {
     MRCNN_REQUIRE(n <= cap, MRCNN_ERR_SHAPE, "mask head: %d rows exceed capacity %d", n, cap);
     if (n <= 0) return;
@@ -404,9 +447,10 @@ void MaskHead::forward_features(hipStream_t s, const float* pooled_nhwc, int n)
     run_conv_dense(s, conv[3], t0, n, pool, pool, t1, 1, 1, ACT_RELU);
     ConvDesc d;
     const int Co = deconv.Cout;
+    d.dtype = dtype;
     d.in = t1; d.B = n; d.H = pool; d.W = pool; d.Cin = deconv.Cin;
     d.in_sW = deconv.Cin; d.in_sH = (long)pool * deconv.Cin; d.in_sB = (long)pool * pool * deconv.Cin;
-    d.wgt = deconv.wgt.as<float>(); d.scale = deconv.scale.as<float>(); d.shift = deconv.shift.as<float>();
+    d.wgt = deconv.wgt.p; d.scale = deconv.scale.as<float>(); d.shift = deconv.shift.as<float>();
     d.OH = pool; d.OW = pool; d.Cout = Co; d.Npad = deconv.Npad;
     d.deconv2 = 1; d.act = ACT_RELU;
     d.out = feat; d.out_sW = Co; d.out_sH = (long)2 * pool * Co; d.out_sB = (long)4 * pool * pool * Co;
@@ -419,9 +463,10 @@ void MaskHead::forward_full(hipStream_t s, int n)
     if (n <= 0) return;
     ConvDesc d;
     const int P2 = 2 * pool;
+    d.dtype = dtype; d.out_f32 = 1;
     d.in = feat; d.B = n; d.H = P2; d.W = P2; d.Cin = final_full.Cin;
     d.in_sW = d.Cin; d.in_sH = (long)P2 * d.Cin; d.in_sB = (long)P2 * P2 * d.Cin;
-    d.wgt = final_full.wgt.as<float>(); d.scale = final_full.scale.as<float>(); d.shift = final_full.shift.as<float>();
+    d.wgt = final_full.wgt.p; d.scale = final_full.scale.as<float>(); d.shift = final_full.shift.as<float>();
     d.OH = P2; d.OW = P2; d.Cout = nc; d.Npad = final_full.Npad;
     d.act = ACT_SIGMOID;
     d.out = full; d.out_sP = nc; d.out_sB = (long)P2 * P2 * nc;
@@ -480,10 +525,11 @@ static void read_std(const MrcwFile& f, const std::string& prefix, float out[4])
         for (int i = 0; i < 4; ++i) out[i] = (float)f.get_double(prefix + "bboxStdDev_" + std::to_string(i), dflt[i]);
 }
 
-void Model::load(int kind_, const std::string& path, int max_batch_)
+void Model::load(int kind_, const std::string& path, int max_batch_, int dtype_)
 {
     require_gpu();
     kind = kind_;
+    dtype = dtype_;
     max_batch = max_batch_ > 0 ? max_batch_ : 1;
     file.load(path);
     const char* want = kind == MRCNN_MODEL_MASKRCNN ? "MaskRCNN" : kind == MRCNN_MODEL_CLASSIFIER ? "Classifier" : "Mask";
@@ -492,8 +538,8 @@ void Model::load(int kind_, const std::string& path, int max_batch_)
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     own_stream = true;
     nc = (int)file.get_int("num_classes");
-    if (kind == MRCNN_MODEL_CLASSIFIER) { cls_head.load(file, max_batch); return; }
-    if (kind == MRCNN_MODEL_MASK) { mask_head.load(file, max_batch); return; }
+    if (kind == MRCNN_MODEL_CLASSIFIER) { cls_head.load(file, max_batch, dtype); return; }
+    if (kind == MRCNN_MODEL_MASK) { mask_head.load(file, max_batch, dtype); return; }
     build_maskrcnn();
 }
 
@@ -552,16 +598,16 @@ void Model::build_maskrcnn()
     {
         MrcwFile cf; cf.load(cp);
         MRCNN_REQUIRE(cf.get_string("kind") == "Classifier", MRCNN_ERR_IO, "'%s' is not a Classifier artefact", cp);
-        cls_head.load(cf, max_batch * max_prop);
+        cls_head.load(cf, max_batch * max_prop, dtype);
         MRCNN_REQUIRE(cls_head.nc == nc, MRCNN_ERR_IO, "Classifier num_classes %d != %d", cls_head.nc, nc);
         MrcwFile mf; mf.load(mp);
         MRCNN_REQUIRE(mf.get_string("kind") == "Mask", MRCNN_ERR_IO, "'%s' is not a Mask artefact", mp);
-        mask_head.load(mf, max_batch * max_det);
+        mask_head.load(mf, max_batch * max_det, dtype);
         MRCNN_REQUIRE(mask_head.nc == nc, MRCNN_ERR_IO, "Mask num_classes %d != %d", mask_head.nc, nc);
     }
 
     // ---- trunk weights ----------------------------------------------------------------------------
-    convs["conv1"] = pack_conv1(f);
+    convs["conv1"] = pack_conv1(f, dtype);
     std::vector<std::vector<std::string>> blocks(6);
     {
         const int n4 = arch == "resnet101" ? 22 : 5;
@@ -574,12 +620,12 @@ void Model::build_maskrcnn()
     for (int st = 2; st <= 5; ++st)
         for (auto& b : blocks[st]) {
             const std::string p = std::to_string(st) + b;
-            for (const char* br : {"2a", "2b", "2c"}) convs["res" + p + "_branch" + br] = pack_conv_oihw(f, "res" + p + "_branch" + br, "bn" + p + "_branch" + br);
-            if (b == "a") convs["res" + p + "_branch1"] = pack_conv_oihw(f, "res" + p + "_branch1", "bn" + p + "_branch1");
+            for (const char* br : {"2a", "2b", "2c"}) convs["res" + p + "_branch" + br] = pack_conv_oihw(f, "res" + p + "_branch" + br, "bn" + p + "_branch" + br, dtype);
+            if (b == "a") convs["res" + p + "_branch1"] = pack_conv_oihw(f, "res" + p + "_branch1", "bn" + p + "_branch1", dtype);
         }
     for (const char* n : {"fpn_c5p5", "fpn_c4p4", "fpn_c3p3", "fpn_c2p2", "fpn_p2", "fpn_p3", "fpn_p4", "fpn_p5", "rpn_conv_shared"})
-        convs[n] = pack_conv_oihw(f, n, "");
-    convs["rpn_heads"] = pack_stacked_1x1(f, {"rpn_class_raw", "rpn_bbox_pred"});
+        convs[n] = pack_conv_oihw(f, n, "", dtype);
+    convs["rpn_heads"] = pack_stacked_1x1(f, {"rpn_class_raw", "rpn_bbox_pred"}, dtype);
     MRCNN_REQUIRE(convs["rpn_heads"].Cout == 6 * na, MRCNN_ERR_IO, "RPN head width %d != 6*anchors_per_location", convs["rpn_heads"].Cout);
 
     // ---- activation plan (pass 0 sizes the arena, pass 1 binds pointers and records the ops) ------
@@ -590,15 +636,17 @@ void Model::build_maskrcnn()
         trunk_ops.clear();
         taps.clear();
         const bool real = pass == 1;
-        auto T = [&](int h, int w, int c) { Tensor4 t; t.H = h; t.W = w; t.C = c; t.p = ar.alloc_f((size_t)Bm * h * w * c); return t; };
+        const int dt = dtype;
+        auto T = [&](int h, int w, int c) { Tensor4 t; t.H = h; t.W = w; t.C = c; t.p = ar.alloc_e((size_t)Bm * h * w * c, dt); return t; };
         auto add = [&](Op op) { if (real) trunk_ops.push_back(std::move(op)); };
         auto conv_op = [&](const std::string& name, const Tensor4& in, const Tensor4& out, int stride, int pad, int act,
                            const Tensor4* res, int res_shift) {
             const PackedConv* pc = &convs.at(name);
             ConvDesc d;
+            d.dtype = dt;
             d.in = in.p; d.H = in.H; d.W = in.W; d.Cin = pc->Cin;
             d.in_sW = in.C; d.in_sH = (long)in.W * in.C; d.in_sB = in.sB();
-            d.wgt = pc->wgt.as<float>(); d.KH = pc->KH; d.KW = pc->KW; d.stride = stride; d.padH = d.padW = pad;
+            d.wgt = pc->wgt.p; d.KH = pc->KH; d.KW = pc->KW; d.stride = stride; d.padH = d.padW = pad;
             d.scale = pc->scale.as<float>(); d.shift = pc->shift.as<float>();
             d.OH = out.H; d.OW = out.W; d.Cout = pc->Cout; d.Npad = pc->Npad;
             d.out = out.p; d.out_sP = out.C; d.out_sB = out.sB();
@@ -608,22 +656,25 @@ void Model::build_maskrcnn()
         };
 
         d_rgb = (uint8_t*)ar.alloc_b((size_t)Bm * H * W * 3);
-        // C1: zero-padded NHWC4 staging, 7×7/2 conv as 7 row-taps of 32 contiguous floats, 3×3/2 max pool
+        // C1: zero-padded NHWC4 (fp32) / NHWC8 (fp16) staging — 16 B per pixel either way — so the 7×7/2 conv
+        // is 7 row-taps of one contiguous 128-B run each; then the 3×3/2 max pool
         const int Hp = H + 6, Wp = W + 6;
-        float* x0 = ar.alloc_f((size_t)Bm * Hp * Wp * 4 + 64);
+        const int pxc = dt == MRCNN_F16 ? 8 : 4;
+        void* x0 = ar.alloc_b((size_t)Bm * Hp * Wp * 16 + 256);
         {
             const float m3[3] = {mean[0], mean[1], mean[2]};
             uint8_t* src = d_rgb;
             const int h = H, w = W;
-            add([=](hipStream_t s, int batch) { preprocess_forward(s, src, batch, h, w, 3, m3, x0); });
+            add([=](hipStream_t s, int batch) { preprocess_forward(s, src, batch, h, w, 3, m3, x0, dt); });
         }
         Tensor4 c1 = T(H / 2, W / 2, 64);
         {
             const PackedConv* pc = &convs.at("conv1");
             ConvDesc d;
-            d.in = x0; d.H = Hp; d.W = Wp; d.Cin = 32;
-            d.in_sW = 4; d.in_sH = (long)Wp * 4; d.in_sB = (long)Hp * Wp * 4;
-            d.wgt = pc->wgt.as<float>(); d.KH = 7; d.KW = 1; d.stride = 2; d.padH = d.padW = 0;
+            d.dtype = dt;
+            d.in = x0; d.H = Hp; d.W = Wp; d.Cin = 8 * pxc;
+            d.in_sW = pxc; d.in_sH = (long)Wp * pxc; d.in_sB = (long)Hp * Wp * pxc;
+            d.wgt = pc->wgt.p; d.KH = 7; d.KW = 1; d.stride = 2; d.padH = d.padW = 0;
             d.scale = pc->scale.as<float>(); d.shift = pc->shift.as<float>();
             d.OH = c1.H; d.OW = c1.W; d.Cout = pc->Cout; d.Npad = pc->Npad;
             d.out = c1.p; d.out_sP = c1.C; d.out_sB = c1.sB(); d.act = ACT_RELU;
@@ -633,7 +684,7 @@ void Model::build_maskrcnn()
         Tensor4 x = T(H / 4, W / 4, 64);
         {
             const Tensor4 i = c1, o = x;
-            add([i, o](hipStream_t s, int batch) { maxpool3x3s2_forward(s, i.p, batch, i.H, i.W, i.C, o.p, o.H, o.W); });
+            add([i, o, dt](hipStream_t s, int batch) { maxpool3x3s2_forward(s, i.p, batch, i.H, i.W, i.C, o.p, o.H, o.W, dt); });
         }
         Tensor4 Cf[6];
         const int f1s[6] = {0, 0, 64, 128, 256, 512}, f3s[6] = {0, 0, 256, 512, 1024, 2048};
@@ -670,33 +721,35 @@ void Model::build_maskrcnn()
         for (int l = 0; l < 4; ++l) {
             P[l] = T(Ls[l].H, Ls[l].W, 256);
             conv_op(pn[l], Ls[l], P[l], 1, 1, ACT_NONE, nullptr, 0);
-            taps[tn[l]] = {P[l].p, P[l].sB()};
+            taps[tn[l]] = {P[l].p, P[l].sB(), dt};
             MRCNN_REQUIRE(P[l].H == fh[l] && P[l].W == fw[l], MRCNN_ERR_SHAPE, "pyramid level %d shape mismatch", l + 2);
         }
         // RPN on P2..P6 (P6 = P5 sub-sampled by 2: read in place through doubled strides)
         rpn_logits = ar.alloc_f((size_t)Bm * A * 2);
         rpn_probs = ar.alloc_f((size_t)Bm * A * 2);
         rpn_deltas = ar.alloc_f((size_t)Bm * A * 4);
-        taps["rpn_probs"] = {rpn_probs, (long)A * 2};
-        taps["rpn_deltas"] = {rpn_deltas, (long)A * 4};
-        float* rpn_feat = ar.alloc_f((size_t)Bm * P[0].H * P[0].W * 512);
+        taps["rpn_probs"] = {rpn_probs, (long)A * 2, MRCNN_F32};
+        taps["rpn_deltas"] = {rpn_deltas, (long)A * 4, MRCNN_F32};
+        void* rpn_feat = ar.alloc_e((size_t)Bm * P[0].H * P[0].W * 512, dt);
         for (int l = 0; l < 5; ++l) {
             const Tensor4& src = P[l < 4 ? l : 3];
             const int sub = l < 4 ? 1 : 2;
             const PackedConv* pc = &convs.at("rpn_conv_shared");
             ConvDesc d;
+            d.dtype = dt;
             d.in = src.p; d.H = fh[l]; d.W = fw[l]; d.Cin = 256;
             d.in_sW = (long)sub * src.C; d.in_sH = (long)sub * src.W * src.C; d.in_sB = src.sB();
-            d.wgt = pc->wgt.as<float>(); d.KH = 3; d.KW = 3; d.stride = 1; d.padH = d.padW = 1;
+            d.wgt = pc->wgt.p; d.KH = 3; d.KW = 3; d.stride = 1; d.padH = d.padW = 1;
             d.scale = pc->scale.as<float>(); d.shift = pc->shift.as<float>();
             d.OH = fh[l]; d.OW = fw[l]; d.Cout = 512; d.Npad = pc->Npad;
             d.out = rpn_feat; d.out_sP = 512; d.out_sB = (long)fh[l] * fw[l] * 512; d.act = ACT_RELU;
             add([d](hipStream_t s, int batch) { ConvDesc x = d; x.B = batch; conv_forward(s, x); });
             const PackedConv* hc = &convs.at("rpn_heads");
             ConvDesc e;
+            e.dtype = dt; e.out_f32 = 1;      // the box path consumes fp32 (ProposalLayer.swift:108-109)
             e.in = rpn_feat; e.H = fh[l]; e.W = fw[l]; e.Cin = 512;
             e.in_sW = 512; e.in_sH = (long)fw[l] * 512; e.in_sB = (long)fh[l] * fw[l] * 512;
-            e.wgt = hc->wgt.as<float>(); e.scale = hc->scale.as<float>(); e.shift = hc->shift.as<float>();
+            e.wgt = hc->wgt.p; e.scale = hc->scale.as<float>(); e.shift = hc->shift.as<float>();
             e.OH = fh[l]; e.OW = fw[l]; e.Cout = hc->Cout; e.Npad = hc->Npad;
             e.out = rpn_logits + lvl_off[l] * 2; e.out_sP = 2 * na; e.out_sB = (long)A * 2;
             e.out2 = rpn_deltas + lvl_off[l] * 4; e.out2_sP = 4 * na; e.out2_sB = (long)A * 4; e.n_split = 2 * na;
@@ -707,17 +760,17 @@ void Model::build_maskrcnn()
             add([=](hipStream_t s, int batch) { softmax_pairs_forward(s, lg, pr, per * batch); });
         }
         rois = ar.alloc_f((size_t)Bm * max_prop * 4);
-        pooled = ar.alloc_f((size_t)Bm * max_prop * cls_pool * cls_pool * 256);
+        pooled = ar.alloc_e((size_t)Bm * max_prop * cls_pool * cls_pool * 256, dt);
         cls6 = ar.alloc_f((size_t)Bm * max_prop * 6);
         detections = ar.alloc_f((size_t)Bm * max_det * 6);
-        pooled_mask = ar.alloc_f((size_t)Bm * max_det * mask_pool * mask_pool * 256);
+        pooled_mask = ar.alloc_e((size_t)Bm * max_det * mask_pool * mask_pool * 256, dt);
         mask_out = ar.alloc_f((size_t)Bm * max_det * 4 * mask_pool * mask_pool);
-        taps["rois"] = {rois, (long)max_prop * 4};
-        taps["pooled"] = {pooled, (long)max_prop * cls_pool * cls_pool * 256};
-        taps["cls6"] = {cls6, (long)max_prop * 6};
-        taps["detections"] = {detections, (long)max_det * 6};
-        taps["pooled_mask"] = {pooled_mask, (long)max_det * mask_pool * mask_pool * 256};
-        taps["mask"] = {mask_out, (long)max_det * 4 * mask_pool * mask_pool};
+        taps["rois"] = {rois, (long)max_prop * 4, MRCNN_F32};
+        taps["pooled"] = {pooled, (long)max_prop * cls_pool * cls_pool * 256, dt};
+        taps["cls6"] = {cls6, (long)max_prop * 6, MRCNN_F32};
+        taps["detections"] = {detections, (long)max_det * 6, MRCNN_F32};
+        taps["pooled_mask"] = {pooled_mask, (long)max_det * mask_pool * mask_pool * 256, dt};
+        taps["mask"] = {mask_out, (long)max_det * 4 * mask_pool * mask_pool, MRCNN_F32};
         void* pws = ar.alloc_b(ProposalWorkspace::bytes(Bm, A, K, max_prop));
         void* dws = ar.alloc_b(DetectionWorkspace::bytes(Bm, max_prop, max_det));
         msel_ws.flags = (int32_t*)ar.alloc_b((size_t)Bm * max_det * 4);
@@ -729,8 +782,8 @@ void Model::build_maskrcnn()
         }
         if (pass == 0) { arena.alloc(ar.off); ar.base = arena.as<char>(); }
     }
-    taps["cls_probs"] = {cls_head.probs, (long)max_prop * nc};
-    taps["cls_bbox"] = {cls_head.bbox, (long)max_prop * nc * 4};
+    taps["cls_probs"] = {cls_head.probs, (long)max_prop * nc, MRCNN_F32};
+    taps["cls_bbox"] = {cls_head.bbox, (long)max_prop * nc * 4, MRCNN_F32};
 }
 
 void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, float* det_out, float* masks_out, bool sync)
@@ -756,7 +809,7 @@ void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, f
     for (int l = 0; l < 4; ++l) { maps.data[l] = P[l].p; maps.H[l] = P[l].H; maps.W[l] = P[l].W; maps.sB[l] = P[l].sB(); }
     const long prow = (long)cls_pool * cls_pool * 256;
     roi_align_forward(s, maps, 256, 1, rois, (long)max_prop * 4, 4, max_prop, batch, cls_pool, roi_img_w, roi_img_h, pooled,
-                      (long)max_prop * prow, prow);
+                      (long)max_prop * prow, prow, dtype);
     timer.mark(s, "PyramidROIAlign-Eval");
     // TimeDistributedClassifier
     cls_head.forward(s, pooled, batch * max_prop, cls6, 6);
@@ -769,15 +822,15 @@ void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, f
     // PyramidROIAlign (mask) on the detections' boxes
     const long mrow = (long)mask_pool * mask_pool * 256;
     roi_align_forward(s, maps, 256, 1, detections, (long)max_det * 6, 6, max_det, batch, mask_pool, roi_img_w, roi_img_h, pooled_mask,
-                      (long)max_det * mrow, mrow);
+                      (long)max_det * mrow, mrow, dtype);
     timer.mark(s, "PyramidROIAlign-Eval-Mask");
     // TimeDistributedMask
     const int HW = 4 * mask_pool * mask_pool;
-    mask_valid_rows_forward(s, pooled_mask, (long)max_det * mrow, mrow, mrow, max_det, batch, msel_ws);
+    mask_valid_rows_forward(s, pooled_mask, (long)max_det * mrow, mrow, mrow, max_det, batch, msel_ws, dtype);
     mask_head.forward_features(s, pooled_mask, batch * max_det);
     mask_select_forward(s, mask_head.feat, (long)max_det * HW * mask_head.deconv.Cout, HW, mask_head.deconv.Cout,
                         mask_head.final_w.as<float>(), mask_head.final_b.as<float>(), nc, detections, (long)max_det * 6, 6, max_det,
-                        batch, msel_ws, mask_out, (long)max_det * HW, HW);
+                        batch, msel_ws, mask_out, (long)max_det * HW, HW, dtype);
     timer.mark(s, "TimeDistributedMask-Eval");
     const hipMemcpyKind back = memspace == MRCNN_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     HIP_CHECK(hipMemcpyAsync(det_out, detections, (size_t)batch * max_det * 6 * 4, back, s));
@@ -822,10 +875,16 @@ void Model::read_tensor(const std::string& name, int image, float* dst, int64_t 
     }
     auto it = taps.find(name);
     MRCNN_REQUIRE(it != taps.end(), MRCNN_ERR_INVALID, "unknown tensor '%s'", name.c_str());
-    const long n = it->second.second;
+    const long n = it->second.per_image;
     if (count) *count = n;
     MRCNN_REQUIRE(dst && cap >= n, MRCNN_ERR_SHAPE, "tensor '%s' needs %ld floats, buffer holds %lld", name.c_str(), n, (long long)cap);
-    HIP_CHECK(hipMemcpy(dst, it->second.first + (size_t)image * n, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (it->second.dtype == MRCNN_F16) {
+        std::vector<uint16_t> tmp((size_t)n);
+        HIP_CHECK(hipMemcpy(tmp.data(), static_cast<const uint16_t*>(it->second.base) + (size_t)image * n, (size_t)n * 2, hipMemcpyDeviceToHost));
+        for (long i = 0; i < n; ++i) dst[i] = half_to_float(tmp[(size_t)i]);
+    } else {
+        HIP_CHECK(hipMemcpy(dst, static_cast<const float*>(it->second.base) + (size_t)image * n, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
 }
 
 }  // namespace mrcnn

@@ -59,14 +59,15 @@ void detection_forward(hipStream_t s, const DetectionWorkspace& ws, const float*
 // ROIAlign (kernels_roialign.hip).  -ffp-contract=off.
 // ================================================================================================
 struct PyramidMaps {
-    const float* data[4];
+    const void* data[4];
     int H[4], W[4];
     long sB[4];          // batch stride in elements
 };
 // layout_nhwc = 1: maps are (B,H,W,C) and out is (B,n,P,P,C); 0: maps (B,C,H,W), out (B,n,C,P,P).
+// dtype: element type of the maps and of the output (MRCNN_F16 only with layout_nhwc = 1).
 void roi_align_forward(hipStream_t s, const PyramidMaps& maps, int C, int layout_nhwc, const float* rois,
                        long rois_sB, long roi_stride, int n_rois, int B, int pool, double image_w,
-                       double image_h, float* out, long out_sB, long out_row_stride);
+                       double image_h, void* out, long out_sB, long out_row_stride, int dtype);
 
 // ================================================================================================
 // Convolution family + element-wise helpers (kernels_conv.hip)
@@ -74,26 +75,29 @@ void roi_align_forward(hipStream_t s, const PyramidMaps& maps, int C, int layout
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
 
 struct ConvDesc {
+    // element type of activations / filters / residual: MRCNN_F32 or MRCNN_F16 (fp32 accumulate)
+    int dtype = MRCNN_F32;
+    int out_f32 = 0;             // with MRCNN_F16: store the output(s) as fp32
     // input NHWC (channel stride 1), arbitrary outer strides in elements
-    const float* in = nullptr;
+    const void* in = nullptr;
     int B = 0, H = 0, W = 0, Cin = 0;
     long in_sB = 0, in_sH = 0, in_sW = 0;
     // filter: packed [Npad][KH*KW*Cin], k contiguous (tap-major, channel-minor)
-    const float* wgt = nullptr;
+    const void* wgt = nullptr;
     int KH = 1, KW = 1, stride = 1, padH = 0, padW = 0;
     // epilogue: y = act(acc*scale[n] + shift[n] + residual)
     const float* scale = nullptr;
     const float* shift = nullptr;
-    const float* res = nullptr;
+    const void* res = nullptr;
     long res_sB = 0, res_sH = 0, res_sW = 0;
     int res_shift = 0;           // residual read at (oh >> res_shift, ow >> res_shift): nearest 2× upsample when 1
     int act = ACT_NONE;
     // output NHWC: address = b*out_sB + (oh*OW+ow)*out_sP + n  (rows of the image contiguous)
-    float* out = nullptr;
+    void* out = nullptr;
     int OH = 0, OW = 0, Cout = 0, Npad = 0;
     long out_sB = 0, out_sP = 0;
     // optional second output: columns >= n_split go to out2 (column n - n_split)
-    float* out2 = nullptr;
+    void* out2 = nullptr;
     int n_split = 0;
     long out2_sB = 0, out2_sP = 0;
     // transposed-conv 2x2 stride 2 scatter: column n = q*Cout + co, q = dy*2+dx → pixel (2oh+dy, 2ow+dx)
@@ -125,9 +129,9 @@ void conv_forward(hipStream_t s, const ConvDesc& d);
 
 // uint8 RGB (B,H,W,3) → fp32 (B, H+2*pad, W+2*pad, 4) minus mean, zero border, channel 3 = 0.
 void preprocess_forward(hipStream_t s, const uint8_t* rgb, int B, int H, int W, int pad, const float mean[3],
-                        float* out);
+                        void* out, int dtype);   // fp32 → NHWC4, fp16 → NHWC8
 // 3×3 stride-2 max pool, Keras 'same' (window clipped at the bottom/right edge). NHWC, C % 4 == 0.
-void maxpool3x3s2_forward(hipStream_t s, const float* in, int B, int H, int W, int C, float* out, int OH, int OW);
+void maxpool3x3s2_forward(hipStream_t s, const void* in, int B, int H, int W, int C, void* out, int OH, int OW, int dtype);
 // softmax over consecutive pairs: logits (n,2) → probs (n,2)
 void softmax_pairs_forward(hipStream_t s, const float* logits, float* probs, long n_pairs);
 // row softmax: logits rows of ld floats, first nc columns → probs (n, nc) contiguous
@@ -138,7 +142,7 @@ void copy_columns_forward(hipStream_t s, const float* src, long ld, int c0, int 
 void classifier_postprocess_forward(hipStream_t s, const float* probs, const float* bbox, int nc, long n,
                                     float* out, long out_row_stride);
 // layout changes between Core ML's CHW and the engine's HWC
-void nchw_to_nhwc_forward(hipStream_t s, const float* in, long n, int C, int H, int W, float* out);
+void nchw_to_nhwc_forward(hipStream_t s, const float* in, long n, int C, int H, int W, void* out, int dtype);
 void nhwc_to_nchw_forward(hipStream_t s, const float* in, long n, int C, int H, int W, float* out);
 // strided row gather: dst[i][0..len) = src[i*src_stride .. +len)
 void copy_rows_forward(hipStream_t s, const float* src, long src_stride, long n, long len, float* dst, long dst_stride);
@@ -150,13 +154,13 @@ struct MaskSelectWorkspace {
     int32_t* kept = nullptr;       // [B]
 };
 // flags/mapping of MultiArrayBatchProvider(removeZeros:true): pooled (B, D, row_len) contiguous rows.
-void mask_valid_rows_forward(hipStream_t s, const float* pooled, long pooled_sB, long row_stride, long row_len,
-                             int D, int B, const MaskSelectWorkspace& ws);
+void mask_valid_rows_forward(hipStream_t s, const void* pooled, long pooled_sB, long row_stride, long row_len,
+                             int D, int B, const MaskSelectWorkspace& ws, int dtype);
 // feat (B, D, HW, C) = ReLU(deconv) NHWC; w (nc, C), bias (nc); detections rows det_stride;
 // out rows out_stride (>= HW).  Writes exactly what TimeDistributedMaskLayer.swift:58-89 writes.
-void mask_select_forward(hipStream_t s, const float* feat, long feat_sB, int HW, int C, const float* w,
+void mask_select_forward(hipStream_t s, const void* feat, long feat_sB, int HW, int C, const float* w,
                          const float* bias, int nc, const float* det, long det_sB, long det_stride, int D, int B,
-                         const MaskSelectWorkspace& ws, float* out, long out_sB, long out_stride);
+                         const MaskSelectWorkspace& ws, float* out, long out_sB, long out_stride, int dtype);
 // Variant for precomputed per-class masks (n_kept-compacted or in-place), used by the stand-alone layer:
 // masks (B, D, nc, HW) in place (row r of the batch = detection r).
 void mask_select_from_full_forward(hipStream_t s, const float* masks, long masks_sB, int HW, int nc,

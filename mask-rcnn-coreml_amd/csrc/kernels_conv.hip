@@ -30,10 +30,12 @@
 namespace mrcnn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgs {
-    const float* in; const float* wgt; const float* scale; const float* shift; const float* res;
-    float* out; float* out2;
+    const void* in; const void* wgt; const float* scale; const float* shift; const void* res;
+    void* out; void* out2;
     long in_sB, in_sH, in_sW;
     long res_sB, res_sH, res_sW;
     long out_sB, out_sP, out_sH, out_sW;
@@ -42,29 +44,55 @@ struct ConvArgs {
     int OH, OW, Cout, ncols, Ktot, M;
     int res_shift, act, n_split, deconv2;
     int tiles_m, tiles_n;
-    int vec_ok;          // epilogue may use 16-B stores / residual loads
+    int vec_ok;          // epilogue may use vector stores / residual loads
+    int out_f32;         // store fp32 even when the activations are fp16 (RPN outputs, class logits, masks)
 };
 
 static constexpr int BM = 128;
-static constexpr int BK = 32;
-static constexpr int LDS_ROW = 36;
+static constexpr int ROW_B = 144;    // LDS row: 128 B of K (32 floats / 64 halfs) + 16 B pad
 
-template <int BN, int TM, int TN, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_f32(const ConvArgs a)
+template <typename T> struct Elem;
+template <> struct Elem<float> { static constexpr int EPV = 4; };        // elements per 16-B vector
+template <> struct Elem<_Float16> { static constexpr int EPV = 8; };
+
+template <typename T> __device__ __forceinline__ float4 load4(const T* p);
+template <> __device__ __forceinline__ float4 load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 load4<_Float16>(const _Float16* p)
+{
+    const f16x4 h = *reinterpret_cast<const f16x4*>(p);
+    return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, float4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+template <> __device__ __forceinline__ void store4<_Float16>(_Float16* p, float4 v)
+{
+    f16x4 h;
+    h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+    *reinterpret_cast<f16x4*>(p) = h;
+}
+
+// T = float   : v_mfma_f32_32x32x2_f32  (exact fp32, 157.3 TFLOP/s peak), K tile = 32
+// T = _Float16: v_mfma_f32_32x32x16_f16 (fp32 accumulate, ~2.5 PFLOP/s peak), K tile = 64
+template <typename T, int BN, int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma(const ConvArgs a)
 {
     static_assert(WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
+    constexpr int EPV = Elem<T>::EPV;
+    constexpr int BK = 8 * EPV;        // K elements per tile (128 bytes)
     constexpr int NT = WM * WN * 64;   // threads per block
     constexpr int RPT = NT / 8;        // tile rows covered by one staging pass (8 threads × 16 B per row)
     constexpr int AP = BM / RPT;       // A rows per thread
     constexpr int BP = BN / RPT;       // B rows per thread
     static_assert(AP >= 1 && BP >= 1, "tile too small for the thread count");
-    constexpr int A_STAGE = BM * LDS_ROW, B_STAGE = BN * LDS_ROW;
+    constexpr int A_STAGE = BM * ROW_B, B_STAGE = BN * ROW_B;     // bytes
     constexpr int SMEM = 2 * (A_STAGE + B_STAGE);
-    constexpr int C_ROW = BN + 4;   // epilogue staging tile, rows padded by one float4
-    static_assert(BM * C_ROW <= SMEM, "the C tile re-uses the operand buffers");
-    __shared__ __attribute__((aligned(16))) float smem[SMEM];
-    float* const As = smem;                 // [2][BM][LDS_ROW]
-    float* const Bs = smem + 2 * A_STAGE;   // [2][BN][LDS_ROW]
+    constexpr int C_ROW = BN + 4;      // epilogue staging tile (fp32), rows padded by one float4
+    static_assert(BM * C_ROW * 4 <= SMEM, "the C tile re-uses the operand buffers");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    unsigned char* const As = smem;                 // [2][BM][ROW_B]
+    unsigned char* const Bs = smem + 2 * A_STAGE;   // [2][BN][ROW_B]
+    const T* const in = static_cast<const T*>(a.in);
+    const T* const wgt = static_cast<const T*>(a.wgt);
 
     // ---- XCD-aware tile assignment (bijective for any block count) ------------------------------
     const int nblocks = a.tiles_m * a.tiles_n;
@@ -92,29 +120,28 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_f32(const ConvArgs a
         const int oh = rem / a.OW, ow = rem - oh * a.OW;
         ih0[p] = oh * a.stride - a.padH;
         iw0[p] = ow * a.stride - a.padW;
-        a_off[p] = (long)b * a.in_sB + (long)ih0[p] * a.in_sH + (long)iw0[p] * a.in_sW + kq * 4;
+        a_off[p] = (long)b * a.in_sB + (long)ih0[p] * a.in_sH + (long)iw0[p] * a.in_sW + kq * EPV;
     }
-    const float* const wbase = a.wgt + (size_t)(n0 + r0) * a.Ktot + kq * 4;
+    const T* const wbase = wgt + (size_t)(n0 + r0) * a.Ktot + kq * EPV;
 
     const int cin_tiles = a.Cin / BK;
     const int KT = a.KH * a.KW * cin_tiles;
 
-    // Register staging of the next K tile, in NAMED registers: with `float4 rb[BP]` (lambda or
-    // not) hipcc (ROCm 7.2) left the array in scratch memory for the 128-wide variant, which put a
-    // vmcnt(0) + scratch round trip between the global loads and the MFMAs and serialised the
-    // pipeline (MFMA pipe busy 64 %).
+    // Register staging of the next K tile, in NAMED registers: with an array (lambda or not) hipcc
+    // (ROCm 7.2) left the B half in scratch memory for the 128-wide variant, which put a vmcnt(0) +
+    // scratch round trip between the global loads and the MFMAs and serialised the pipeline.
     static_assert(AP <= 4 && BP <= 4, "staging registers are spelled out for <= 4 A rows / <= 4 B rows per thread");
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = make_uint4(0u, 0u, 0u, 0u);
     int kh = 0, kw = 0, ct = 0;      // position of the NEXT tile to load
 #define MRCNN_LD_A(P)                                                                                          \
     if constexpr (AP > P) {                                                                                    \
         const int ih = ih0[P] + kh, iw = iw0[P] + kw;                                                          \
         const bool ok = a_ok[P] && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;               \
-        ra##P = ok ? *reinterpret_cast<const float4*>(a.in + a_off[P] + tap_off) : make_float4(0.f, 0.f, 0.f, 0.f); \
+        ra##P = ok ? *reinterpret_cast<const uint4*>(in + a_off[P] + tap_off) : make_uint4(0u, 0u, 0u, 0u);    \
     }
 #define MRCNN_LD_B(P) \
-    if constexpr (BP > P) rb##P = *reinterpret_cast<const float4*>(wbase + (size_t)(RPT * P) * a.Ktot + (size_t)kt_next * BK);
+    if constexpr (BP > P) rb##P = *reinterpret_cast<const uint4*>(wbase + (size_t)(RPT * P) * a.Ktot + (size_t)kt_next * BK);
 #define MRCNN_LOAD_TILE(KT_)                                                                                   \
     {                                                                                                          \
         const long tap_off = (long)kh * a.in_sH + (long)kw * a.in_sW + ct * BK;                                \
@@ -123,12 +150,12 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_f32(const ConvArgs a
         MRCNN_LD_B(0) MRCNN_LD_B(1) MRCNN_LD_B(2) MRCNN_LD_B(3)                                                \
         if (++ct == cin_tiles) { ct = 0; if (++kw == a.KW) { kw = 0; ++kh; } }                                 \
     }
-#define MRCNN_ST_A(P) if constexpr (AP > P) *reinterpret_cast<float4*>(sa + (RPT * P) * LDS_ROW) = ra##P;
-#define MRCNN_ST_B(P) if constexpr (BP > P) *reinterpret_cast<float4*>(sb + (RPT * P) * LDS_ROW) = rb##P;
+#define MRCNN_ST_A(P) if constexpr (AP > P) *reinterpret_cast<uint4*>(sa + (RPT * P) * ROW_B) = ra##P;
+#define MRCNN_ST_B(P) if constexpr (BP > P) *reinterpret_cast<uint4*>(sb + (RPT * P) * ROW_B) = rb##P;
 #define MRCNN_STORE_TILE(BUF_)                                                                                 \
     {                                                                                                          \
-        float* const sa = &As[(BUF_) * A_STAGE + r0 * LDS_ROW + kq * 4];                                       \
-        float* const sb = &Bs[(BUF_) * B_STAGE + r0 * LDS_ROW + kq * 4];                                       \
+        unsigned char* const sa = As + (BUF_) * A_STAGE + r0 * ROW_B + kq * 16;                                \
+        unsigned char* const sb = Bs + (BUF_) * B_STAGE + r0 * ROW_B + kq * 16;                                \
         MRCNN_ST_A(0) MRCNN_ST_A(1) MRCNN_ST_A(2) MRCNN_ST_A(3)                                                \
         MRCNN_ST_B(0) MRCNN_ST_B(1) MRCNN_ST_B(2) MRCNN_ST_B(3)                                                \
     }
@@ -145,65 +172,53 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_f32(const ConvArgs a
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-#ifndef MRCNN_EARLY_STORE
-#define MRCNN_EARLY_STORE 1
-#endif
-#ifndef MRCNN_SETPRIO
-#define MRCNN_SETPRIO 0
-#endif
-    // Pipeline: tile k+1 sits in registers while tile k is computed from LDS.  With EARLY_STORE the
-    // registers are written to the other LDS buffer at the TOP of step k (that buffer was last read in
-    // step k-1, which every wave left through the barrier) and immediately re-used for the global
-    // loads of tile k+2, so neither the vmcnt wait nor the ds_writes sit between the last MFMA of a
-    // step and its barrier.
+    // Pipeline: tile k+1 sits in registers while tile k is computed from LDS.  The registers are
+    // written to the other LDS buffer at the TOP of step k (that buffer was last read in step k-1,
+    // which every wave left through the barrier) and immediately re-used for the global loads of
+    // tile k+2, so neither the vmcnt wait nor the ds_writes sit between the last MFMA of a step
+    // and its barrier.
     MRCNN_LOAD_TILE(0)
     MRCNN_STORE_TILE(0)
-#if MRCNN_EARLY_STORE
     if (KT > 1) MRCNN_LOAD_TILE(1)
-#endif
     __syncthreads();
 
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
-#if MRCNN_EARLY_STORE
         if (kt + 1 < KT) MRCNN_STORE_TILE(buf ^ 1)
         if (kt + 2 < KT) MRCNN_LOAD_TILE(kt + 2)
-#else
-        if (kt + 1 < KT) MRCNN_LOAD_TILE(kt + 1)
-#endif
-        const float* as = &As[buf * A_STAGE + (wm * TM * 32 + l31) * LDS_ROW + kk * 4];
-        const float* bs = &Bs[buf * B_STAGE + (wn * TN * 32 + l31) * LDS_ROW + kk * 4];
-#if MRCNN_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
+        const unsigned char* as = As + buf * A_STAGE + (wm * TM * 32 + l31) * ROW_B + kk * 16;
+        const unsigned char* bs = Bs + buf * B_STAGE + (wn * TN * 32 + l31) * ROW_B + kk * 16;
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
-            float af[TM][4], bf[TN][4];
+            uint4 av[TM], bv[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const float4 v = *reinterpret_cast<const float4*>(as + i * 32 * LDS_ROW + t4 * 8);
-                af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
-            }
+            for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const uint4*>(as + i * 32 * ROW_B + t4 * 32);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const float4 v = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_ROW + t4 * 8);
-                bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
-            }
-            // consecutive MFMAs go to different accumulators (no back-to-back dependent issue)
+            for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const uint4*>(bs + j * 32 * ROW_B + t4 * 32);
+            if constexpr (sizeof(T) == 4) {
+                // fp32: lane kk owns k = 8*t4 + 4*kk + {0..3} — the same permutation of K on both
+                // operands, so one ds_read_b128 feeds four MFMA steps; consecutive MFMAs go to
+                // different accumulators.
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const uint32_t au = c == 0 ? av[i].x : c == 1 ? av[i].y : c == 2 ? av[i].z : av[i].w;
+                            const uint32_t bu = c == 0 ? bv[j].x : c == 1 ? bv[j].y : c == 2 ? bv[j].z : bv[j].w;
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(au), __uint_as_float(bu), acc[i][j], 0, 0, 0);
+                        }
+            } else {
+                // fp16: lane kk owns k = 16*t4 + 8*kk + {0..7}: one ds_read_b128 = one MFMA operand
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][c], bf[j][c], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[i]), __builtin_bit_cast(f16x8, bv[j]),
+                                                                           acc[i][j], 0, 0, 0);
+            }
         }
-#if MRCNN_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-#if !MRCNN_EARLY_STORE
-        if (kt + 1 < KT) MRCNN_STORE_TILE(buf ^ 1)
-#endif
         __syncthreads();
     }
 
@@ -213,9 +228,9 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_f32(const ConvArgs a
 #undef MRCNN_LD_B
 #undef MRCNN_ST_A
 #undef MRCNN_ST_B
-    // ---- epilogue: accumulators → LDS → full-row 16-B stores ------------------------------------
+    // ---- epilogue: accumulators → LDS → full-row vector stores ----------------------------------
     // (the loop's final barrier guarantees nobody still reads the operand buffers)
-    constexpr int TPR = BN / 4;       // threads per output row (one float4 each)
+    constexpr int TPR = BN / 4;       // threads per output row (4 columns each)
     constexpr int RPP = NT / TPR;     // rows per pass
     constexpr int NPASS = BM / RPP;
     const int c4 = t % TPR, rr = t / TPR;
@@ -225,6 +240,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_f32(const ConvArgs a
     const bool dense_res = a.res_sB == (long)ohw * a.res_sW && a.res_shift == 0;
     const bool need_bp = !dense_out || a.out2 != nullptr || a.deconv2 || (a.res && !dense_res);
     const bool need_yx = a.deconv2 || (a.res && a.res_shift);
+    const T* const res = static_cast<const T*>(a.res);
 
     // Residual / scale / shift are fetched BEFORE the accumulators are staged through LDS: `res` and
     // `out` may alias as far as the compiler knows, so inside the store loop every residual load would
@@ -234,7 +250,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_f32(const ConvArgs a
     if (a.vec_ok && col_ok) {
         if (a.scale) sc = *reinterpret_cast<const float4*>(a.scale + n);
         if (a.shift) sh = *reinterpret_cast<const float4*>(a.shift + n);
-        if (a.res) {
+        if (res) {
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int m = m0 + rr + ps * RPP;
@@ -249,13 +265,13 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_f32(const ConvArgs a
                             ro = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
                         } else ro = (long)b * a.res_sB + (long)pix * a.res_sW;
                     }
-                    rv[ps] = *reinterpret_cast<const float4*>(a.res + ro + n);
+                    rv[ps] = load4<T>(res + ro + n);
                 }
             }
         }
     }
 
-    float* const Cs = smem;
+    float* const Cs = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -281,7 +297,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_f32(const ConvArgs a
             if (need_yx) { oh = pix / a.OW; ow = pix - oh * a.OW; }
             float4 v = *reinterpret_cast<const float4*>(&Cs[r * C_ROW + c4 * 4]);
             v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-            if (a.res) { v.x += rv[ps].x; v.y += rv[ps].y; v.z += rv[ps].z; v.w += rv[ps].w; }
+            if (res) { v.x += rv[ps].x; v.y += rv[ps].y; v.z += rv[ps].z; v.w += rv[ps].w; }
             if (a.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             else if (a.act == ACT_SIGMOID) {
                 v.x = 1.0f / (1.0f + expf(-v.x)); v.y = 1.0f / (1.0f + expf(-v.y));
@@ -290,7 +306,8 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_f32(const ConvArgs a
             long o;
             if (a.deconv2) o = (long)b * a.out_sB + (long)(2 * oh + (qd >> 1)) * a.out_sH + (long)(2 * ow + (qd & 1)) * a.out_sW + co;
             else o = (dense_out ? (long)m * a.out_sP : (long)b * a.out_sB + (long)pix * a.out_sP) + n;
-            *reinterpret_cast<float4*>(a.out + o) = v;
+            if (a.out_f32) store4<float>(static_cast<float*>(a.out) + o, v);
+            else store4<T>(static_cast<T*>(a.out) + o, v);
         }
     } else {
         for (int r = rr; r < BM; r += RPP) {
@@ -304,22 +321,27 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_f32(const ConvArgs a
                 if (nn >= a.ncols) break;
                 float v = Cs[r * C_ROW + c4 * 4 + c];
                 v = v * (a.scale ? a.scale[nn] : 1.0f) + (a.shift ? a.shift[nn] : 0.0f);
-                if (a.res) {
+                if (res) {
                     long ro;
                     if (a.res_shift) ro = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
                     else ro = (long)b * a.res_sB + (long)pix * a.res_sW;
-                    v += a.res[ro + nn];
+                    v += (float)res[ro + nn];
                 }
                 if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
                 else if (a.act == ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                long o;
+                void* dst = a.out;
                 if (a.deconv2) {
                     const int qd = nn / a.Cout, co = nn - qd * a.Cout;
-                    a.out[(long)b * a.out_sB + (long)(2 * oh + (qd >> 1)) * a.out_sH + (long)(2 * ow + (qd & 1)) * a.out_sW + co] = v;
+                    o = (long)b * a.out_sB + (long)(2 * oh + (qd >> 1)) * a.out_sH + (long)(2 * ow + (qd & 1)) * a.out_sW + co;
                 } else if (a.out2 && nn >= a.n_split) {
-                    a.out2[(long)b * a.out2_sB + (long)pix * a.out2_sP + (nn - a.n_split)] = v;
+                    dst = a.out2;
+                    o = (long)b * a.out2_sB + (long)pix * a.out2_sP + (nn - a.n_split);
                 } else {
-                    a.out[(long)b * a.out_sB + (long)pix * a.out_sP + nn] = v;
+                    o = (long)b * a.out_sB + (long)pix * a.out_sP + nn;
                 }
+                if (a.out_f32) static_cast<float*>(dst)[o] = v;
+                else static_cast<T*>(dst)[o] = (T)v;
             }
         }
     }
@@ -367,9 +389,21 @@ int conv_n_tile(int Cout)
     return 32;
 }
 
+template <typename T>
+static void conv_launch(hipStream_t s, const ConvArgs& a, int bn)
+{
+    const dim3 grid(a.tiles_m * a.tiles_n);
+    if (bn == 128) hipLaunchKernelGGL((k_conv_mfma<T, 128, 1, 2, 4, 2>), grid, dim3(512), 0, s, a);
+    else if (bn == 64) hipLaunchKernelGGL((k_conv_mfma<T, 64, 1, 1, 4, 2>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((k_conv_mfma<T, 32, 1, 1, 4, 1>), grid, dim3(256), 0, s, a);
+}
+
 void conv_forward(hipStream_t s, const ConvDesc& d)
 {
-    MRCNN_REQUIRE(d.Cin % BK == 0, MRCNN_ERR_SHAPE, "conv: Cin %d not a multiple of %d", d.Cin, BK);
+    const bool half = d.dtype == MRCNN_F16;
+    MRCNN_REQUIRE(d.dtype == MRCNN_F32 || half, MRCNN_ERR_UNSUPPORTED, "conv: dtype %d", d.dtype);
+    const int bk = half ? 64 : 32, es = half ? 2 : 4;
+    MRCNN_REQUIRE(d.Cin % bk == 0, MRCNN_ERR_SHAPE, "conv: Cin %d not a multiple of %d", d.Cin, bk);
     ConvArgs a;
     a.in = d.in; a.wgt = d.wgt; a.scale = d.scale; a.shift = d.shift; a.res = d.res; a.out = d.out; a.out2 = d.out2;
     a.in_sB = d.in_sB; a.in_sH = d.in_sH; a.in_sW = d.in_sW;
@@ -384,6 +418,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     MRCNN_REQUIRE(M > 0 && M < (1L << 31) - BM, MRCNN_ERR_SHAPE, "conv: M out of range");
     a.M = (int)M;
     a.res_shift = d.res_shift; a.act = d.act; a.n_split = d.n_split; a.deconv2 = d.deconv2;
+    a.out_f32 = (!half || d.out_f32) ? 1 : 0;
     // Tile choice: the widest N tile the packed weights allow, narrowed while the grid would leave
     // the chip under-filled (< 2 blocks per CU) — C5, the top FPN levels and the small RPN levels.
     const int bn_max = conv_n_tile(a.ncols);
@@ -391,18 +426,17 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     a.tiles_m = (a.M + BM - 1) / BM;
     int bn = bn_max;
     while (bn > 32 && (long)a.tiles_m * (d.Npad / bn) < 512) bn >>= 1;
-    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    a.vec_ok = a.ncols % 4 == 0 && d.out2 == nullptr && d.out_sP % 4 == 0 && d.out_sB % 4 == 0 && al16(d.out) &&
-               (!d.scale || al16(d.scale)) && (!d.shift || al16(d.shift)) &&
-               (!d.res || (d.res_sW % 4 == 0 && d.res_sH % 4 == 0 && d.res_sB % 4 == 0 && al16(d.res))) &&
+    const size_t out_es = a.out_f32 ? 4 : 2;
+    auto al = [](const void* p, size_t n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
+    a.vec_ok = a.ncols % 4 == 0 && d.out2 == nullptr && d.out_sP % 4 == 0 && d.out_sB % 4 == 0 && al(d.out, 4 * out_es) &&
+               (!d.scale || al(d.scale, 16)) && (!d.shift || al(d.shift, 16)) &&
+               (!d.res || (d.res_sW % 4 == 0 && d.res_sH % 4 == 0 && d.res_sB % 4 == 0 && al(d.res, 4 * (size_t)es))) &&
                (!d.deconv2 || (d.Cout % 4 == 0 && d.out_sH % 4 == 0 && d.out_sW % 4 == 0));
     a.tiles_n = d.Npad / bn;
-    const dim3 grid(a.tiles_m * a.tiles_n);
     ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
     const int e0 = prof ? prof_event(prof, s) : 0;
-    if (bn == 128) hipLaunchKernelGGL((k_conv_mfma_f32<128, 1, 2, 4, 2>), grid, dim3(512), 0, s, a);
-    else if (bn == 64) hipLaunchKernelGGL((k_conv_mfma_f32<64, 1, 1, 4, 2>), grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((k_conv_mfma_f32<32, 1, 1, 4, 1>), grid, dim3(256), 0, s, a);
+    if (half) conv_launch<_Float16>(s, a, bn);
+    else conv_launch<float>(s, a, bn);
     if (prof) {
         const int e1 = prof_event(prof, s);
         const double k = d.algo_k > 0 ? d.algo_k : a.Ktot;
@@ -414,8 +448,10 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
 // ================================================================================================
 // element-wise helpers
 // ================================================================================================
+// fp32: NHWC4 (16 B per pixel); fp16: NHWC8 (16 B per pixel) — either way one 16-B store per pixel
+template <typename T>
 __global__ __launch_bounds__(256) void k_preprocess(const uint8_t* __restrict__ rgb, int B, int H, int W, int pad,
-                                                    float mr, float mg, float mb, float* __restrict__ out)
+                                                    float mr, float mg, float mb, void* __restrict__ out)
 {
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     const long total = (long)B * Hp * Wp;
@@ -423,26 +459,35 @@ __global__ __launch_bounds__(256) void k_preprocess(const uint8_t* __restrict__ 
         const int x = (int)(e % Wp);
         const int y = (int)((e / Wp) % Hp);
         const int b = (int)(e / ((long)Wp * Hp));
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float r = 0.f, g = 0.f, bl = 0.f;
         const int sy = y - pad, sx = x - pad;
         if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) {
             const uint8_t* p = rgb + (((long)b * H + sy) * W + sx) * 3;
-            v.x = (float)p[0] - mr; v.y = (float)p[1] - mg; v.z = (float)p[2] - mb;
+            r = (float)p[0] - mr; g = (float)p[1] - mg; bl = (float)p[2] - mb;
         }
-        reinterpret_cast<float4*>(out)[e] = v;
+        if constexpr (sizeof(T) == 4) {
+            reinterpret_cast<float4*>(out)[e] = make_float4(r, g, bl, 0.f);
+        } else {
+            f16x8 h;
+            h[0] = (_Float16)r; h[1] = (_Float16)g; h[2] = (_Float16)bl;
+            h[3] = h[4] = h[5] = h[6] = h[7] = (_Float16)0.f;
+            reinterpret_cast<f16x8*>(out)[e] = h;
+        }
     }
 }
 
-void preprocess_forward(hipStream_t s, const uint8_t* rgb, int B, int H, int W, int pad, const float mean[3], float* out)
+void preprocess_forward(hipStream_t s, const uint8_t* rgb, int B, int H, int W, int pad, const float mean[3], void* out, int dtype)
 {
     const long total = (long)B * (H + 2 * pad) * (W + 2 * pad);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_preprocess, dim3(grid), dim3(256), 0, s, rgb, B, H, W, pad, mean[0], mean[1], mean[2], out);
+    if (dtype == MRCNN_F16) hipLaunchKernelGGL(k_preprocess<_Float16>, dim3(grid), dim3(256), 0, s, rgb, B, H, W, pad, mean[0], mean[1], mean[2], out);
+    else hipLaunchKernelGGL(k_preprocess<float>, dim3(grid), dim3(256), 0, s, rgb, B, H, W, pad, mean[0], mean[1], mean[2], out);
     HIP_CHECK(hipGetLastError());
 }
 
-__global__ __launch_bounds__(256) void k_maxpool3x3s2(const float* __restrict__ in, int B, int H, int W, int C4,
-                                                      float* __restrict__ out, int OH, int OW)
+template <typename T>
+__global__ __launch_bounds__(256) void k_maxpool3x3s2(const T* __restrict__ in, int B, int H, int W, int C4,
+                                                      T* __restrict__ out, int OH, int OW)
 {
     const long total = (long)B * OH * OW * C4;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
@@ -457,20 +502,22 @@ __global__ __launch_bounds__(256) void k_maxpool3x3s2(const float* __restrict__ 
             for (int dx = 0; dx < 3; ++dx) {
                 const int x = 2 * ox + dx;
                 if (x >= W) break;
-                const float4 v = reinterpret_cast<const float4*>(in)[(((long)b * H + y) * W + x) * C4 + c];
+                const float4 v = load4<T>(in + ((((long)b * H + y) * W + x) * C4 + c) * 4);
                 m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
             }
         }
-        reinterpret_cast<float4*>(out)[e] = m;
+        store4<T>(out + e * 4, m);
     }
 }
 
-void maxpool3x3s2_forward(hipStream_t s, const float* in, int B, int H, int W, int C, float* out, int OH, int OW)
+void maxpool3x3s2_forward(hipStream_t s, const void* in, int B, int H, int W, int C, void* out, int OH, int OW, int dtype)
 {
     MRCNN_REQUIRE(C % 4 == 0, MRCNN_ERR_SHAPE, "maxpool: C %% 4 != 0");
     const long total = (long)B * OH * OW * (C / 4);
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(k_maxpool3x3s2, dim3(grid), dim3(256), 0, s, in, B, H, W, C / 4, out, OH, OW);
+    if (dtype == MRCNN_F16)
+        hipLaunchKernelGGL(k_maxpool3x3s2<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)in, B, H, W, C / 4, (_Float16*)out, OH, OW);
+    else hipLaunchKernelGGL(k_maxpool3x3s2<float>, dim3(grid), dim3(256), 0, s, (const float*)in, B, H, W, C / 4, (float*)out, OH, OW);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -572,14 +619,15 @@ void classifier_postprocess_forward(hipStream_t s, const float* probs, const flo
     HIP_CHECK(hipGetLastError());
 }
 
-__global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float* __restrict__ in, long n, int C, int HW, float* __restrict__ out)
+template <typename T>
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float* __restrict__ in, long n, int C, int HW, T* __restrict__ out)
 {
     const long total = n * C * HW;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const int c = (int)(e % C);
         const int p = (int)((e / C) % HW);
         const long i = e / ((long)C * HW);
-        out[e] = in[(i * C + c) * HW + p];
+        out[e] = (T)in[(i * C + c) * HW + p];
     }
 }
 __global__ __launch_bounds__(256) void k_nhwc_to_nchw(const float* __restrict__ in, long n, int C, int HW, float* __restrict__ out)
@@ -592,12 +640,13 @@ __global__ __launch_bounds__(256) void k_nhwc_to_nchw(const float* __restrict__ 
         out[e] = in[(i * HW + p) * C + c];
     }
 }
-void nchw_to_nhwc_forward(hipStream_t s, const float* in, long n, int C, int H, int W, float* out)
+void nchw_to_nhwc_forward(hipStream_t s, const float* in, long n, int C, int H, int W, void* out, int dtype)
 {
     const long total = n * C * H * W;
     if (total <= 0) return;
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(grid), dim3(256), 0, s, in, n, C, H * W, out);
+    if (dtype == MRCNN_F16) hipLaunchKernelGGL(k_nchw_to_nhwc<_Float16>, dim3(grid), dim3(256), 0, s, in, n, C, H * W, (_Float16*)out);
+    else hipLaunchKernelGGL(k_nchw_to_nhwc<float>, dim3(grid), dim3(256), 0, s, in, n, C, H * W, (float*)out);
     HIP_CHECK(hipGetLastError());
 }
 void nhwc_to_nchw_forward(hipStream_t s, const float* in, long n, int C, int H, int W, float* out)
@@ -632,13 +681,14 @@ void copy_rows_forward(hipStream_t s, const float* src, long src_stride, long n,
 // ================================================================================================
 // MultiArrayBatchProvider(removeZeros:true) (TimeDistributedClassifierLayer.swift:116-127): a row is
 // kept iff every element is != 0.
-__global__ __launch_bounds__(256) void k_mask_row_flags(const float* __restrict__ pooled, long pooled_sB, long row_stride,
+template <typename T>
+__global__ __launch_bounds__(256) void k_mask_row_flags(const T* __restrict__ pooled, long pooled_sB, long row_stride,
                                                         long row_len, int D, int32_t* __restrict__ flags)
 {
     const int d = blockIdx.x, b = blockIdx.y;
-    const float* r = pooled + (size_t)b * pooled_sB + (size_t)d * row_stride;
+    const T* r = pooled + (size_t)b * pooled_sB + (size_t)d * row_stride;
     int ok = 1;
-    for (long e = threadIdx.x; e < row_len; e += 256) ok &= (r[e] != 0.0f) ? 1 : 0;
+    for (long e = threadIdx.x; e < row_len; e += 256) ok &= ((float)r[e] != 0.0f) ? 1 : 0;
     ok = __syncthreads_and(ok);
     if (threadIdx.x == 0) flags[(size_t)b * D + d] = ok;
 }
@@ -653,11 +703,13 @@ __global__ void k_mask_row_compact(const int32_t* __restrict__ flags, int D, int
     kept[b] = k;
 }
 
-void mask_valid_rows_forward(hipStream_t s, const float* pooled, long pooled_sB, long row_stride, long row_len, int D,
-                             int B, const MaskSelectWorkspace& ws)
+void mask_valid_rows_forward(hipStream_t s, const void* pooled, long pooled_sB, long row_stride, long row_len, int D,
+                             int B, const MaskSelectWorkspace& ws, int dtype)
 {
     if (D <= 0 || B <= 0) return;
-    hipLaunchKernelGGL(k_mask_row_flags, dim3(D, B), dim3(256), 0, s, pooled, pooled_sB, row_stride, row_len, D, ws.flags);
+    if (dtype == MRCNN_F16)
+        hipLaunchKernelGGL(k_mask_row_flags<_Float16>, dim3(D, B), dim3(256), 0, s, (const _Float16*)pooled, pooled_sB, row_stride, row_len, D, ws.flags);
+    else hipLaunchKernelGGL(k_mask_row_flags<float>, dim3(D, B), dim3(256), 0, s, (const float*)pooled, pooled_sB, row_stride, row_len, D, ws.flags);
     hipLaunchKernelGGL(k_mask_row_compact, dim3(B), dim3(64), 0, s, ws.flags, D, ws.mapping, ws.kept);
     HIP_CHECK(hipGetLastError());
 }
@@ -666,7 +718,8 @@ void mask_valid_rows_forward(hipStream_t s, const float* pooled, long pooled_sB,
 // sigmoid, of which the reference keeps one channel) evaluated for the selected class only.
 // Compact index i = blockIdx.y: row actual = mapping[i] is written with class detections[i][4]
 // (:71 reads the compact index); rows i >= kept are zero padding (:87-89).
-__global__ __launch_bounds__(256) void k_mask_select(const float* __restrict__ feat, long feat_sB, int HW, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void k_mask_select(const T* __restrict__ feat, long feat_sB, int HW, int C,
                                                      const float* __restrict__ w, const float* __restrict__ bias, int nc,
                                                      const float* __restrict__ det, long det_sB, long det_stride, int D,
                                                      const int32_t* __restrict__ mapping, const int32_t* __restrict__ kept,
@@ -685,11 +738,11 @@ __global__ __launch_bounds__(256) void k_mask_select(const float* __restrict__ f
     int cid = (int)det[(size_t)b * det_sB + (size_t)i * det_stride + 4];
     cid = cid < 0 ? 0 : (cid >= nc ? nc - 1 : cid);
     const float* wr = w + (size_t)cid * C;
-    const float* f = feat + (size_t)b * feat_sB + (size_t)actual * HW * C;
+    const T* f = feat + (size_t)b * feat_sB + (size_t)actual * HW * C;
     for (int p = blockIdx.x * 4 + wave; p < HW; p += gridDim.x * 4) {
         float sum = 0.f;
         for (int c = lane * 4; c < C; c += 256) {
-            const float4 x = *reinterpret_cast<const float4*>(f + (size_t)p * C + c);
+            const float4 x = load4<T>(f + (size_t)p * C + c);
             const float4 y = *reinterpret_cast<const float4*>(wr + c);
             sum += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
         }
@@ -699,14 +752,18 @@ __global__ __launch_bounds__(256) void k_mask_select(const float* __restrict__ f
     // the reference copies `stride` elements per row (:83); HW == stride for the 28×28 output
 }
 
-void mask_select_forward(hipStream_t s, const float* feat, long feat_sB, int HW, int C, const float* w,
+void mask_select_forward(hipStream_t s, const void* feat, long feat_sB, int HW, int C, const float* w,
                          const float* bias, int nc, const float* det, long det_sB, long det_stride, int D, int B,
-                         const MaskSelectWorkspace& ws, float* out, long out_sB, long out_stride)
+                         const MaskSelectWorkspace& ws, float* out, long out_sB, long out_stride, int dtype)
 {
     if (D <= 0 || B <= 0) return;
     MRCNN_REQUIRE(C % 4 == 0, MRCNN_ERR_SHAPE, "mask head: C %% 4 != 0");
-    hipLaunchKernelGGL(k_mask_select, dim3(49, D, B), dim3(256), 0, s, feat, feat_sB, HW, C, w, bias, nc, det, det_sB,
-                       det_stride, D, ws.mapping, ws.kept, out, out_sB, out_stride);
+    if (dtype == MRCNN_F16)
+        hipLaunchKernelGGL(k_mask_select<_Float16>, dim3(49, D, B), dim3(256), 0, s, (const _Float16*)feat, feat_sB, HW, C, w, bias, nc, det,
+                           det_sB, det_stride, D, ws.mapping, ws.kept, out, out_sB, out_stride);
+    else
+        hipLaunchKernelGGL(k_mask_select<float>, dim3(49, D, B), dim3(256), 0, s, (const float*)feat, feat_sB, HW, C, w, bias, nc, det, det_sB,
+                           det_stride, D, ws.mapping, ws.kept, out, out_sB, out_stride);
     HIP_CHECK(hipGetLastError());
 }
 

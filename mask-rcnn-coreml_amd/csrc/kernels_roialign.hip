@@ -69,38 +69,57 @@ __device__ __forceinline__ float bilerp(float tl, float tr, float bl, float br, 
     return top + (bot - top) * ly;
 }
 
-// NHWC: block = one ROI; thread = (channel quad, point group).
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 ld4<_Float16>(const _Float16* p)
+{
+    const h16x4 h = *reinterpret_cast<const h16x4*>(p);
+    return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, float4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+template <> __device__ __forceinline__ void st4<_Float16>(_Float16* p, float4 v)
+{
+    h16x4 h;
+    h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;   // RNE
+    *reinterpret_cast<h16x4*>(p) = h;
+}
+
+// NHWC: block = one ROI; thread = (channel quad, point group).  fp16 maps: the bilinear arithmetic
+// is the same fp32 sequence on the widened samples, rounded once to fp16 on store.
+template <typename T>
 __global__ __launch_bounds__(256) void k_roi_align_nhwc(PyramidMaps maps, int C, const float* __restrict__ rois,
                                                         long rois_sB, long roi_stride, int P, double ratio,
-                                                        float* __restrict__ out, long out_sB, long out_row_stride)
+                                                        T* __restrict__ out, long out_sB, long out_row_stride)
 {
     const int roi = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
     const RoiGeom g = roi_geom(rois + (size_t)b * rois_sB + (size_t)roi * roi_stride, ratio);
-    float* o = out + (size_t)b * out_sB + (size_t)roi * out_row_stride;
+    T* o = out + (size_t)b * out_sB + (size_t)roi * out_row_stride;
     const int C4 = C >> 2;
     const int total = P * P * C4;
     if (g.level < 0) {
-        for (int e = t; e < total; e += 256) reinterpret_cast<float4*>(o)[e] = make_float4(0, 0, 0, 0);
+        for (int e = t; e < total; e += 256) st4<T>(o + (size_t)e * 4, make_float4(0, 0, 0, 0));
         return;
     }
     const int H = maps.H[g.level], W = maps.W[g.level];
-    const float* m = maps.data[g.level] + (size_t)b * maps.sB[g.level];
+    const T* m = static_cast<const T*>(maps.data[g.level]) + (size_t)b * maps.sB[g.level];
     for (int e = t; e < total; e += 256) {
         const int cq = e % C4, pt = e / C4;
         const int py = pt / P, px = pt % P;
         const Sample s = make_sample(g, H, W, P, py, px);
         float4 v = make_float4(0, 0, 0, 0);
         if (s.ok) {
-            const float4 tl = reinterpret_cast<const float4*>(m + ((size_t)s.t * W + s.l) * C)[cq];
-            const float4 tr = reinterpret_cast<const float4*>(m + ((size_t)s.t * W + s.r) * C)[cq];
-            const float4 bl = reinterpret_cast<const float4*>(m + ((size_t)s.b * W + s.l) * C)[cq];
-            const float4 br = reinterpret_cast<const float4*>(m + ((size_t)s.b * W + s.r) * C)[cq];
+            const float4 tl = ld4<T>(m + ((size_t)s.t * W + s.l) * C + cq * 4);
+            const float4 tr = ld4<T>(m + ((size_t)s.t * W + s.r) * C + cq * 4);
+            const float4 bl = ld4<T>(m + ((size_t)s.b * W + s.l) * C + cq * 4);
+            const float4 br = ld4<T>(m + ((size_t)s.b * W + s.r) * C + cq * 4);
             v.x = bilerp(tl.x, tr.x, bl.x, br.x, s.lx, s.ly);
             v.y = bilerp(tl.y, tr.y, bl.y, br.y, s.lx, s.ly);
             v.z = bilerp(tl.z, tr.z, bl.z, br.z, s.lx, s.ly);
             v.w = bilerp(tl.w, tr.w, bl.w, br.w, s.lx, s.ly);
         }
-        reinterpret_cast<float4*>(o)[(size_t)pt * C4 + cq] = v;
+        st4<T>(o + ((size_t)pt * C4 + cq) * 4, v);
     }
 }
 
@@ -119,7 +138,7 @@ __global__ __launch_bounds__(256) void k_roi_align_nchw(PyramidMaps maps, int C,
         return;
     }
     const int H = maps.H[g.level], W = maps.W[g.level];
-    const float* m = maps.data[g.level] + (size_t)b * maps.sB[g.level];
+    const float* m = static_cast<const float*>(maps.data[g.level]) + (size_t)b * maps.sB[g.level];
     for (int e = threadIdx.x; e < total; e += 256) {
         const int px = e % P, py = (e / P) % P, c = e / (P * P);
         const Sample s = make_sample(g, H, W, P, py, px);
@@ -135,17 +154,22 @@ __global__ __launch_bounds__(256) void k_roi_align_nchw(PyramidMaps maps, int C,
 
 void roi_align_forward(hipStream_t s, const PyramidMaps& maps, int C, int layout_nhwc, const float* rois,
                        long rois_sB, long roi_stride, int n_rois, int B, int pool, double image_w,
-                       double image_h, float* out, long out_sB, long out_row_stride)
+                       double image_h, void* out, long out_sB, long out_row_stride, int dtype)
 {
     if (n_rois <= 0 || B <= 0) return;
     const double ratio = 224.0 / sqrt(image_w * image_h);    // PyramidROIAlignLayer.swift:98,357
     if (layout_nhwc) {
         MRCNN_REQUIRE(C % 4 == 0, MRCNN_ERR_SHAPE, "ROIAlign: channel count %d not a multiple of 4", C);
-        hipLaunchKernelGGL(k_roi_align_nhwc, dim3(n_rois, B), dim3(256), 0, s, maps, C, rois, rois_sB, roi_stride, pool,
-                           ratio, out, out_sB, out_row_stride);
+        if (dtype == MRCNN_F16)
+            hipLaunchKernelGGL(k_roi_align_nhwc<_Float16>, dim3(n_rois, B), dim3(256), 0, s, maps, C, rois, rois_sB, roi_stride, pool,
+                               ratio, (_Float16*)out, out_sB, out_row_stride);
+        else
+            hipLaunchKernelGGL(k_roi_align_nhwc<float>, dim3(n_rois, B), dim3(256), 0, s, maps, C, rois, rois_sB, roi_stride, pool,
+                               ratio, (float*)out, out_sB, out_row_stride);
     } else {
+        MRCNN_REQUIRE(dtype == MRCNN_F32, MRCNN_ERR_UNSUPPORTED, "ROIAlign: the CHW layout is fp32 only");
         hipLaunchKernelGGL(k_roi_align_nchw, dim3(n_rois, B), dim3(256), 0, s, maps, C, rois, rois_sB, roi_stride, pool,
-                           ratio, out, out_sB, out_row_stride);
+                           ratio, (float*)out, out_sB, out_row_stride);
     }
     HIP_CHECK(hipGetLastError());
 }

@@ -19,6 +19,7 @@ import numpy as np
 from . import _lib
 from .config import MaskRCNNConfig
 
+DTYPES = {"f32": _lib.F32, "f16": _lib.F16}
 STAGES = ["Trunk", "Proposal-Eval", "PyramidROIAlign-Eval", "TimeDistributedClassifierLayer-Eval", "Detection-Eval",
           "PyramidROIAlign-Eval-Mask", "TimeDistributedMask-Eval"]
 
@@ -54,13 +55,14 @@ class MaskRCNN(_Model):
     ``MaskRCNNConfig.defaultConfig()`` which must be set first (AppDelegate.swift:18-20)."""
     KIND = _lib.MODEL_MASKRCNN
 
-    def __init__(self, path: str, max_batch: int = 1):
+    def __init__(self, path: str, max_batch: int = 1, compute_dtype: str = "f32"):
         cfg = MaskRCNNConfig.defaultConfig()
         for name in ("anchorsURL", "compiledClassifierModelURL", "compiledMaskModelURL"):
             if getattr(cfg, name) is None:
                 # the reference force-unwraps and crashes (ProposalLayer.swift:68); we raise
                 raise _lib.MrcnnError(6, f"MaskRCNNConfig.defaultConfig().{name} must be set before loading MaskRCNN")
-        super().__init__(path, max_batch)
+        super().__init__(path, max_batch, DTYPES[compute_dtype])
+        self.compute_dtype = compute_dtype
         self.max_batch = max_batch
         self.image_height = self.get_int("image_height")
         self.image_width = self.get_int("image_width")
@@ -142,8 +144,8 @@ class MaskRCNN(_Model):
 class Classifier(_Model):
     KIND = _lib.MODEL_CLASSIFIER
 
-    def __init__(self, path: str, max_rows: int = 1000):
-        super().__init__(path, max_rows)
+    def __init__(self, path: str, max_rows: int = 1000, compute_dtype: str = "f32"):
+        super().__init__(path, max_rows, DTYPES[compute_dtype])
         self.num_classes = self.get_int("num_classes")
 
     def prediction(self, feature_map: np.ndarray) -> Dict[str, np.ndarray]:
@@ -164,8 +166,8 @@ class Classifier(_Model):
 class Mask(_Model):
     KIND = _lib.MODEL_MASK
 
-    def __init__(self, path: str, max_rows: int = 100):
-        super().__init__(path, max_rows)
+    def __init__(self, path: str, max_rows: int = 100, compute_dtype: str = "f32"):
+        super().__init__(path, max_rows, DTYPES[compute_dtype])
         self.num_classes = self.get_int("num_classes")
 
     def prediction(self, feature_map: np.ndarray) -> Dict[str, np.ndarray]:
@@ -180,7 +182,7 @@ class Mask(_Model):
         return {"masks": masks[0] if single else masks}
 
 
-def load_maskrcnn(model_dir: str, max_batch: int = 1) -> MaskRCNN:
+def load_maskrcnn(model_dir: str, max_batch: int = 1, compute_dtype: str = "f32") -> MaskRCNN:
     """Sets MaskRCNNConfig from a directory holding MaskRCNN.mrcw / Classifier.mrcw / Mask.mrcw /
     anchors.bin (the four artefacts of DownloadCommand.swift:10-32) and loads the main model —
     the sequence of EvaluateCommand.swift:144-153."""
@@ -188,4 +190,4 @@ def load_maskrcnn(model_dir: str, max_batch: int = 1) -> MaskRCNN:
     cfg.anchorsURL = os.path.join(model_dir, "anchors.bin")
     cfg.compiledClassifierModelURL = os.path.join(model_dir, "Classifier.mrcw")
     cfg.compiledMaskModelURL = os.path.join(model_dir, "Mask.mrcw")
-    return MaskRCNN(os.path.join(model_dir, "MaskRCNN.mrcw"), max_batch=max_batch)
+    return MaskRCNN(os.path.join(model_dir, "MaskRCNN.mrcw"), max_batch=max_batch, compute_dtype=compute_dtype)
