@@ -13,7 +13,7 @@ Weights are seeded synthetic weights of the exact architecture ("forced full loa
 100 detections per image, so no data-dependent stage idles); there is no network for checkpoints.
 
 Rank 0 prints ONE JSON line with, besides the contract fields:
-  roofline     — dominant kernel k_conv_mfma_f32<128,1,2,4,2> (fp32 MFMA implicit-GEMM conv): its
+  roofline     — dominant kernel k_conv_mfma_glds<float,128,1,2,4,2> (fp32 MFMA implicit-GEMM conv): its
                  ALGORITHMIC flops per launch ÷ its average launch duration, both measured live with HIP
                  events on the launching stream over the timed region; peak = 157.3 TFLOP/s (dense fp32 MFMA)
   cpu_baseline — the oracle (torch-CPU fp32 network + the C restatement of the custom layers) timed on this
@@ -34,6 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_FP16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: bf16/f16 MFMA dense peak (not the 2:1-sparse figure)
 GFLOP_PER_IMAGE_SURVEY = 777.3         # SURVEY.md §8(d), R101 1024² 81 classes
 
 
@@ -45,6 +46,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
     ap.add_argument("--arch", default="resnet101")
     ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
+                    help="compute dtype of the convolutions: f32 = exact-fp32 MFMA (default, the parity baseline); "
+                         "f16 = fp16 MFMA with fp32 accumulation (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=3)
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
@@ -73,7 +77,7 @@ def main():
     cfg = pkg.ModelConfig(architecture=args.arch, input_image_shape=(args.size, args.size, 3))
     model_dir = tempfile.mkdtemp(prefix=f"mrcnn_bench_r{rank}_")
     weights.save_synthetic_models(model_dir, cfg, seed=0, forced_load=True)
-    m = models.load_maskrcnn(model_dir, max_batch=args.batch)
+    m = models.load_maskrcnn(model_dir, max_batch=args.batch, compute_dtype=args.dtype)
     B = args.batch
     # synthetic batch, uint8 uniform[0,255], seed 1; a different slice of the stream per rank
     rng = np.random.default_rng(1)
@@ -123,7 +127,7 @@ def main():
             "metric": "images/sec (1024x1024, COCO-80)", "value": round(value, 3), "unit": "images/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: {args.arch}+FPN {args.size}x{args.size}, batch {B} per GPU, "
                                    f"81 classes, pre_nms 6000, max_proposals 1000, max_detections 100; "
                                    f"synthetic seeded weights (forced full load)",
@@ -137,10 +141,12 @@ def main():
             all_fl = sum(v[2] for v in prof.values())
             if launches:
                 achieved = flops / (ms * 1e-3) / 1e12
+                peak = PEAK_FP16_MFMA_TFLOPS if args.dtype == "f16" else PEAK_FP32_MFMA_TFLOPS
                 out["roofline"] = {
-                    "kernel": "k_conv_mfma_f32<128,1,2,4,2>", "bound": "mfma", "achieved": round(achieved, 2),
-                    "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "traffic": pmc_traffic(),
+                    "kernel": f"k_conv_mfma_glds<{'_Float16' if args.dtype == 'f16' else 'float'},128,1,2,4,2>", "bound": "mfma",
+                    "achieved": round(achieved, 2),
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                    "traffic": pmc_traffic() if args.dtype == "f32" else None,
                     "launches_per_step": launches // args.steps,
                     "avg_launch_ms": round(ms / launches, 4),
                     "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),

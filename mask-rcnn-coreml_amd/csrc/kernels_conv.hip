@@ -46,6 +46,7 @@ struct ConvArgs {
     int tiles_m, tiles_n;
     int vec_ok;          // epilogue may use vector stores / residual loads
     int out_f32;         // store fp32 even when the activations are fp16 (RPN outputs, class logits, masks)
+    const void* zero_page;   // >= 16 B of zeros in HBM: source of out-of-image taps for the DMA variant
 };
 
 static constexpr int BM = 128;
@@ -71,163 +72,17 @@ template <> __device__ __forceinline__ void store4<_Float16>(_Float16* p, float4
     *reinterpret_cast<f16x4*>(p) = h;
 }
 
-// T = float   : v_mfma_f32_32x32x2_f32  (exact fp32, 157.3 TFLOP/s peak), K tile = 32
-// T = _Float16: v_mfma_f32_32x32x16_f16 (fp32 accumulate, ~2.5 PFLOP/s peak), K tile = 64
-template <typename T, int BN, int TM, int TN, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma(const ConvArgs a)
+// Epilogue shared by the conv kernels: accumulators → LDS (fp32 C tile) → full-row vector stores with
+// fused scale/shift (BN + bias), residual, activation, column split / 2×2 scatter.
+template <typename T, int BN, int TM, int TN, int WM, int WN, int C_ROW>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned char* smem, int m0, int n0)
 {
-    static_assert(WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
-    constexpr int EPV = Elem<T>::EPV;
-    constexpr int BK = 8 * EPV;        // K elements per tile (128 bytes)
-    constexpr int NT = WM * WN * 64;   // threads per block
-    constexpr int RPT = NT / 8;        // tile rows covered by one staging pass (8 threads × 16 B per row)
-    constexpr int AP = BM / RPT;       // A rows per thread
-    constexpr int BP = BN / RPT;       // B rows per thread
-    static_assert(AP >= 1 && BP >= 1, "tile too small for the thread count");
-    constexpr int A_STAGE = BM * ROW_B, B_STAGE = BN * ROW_B;     // bytes
-    constexpr int SMEM = 2 * (A_STAGE + B_STAGE);
-    constexpr int C_ROW = BN + 4;      // epilogue staging tile (fp32), rows padded by one float4
-    static_assert(BM * C_ROW * 4 <= SMEM, "the C tile re-uses the operand buffers");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
-    unsigned char* const As = smem;                 // [2][BM][ROW_B]
-    unsigned char* const Bs = smem + 2 * A_STAGE;   // [2][BN][ROW_B]
-    const T* const in = static_cast<const T*>(a.in);
-    const T* const wgt = static_cast<const T*>(a.wgt);
-
-    // ---- XCD-aware tile assignment (bijective for any block count) ------------------------------
-    const int nblocks = a.tiles_m * a.tiles_n;
-    const int bid = blockIdx.x;
-    const int q = nblocks >> 3, r8 = nblocks & 7;
-    const int xcd = bid & 7, local = bid >> 3;
-    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + local;
-    const int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
-    const int m0 = mt * BM, n0 = nt * BN;
-
+    constexpr int NT = WM * WN * 64;
     const int t = threadIdx.x;
-    const int kq = t & 7, r0 = t >> 3;
-
-    // ---- per-thread A rows: output pixel → input window origin ----------------------------------
-    long a_off[AP];
-    int ih0[AP], iw0[AP];
-    bool a_ok[AP];
-    const int ohw = a.OH * a.OW;
-#pragma unroll
-    for (int p = 0; p < AP; ++p) {
-        const int m = m0 + r0 + RPT * p;
-        a_ok[p] = m < a.M;
-        const int mm = a_ok[p] ? m : 0;
-        const int b = mm / ohw, rem = mm - b * ohw;
-        const int oh = rem / a.OW, ow = rem - oh * a.OW;
-        ih0[p] = oh * a.stride - a.padH;
-        iw0[p] = ow * a.stride - a.padW;
-        a_off[p] = (long)b * a.in_sB + (long)ih0[p] * a.in_sH + (long)iw0[p] * a.in_sW + kq * EPV;
-    }
-    const T* const wbase = wgt + (size_t)(n0 + r0) * a.Ktot + kq * EPV;
-
-    const int cin_tiles = a.Cin / BK;
-    const int KT = a.KH * a.KW * cin_tiles;
-
-    // Register staging of the next K tile, in NAMED registers: with an array (lambda or not) hipcc
-    // (ROCm 7.2) left the B half in scratch memory for the 128-wide variant, which put a vmcnt(0) +
-    // scratch round trip between the global loads and the MFMAs and serialised the pipeline.
-    static_assert(AP <= 4 && BP <= 4, "staging registers are spelled out for <= 4 A rows / <= 4 B rows per thread");
-    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = make_uint4(0u, 0u, 0u, 0u);
-    int kh = 0, kw = 0, ct = 0;      // position of the NEXT tile to load
-#define MRCNN_LD_A(P)                                                                                          \
-    if constexpr (AP > P) {                                                                                    \
-        const int ih = ih0[P] + kh, iw = iw0[P] + kw;                                                          \
-        const bool ok = a_ok[P] && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;               \
-        ra##P = ok ? *reinterpret_cast<const uint4*>(in + a_off[P] + tap_off) : make_uint4(0u, 0u, 0u, 0u);    \
-    }
-#define MRCNN_LD_B(P) \
-    if constexpr (BP > P) rb##P = *reinterpret_cast<const uint4*>(wbase + (size_t)(RPT * P) * a.Ktot + (size_t)kt_next * BK);
-#define MRCNN_LOAD_TILE(KT_)                                                                                   \
-    {                                                                                                          \
-        const long tap_off = (long)kh * a.in_sH + (long)kw * a.in_sW + ct * BK;                                \
-        const int kt_next = (KT_);                                                                             \
-        MRCNN_LD_A(0) MRCNN_LD_A(1) MRCNN_LD_A(2) MRCNN_LD_A(3)                                                \
-        MRCNN_LD_B(0) MRCNN_LD_B(1) MRCNN_LD_B(2) MRCNN_LD_B(3)                                                \
-        if (++ct == cin_tiles) { ct = 0; if (++kw == a.KW) { kw = 0; ++kh; } }                                 \
-    }
-#define MRCNN_ST_A(P) if constexpr (AP > P) *reinterpret_cast<uint4*>(sa + (RPT * P) * ROW_B) = ra##P;
-#define MRCNN_ST_B(P) if constexpr (BP > P) *reinterpret_cast<uint4*>(sb + (RPT * P) * ROW_B) = rb##P;
-#define MRCNN_STORE_TILE(BUF_)                                                                                 \
-    {                                                                                                          \
-        unsigned char* const sa = As + (BUF_) * A_STAGE + r0 * ROW_B + kq * 16;                                \
-        unsigned char* const sb = Bs + (BUF_) * B_STAGE + r0 * ROW_B + kq * 16;                                \
-        MRCNN_ST_A(0) MRCNN_ST_A(1) MRCNN_ST_A(2) MRCNN_ST_A(3)                                                \
-        MRCNN_ST_B(0) MRCNN_ST_B(1) MRCNN_ST_B(2) MRCNN_ST_B(3)                                                \
-    }
-
     const int wave = t >> 6, lane = t & 63;
     const int wm = wave / WN, wn = wave - wm * WN;
     const int l31 = lane & 31, kk = lane >> 5;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    // Pipeline: tile k+1 sits in registers while tile k is computed from LDS.  The registers are
-    // written to the other LDS buffer at the TOP of step k (that buffer was last read in step k-1,
-    // which every wave left through the barrier) and immediately re-used for the global loads of
-    // tile k+2, so neither the vmcnt wait nor the ds_writes sit between the last MFMA of a step
-    // and its barrier.
-    MRCNN_LOAD_TILE(0)
-    MRCNN_STORE_TILE(0)
-    if (KT > 1) MRCNN_LOAD_TILE(1)
-    __syncthreads();
-
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < KT) MRCNN_STORE_TILE(buf ^ 1)
-        if (kt + 2 < KT) MRCNN_LOAD_TILE(kt + 2)
-        const unsigned char* as = As + buf * A_STAGE + (wm * TM * 32 + l31) * ROW_B + kk * 16;
-        const unsigned char* bs = Bs + buf * B_STAGE + (wn * TN * 32 + l31) * ROW_B + kk * 16;
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
-            uint4 av[TM], bv[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const uint4*>(as + i * 32 * ROW_B + t4 * 32);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const uint4*>(bs + j * 32 * ROW_B + t4 * 32);
-            if constexpr (sizeof(T) == 4) {
-                // fp32: lane kk owns k = 8*t4 + 4*kk + {0..3} — the same permutation of K on both
-                // operands, so one ds_read_b128 feeds four MFMA steps; consecutive MFMAs go to
-                // different accumulators.
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) {
-                            const uint32_t au = c == 0 ? av[i].x : c == 1 ? av[i].y : c == 2 ? av[i].z : av[i].w;
-                            const uint32_t bu = c == 0 ? bv[j].x : c == 1 ? bv[j].y : c == 2 ? bv[j].z : bv[j].w;
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(au), __uint_as_float(bu), acc[i][j], 0, 0, 0);
-                        }
-            } else {
-                // fp16: lane kk owns k = 16*t4 + 8*kk + {0..7}: one ds_read_b128 = one MFMA operand
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[i]), __builtin_bit_cast(f16x8, bv[j]),
-                                                                           acc[i][j], 0, 0, 0);
-            }
-        }
-        __syncthreads();
-    }
-
-#undef MRCNN_LOAD_TILE
-#undef MRCNN_STORE_TILE
-#undef MRCNN_LD_A
-#undef MRCNN_LD_B
-#undef MRCNN_ST_A
-#undef MRCNN_ST_B
+    const int ohw = a.OH * a.OW;
     // ---- epilogue: accumulators → LDS → full-row vector stores ----------------------------------
     // (the loop's final barrier guarantees nobody still reads the operand buffers)
     constexpr int TPR = BN / 4;       // threads per output row (4 columns each)
@@ -347,6 +202,342 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma(const ConvArgs a)
     }
 }
 
+// T = float   : v_mfma_f32_32x32x2_f32  (exact fp32, 157.3 TFLOP/s peak), K tile = 32
+// T = _Float16: v_mfma_f32_32x32x16_f16 (fp32 accumulate, ~2.5 PFLOP/s peak), K tile = 64
+template <typename T, int BN, int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma(const ConvArgs a)
+{
+    static_assert(WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
+    constexpr int EPV = Elem<T>::EPV;
+    constexpr int BK = 8 * EPV;        // K elements per tile (128 bytes)
+    constexpr int NT = WM * WN * 64;   // threads per block
+    constexpr int RPT = NT / 8;        // tile rows covered by one staging pass (8 threads × 16 B per row)
+    constexpr int AP = BM / RPT;       // A rows per thread
+    constexpr int BP = BN / RPT;       // B rows per thread
+    static_assert(AP >= 1 && BP >= 1, "tile too small for the thread count");
+    constexpr int A_STAGE = BM * ROW_B, B_STAGE = BN * ROW_B;     // bytes
+    constexpr int SMEM = 2 * (A_STAGE + B_STAGE);
+    constexpr int C_ROW = BN + 4;      // epilogue staging tile (fp32), rows padded by one float4
+    static_assert(BM * C_ROW * 4 <= SMEM, "the C tile re-uses the operand buffers");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    unsigned char* const As = smem;                 // [2][BM][ROW_B]
+    unsigned char* const Bs = smem + 2 * A_STAGE;   // [2][BN][ROW_B]
+    const T* const in = static_cast<const T*>(a.in);
+    const T* const wgt = static_cast<const T*>(a.wgt);
+
+    // ---- XCD-aware tile assignment (bijective for any block count) ------------------------------
+    const int nblocks = a.tiles_m * a.tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nblocks >> 3, r8 = nblocks & 7;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + local;
+    const int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int t = threadIdx.x;
+    const int kq = t & 7, r0 = t >> 3;
+
+    // ---- per-thread A rows: output pixel → input window origin ----------------------------------
+    long a_off[AP];
+    int ih0[AP], iw0[AP];
+    bool a_ok[AP];
+    const int ohw = a.OH * a.OW;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+        const int m = m0 + r0 + RPT * p;
+        a_ok[p] = m < a.M;
+        const int mm = a_ok[p] ? m : 0;
+        const int b = mm / ohw, rem = mm - b * ohw;
+        const int oh = rem / a.OW, ow = rem - oh * a.OW;
+        ih0[p] = oh * a.stride - a.padH;
+        iw0[p] = ow * a.stride - a.padW;
+        a_off[p] = (long)b * a.in_sB + (long)ih0[p] * a.in_sH + (long)iw0[p] * a.in_sW + kq * EPV;
+#ifdef MRCNN_DBG_HOTLOAD
+        a_off[p] = (long)(1 - a.padH) * a.in_sH + (long)(1 - a.padW) * a.in_sW + kq * EPV + p * 64;   // every row hits the same lines
+        ih0[p] = 1; iw0[p] = 1;
+#endif
+    }
+#ifdef MRCNN_DBG_HOTLOAD
+    const T* const wbase = wgt + kq * EPV;
+#else
+    const T* const wbase = wgt + (size_t)(n0 + r0) * a.Ktot + kq * EPV;
+#endif
+
+    const int cin_tiles = a.Cin / BK;
+    const int KT = a.KH * a.KW * cin_tiles;
+
+    // Register staging of the next K tile, in NAMED registers: with an array (lambda or not) hipcc
+    // (ROCm 7.2) left the B half in scratch memory for the 128-wide variant, which put a vmcnt(0) +
+    // scratch round trip between the global loads and the MFMAs and serialised the pipeline.
+    static_assert(AP <= 4 && BP <= 4, "staging registers are spelled out for <= 4 A rows / <= 4 B rows per thread");
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = make_uint4(0u, 0u, 0u, 0u);
+    int kh = 0, kw = 0, ct = 0;      // position of the NEXT tile to load
+#define MRCNN_LD_A(P)                                                                                          \
+    if constexpr (AP > P) {                                                                                    \
+        const int ih = ih0[P] + kh, iw = iw0[P] + kw;                                                          \
+        const bool ok = a_ok[P] && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;               \
+        ra##P = ok ? *reinterpret_cast<const uint4*>(in + a_off[P] + tap_off) : make_uint4(0u, 0u, 0u, 0u);    \
+    }
+#define MRCNN_LD_B(P) \
+    if constexpr (BP > P) rb##P = *reinterpret_cast<const uint4*>(wbase + (size_t)(RPT * P) * a.Ktot + (size_t)kt_next * BK);
+#define MRCNN_LOAD_TILE(KT_)                                                                                   \
+    {                                                                                                          \
+        const long tap_off = (long)kh * a.in_sH + (long)kw * a.in_sW + ct * BK;                                \
+        const int kt_next = (KT_);                                                                             \
+        MRCNN_LD_A(0) MRCNN_LD_A(1) MRCNN_LD_A(2) MRCNN_LD_A(3)                                                \
+        MRCNN_LD_B(0) MRCNN_LD_B(1) MRCNN_LD_B(2) MRCNN_LD_B(3)                                                \
+        if (++ct == cin_tiles) { ct = 0; if (++kw == a.KW) { kw = 0; ++kh; } }                                 \
+    }
+#define MRCNN_ST_A(P) if constexpr (AP > P) *reinterpret_cast<uint4*>(sa + (RPT * P) * ROW_B) = ra##P;
+#define MRCNN_ST_B(P) if constexpr (BP > P) *reinterpret_cast<uint4*>(sb + (RPT * P) * ROW_B) = rb##P;
+#define MRCNN_STORE_TILE(BUF_)                                                                                 \
+    {                                                                                                          \
+        unsigned char* const sa = As + (BUF_) * A_STAGE + r0 * ROW_B + kq * 16;                                \
+        unsigned char* const sb = Bs + (BUF_) * B_STAGE + r0 * ROW_B + kq * 16;                                \
+        MRCNN_ST_A(0) MRCNN_ST_A(1) MRCNN_ST_A(2) MRCNN_ST_A(3)                                                \
+        MRCNN_ST_B(0) MRCNN_ST_B(1) MRCNN_ST_B(2) MRCNN_ST_B(3)                                                \
+    }
+
+    const int wave = t >> 6, lane = t & 63;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int l31 = lane & 31, kk = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // Pipeline: tile k+1 sits in registers while tile k is computed from LDS.  The registers are
+    // written to the other LDS buffer at the TOP of step k (that buffer was last read in step k-1,
+    // which every wave left through the barrier) and immediately re-used for the global loads of
+    // tile k+2, so neither the vmcnt wait nor the ds_writes sit between the last MFMA of a step
+    // and its barrier.
+    MRCNN_LOAD_TILE(0)
+    MRCNN_STORE_TILE(0)
+    if (KT > 1) MRCNN_LOAD_TILE(1)
+    __syncthreads();
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+#ifndef MRCNN_DBG_NOLOAD
+        if (kt + 1 < KT) MRCNN_STORE_TILE(buf ^ 1)
+        if (kt + 2 < KT) MRCNN_LOAD_TILE(kt + 2)
+#endif
+        const unsigned char* as = As + buf * A_STAGE + (wm * TM * 32 + l31) * ROW_B + kk * 16;
+        const unsigned char* bs = Bs + buf * B_STAGE + (wn * TN * 32 + l31) * ROW_B + kk * 16;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            uint4 av[TM], bv[TN];
+#ifdef MRCNN_DBG_NOLDS
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = make_uint4(kt + i, t4, lane, 1u);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = make_uint4(kt + j, t4 + 1, lane, 2u);
+#else
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const uint4*>(as + i * 32 * ROW_B + t4 * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const uint4*>(bs + j * 32 * ROW_B + t4 * 32);
+#endif
+            if constexpr (sizeof(T) == 4) {
+                // fp32: lane kk owns k = 8*t4 + 4*kk + {0..3} — the same permutation of K on both
+                // operands, so one ds_read_b128 feeds four MFMA steps; consecutive MFMAs go to
+                // different accumulators.
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const uint32_t au = c == 0 ? av[i].x : c == 1 ? av[i].y : c == 2 ? av[i].z : av[i].w;
+                            const uint32_t bu = c == 0 ? bv[j].x : c == 1 ? bv[j].y : c == 2 ? bv[j].z : bv[j].w;
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(au), __uint_as_float(bu), acc[i][j], 0, 0, 0);
+                        }
+            } else {
+                // fp16: lane kk owns k = 16*t4 + 8*kk + {0..7}: one ds_read_b128 = one MFMA operand
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[i]), __builtin_bit_cast(f16x8, bv[j]),
+                                                                           acc[i][j], 0, 0, 0);
+            }
+        }
+#ifndef MRCNN_DBG_NOBAR
+        __syncthreads();
+#endif
+    }
+
+#undef MRCNN_LOAD_TILE
+#undef MRCNN_STORE_TILE
+#undef MRCNN_LD_A
+#undef MRCNN_LD_B
+#undef MRCNN_ST_A
+#undef MRCNN_ST_B
+    conv_epilogue<T, BN, TM, TN, WM, WN, C_ROW>(a, acc, smem, m0, n0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Variant with direct global→LDS staging (global_load_lds_dwordx4): no VGPR round trip, no ds_write,
+// no address/register traffic between the loads and the MFMAs — the register-staged loop above loses
+// 13 % (fp32) / 40 % (fp16) of the MFMA rate to that path even with cache-hot loads.
+//   * LDS rows are unpadded 128-B K runs (the DMA writes wave-uniform base + lane×16, so rows cannot
+//     be padded); bank conflicts are removed by an XOR swizzle instead: 16-B chunk c of row r lives
+//     at chunk position c ^ ((r >> 1) & 7).  The permutation is applied to the per-lane SOURCE
+//     address (inside one 128-B line, so coalescing is unchanged) and to the ds_read address.
+//     For ds_read_b128's 16-lane groups the pairs (r & 1, (r >> 1) & 7) are all distinct → conflict-free.
+//   * out-of-image taps (zero padding) read from a 16-B zero page instead of being predicated.
+//   * two LDS buffers: the DMA of tile k+1 is issued right after the barrier that retired buffer
+//     (k+1)&1 and lands while tile k is being multiplied; one vmcnt(0) + barrier per K step.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BN, int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs a)
+{
+    static_assert(WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
+    constexpr int EPV = Elem<T>::EPV;
+    constexpr int BK = 8 * EPV;
+    constexpr int NT = WM * WN * 64;
+    constexpr int RPT = NT / 8;
+    constexpr int AP = BM / RPT;
+    constexpr int BP = BN / RPT;
+    static_assert(AP >= 1 && BP >= 1 && AP <= 4 && BP <= 4 && RPT % 16 == 0, "staging shape");
+    constexpr int ROWB = 128;
+    constexpr int A_STAGE = BM * ROWB, B_STAGE = BN * ROWB;
+    constexpr int C_ROW = BN;                                   // fp32 C tile, unpadded
+    constexpr int SMEM_OPS = 2 * (A_STAGE + B_STAGE);
+    constexpr int SMEM = SMEM_OPS > BM * C_ROW * 4 ? SMEM_OPS : BM * C_ROW * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    const T* const in = static_cast<const T*>(a.in);
+    const T* const wgt = static_cast<const T*>(a.wgt);
+    const T* const zero = static_cast<const T*>(a.zero_page);
+
+    const int nblocks = a.tiles_m * a.tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nblocks >> 3, r8 = nblocks & 7;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + local;
+    const int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int t = threadIdx.x;
+    const int wave = t >> 6, lane = t & 63;
+    const int r0 = t >> 3;                              // row inside a staging pass
+    const int kq = (t & 7) ^ ((r0 >> 1) & 7);           // SOURCE chunk held at LDS chunk position (t & 7)
+
+    long a_off[AP];
+    int ih0[AP], iw0[AP];
+    bool a_ok[AP];
+    const int ohw = a.OH * a.OW;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+        const int m = m0 + r0 + RPT * p;
+        a_ok[p] = m < a.M;
+        const int mm = a_ok[p] ? m : 0;
+        const int b = mm / ohw, rem = mm - b * ohw;
+        const int oh = rem / a.OW, ow = rem - oh * a.OW;
+        ih0[p] = oh * a.stride - a.padH;
+        iw0[p] = ow * a.stride - a.padW;
+        a_off[p] = (long)b * a.in_sB + (long)ih0[p] * a.in_sH + (long)iw0[p] * a.in_sW + kq * EPV;
+    }
+    const T* const wbase = wgt + (size_t)(n0 + r0) * a.Ktot + kq * EPV;
+    const int cin_tiles = a.Cin / BK;
+    const int KT = a.KH * a.KW * cin_tiles;
+    // wave-uniform LDS destinations: this wave's 8 rows of each staging pass
+    const int wrow = __builtin_amdgcn_readfirstlane(wave) * 8;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);   // LDS byte address of smem
+
+    int kh = 0, kw = 0, ct = 0;
+    // The DMA is issued through inline asm on purpose: with the builtin hipcc treats it as an LDS
+    // store it must order against every later ds_read and drains it with vmcnt(0) at the top of the
+    // step, which makes the copy synchronous.  In asm the compiler does not count it, so the waits
+    // are placed by hand: vmcnt(0) right before the barrier that hands the buffer over.
+    // (M0 = wave-uniform LDS byte address; each lane's 16 B land at M0 + lane*16.)
+#define MRCNN_GLDS(SRC, DST)                                                                                   \
+    {                                                                                                          \
+        unsigned keep_m0;                                                                                      \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_m0)                                                                          \
+                     : "v"(SRC), "s"(DST)                                                                      \
+                     : "memory");                                                                              \
+    }
+#define MRCNN_DMA_TILE(KT_, BUF_)                                                                              \
+    {                                                                                                          \
+        const long tap_off = (long)kh * a.in_sH + (long)kw * a.in_sW + ct * BK;                                \
+        const unsigned da = lds0 + (BUF_) * A_STAGE + wrow * ROWB;                                             \
+        const unsigned db = lds0 + 2 * A_STAGE + (BUF_) * B_STAGE + wrow * ROWB;                               \
+        _Pragma("unroll") for (int p = 0; p < AP; ++p) {                                                       \
+            const int ih = ih0[p] + kh, iw = iw0[p] + kw;                                                      \
+            const bool ok = a_ok[p] && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;           \
+            const T* src = ok ? in + a_off[p] + tap_off : zero;                                                \
+            MRCNN_GLDS(src, da + p * RPT * ROWB);                                                              \
+        }                                                                                                      \
+        _Pragma("unroll") for (int p = 0; p < BP; ++p)                                                         \
+            MRCNN_GLDS(wbase + (size_t)(RPT * p) * a.Ktot + (size_t)(KT_) * BK, db + p * RPT * ROWB);          \
+        if (++ct == cin_tiles) { ct = 0; if (++kw == a.KW) { kw = 0; ++kh; } }                                 \
+    }
+
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int swz = (l31 >> 1) & 7;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    MRCNN_DMA_TILE(0, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();          // tile 0 is in LDS
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) MRCNN_DMA_TILE(kt + 1, buf ^ 1)
+        const unsigned char* as = smem + buf * A_STAGE + (wm * TM * 32 + l31) * ROWB;
+        const unsigned char* bs = smem + 2 * A_STAGE + buf * B_STAGE + (wn * TN * 32 + l31) * ROWB;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const int co = ((t4 * 2 + kk) ^ swz) << 4;
+            uint4 av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const uint4*>(as + i * 32 * ROWB + co);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const uint4*>(bs + j * 32 * ROWB + co);
+            if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const uint32_t au = c == 0 ? av[i].x : c == 1 ? av[i].y : c == 2 ? av[i].z : av[i].w;
+                            const uint32_t bu = c == 0 ? bv[j].x : c == 1 ? bv[j].y : c == 2 ? bv[j].z : bv[j].w;
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(au), __uint_as_float(bu), acc[i][j], 0, 0, 0);
+                        }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[i]), __builtin_bit_cast(f16x8, bv[j]),
+                                                                           acc[i][j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt+1 have landed
+        __syncthreads();                                     // ... and every wave is done reading `buf`
+    }
+#undef MRCNN_DMA_TILE
+#undef MRCNN_GLDS
+    conv_epilogue<T, BN, TM, TN, WM, WN, C_ROW>(a, acc, smem, m0, n0);
+}
+
 static thread_local ConvProfile* g_prof = nullptr;
 void conv_set_profiler(ConvProfile* p) { g_prof = p; }
 void ConvProfile::reset()
@@ -393,9 +584,18 @@ template <typename T>
 static void conv_launch(hipStream_t s, const ConvArgs& a, int bn)
 {
     const dim3 grid(a.tiles_m * a.tiles_n);
+#ifndef MRCNN_GLDS_STAGING
+#define MRCNN_GLDS_STAGING 1
+#endif
+#if MRCNN_GLDS_STAGING
+    if (bn == 128) hipLaunchKernelGGL((k_conv_mfma_glds<T, 128, 1, 2, 4, 2>), grid, dim3(512), 0, s, a);
+    else if (bn == 64) hipLaunchKernelGGL((k_conv_mfma_glds<T, 64, 1, 1, 4, 2>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((k_conv_mfma_glds<T, 32, 1, 1, 4, 1>), grid, dim3(256), 0, s, a);
+#else
     if (bn == 128) hipLaunchKernelGGL((k_conv_mfma<T, 128, 1, 2, 4, 2>), grid, dim3(512), 0, s, a);
     else if (bn == 64) hipLaunchKernelGGL((k_conv_mfma<T, 64, 1, 1, 4, 2>), grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL((k_conv_mfma<T, 32, 1, 1, 4, 1>), grid, dim3(256), 0, s, a);
+#endif
 }
 
 void conv_forward(hipStream_t s, const ConvDesc& d)
@@ -419,6 +619,12 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     a.M = (int)M;
     a.res_shift = d.res_shift; a.act = d.act; a.n_split = d.n_split; a.deconv2 = d.deconv2;
     a.out_f32 = (!half || d.out_f32) ? 1 : 0;
+    static void* zero_page = nullptr;     // one per process (single device per process)
+    if (!zero_page) {
+        HIP_CHECK(hipMalloc(&zero_page, 256));
+        HIP_CHECK(hipMemset(zero_page, 0, 256));
+    }
+    a.zero_page = zero_page;
     // Tile choice: the widest N tile the packed weights allow, narrowed while the grid would leave
     // the chip under-filled (< 2 blocks per CU) — C5, the top FPN levels and the small RPN levels.
     const int bn_max = conv_n_tile(a.ncols);
