@@ -226,6 +226,13 @@ typedef struct {
  * number kept in *count. */
 MRCNN_API int mrcnn_detections_decode(const float* detections, int64_t n_rows, int64_t row_stride,
                                       mrcnn_detection* out, int64_t capacity, int64_t* count);
+/* Mask paste: per-instance 28×28 sigmoid masks → full-resolution binary masks
+ * (n, image_h, image_w) uint8 {0,1}: resize to the detection's box and threshold.  Replaces what the
+ * example app does with CoreGraphics when drawing (Example/Source/DetectionRenderer.swift:13-24).
+ * Box pixels = round-half-even(y*(H-1)) with +1 on the far edge (Matterport denorm_boxes), bilinear
+ * with half-pixel centres, `>= threshold`; rows with score <= 0 give empty masks. image_w % 4 == 0. */
+MRCNN_API int mrcnn_paste_masks(const float* detections, int64_t det_stride, const float* masks, int n, int mask_size,
+                                int image_h, int image_w, float threshold, int memspace, uint8_t* out);
 /* 28×28 mask → 8-bit: UInt8(255 - v/2*255) (Detection.swift:83-85). */
 MRCNN_API int mrcnn_mask_to_u8(const float* mask, int64_t n, uint8_t* out);
 

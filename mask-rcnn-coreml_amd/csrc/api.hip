@@ -722,6 +722,30 @@ extern "C" int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout
 }
 
 // ================================================================================================
+// mask paste (DetectionRenderer.swift:13-24)
+// ================================================================================================
+extern "C" int mrcnn_paste_masks(const float* detections, int64_t det_stride, const float* masks, int n, int mask_size, int image_h,
+                                 int image_w, float threshold, int memspace, uint8_t* out)
+{
+    return guarded([&] {
+        require_gpu();
+        MRCNN_REQUIRE(detections && masks && out && n >= 0 && det_stride >= 6 && mask_size >= 2 && image_h > 0 && image_w > 0,
+                      MRCNN_ERR_INVALID, "bad paste_masks argument");
+        if (n == 0) return;
+        Stream st;
+        DevBuf td, tm, to;
+        const float* d = stage_rows(detections, memspace, n, det_stride, det_stride, td);
+        const float* m = stage_rows(masks, memspace, n, (long)mask_size * mask_size, (long)mask_size * mask_size, tm);
+        uint8_t* o = out;
+        const size_t bytes = (size_t)n * image_h * image_w;
+        if (memspace != MRCNN_DEVICE) { to.alloc(bytes); o = to.as<uint8_t>(); }
+        paste_masks_forward(st.s, d, det_stride, m, n, mask_size, image_h, image_w, threshold, o);
+        HIP_CHECK(hipStreamSynchronize(st.s));
+        if (memspace != MRCNN_DEVICE) HIP_CHECK(hipMemcpy(out, to.p, bytes, hipMemcpyDeviceToHost));
+    });
+}
+
+// ================================================================================================
 // result decoding (Detection.swift:23-99) — host
 // ================================================================================================
 extern "C" int mrcnn_detections_decode(const float* det, int64_t n_rows, int64_t row_stride, mrcnn_detection* out, int64_t capacity,

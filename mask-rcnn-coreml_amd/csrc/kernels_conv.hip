@@ -49,7 +49,7 @@ struct ConvArgs {
     const void* zero_page;   // >= 16 B of zeros in HBM: source of out-of-image taps for the DMA variant
 };
 
-static constexpr int BM = 128;
+static constexpr int BM_DEFAULT = 128;   // rows of the block tile = WM*TM*32 (128, or 256 for the tall variant)
 static constexpr int ROW_B = 144;    // LDS row: 128 B of K (32 floats / 64 halfs) + 16 B pad
 
 template <typename T> struct Elem;
@@ -78,6 +78,7 @@ template <typename T, int BN, int TM, int TN, int WM, int WN, int C_ROW>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned char* smem, int m0, int n0)
 {
     constexpr int NT = WM * WN * 64;
+    constexpr int BM = WM * TM * 32;
     const int t = threadIdx.x;
     const int wave = t >> 6, lane = t & 63;
     const int wm = wave / WN, wn = wave - wm * WN;
@@ -207,7 +208,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
 template <typename T, int BN, int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma(const ConvArgs a)
 {
-    static_assert(WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
+    constexpr int BM = WM * TM * 32;
+    static_assert(WN * TN * 32 == BN, "tile shape");
     constexpr int EPV = Elem<T>::EPV;
     constexpr int BK = 8 * EPV;        // K elements per tile (128 bytes)
     constexpr int NT = WM * WN * 64;   // threads per block
@@ -397,7 +399,8 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma(const ConvArgs a)
 template <typename T, int BN, int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs a)
 {
-    static_assert(WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
+    constexpr int BM = WM * TM * 32;
+    static_assert(WN * TN * 32 == BN, "tile shape");
     constexpr int EPV = Elem<T>::EPV;
     constexpr int BK = 8 * EPV;
     constexpr int NT = WM * WN * 64;
@@ -581,9 +584,13 @@ int conv_n_tile(int Cout)
 }
 
 template <typename T>
-static void conv_launch(hipStream_t s, const ConvArgs& a, int bn)
+static void conv_launch(hipStream_t s, const ConvArgs& a, int bn, int bm)
 {
     const dim3 grid(a.tiles_m * a.tiles_n);
+    if (bm == 256) {
+        hipLaunchKernelGGL((k_conv_mfma_glds<T, 128, 2, 2, 4, 2>), grid, dim3(512), 0, s, a);
+        return;
+    }
 #ifndef MRCNN_GLDS_STAGING
 #define MRCNN_GLDS_STAGING 1
 #endif
@@ -615,7 +622,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     a.ncols = d.deconv2 ? 4 * d.Cout : d.Cout;
     a.Ktot = d.KH * d.KW * d.Cin;
     const long M = (long)d.B * d.OH * d.OW;
-    MRCNN_REQUIRE(M > 0 && M < (1L << 31) - BM, MRCNN_ERR_SHAPE, "conv: M out of range");
+    MRCNN_REQUIRE(M > 0 && M < (1L << 31) - 256, MRCNN_ERR_SHAPE, "conv: M out of range");
     a.M = (int)M;
     a.res_shift = d.res_shift; a.act = d.act; a.n_split = d.n_split; a.deconv2 = d.deconv2;
     a.out_f32 = (!half || d.out_f32) ? 1 : 0;
@@ -629,9 +636,16 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     // the chip under-filled (< 2 blocks per CU) — C5, the top FPN levels and the small RPN levels.
     const int bn_max = conv_n_tile(a.ncols);
     MRCNN_REQUIRE(d.Npad % bn_max == 0 && d.Npad >= a.ncols, MRCNN_ERR_SHAPE, "conv: Npad %d incompatible with tile %d", d.Npad, bn_max);
-    a.tiles_m = (a.M + BM - 1) / BM;
+#ifndef MRCNN_TALL_TILE
+#define MRCNN_TALL_TILE 0
+#endif
+    // 256×128 "tall" tile (one block per CU, 1.33× the arithmetic intensity of 128×128): selected by
+    // MRCNN_TALL_TILE (1 = fp16 only, 2 = both dtypes) for layers with enough rows to fill the chip.
+    int bm = BM_DEFAULT;
+    if (MRCNN_TALL_TILE && bn_max == 128 && (half || MRCNN_TALL_TILE == 2) && (long)((a.M + 255) / 256) * (d.Npad / 128) >= 512) bm = 256;
+    a.tiles_m = (a.M + bm - 1) / bm;
     int bn = bn_max;
-    while (bn > 32 && (long)a.tiles_m * (d.Npad / bn) < 512) bn >>= 1;
+    while (bm == BM_DEFAULT && bn > 32 && (long)a.tiles_m * (d.Npad / bn) < 512) bn >>= 1;
     const size_t out_es = a.out_f32 ? 4 : 2;
     auto al = [](const void* p, size_t n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
     a.vec_ok = a.ncols % 4 == 0 && d.out2 == nullptr && d.out_sP % 4 == 0 && d.out_sB % 4 == 0 && al(d.out, 4 * out_es) &&
@@ -641,8 +655,8 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     a.tiles_n = d.Npad / bn;
     ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
     const int e0 = prof ? prof_event(prof, s) : 0;
-    if (half) conv_launch<_Float16>(s, a, bn);
-    else conv_launch<float>(s, a, bn);
+    if (half) conv_launch<_Float16>(s, a, bn, bm);
+    else conv_launch<float>(s, a, bn, bm);
     if (prof) {
         const int e1 = prof_event(prof, s);
         const double k = d.algo_k > 0 ? d.algo_k : a.Ktot;

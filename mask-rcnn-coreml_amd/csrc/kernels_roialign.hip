@@ -174,4 +174,70 @@ void roi_align_forward(hipStream_t s, const PyramidMaps& maps, int C, int layout
     HIP_CHECK(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------------
+// Mask paste: 28×28 sigmoid mask → full-resolution binary instance mask.
+// The reference only does this when drawing (Example/Source/DetectionRenderer.swift:13-24 stretches
+// the CGImage mask of Detection.swift:83-98 over the box with CoreGraphics); for mask AP the mask has
+// to be resized to its box and thresholded.  Conventions (unpinned — CoreGraphics' resampler is
+// closed): box pixels as in Matterport's denorm_boxes (round-half-even of y*(H-1), +1 on the far
+// edge), bilinear resampling with half-pixel centres and edge clamp, `>= threshold`.
+// HBM-bound: n×H×W bytes written once (16 B per lane); the 3 KB mask is read through L1.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_paste_masks(const float* __restrict__ det, long det_stride,
+                                                     const float* __restrict__ masks, int S, int H, int W, float thr,
+                                                     uint8_t* __restrict__ out)
+{
+    const int inst = blockIdx.y;
+    const float* d = det + (size_t)inst * det_stride;
+    const float* m = masks + (size_t)inst * S * S;
+    // denorm_boxes: around(box * (H-1, W-1, H-1, W-1) + (0, 0, 1, 1))
+    const int y1 = (int)rint((double)d[0] * (double)(H - 1));
+    const int x1 = (int)rint((double)d[1] * (double)(W - 1));
+    const int y2 = (int)rint((double)d[2] * (double)(H - 1) + 1.0);
+    const int x2 = (int)rint((double)d[3] * (double)(W - 1) + 1.0);
+    const int bh = y2 - y1, bw = x2 - x1;
+    const bool empty = bh <= 0 || bw <= 0 || !(d[5] > 0.0f);
+    const float sy_scale = empty ? 0.f : (float)S / (float)bh;
+    const float sx_scale = empty ? 0.f : (float)S / (float)bw;
+    uint8_t* o = out + (size_t)inst * H * W;
+    const long quads = (long)H * W / 4;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < quads; e += (long)gridDim.x * 256) {
+        const long p0 = e * 4;
+        const int y = (int)(p0 / W), xb = (int)(p0 - (long)y * W);
+        uint32_t packed = 0;
+        if (!empty && y >= y1 && y < y2) {
+            float sy = ((float)(y - y1) + 0.5f) * sy_scale - 0.5f;
+            sy = fminf(fmaxf(sy, 0.0f), (float)(S - 1));
+            const int ya = (int)floorf(sy), yb = min(ya + 1, S - 1);
+            const float fy = sy - (float)ya;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = xb + k;
+                if (x < x1 || x >= x2) continue;
+                float sx = ((float)(x - x1) + 0.5f) * sx_scale - 0.5f;
+                sx = fminf(fmaxf(sx, 0.0f), (float)(S - 1));
+                const int xa = (int)floorf(sx), xc = min(xa + 1, S - 1);
+                const float fx = sx - (float)xa;
+                const float a = m[ya * S + xa], b = m[ya * S + xc], c = m[yb * S + xa], dd = m[yb * S + xc];
+                const float top = a + (b - a) * fx;
+                const float bot = c + (dd - c) * fx;
+                const float v = top + (bot - top) * fy;
+                if (v >= thr) packed |= 1u << (8 * k);
+            }
+        }
+        reinterpret_cast<uint32_t*>(o)[e] = packed;
+    }
+}
+
+void paste_masks_forward(hipStream_t s, const float* det, long det_stride, const float* masks, int n, int S, int H, int W,
+                         float thr, uint8_t* out)
+{
+    if (n <= 0) return;
+    MRCNN_REQUIRE(W % 4 == 0, MRCNN_ERR_SHAPE, "paste_masks: image width %d not a multiple of 4", W);
+    const long quads = (long)H * W / 4;
+    const int gx = (int)((quads + 255) / 256 < 1024 ? (quads + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_paste_masks, dim3(gx, n), dim3(256), 0, s, det, det_stride, masks, S, H, W, thr, out);
+    HIP_CHECK(hipGetLastError());
+}
+
 }  // namespace mrcnn

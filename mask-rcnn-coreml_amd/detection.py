@@ -1,5 +1,5 @@
 """Result decoding: the public ``Detection`` type and ``IOU`` of the reference library target
-(``Sources/Mask-RCNN-CoreML/Detection.swift:15-99``, ``Utils.swift:232``), plus the GPU-free mask
+(``Sources/Mask-RCNN-CoreML/Detection.swift:15-99``, ``Utils.swift:232``), plus the mask
 paste that the example app performs when drawing (``Example/Source/DetectionRenderer.swift:13-24``).
 Host-side like the reference; the arithmetic lives in libmaskrcnn_hip.so (``mrcnn_detections_decode``,
 ``mrcnn_mask_to_u8``, ``mrcnn_iou``).
@@ -62,24 +62,15 @@ def IOU(a_xywh, b_xywh) -> float:
     return float(_lib.lib().mrcnn_iou(a.ctypes.data_as(f32p), b.ctypes.data_as(f32p)))
 
 
-def paste_mask(mask28: np.ndarray, box_xywh, image_w: int, image_h: int, threshold: float = 0.5) -> np.ndarray:
-    """Resize a 28×28 probability mask to its box (bilinear) and threshold it into a full-image
-    boolean mask — what DetectionRenderer.renderMask does with CoreGraphics when drawing."""
-    x, y, w, h = box_xywh
-    x0, y0 = int(round(x * image_w)), int(round(y * image_h))
-    bw, bh = max(1, int(round(w * image_w))), max(1, int(round(h * image_h)))
-    ys = (np.arange(bh) + 0.5) * mask28.shape[0] / bh - 0.5
-    xs = (np.arange(bw) + 0.5) * mask28.shape[1] / bw - 0.5
-    y0i = np.clip(np.floor(ys).astype(int), 0, mask28.shape[0] - 1); y1i = np.clip(y0i + 1, 0, mask28.shape[0] - 1)
-    x0i = np.clip(np.floor(xs).astype(int), 0, mask28.shape[1] - 1); x1i = np.clip(x0i + 1, 0, mask28.shape[1] - 1)
-    fy = np.clip(ys - np.floor(ys), 0, 1)[:, None]; fx = np.clip(xs - np.floor(xs), 0, 1)[None, :]
-    m = mask28.astype(np.float32)
-    top = m[y0i][:, x0i] * (1 - fx) + m[y0i][:, x1i] * fx
-    bot = m[y1i][:, x0i] * (1 - fx) + m[y1i][:, x1i] * fx
-    r = top * (1 - fy) + bot * fy
-    full = np.zeros((image_h, image_w), dtype=bool)
-    ys0, xs0 = max(0, y0), max(0, x0)
-    ys1, xs1 = min(image_h, y0 + bh), min(image_w, x0 + bw)
-    if ys1 > ys0 and xs1 > xs0:
-        full[ys0:ys1, xs0:xs1] = r[ys0 - y0:ys1 - y0, xs0 - x0:xs1 - x0] >= threshold
-    return full
+def paste_masks(detections: np.ndarray, masks: np.ndarray, image_h: int, image_w: int, threshold: float = 0.5) -> np.ndarray:
+    """Full-resolution binary instance masks (n, image_h, image_w) uint8 from "detections" (n,6) and
+    "mask" (n,S,S): each mask is resized to its box and thresholded on the GPU (``mrcnn_paste_masks``) —
+    the step DetectionRenderer.renderMask (Example/Source/DetectionRenderer.swift:13-24) leaves to
+    CoreGraphics when drawing, and the one mask AP needs."""
+    det = np.ascontiguousarray(detections, dtype=np.float32)
+    m = np.ascontiguousarray(masks, dtype=np.float32)
+    n = det.shape[0]
+    out = np.empty((n, image_h, image_w), dtype=np.uint8)
+    _lib.check(_lib.lib().mrcnn_paste_masks(det.ctypes.data, det.shape[1], m.ctypes.data, n, m.shape[1], image_h, image_w,
+                                            C.c_float(threshold), _lib.HOST, out.ctypes.data))
+    return out

@@ -220,3 +220,43 @@ def mask_to_u8(mask) -> np.ndarray:
     out = np.empty(m.shape, dtype=np.uint8)
     lib().orc_mask_to_u8(_p(m, C.c_double), m.size, _p(out, C.c_uint8))
     return out
+
+
+def paste_masks(detections, masks, image_h: int, image_w: int, threshold: float = 0.5) -> np.ndarray:
+    """numpy restatement of the mask paste (reference: DetectionRenderer.swift:13-24 leaves the
+    resize to CoreGraphics, so the conventions are OURS and unpinned): Matterport denorm_boxes pixels
+    (np.around = round-half-even, +1 on the far edge), bilinear with half-pixel centres and edge clamp in
+    float32, `>= threshold`.  Returns (n, image_h, image_w) uint8."""
+    f = np.float32
+    det = _f32(detections)
+    m = _f32(masks)
+    n, S = det.shape[0], m.shape[1]
+    out = np.zeros((n, image_h, image_w), dtype=np.uint8)
+    for i in range(n):
+        if not det[i, 5] > 0:
+            continue
+        y1 = int(np.around(np.float64(det[i, 0]) * (image_h - 1)))
+        x1 = int(np.around(np.float64(det[i, 1]) * (image_w - 1)))
+        y2 = int(np.around(np.float64(det[i, 2]) * (image_h - 1) + 1.0))
+        x2 = int(np.around(np.float64(det[i, 3]) * (image_w - 1) + 1.0))
+        bh, bw = y2 - y1, x2 - x1
+        if bh <= 0 or bw <= 0:
+            continue
+        ys = np.arange(max(y1, 0), min(y2, image_h))
+        xs = np.arange(max(x1, 0), min(x2, image_w))
+        if ys.size == 0 or xs.size == 0:
+            continue
+        sy = ((ys - y1).astype(f) + f(0.5)) * (f(S) / f(bh)) - f(0.5)
+        sx = ((xs - x1).astype(f) + f(0.5)) * (f(S) / f(bw)) - f(0.5)
+        sy = np.minimum(np.maximum(sy, f(0)), f(S - 1)).astype(f)
+        sx = np.minimum(np.maximum(sx, f(0)), f(S - 1)).astype(f)
+        ya = np.floor(sy).astype(np.int64); yb = np.minimum(ya + 1, S - 1)
+        xa = np.floor(sx).astype(np.int64); xc = np.minimum(xa + 1, S - 1)
+        fy = (sy - ya.astype(f)).astype(f)[:, None]
+        fx = (sx - xa.astype(f)).astype(f)[None, :]
+        a = m[i][ya][:, xa]; b = m[i][ya][:, xc]; c = m[i][yb][:, xa]; d = m[i][yb][:, xc]
+        top = (a + ((b - a).astype(f) * fx).astype(f)).astype(f)
+        bot = (c + ((d - c).astype(f) * fx).astype(f)).astype(f)
+        v = (top + ((bot - top).astype(f) * fy).astype(f)).astype(f)
+        out[i][np.ix_(ys, xs)] = (v >= f(threshold)).astype(np.uint8)
+    return out

@@ -298,3 +298,26 @@ def test_layer_errors(pkg):
     ML = pkg.MLMultiArray
     with pytest.raises(Exception):
         layer.evaluate([ML(np.zeros((4, 4), np.float32))], [ML(np.zeros((100, 6), np.float32))])   # missing input
+
+
+def test_paste_masks(pkg, orc):
+    """GPU mask paste (resize-to-box + threshold) vs the numpy restatement: bit-exact."""
+    import importlib
+    D = importlib.import_module("mask-rcnn-coreml_amd.detection")
+    rng = np.random.default_rng(21)
+    n, H, W = 24, 256, 320
+    y1 = rng.random(n) * 0.7; x1 = rng.random(n) * 0.7
+    det = np.zeros((n, 6), np.float32)
+    det[:, 0] = y1; det[:, 1] = x1
+    det[:, 2] = np.minimum(1.0, y1 + 0.02 + rng.random(n) * 0.5); det[:, 3] = np.minimum(1.0, x1 + 0.02 + rng.random(n) * 0.5)
+    det[:, 4] = rng.integers(1, 80, n); det[:, 5] = 0.7 + 0.3 * rng.random(n)
+    det[3] = [0, 0, 1, 1, 5, 0.99]               # whole image
+    det[4] = [0.5, 0.5, 0.5, 0.5, 5, 0.9]        # one-pixel box
+    det[5] = 0                                   # padding row → empty mask
+    masks = rng.random((n, 28, 28)).astype(np.float32)
+    masks[6] = 0.5                               # exactly on the threshold: kept (>=)
+    got = D.paste_masks(det, masks, H, W, 0.5)
+    want = orc.paste_masks(det, masks, H, W, 0.5)
+    np.testing.assert_array_equal(got, want)
+    assert got[5].sum() == 0 and got[3].all() == (masks[3] >= 0.5).all() and got[6].sum() > 0
+    assert set(np.unique(got)) <= {0, 1}
