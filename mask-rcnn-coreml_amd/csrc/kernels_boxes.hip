@@ -297,14 +297,22 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes
         const int gj = cb * 64 + j;
         if (gj <= i || gj >= n) continue;
         if (cls && ccls[j] != mycls) continue;
-        if (iou_yxyx(cbox[j], me) > thr) bits |= 1ull << j;     // IOU(anchorA = candidate, anchorB = selected)
+        // exact float pre-test: disjoint (or merely touching) boxes have intersection 0, hence IoU 0
+        const float4 o = cbox[j];
+        if (fminf(fmaxf(o.x, o.z), fmaxf(me.x, me.z)) <= fmaxf(fminf(o.x, o.z), fminf(me.x, me.z)) ||
+            fminf(fmaxf(o.y, o.w), fmaxf(me.y, me.w)) <= fmaxf(fminf(o.y, o.w), fminf(me.y, me.w)))
+            continue;
+        if (iou_yxyx(o, me) > thr) bits |= 1ull << j;           // IOU(anchorA = candidate, anchorB = selected)
     }
     mask[(size_t)b * mask_sB + (size_t)i * W + cb] = bits;
 }
 
 // ------------------------------------------------------------------------------------------------
-// NMS part 2: greedy scan (nonMaxSupression, Utils.swift:185-218).  One 256-thread block per image.
-// Wave 0 resolves each 64-candidate chunk; all waves then OR the kept rows into `removed`.
+// NMS part 2: greedy scan (nonMaxSupression, Utils.swift:185-218).  One 256-thread block per image,
+// candidates in chunks of 64.  For chunk c the "already suppressed" word is the OR of word c of the
+// rows kept so far — up to max_keep independent 8-B loads spread over the block, ONE memory latency
+// per chunk (an incremental removed[] array needed up to 64 dependent row sweeps per chunk and made
+// the scan 8x slower).  Wave 0 then resolves the chunk from the diagonal word with ballot/readlane.
 // per_class_max > 0: candidates carry classes; a class stops selecting after per_class_max keeps
 // (each class is its own nonMaxSupression call in DetectionLayer.swift:170-183).
 // ------------------------------------------------------------------------------------------------
@@ -317,29 +325,41 @@ __global__ __launch_bounds__(256) void k_nms_scan(const float* __restrict__ boxe
                                                   int32_t* __restrict__ keep_count)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* removed = reinterpret_cast<uint64_t*>(smem);                 // [W]
-    int32_t* kept_cls = reinterpret_cast<int32_t*>(smem + (size_t)W * 8);   // [max_keep] (per-class mode)
-    __shared__ uint64_t s_keptmask;
+    int32_t* kept = reinterpret_cast<int32_t*>(smem);                           // [max_keep] rows kept so far
+    int32_t* kept_cls = reinterpret_cast<int32_t*>(smem + (size_t)max_keep * 4);  // [max_keep] (per-class mode)
+    constexpr int NCLS = 1024;
+    __shared__ int cls_cnt[NCLS];            // keeps per class id < NCLS (larger ids: counted from kept_cls)
+    __shared__ uint64_t s_part[4];
     __shared__ int s_kc;
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int n = n_dev ? n_dev[b] : n_const;
     const int nW = (n + 63) / 64;
-    for (int i = t; i < W; i += 256) removed[i] = 0;
+    if (per_class_max > 0)
+        for (int i = t; i < NCLS; i += 256) cls_cnt[i] = 0;
     if (t == 0) s_kc = 0;
     __syncthreads();
     const float* bx = boxes + (size_t)b * boxes_sB;
     const uint64_t* mk = mask + (size_t)b * mask_sB;
     int32_t* kidx = keep_idx + (size_t)b * keep_sB;
     for (int c = 0; c < nW; ++c) {
+        const int kc0 = s_kc;
+        // word c of every row kept so far (rows live in earlier chunks, so the word is in the computed triangle)
+        uint64_t acc = 0;
+        for (int k = t; k < kc0; k += 256) acc |= mk[(size_t)kept[k] * W + c];
+        uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo |= __shfl_xor(lo, o); hi |= __shfl_xor(hi, o); }
+        if (lane == 0) s_part[wv] = ((uint64_t)hi << 32) | lo;
+        __syncthreads();
         if (wv == 0) {
+            const uint64_t removed = s_part[0] | s_part[1] | s_part[2] | s_part[3];
             const int row = c * 64 + lane;
             const bool inr = row < n;
             const uint64_t diag = inr ? mk[(size_t)row * W + c] : 0ull;
             const bool ok = inr && rect_selectable(*reinterpret_cast<const float4*>(bx + (size_t)(inr ? row : 0) * 4));
             const int mycls = (cls && inr) ? cls[(size_t)b * cls_sB + row] : 0;
-            uint64_t m = __ballot(ok) & ~removed[c];
-            uint64_t keptmask = 0;
-            int kc = s_kc;
+            uint64_t m = __ballot(ok) & ~removed;
+            int kc = kc0;
             while (m != 0ull && kc < max_keep) {
                 const int i = __ffsll((unsigned long long)m) - 1;
                 m &= ~(1ull << i);
@@ -347,44 +367,34 @@ __global__ __launch_bounds__(256) void k_nms_scan(const float* __restrict__ boxe
                 int ci = 0;
                 if (per_class_max > 0) {
                     ci = __shfl(mycls, i);
-                    int cnt = 0;
-                    for (int base = 0; base < kc; base += 64) {
-                        const bool eq = (base + lane < kc) && kept_cls[base + lane] == ci;
-                        cnt += __popcll(__ballot(eq));
+                    int cnt;
+                    if ((unsigned)ci < (unsigned)NCLS) cnt = cls_cnt[ci];
+                    else {
+                        cnt = 0;
+                        for (int base = 0; base < kc; base += 64) {
+                            const bool eq = (base + lane < kc) && kept_cls[base + lane] == ci;
+                            cnt += __popcll(__ballot(eq));
+                        }
                     }
                     take = cnt < per_class_max;
+                    if (take && (unsigned)ci < (unsigned)NCLS) cls_cnt[ci] = cnt + 1;   // every lane, same value
                 }
                 if (take) {
-                    keptmask |= 1ull << i;
                     if (lane == 0) {
                         kidx[kc] = c * 64 + i;
+                        kept[kc] = c * 64 + i;
                         if (per_class_max > 0) kept_cls[kc] = ci;
                     }
                     ++kc;
-                    const uint32_t lo = __shfl((uint32_t)(diag & 0xFFFFFFFFull), i);
-                    const uint32_t hi = __shfl((uint32_t)(diag >> 32), i);
-                    m &= ~(((uint64_t)hi << 32) | lo);
+                    const uint32_t dlo = __shfl((uint32_t)(diag & 0xFFFFFFFFull), i);
+                    const uint32_t dhi = __shfl((uint32_t)(diag >> 32), i);
+                    m &= ~(((uint64_t)dhi << 32) | dlo);
                 }
             }
-            if (lane == 0) { s_keptmask = keptmask; s_kc = kc; }
+            if (lane == 0) s_kc = kc;
         }
         __syncthreads();
-        const uint64_t km = s_keptmask;
-        const int kc_now = s_kc;
-        if (km != 0ull) {
-            for (int w = c + 1 + t; w < nW; w += 256) {
-                uint64_t acc = 0;
-                uint64_t mm = km;
-                while (mm) {
-                    const int i = __ffsll((unsigned long long)mm) - 1;
-                    mm &= mm - 1;
-                    acc |= mk[(size_t)(c * 64 + i) * W + w];
-                }
-                removed[w] |= acc;
-            }
-        }
-        __syncthreads();
-        if (kc_now >= max_keep) break;
+        if (s_kc >= max_keep) break;
     }
     if (t == 0) keep_count[b] = s_kc;
 }
@@ -443,7 +453,7 @@ void proposal_forward(hipStream_t s, const ProposalWorkspace& ws, const float* p
     const long boxes_sB = (long)K * 4, mask_sB = (long)K * ws.W;
     hipLaunchKernelGGL(k_nms_mask, dim3(ws.W, ws.W, B), dim3(64), 0, s, ws.boxes, boxes_sB, (const int32_t*)nullptr, 0L,
                        (const int32_t*)nullptr, K, nms_thr, ws.nms_mask, mask_sB, ws.W);
-    hipLaunchKernelGGL(k_nms_scan, dim3(B), dim3(256), (size_t)ws.W * 8, s, ws.boxes, boxes_sB, (const int32_t*)nullptr, 0L,
+    hipLaunchKernelGGL(k_nms_scan, dim3(B), dim3(256), (size_t)ws.max_keep * 4, s, ws.boxes, boxes_sB, (const int32_t*)nullptr, 0L,
                        (const int32_t*)nullptr, K, ws.nms_mask, mask_sB, ws.W, ws.max_keep, 0, ws.keep_idx,
                        (long)ws.max_keep, ws.keep_count);
     hipLaunchKernelGGL(k_write_rois, dim3(B), dim3(256), 0, s, ws.boxes, boxes_sB, ws.keep_idx, (long)ws.max_keep,
@@ -602,7 +612,7 @@ void detection_forward(hipStream_t s, const DetectionWorkspace& ws, const float*
         HIP_CHECK(hipFuncSetAttribute((const void*)k_det_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         attr_set = true;
     }
-    const size_t scan_lds = (size_t)ws.W * 8 + (size_t)N * 4;
+    const size_t scan_lds = (size_t)N * 8;
     MRCNN_REQUIRE(scan_lds <= 64 * 1024, MRCNN_ERR_UNSUPPORTED, "DetectionLayer: too many regions (%d)", N);
     hipLaunchKernelGGL(k_nms_scan, dim3(B), dim3(256), scan_lds, s, ws.boxes, boxes_sB, ws.cls, (long)N, ws.count, 0,
                        ws.nms_mask, mask_sB, ws.W, N, ws.max_det, ws.keep_idx, (long)N, ws.keep_count);
