@@ -226,6 +226,12 @@ typedef struct {
  * number kept in *count. */
 MRCNN_API int mrcnn_detections_decode(const float* detections, int64_t n_rows, int64_t row_stride,
                                       mrcnn_detection* out, int64_t capacity, int64_t* count);
+/* Anchors on demand (the reference's own TODO, MaskRCNNConfig.swift:14): writes the (A,4) float32
+ * normalized (y1,x1,y2,x2) anchors that the converter dumps to anchors.bin (task.py:173-176) for the
+ * default scales (32..512), ratios (0.5,1,2) and strides (4..64).  Host code.  Call with out = NULL to
+ * query *count = A. */
+MRCNN_API int mrcnn_generate_anchors(int image_h, int image_w, float* out, int64_t capacity, int64_t* count);
+
 /* Mask paste: per-instance 28×28 sigmoid masks → full-resolution binary masks
  * (n, image_h, image_w) uint8 {0,1}: resize to the detection's box and threshold.  Replaces what the
  * example app does with CoreGraphics when drawing (Example/Source/DetectionRenderer.swift:13-24).

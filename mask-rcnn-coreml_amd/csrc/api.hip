@@ -722,6 +722,42 @@ extern "C" int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout
 }
 
 // ================================================================================================
+// anchors on demand (MaskRCNNConfig.swift:14 "TODO: generate the anchors on demand")
+// Host code.  Restates the published Matterport generator the reference's converter dumps to
+// anchors.bin (task.py:173-176): level-major P2..P6, then y, x, ratio; float64 arithmetic, one
+// rounding to float32 at the end — bit-identical to mask-rcnn-coreml_amd/anchors.py.
+// ================================================================================================
+extern "C" int mrcnn_generate_anchors(int image_h, int image_w, float* out, int64_t capacity, int64_t* count)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(image_h > 0 && image_w > 0 && count, MRCNN_ERR_INVALID, "bad generate_anchors argument");
+        const double scales[5] = {32, 64, 128, 256, 512}, ratios[3] = {0.5, 1.0, 2.0};
+        const int strides[5] = {4, 8, 16, 32, 64};
+        int64_t n = 0;
+        for (int l = 0; l < 5; ++l) n += (int64_t)((image_h + strides[l] - 1) / strides[l]) * ((image_w + strides[l] - 1) / strides[l]) * 3;
+        *count = n;
+        if (!out) return;
+        MRCNN_REQUIRE(capacity >= n * 4, MRCNN_ERR_SHAPE, "anchors need %lld floats, buffer holds %lld", (long long)n * 4, (long long)capacity);
+        const double sy = (double)(image_h - 1), sx = (double)(image_w - 1);
+        float* o = out;
+        for (int l = 0; l < 5; ++l) {
+            const int fh = (image_h + strides[l] - 1) / strides[l], fw = (image_w + strides[l] - 1) / strides[l];
+            for (int y = 0; y < fh; ++y)
+                for (int x = 0; x < fw; ++x)
+                    for (int r = 0; r < 3; ++r) {
+                        const double h = scales[l] / sqrt(ratios[r]), w = scales[l] * sqrt(ratios[r]);
+                        const double cy = (double)(y * strides[l]), cx = (double)(x * strides[l]);
+                        o[0] = (float)(((cy - 0.5 * h) - 0.0) / sy);
+                        o[1] = (float)(((cx - 0.5 * w) - 0.0) / sx);
+                        o[2] = (float)(((cy + 0.5 * h) - 1.0) / sy);
+                        o[3] = (float)(((cx + 0.5 * w) - 1.0) / sx);
+                        o += 4;
+                    }
+        }
+    });
+}
+
+// ================================================================================================
 // mask paste (DetectionRenderer.swift:13-24)
 // ================================================================================================
 extern "C" int mrcnn_paste_masks(const float* detections, int64_t det_stride, const float* masks, int n, int mask_size, int image_h,

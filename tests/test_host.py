@@ -48,6 +48,27 @@ def test_anchors_bin_layout(pkg, anchors_mod, tmp_path):
         anchors_mod.read_anchors_bin(p)
 
 
+def test_c_anchor_generator_matches_python(pkg, anchors_mod):
+    """mrcnn_generate_anchors (host C, the reference's "generate the anchors on demand" TODO) is
+    bit-identical to the Python generator that writes anchors.bin."""
+    import ctypes as C
+    lib_mod = importlib.import_module("mask-rcnn-coreml_amd._lib")
+    if not os.path.exists(lib_mod.SO_PATH):
+        pytest.skip("library not built")
+    L = lib_mod.lib()
+    for h, w in ((128, 128), (256, 192), (1024, 1024)):
+        cfg = pkg.ModelConfig(input_image_shape=(h, w, 3))
+        want = anchors_mod.generate_anchors(cfg)
+        cnt = C.c_int64(0)
+        lib_mod.check(L.mrcnn_generate_anchors(h, w, None, 0, C.byref(cnt)))
+        assert cnt.value == want.shape[0] == cfg.num_anchors()
+        got = np.empty((cnt.value, 4), np.float32)
+        lib_mod.check(L.mrcnn_generate_anchors(h, w, got.ctypes.data, got.size, C.byref(cnt)))
+        np.testing.assert_array_equal(got, want)
+    with pytest.raises(lib_mod.MrcnnError):
+        lib_mod.check(L.mrcnn_generate_anchors(64, 64, np.empty(8, np.float32).ctypes.data, 8, C.byref(cnt)))
+
+
 def test_mrcw_roundtrip_and_synthetic_models(pkg, weights_mod, tmp_path):
     cfg = pkg.ModelConfig(architecture="resnet50", input_image_shape=(64, 64, 3), num_classes=5)
     paths = weights_mod.save_synthetic_models(str(tmp_path), cfg, seed=3)
@@ -115,6 +136,56 @@ def test_no_cpu_fallback_without_gpu(pkg, tmp_path):
     d = pkg.Detection.detectionsFromFeatureValue(det, np.full((2, 28, 28), 0.5, np.float32))
     assert len(d) == 1 and d[0].classId == 3 and d[0].mask[0, 0] == 191
     assert abs(pkg.IOU((0, 0, 1, 1), (0.5, 0, 1, 1)) - 1 / 3) < 1e-6
+
+
+def _results_proto_classes():
+    """The reference's results.proto rebuilt with google.protobuf from the field numbers in
+    Sources/maskrcnn/results.pb.swift — an independent codec to check the hand-written one against."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    fd = descriptor_pb2.FileDescriptorProto(name="results.proto", package="maskrcnn", syntax="proto3")
+    T = descriptor_pb2.FieldDescriptorProto
+
+    def msg(name, fields):
+        m = fd.message_type.add(name=name)
+        for no, fname, ftype, label, tname in fields:
+            f = m.field.add(name=fname, number=no, type=ftype, label=label)
+            if tname:
+                f.type_name = ".maskrcnn." + tname
+    O, R = T.LABEL_OPTIONAL, T.LABEL_REPEATED
+    msg("Origin", [(1, "x", T.TYPE_DOUBLE, O, None), (2, "y", T.TYPE_DOUBLE, O, None)])
+    msg("Size", [(1, "width", T.TYPE_DOUBLE, O, None), (2, "height", T.TYPE_DOUBLE, O, None)])
+    msg("Rect", [(1, "origin", T.TYPE_MESSAGE, O, "Origin"), (2, "size", T.TYPE_MESSAGE, O, "Size")])
+    msg("ImageInfo", [(1, "datasetId", T.TYPE_STRING, O, None), (2, "id", T.TYPE_STRING, O, None),
+                      (3, "width", T.TYPE_INT32, O, None), (4, "height", T.TYPE_INT32, O, None)])
+    msg("Detection", [(1, "probability", T.TYPE_DOUBLE, O, None), (2, "classId", T.TYPE_INT32, O, None),
+                      (3, "classLabel", T.TYPE_STRING, O, None), (4, "boundingBox", T.TYPE_MESSAGE, O, "Rect")])
+    msg("Result", [(1, "imageInfo", T.TYPE_MESSAGE, O, "ImageInfo"), (2, "detections", T.TYPE_MESSAGE, R, "Detection")])
+    msg("Results", [(1, "results", T.TYPE_MESSAGE, R, "Result")])
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    return message_factory.GetMessageClass(pool.FindMessageTypeByName("maskrcnn.Results"))
+
+
+def test_results_proto_wire_format():
+    rp = importlib.import_module("mask-rcnn-coreml_amd.results_pb")
+    det = np.zeros((5, 6), np.float32)
+    det[0] = [0.1, 0.2, 0.5, 0.8, 17, 0.9]
+    det[1] = [0.0, 0.0, 1.0, 1.0, 3, 0.7]            # not > 0.7: dropped (EvaluateCommand.swift:216)
+    det[2] = [0.25, 0.5, 0.75, 1.0, 1, 1.0]
+    pbs = rp.detections_to_pb(det)
+    assert [d.classId for d in pbs] == [17, 1] and all(d.classLabel == "test" for d in pbs)
+    assert pbs[0].x == float(np.float32(0.2)) and pbs[0].height == float(np.float32(0.5)) - float(np.float32(0.1))
+    results = [rp.PBResult("coco", "139", 640, 426, pbs), rp.PBResult("coco", "285", 0, 0, [])]
+    data = rp.encode_results(results)
+    assert rp.decode_results(data) == results                                # own round trip
+    Results = _results_proto_classes()
+    m = Results()
+    m.ParseFromString(data)                                                  # protobuf accepts our bytes
+    assert len(m.results) == 2 and m.results[0].imageInfo.id == "139" and m.results[0].imageInfo.width == 640
+    d0 = m.results[0].detections[0]
+    assert (d0.probability, d0.classId, d0.classLabel) == (pbs[0].probability, 17, "test")
+    assert (d0.boundingBox.origin.x, d0.boundingBox.size.height) == (pbs[0].x, pbs[0].height)
+    assert m.SerializeToString(deterministic=True) == data                   # and produces the same bytes
 
 
 def test_oracle_and_product_do_not_mix():
