@@ -232,6 +232,13 @@ MRCNN_API int mrcnn_detections_decode(const float* detections, int64_t n_rows, i
  * query *count = A. */
 MRCNN_API int mrcnn_generate_anchors(int image_h, int image_w, float* out, int64_t capacity, int64_t* count);
 
+/* Letterbox: Vision's `.scaleFit` (EvaluateCommand.swift:157, ViewController.swift:45) on
+ * the GPU — RGB8 (h,w,3) resized with preserved aspect ratio (bilinear, half-pixel centres) and centred in
+ * an (H,W,3) canvas with black borders.  _geometry returns the content size and offsets (host arithmetic)
+ * so that callers can map normalized boxes back to the source image. */
+MRCNN_API int mrcnn_letterbox_geometry(int h, int w, int H, int W, int* nh, int* nw, int* pad_y, int* pad_x);
+MRCNN_API int mrcnn_letterbox_rgb(const uint8_t* src, int h, int w, int memspace, uint8_t* dst, int H, int W);
+
 /* Mask paste: per-instance 28×28 sigmoid masks → full-resolution binary masks
  * (n, image_h, image_w) uint8 {0,1}: resize to the detection's box and threshold.  Replaces what the
  * example app does with CoreGraphics when drawing (Example/Source/DetectionRenderer.swift:13-24).

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "mrcnn_maskrcnn_predict_async", "mrcnn_classifier_predict", "mrcnn_mask_predict", "mrcnn_model_get_int",
     "mrcnn_model_read_tensor", "mrcnn_model_enable_timing", "mrcnn_model_stage_ms", "mrcnn_bench_conv",
     "mrcnn_model_conv_profile_enable", "mrcnn_model_conv_profile_get", "mrcnn_bench_conv_dtype",
-    "mrcnn_detections_decode", "mrcnn_mask_to_u8", "mrcnn_paste_masks", "mrcnn_generate_anchors",
+    "mrcnn_detections_decode", "mrcnn_mask_to_u8", "mrcnn_paste_masks", "mrcnn_generate_anchors", "mrcnn_letterbox_geometry", "mrcnn_letterbox_rgb",
 ]
 
 
@@ -110,6 +110,9 @@ def lib():
     L.mrcnn_bench_conv_dtype.argtypes = [C.c_int] * 9 + [f32p, C.POINTER(C.c_double)]
     L.mrcnn_detections_decode.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(DetectionRecord), C.c_int64, i64p]
     L.mrcnn_mask_to_u8.argtypes = [vp, C.c_int64, vp]
+    ip = C.POINTER(C.c_int)
+    L.mrcnn_letterbox_geometry.argtypes = [C.c_int] * 4 + [ip] * 4
+    L.mrcnn_letterbox_rgb.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int]
     L.mrcnn_generate_anchors.argtypes = [C.c_int, C.c_int, vp, C.c_int64, i64p]
     L.mrcnn_paste_masks.argtypes = [vp, C.c_int64, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp]
     _lib = L

@@ -758,6 +758,44 @@ extern "C" int mrcnn_generate_anchors(int image_h, int image_w, float* out, int6
 }
 
 // ================================================================================================
+// letterbox (`.scaleFit`, EvaluateCommand.swift:157)
+// ================================================================================================
+extern "C" int mrcnn_letterbox_geometry(int h, int w, int H, int W, int* nh, int* nw, int* pad_y, int* pad_x)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(h > 0 && w > 0 && H > 0 && W > 0 && nh && nw && pad_y && pad_x, MRCNN_ERR_INVALID, "bad letterbox argument");
+        const double sc = fmin((double)W / (double)w, (double)H / (double)h);
+        int a = (int)floor((double)h * sc + 0.5), b = (int)floor((double)w * sc + 0.5);
+        a = a < 1 ? 1 : (a > H ? H : a);
+        b = b < 1 ? 1 : (b > W ? W : b);
+        *nh = a; *nw = b; *pad_y = (H - a) / 2; *pad_x = (W - b) / 2;
+    });
+}
+
+extern "C" int mrcnn_letterbox_rgb(const uint8_t* src, int h, int w, int memspace, uint8_t* dst, int H, int W)
+{
+    return guarded([&] {
+        require_gpu();
+        MRCNN_REQUIRE(src && dst, MRCNN_ERR_INVALID, "null buffer");
+        int nh, nw, py, px;
+        MRCNN_REQUIRE(mrcnn_letterbox_geometry(h, w, H, W, &nh, &nw, &py, &px) == MRCNN_OK, MRCNN_ERR_INVALID, "bad letterbox geometry");
+        Stream st;
+        DevBuf ts, td;
+        const uint8_t* s = src;
+        uint8_t* d = dst;
+        if (memspace != MRCNN_DEVICE) {
+            ts.alloc((size_t)h * w * 3);
+            HIP_CHECK(hipMemcpy(ts.p, src, (size_t)h * w * 3, hipMemcpyHostToDevice));
+            td.alloc((size_t)H * W * 3);
+            s = ts.as<uint8_t>(); d = td.as<uint8_t>();
+        }
+        letterbox_forward(st.s, s, h, w, d, H, W, nh, nw, py, px);
+        HIP_CHECK(hipStreamSynchronize(st.s));
+        if (memspace != MRCNN_DEVICE) HIP_CHECK(hipMemcpy(dst, td.p, (size_t)H * W * 3, hipMemcpyDeviceToHost));
+    });
+}
+
+// ================================================================================================
 // mask paste (DetectionRenderer.swift:13-24)
 // ================================================================================================
 extern "C" int mrcnn_paste_masks(const float* detections, int64_t det_stride, const float* masks, int n, int mask_size, int image_h,

@@ -69,6 +69,8 @@ void roi_align_forward(hipStream_t s, const PyramidMaps& maps, int C, int layout
                        long rois_sB, long roi_stride, int n_rois, int B, int pool, double image_w,
                        double image_h, void* out, long out_sB, long out_row_stride, int dtype);
 
+// `.scaleFit` letterbox of an RGB8 image into an H×W canvas (content nh×nw at offset (py,px)).
+void letterbox_forward(hipStream_t s, const uint8_t* src, int h, int w, uint8_t* dst, int H, int W, int nh, int nw, int py, int px);
 // Full-resolution binary instance masks from the 28×28 sigmoid masks (resize to box + threshold).
 void paste_masks_forward(hipStream_t s, const float* det, long det_stride, const float* masks, int n, int S, int H, int W,
                          float thr, uint8_t* out);

@@ -240,4 +240,51 @@ void paste_masks_forward(hipStream_t s, const float* det, long det_stride, const
     HIP_CHECK(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------------
+// Letterbox: the host's `.scaleFit` step (VNCoreMLRequest.imageCropAndScaleOption,
+// EvaluateCommand.swift:157, ViewController.swift:45) on the GPU: aspect-preserving bilinear resize
+// (half-pixel centres, edge clamp, round-half-up to 8 bit) centred in an H×W canvas, black borders.
+// Vision's resampler is closed source → convention unpinned.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_letterbox(const uint8_t* __restrict__ src, int h, int w, uint8_t* __restrict__ dst,
+                                                   int H, int W, int nh, int nw, int py, int px)
+{
+    const long total = (long)H * W;
+    const float ry = (float)h / (float)nh, rx = (float)w / (float)nw;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int Y = (int)(e / W), X = (int)(e - (long)Y * W);
+        const int y = Y - py, x = X - px;
+        uint8_t o0 = 0, o1 = 0, o2 = 0;
+        if ((unsigned)y < (unsigned)nh && (unsigned)x < (unsigned)nw) {
+            float sy = ((float)y + 0.5f) * ry - 0.5f, sx = ((float)x + 0.5f) * rx - 0.5f;
+            sy = fminf(fmaxf(sy, 0.0f), (float)(h - 1));
+            sx = fminf(fmaxf(sx, 0.0f), (float)(w - 1));
+            const int ya = (int)floorf(sy), yb = min(ya + 1, h - 1), xa = (int)floorf(sx), xb = min(xa + 1, w - 1);
+            const float fy = sy - (float)ya, fx = sx - (float)xa;
+            const uint8_t* a = src + ((long)ya * w + xa) * 3;
+            const uint8_t* b = src + ((long)ya * w + xb) * 3;
+            const uint8_t* c = src + ((long)yb * w + xa) * 3;
+            const uint8_t* d = src + ((long)yb * w + xb) * 3;
+            uint8_t r[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float top = (float)a[k] + ((float)b[k] - (float)a[k]) * fx;
+                const float bot = (float)c[k] + ((float)d[k] - (float)c[k]) * fx;
+                const float v = top + (bot - top) * fy;
+                r[k] = (uint8_t)floorf(v + 0.5f);
+            }
+            o0 = r[0]; o1 = r[1]; o2 = r[2];
+        }
+        dst[e * 3 + 0] = o0; dst[e * 3 + 1] = o1; dst[e * 3 + 2] = o2;
+    }
+}
+
+void letterbox_forward(hipStream_t s, const uint8_t* src, int h, int w, uint8_t* dst, int H, int W, int nh, int nw, int py, int px)
+{
+    const long total = (long)H * W;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_letterbox, dim3(grid), dim3(256), 0, s, src, h, w, dst, H, W, nh, nw, py, px);
+    HIP_CHECK(hipGetLastError());
+}
+
 }  // namespace mrcnn

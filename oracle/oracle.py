@@ -260,3 +260,33 @@ def paste_masks(detections, masks, image_h: int, image_w: int, threshold: float 
         v = (top + ((bot - top).astype(f) * fy).astype(f)).astype(f)
         out[i][np.ix_(ys, xs)] = (v >= f(threshold)).astype(np.uint8)
     return out
+
+
+def letterbox(image, H: int, W: int) -> np.ndarray:
+    """numpy restatement of the GPU letterbox (`.scaleFit`, EvaluateCommand.swift:157; Vision's resampler is
+    closed → OUR convention, unpinned): aspect-preserving bilinear (half-pixel centres, edge clamp, float32,
+    round-half-up), centred, black borders."""
+    f = np.float32
+    img = np.ascontiguousarray(image, dtype=np.uint8)
+    h, w = img.shape[:2]
+    sc = min(W / w, H / h)
+    nh = min(H, max(1, int(np.floor(h * sc + 0.5))))
+    nw = min(W, max(1, int(np.floor(w * sc + 0.5))))
+    py, px = (H - nh) // 2, (W - nw) // 2
+    ry, rx = f(h) / f(nh), f(w) / f(nw)
+    sy = (np.arange(nh).astype(f) + f(0.5)) * ry - f(0.5)
+    sx = (np.arange(nw).astype(f) + f(0.5)) * rx - f(0.5)
+    sy = np.minimum(np.maximum(sy, f(0)), f(h - 1)).astype(f)
+    sx = np.minimum(np.maximum(sx, f(0)), f(w - 1)).astype(f)
+    ya = np.floor(sy).astype(np.int64); yb = np.minimum(ya + 1, h - 1)
+    xa = np.floor(sx).astype(np.int64); xb = np.minimum(xa + 1, w - 1)
+    fy = (sy - ya.astype(f)).astype(f)[:, None, None]
+    fx = (sx - xa.astype(f)).astype(f)[None, :, None]
+    src = img.astype(f)
+    a = src[ya][:, xa]; b = src[ya][:, xb]; c = src[yb][:, xa]; d = src[yb][:, xb]
+    top = (a + ((b - a).astype(f) * fx).astype(f)).astype(f)
+    bot = (c + ((d - c).astype(f) * fx).astype(f)).astype(f)
+    v = (top + ((bot - top).astype(f) * fy).astype(f)).astype(f)
+    out = np.zeros((H, W, 3), dtype=np.uint8)
+    out[py:py + nh, px:px + nw] = np.floor(v + f(0.5)).astype(np.uint8)
+    return out

@@ -321,3 +321,36 @@ def test_paste_masks(pkg, orc):
     np.testing.assert_array_equal(got, want)
     assert got[5].sum() == 0 and got[3].all() == (masks[3] >= 0.5).all() and got[6].sum() > 0
     assert set(np.unique(got)) <= {0, 1}
+
+
+@pytest.mark.parametrize("h,w", [(480, 640), (640, 427), (100, 100), (1024, 1024), (1500, 700)])
+def test_letterbox(pkg, orc, h, w):
+    """GPU `.scaleFit` letterbox vs the numpy restatement: bit-exact; geometry helper consistent."""
+    import importlib
+    E = importlib.import_module("mask-rcnn-coreml_amd.evaluate")
+    img = np.random.default_rng(h * 7 + w).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    got = E.letterbox(img, 256, 256)
+    np.testing.assert_array_equal(got, orc.letterbox(img, 256, 256))
+    nh, nw, py, px = E.letterbox_geometry(h, w, 256, 256)
+    assert max(nh, nw) == 256 and (got[:py] == 0).all() and (got[:, :px] == 0).all()
+    boxes = np.array([[py / 256, px / 256, (py + nh) / 256, (px + nw) / 256, 1, 0.9]], np.float32)
+    np.testing.assert_allclose(E.unletterbox_boxes(boxes, h, w, 256, 256)[0, :4], [0, 0, 1, 1], atol=1e-6)
+
+
+def test_evaluate_harness(pkg, small_model):
+    """The `maskrcnn evaluate` counterpart: letterbox → predict → results.proto, per-image timing,
+    first `limit` images sorted by id (EvaluateCommand.swift:165-194)."""
+    import importlib
+    E = importlib.import_module("mask-rcnn-coreml_amd.evaluate")
+    rp = importlib.import_module("mask-rcnn-coreml_amd.results_pb")
+    models = importlib.import_module("mask-rcnn-coreml_amd.models")
+    d, cfg = small_model
+    m = models.load_maskrcnn(d, max_batch=1)
+    rng = np.random.default_rng(3)
+    images = [(i, rng.integers(0, 256, (90 + 10 * i, 160 - 7 * i, 3), dtype=np.uint8)) for i in (9, 3, 5, 1, 7, 2, 8)]
+    data, secs, results = E.evaluate(m, images, dataset_id="synthetic", limit=5, verbose=False)
+    assert [r.id for r in results] == ["1", "2", "3", "5", "7"] and len(secs) == 5 and all(s > 0 for s in secs)
+    assert rp.decode_results(data) == results
+    lb = E.letterbox(dict(images)[3], cfg.image_height, cfg.image_width)
+    want = rp.detections_to_pb(m.prediction(lb)["detections"])
+    assert results[2].detections == want and (results[2].width, results[2].height) == (160 - 21, 120)
