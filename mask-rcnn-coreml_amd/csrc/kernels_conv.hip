@@ -396,7 +396,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma(const ConvArgs a)
 //   * two LDS buffers: the DMA of tile k+1 is issued right after the barrier that retired buffer
 //     (k+1)&1 and lands while tile k is being multiplied; one vmcnt(0) + barrier per K step.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BN, int TM, int TN, int WM, int WN>
+template <typename T, int BN, int TM, int TN, int WM, int WN, int STAGES = 2>
 __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs a)
 {
     constexpr int BM = WM * TM * 32;
@@ -411,7 +411,9 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
     constexpr int ROWB = 128;
     constexpr int A_STAGE = BM * ROWB, B_STAGE = BN * ROWB;
     constexpr int C_ROW = BN;                                   // fp32 C tile, unpadded
-    constexpr int SMEM_OPS = 2 * (A_STAGE + B_STAGE);
+    static_assert(STAGES == 2 || STAGES == 3, "ring depth");
+    constexpr int NLOADS = AP + BP;                              // DMA instructions per tile per thread
+    constexpr int SMEM_OPS = STAGES * (A_STAGE + B_STAGE);
     constexpr int SMEM = SMEM_OPS > BM * C_ROW * 4 ? SMEM_OPS : BM * C_ROW * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     const T* const in = static_cast<const T*>(a.in);
@@ -446,7 +448,6 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
         iw0[p] = ow * a.stride - a.padW;
         a_off[p] = (long)b * a.in_sB + (long)ih0[p] * a.in_sH + (long)iw0[p] * a.in_sW + kq * EPV;
     }
-    const T* const wbase = wgt + (size_t)(n0 + r0) * a.Ktot + kq * EPV;
     const int cin_tiles = a.Cin / BK;
     const int KT = a.KH * a.KW * cin_tiles;
     // wave-uniform LDS destinations: this wave's 8 rows of each staging pass
@@ -454,35 +455,49 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);   // LDS byte address of smem
 
-    int kh = 0, kw = 0, ct = 0;
-    // The DMA is issued through inline asm on purpose: with the builtin hipcc treats it as an LDS
+    // ---- DMA address generation, kept off the per-tile critical path ------------------------------
+    // A (activations): one 64-bit source pointer per staged row, advanced by a per-row step each tile
+    //   (step = one K tile, or 0 when the tap falls outside the image and the row reads the zero page);
+    //   the bounds test and the select run only when the TAP changes (every Cin/BK tiles).
+    // B (filters): scalar base (advanced by one K tile) + loop-invariant 32-bit per-lane byte offset.
+    // The DMA itself goes through inline asm on purpose: with the builtin hipcc treats it as an LDS
     // store it must order against every later ds_read and drains it with vmcnt(0) at the top of the
     // step, which makes the copy synchronous.  In asm the compiler does not count it, so the waits
-    // are placed by hand: vmcnt(0) right before the barrier that hands the buffer over.
-    // (M0 = wave-uniform LDS byte address; each lane's 16 B land at M0 + lane*16.)
-#define MRCNN_GLDS(SRC, DST)                                                                                   \
-    {                                                                                                          \
-        unsigned keep_m0;                                                                                      \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
-                     : "=&s"(keep_m0)                                                                          \
-                     : "v"(SRC), "s"(DST)                                                                      \
-                     : "memory");                                                                              \
+    // are placed by hand (M0 = wave-uniform LDS byte address; lane i's 16 B land at M0 + 16 i).
+    static_assert(AP <= 4 && BP <= 2, "per-row DMA state is spelled out for <= 4 A rows / <= 2 B rows");
+    const T *pa0 = zero, *pa1 = zero, *pa2 = zero, *pa3 = zero;
+    unsigned sa0 = 0, sa1 = 0, sa2 = 0, sa3 = 0;
+    const unsigned vb0 = (unsigned)(((size_t)r0 * a.Ktot + kq * EPV) * sizeof(T));
+    const unsigned vb1 = (unsigned)(((size_t)(r0 + RPT) * a.Ktot + kq * EPV) * sizeof(T));
+    const T* sb = wgt + (size_t)n0 * a.Ktot;                 // uniform
+    int kh = 0, kw = 0, ct = 0;
+#define MRCNN_SET_TAP(P)                                                                                       \
+    if constexpr (AP > P) {                                                                                    \
+        const int ih = ih0[P] + kh, iw = iw0[P] + kw;                                                          \
+        const bool ok = a_ok[P] && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;               \
+        pa##P = ok ? in + a_off[P] + (long)kh * a.in_sH + (long)kw * a.in_sW : zero;                           \
+        sa##P = ok ? BK : 0;                                                                                   \
     }
+#define MRCNN_GLDS_V(SRC, DST)                                                                                 \
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(SRC), "s"(DST) : "memory", "m0");
+#define MRCNN_GLDS_S(VOFF, SBASE, DST)                                                                         \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(VOFF), "s"(SBASE), "s"(DST) : "memory", "m0");
+#define MRCNN_DMA_A(P) if constexpr (AP > P) { MRCNN_GLDS_V(pa##P, da + P * RPT * ROWB); pa##P += sa##P; }
 #define MRCNN_DMA_TILE(KT_, BUF_)                                                                              \
     {                                                                                                          \
-        const long tap_off = (long)kh * a.in_sH + (long)kw * a.in_sW + ct * BK;                                \
         const unsigned da = lds0 + (BUF_) * A_STAGE + wrow * ROWB;                                             \
-        const unsigned db = lds0 + 2 * A_STAGE + (BUF_) * B_STAGE + wrow * ROWB;                               \
-        _Pragma("unroll") for (int p = 0; p < AP; ++p) {                                                       \
-            const int ih = ih0[p] + kh, iw = iw0[p] + kw;                                                      \
-            const bool ok = a_ok[p] && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;           \
-            const T* src = ok ? in + a_off[p] + tap_off : zero;                                                \
-            MRCNN_GLDS(src, da + p * RPT * ROWB);                                                              \
+        const unsigned db = lds0 + STAGES * A_STAGE + (BUF_) * B_STAGE + wrow * ROWB;                          \
+        MRCNN_DMA_A(0) MRCNN_DMA_A(1) MRCNN_DMA_A(2) MRCNN_DMA_A(3)                                            \
+        MRCNN_GLDS_S(vb0, sb, db);                                                                             \
+        if constexpr (BP > 1) MRCNN_GLDS_S(vb1, sb, db + RPT * ROWB);                                          \
+        sb += BK;                                                                                              \
+        if (++ct == cin_tiles) {                                                                               \
+            ct = 0;                                                                                            \
+            if (++kw == a.KW) { kw = 0; ++kh; }                                                                \
+            MRCNN_SET_TAP(0) MRCNN_SET_TAP(1) MRCNN_SET_TAP(2) MRCNN_SET_TAP(3)                                \
         }                                                                                                      \
-        _Pragma("unroll") for (int p = 0; p < BP; ++p)                                                         \
-            MRCNN_GLDS(wbase + (size_t)(RPT * p) * a.Ktot + (size_t)(KT_) * BK, db + p * RPT * ROWB);          \
-        if (++ct == cin_tiles) { ct = 0; if (++kw == a.KW) { kw = 0; ++kh; } }                                 \
     }
+    MRCNN_SET_TAP(0) MRCNN_SET_TAP(1) MRCNN_SET_TAP(2) MRCNN_SET_TAP(3)
 
     const int wm = wave / WN, wn = wave - wm * WN;
     const int l31 = lane & 31, kk = lane >> 5;
@@ -496,15 +511,23 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+    // STAGES == 2: the DMA of tile k+1 is issued at the top of step k and must land within the step.
+    // STAGES == 3: two tiles in flight — tile k+2 is issued at the top of step k and only tile k+1 is
+    // waited for (counted vmcnt: the NLOADS most recent DMAs may stay outstanding across the barrier).
     MRCNN_DMA_TILE(0, 0)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (STAGES == 3 && KT > 1) MRCNN_DMA_TILE(1, 1)
+    if (STAGES == 3 && KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();          // tile 0 is in LDS
 
+    int buf = 0;
     for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < KT) MRCNN_DMA_TILE(kt + 1, buf ^ 1)
+        const int nxt = kt + STAGES - 1;                      // tile whose DMA starts in this step
+        int nbuf = buf + STAGES - 1;
+        if (nbuf >= STAGES) nbuf -= STAGES;
+        if (nxt < KT) MRCNN_DMA_TILE(nxt, nbuf)
         const unsigned char* as = smem + buf * A_STAGE + (wm * TM * 32 + l31) * ROWB;
-        const unsigned char* bs = smem + 2 * A_STAGE + buf * B_STAGE + (wn * TN * 32 + l31) * ROWB;
+        const unsigned char* bs = smem + STAGES * A_STAGE + buf * B_STAGE + (wn * TN * 32 + l31) * ROWB;
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
             const int co = ((t4 * 2 + kk) ^ swz) << 4;
@@ -533,11 +556,17 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
                                                                            acc[i][j], 0, 0, 0);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt+1 have landed
+        // tile kt+1 must have landed before the barrier hands its buffer over
+        if (STAGES == 3 && nxt < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                     // ... and every wave is done reading `buf`
+        if (++buf == STAGES) buf = 0;
     }
 #undef MRCNN_DMA_TILE
-#undef MRCNN_GLDS
+#undef MRCNN_DMA_A
+#undef MRCNN_GLDS_V
+#undef MRCNN_GLDS_S
+#undef MRCNN_SET_TAP
     conv_epilogue<T, BN, TM, TN, WM, WN, C_ROW>(a, acc, smem, m0, n0);
 }
 
@@ -587,8 +616,11 @@ template <typename T>
 static void conv_launch(hipStream_t s, const ConvArgs& a, int bn, int bm)
 {
     const dim3 grid(a.tiles_m * a.tiles_n);
+#ifndef MRCNN_TALL_STAGES
+#define MRCNN_TALL_STAGES 3
+#endif
     if (bm == 256) {
-        hipLaunchKernelGGL((k_conv_mfma_glds<T, 128, 2, 2, 4, 2>), grid, dim3(512), 0, s, a);
+        hipLaunchKernelGGL((k_conv_mfma_glds<T, 128, 2, 2, 4, 2, MRCNN_TALL_STAGES>), grid, dim3(512), 0, s, a);
         return;
     }
 #ifndef MRCNN_GLDS_STAGING
