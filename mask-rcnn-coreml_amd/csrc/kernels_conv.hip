@@ -520,48 +520,58 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();          // tile 0 is in LDS
 
-    int buf = 0;
-    for (int kt = 0; kt < KT; ++kt) {
-        const int nxt = kt + STAGES - 1;                      // tile whose DMA starts in this step
-        int nbuf = buf + STAGES - 1;
-        if (nbuf >= STAGES) nbuf -= STAGES;
-        if (nxt < KT) MRCNN_DMA_TILE(nxt, nbuf)
-        const unsigned char* as = smem + buf * A_STAGE + (wm * TM * 32 + l31) * ROWB;
-        const unsigned char* bs = smem + STAGES * A_STAGE + buf * B_STAGE + (wn * TN * 32 + l31) * ROWB;
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
-            const int co = ((t4 * 2 + kk) ^ swz) << 4;
-            uint4 av[TM], bv[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const uint4*>(as + i * 32 * ROWB + co);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const uint4*>(bs + j * 32 * ROWB + co);
-            if constexpr (sizeof(T) == 4) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) {
-                            const uint32_t au = c == 0 ? av[i].x : c == 1 ? av[i].y : c == 2 ? av[i].z : av[i].w;
-                            const uint32_t bu = c == 0 ? bv[j].x : c == 1 ? bv[j].y : c == 2 ? bv[j].z : bv[j].w;
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(au), __uint_as_float(bu), acc[i][j], 0, 0, 0);
-                        }
-            } else {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[i]), __builtin_bit_cast(f16x8, bv[j]),
-                                                                           acc[i][j], 0, 0, 0);
-            }
-        }
-        // tile kt+1 must have landed before the barrier hands its buffer over
-        if (STAGES == 3 && nxt < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                     // ... and every wave is done reading `buf`
-        if (++buf == STAGES) buf = 0;
+    // One K step on buffer BUF; the DMA of tile KTV + STAGES - 1 goes to buffer NBUF.  BUF / NBUF are
+    // compile-time constants in the 2-stage path (loop unrolled by two), so every LDS offset folds
+    // into an instruction immediate and the four swizzled lane addresses are loop-invariant.
+    const unsigned char* const la = smem + (wm * TM * 32 + l31) * ROWB;
+    const unsigned char* const lb = smem + STAGES * A_STAGE + (wn * TN * 32 + l31) * ROWB;
+    const int co0 = ((0 + kk) ^ swz) << 4, co1 = ((2 + kk) ^ swz) << 4, co2 = ((4 + kk) ^ swz) << 4, co3 = ((6 + kk) ^ swz) << 4;
+#define MRCNN_KGROUP(BUF, CO)                                                                                  \
+    {                                                                                                          \
+        uint4 av[TM], bv[TN];                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const uint4*>(la + (BUF) * A_STAGE + i * 32 * ROWB + (CO)); \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const uint4*>(lb + (BUF) * B_STAGE + j * 32 * ROWB + (CO)); \
+        if constexpr (sizeof(T) == 4) {                                                                        \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                      \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
+                    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                           \
+                        const uint32_t au = c == 0 ? av[i].x : c == 1 ? av[i].y : c == 2 ? av[i].z : av[i].w;  \
+                        const uint32_t bu = c == 0 ? bv[j].x : c == 1 ? bv[j].y : c == 2 ? bv[j].z : bv[j].w;  \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(au), __uint_as_float(bu), acc[i][j], 0, 0, 0); \
+                    }                                                                                          \
+        } else {                                                                                               \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                     \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[i]),       \
+                                                                       __builtin_bit_cast(f16x8, bv[j]), acc[i][j], 0, 0, 0); \
+        }                                                                                                      \
     }
+#define MRCNN_STEP(BUF, NBUF, KTV)                                                                             \
+    {                                                                                                          \
+        const bool more = (KTV) + STAGES - 1 < KT;                                                             \
+        if (more) MRCNN_DMA_TILE((KTV) + STAGES - 1, NBUF)                                                     \
+        MRCNN_KGROUP(BUF, co0) MRCNN_KGROUP(BUF, co1) MRCNN_KGROUP(BUF, co2) MRCNN_KGROUP(BUF, co3)            \
+        /* tile KTV+1 must have landed before the barrier hands its buffer over */                             \
+        if (STAGES == 3 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");                 \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
+        __syncthreads(); /* ... and every wave is done reading BUF */                                          \
+    }
+    if constexpr (STAGES == 2) {
+        for (int kt = 0; kt < KT; kt += 2) {
+            MRCNN_STEP(0, 1, kt)
+            if (kt + 1 < KT) MRCNN_STEP(1, 0, kt + 1)
+        }
+    } else {
+        int buf = 0;
+        for (int kt = 0; kt < KT; ++kt) {
+            int nbuf = buf + STAGES - 1;
+            if (nbuf >= STAGES) nbuf -= STAGES;
+            MRCNN_STEP(buf, nbuf, kt)
+            if (++buf == STAGES) buf = 0;
+        }
+    }
+#undef MRCNN_STEP
+#undef MRCNN_KGROUP
 #undef MRCNN_DMA_TILE
 #undef MRCNN_DMA_A
 #undef MRCNN_GLDS_V
