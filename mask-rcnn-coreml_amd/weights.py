@@ -151,6 +151,37 @@ def trunk_layers(cfg: ModelConfig):
     return L
 
 
+def tensor_shapes(cfg: ModelConfig) -> Dict[str, Dict[str, Tuple[int, ...]]]:
+    """{"MaskRCNN" | "Classifier" | "Mask": {tensor name: shape}} — the complete tensor inventory the
+    engine's plan builder asks a set of .mrcw files for (Core ML layouts, see the module docstring)."""
+    def bn(c):
+        return {k: (c,) for k in ("gamma", "beta", "mean", "variance")}
+
+    main: Dict[str, Tuple[int, ...]] = {}
+    for conv, b, cin, cout, k in trunk_layers(cfg):
+        main[f"{conv}/kernel"] = (cout, cin, k, k)
+        main[f"{conv}/bias"] = (cout,)
+        if b:
+            for kk, sh in bn(cout).items():
+                main[f"{b}/{kk}"] = sh
+    nc, ps = cfg.num_classes, cfg.classifier_pool_size
+    cls: Dict[str, Tuple[int, ...]] = {"mrcnn_class_conv1/kernel": (1024, 256, ps, ps), "mrcnn_class_conv1/bias": (1024,),
+                                       "mrcnn_class_conv2/kernel": (1024, 1024, 1, 1), "mrcnn_class_conv2/bias": (1024,),
+                                       "mrcnn_class_logits/kernel": (nc, 1024), "mrcnn_class_logits/bias": (nc,),
+                                       "mrcnn_bbox_fc/kernel": (nc * 4, 1024), "mrcnn_bbox_fc/bias": (nc * 4,)}
+    for i in (1, 2):
+        for kk, sh in bn(1024).items():
+            cls[f"mrcnn_class_bn{i}/{kk}"] = sh
+    mask: Dict[str, Tuple[int, ...]] = {"mrcnn_mask_deconv/kernel": (256, 256, 2, 2), "mrcnn_mask_deconv/bias": (256,),
+                                        "mrcnn_mask/kernel": (nc, 256, 1, 1), "mrcnn_mask/bias": (nc,)}
+    for i in range(1, 5):
+        mask[f"mrcnn_mask_conv{i}/kernel"] = (256, 256, 3, 3)
+        mask[f"mrcnn_mask_conv{i}/bias"] = (256,)
+        for kk, sh in bn(256).items():
+            mask[f"mrcnn_mask_bn{i}/{kk}"] = sh
+    return {"MaskRCNN": main, "Classifier": cls, "Mask": mask}
+
+
 def _he(rng, shape, fan_in, gain=1.0):
     return (rng.standard_normal(shape, dtype=np.float32) * np.float32(gain * np.sqrt(2.0 / fan_in)))
 

@@ -161,6 +161,34 @@ def test_engine_errors(pkg, small_model, tmp_path):
     assert "anchors" in str(e.value)
 
 
+def test_engine_loads_converted_artefacts(pkg, small_model, weights_mod, tmp_path):
+    """`maskrcnn convert` products (from a Keras-layout checkpoint dict) drive the engine exactly like the
+    artefacts they were derived from — with fp16 tensors (task.py:90) and with fp32 tensors in the file."""
+    il = __import__("importlib")
+    models, conv = il.import_module("mask-rcnn-coreml_amd.models"), il.import_module("mask-rcnn-coreml_amd.convert")
+    anchors = il.import_module("mask-rcnn-coreml_amd.anchors")
+    d, cfg = small_model
+    images = rand_images(2, cfg.image_height, cfg.image_width, seed=9)
+    det0, mask0 = models.load_maskrcnn(d, max_batch=2).predict(images)
+    keras = {}
+    for kind in ("MaskRCNN", "Classifier", "Mask"):
+        _, tensors = weights_mod.read_mrcw(os.path.join(d, f"{kind}.mrcw"))
+        for n, a in tensors.items():
+            keras[conv.keras_name(n)] = np.ascontiguousarray(conv.to_keras_layout(n, a.astype(np.float32)))
+    for wd in ("f16", "f32"):
+        out = tmp_path / wd
+        out.mkdir()
+        converted, unused = conv.convert_tensors(keras, cfg, weights_dtype=wd)
+        assert not unused
+        for kind, (meta, tensors) in converted.items():
+            weights_mod.write_mrcw(str(out / f"{kind}.mrcw"), meta, tensors)
+        anchors.write_anchors_bin(str(out / "anchors.bin"), cfg)
+        det, mask = models.load_maskrcnn(str(out), max_batch=2).predict(images)
+        np.testing.assert_array_equal(det, det0)
+        np.testing.assert_array_equal(mask, mask0)
+    assert (det0[:, :, 5] > 0).any()
+
+
 def test_engine_resnet101_256(pkg, orc, tmp_path_factory, weights_mod):
     """ResNet-101 (23 C4 blocks) at 256² with the default 81 classes, batch 2."""
     from oracle.network import load_oracle_model
