@@ -7,19 +7,15 @@
 // RPN / box / mask heads (inner products as 1×1 convolutions, the 2×2 stride-2 transposed
 // convolution as a scatter GEMM), soft-max and sigmoid.
 //
-// Kernel design (fp32, exact f32 MFMA `v_mfma_f32_32x32x2_f32`, 157.3 TFLOP/s peak):
+// Kernel design (fp32: exact f32 MFMA `v_mfma_f32_32x32x2_f32`; fp16: `v_mfma_f32_32x32x16_f16`):
 //   implicit GEMM  out[m][n] = Σ_k A[m][k]·Wt[n][k],  m = (image, oh, ow), k = (tap, cin), n = cout
 //   * activations NHWC and filters packed [cout][tap][cin], so BOTH operands are "rows of K":
-//     every global load is a 16-B piece of a 128-B contiguous run (32 channels of one tap);
-//   * 128×BN×32 block tile, 4 waves (wave64), each wave a (TM×32)×(TN×32) sub-tile of 32×32 MFMA
-//     accumulators; K is permuted inside the tile (lane kk∈{0,1} owns k = 8t+4kk+{0..3}) so a lane
-//     fetches its operands for four MFMA steps with ONE ds_read_b128 — identical permutation on
-//     both operands, so the sum is unchanged;
-//   * LDS rows padded to 36 floats (144 B): the 16-lane groups of ds_read_b128 hit 16 distinct
-//     16-B bank slots (36·r mod 64 is a permutation of the multiples of 4 for r = 0..15), and the
-//     8-lane groups of ds_write_b128 write 128 contiguous bytes — conflict-free both ways;
-//   * double-buffered LDS + register prefetch: the global loads of tile k+1 are issued before the
-//     MFMAs of tile k and written to the other buffer after them; one barrier per K step;
+//     every global load is a 16-B piece of a 128-B contiguous run (32 fp32 / 64 fp16 channels of one tap);
+//   * 128×BN block tile, K tile of 128 B, 8 waves (wave64) as 4×2, each wave a (TM×32)×(TN×32) sub-tile
+//     of 32×32 MFMA accumulators; K is permuted inside the tile (lane kk∈{0,1} owns one 16-B chunk of
+//     every 32-B pair) so a lane fetches its operands for four fp32 MFMA steps / one fp16 MFMA with ONE
+//     ds_read_b128 — identical permutation on both operands, so the sum is unchanged;
+//   * operands go global→LDS by DMA into two XOR-swizzled buffers (details at the kernel below);
 //   * fused epilogue: per-channel scale/shift (folded BN + bias), residual (optionally read at
 //     (oh>>1, ow>>1): FPN top-down upsample+add), ReLU / sigmoid, optional column split into two
 //     outputs (RPN class + bbox from one GEMM) or 2×2 scatter (transposed conv);
@@ -49,8 +45,7 @@ struct ConvArgs {
     const void* zero_page;   // >= 16 B of zeros in HBM: source of out-of-image taps for the DMA variant
 };
 
-static constexpr int BM_DEFAULT = 128;   // rows of the block tile = WM*TM*32 (128, or 256 for the tall variant)
-static constexpr int ROW_B = 144;    // LDS row: 128 B of K (32 floats / 64 halfs) + 16 B pad
+static constexpr int BM_DEFAULT = 128;   // rows of the block tile = WM*TM*32
 
 template <typename T> struct Elem;
 template <> struct Elem<float> { static constexpr int EPV = 4; };        // elements per 16-B vector
@@ -203,190 +198,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
     }
 }
 
-// T = float   : v_mfma_f32_32x32x2_f32  (exact fp32, 157.3 TFLOP/s peak), K tile = 32
-// T = _Float16: v_mfma_f32_32x32x16_f16 (fp32 accumulate, ~2.5 PFLOP/s peak), K tile = 64
-template <typename T, int BN, int TM, int TN, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma(const ConvArgs a)
-{
-    constexpr int BM = WM * TM * 32;
-    static_assert(WN * TN * 32 == BN, "tile shape");
-    constexpr int EPV = Elem<T>::EPV;
-    constexpr int BK = 8 * EPV;        // K elements per tile (128 bytes)
-    constexpr int NT = WM * WN * 64;   // threads per block
-    constexpr int RPT = NT / 8;        // tile rows covered by one staging pass (8 threads × 16 B per row)
-    constexpr int AP = BM / RPT;       // A rows per thread
-    constexpr int BP = BN / RPT;       // B rows per thread
-    static_assert(AP >= 1 && BP >= 1, "tile too small for the thread count");
-    constexpr int A_STAGE = BM * ROW_B, B_STAGE = BN * ROW_B;     // bytes
-    constexpr int SMEM = 2 * (A_STAGE + B_STAGE);
-    constexpr int C_ROW = BN + 4;      // epilogue staging tile (fp32), rows padded by one float4
-    static_assert(BM * C_ROW * 4 <= SMEM, "the C tile re-uses the operand buffers");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
-    unsigned char* const As = smem;                 // [2][BM][ROW_B]
-    unsigned char* const Bs = smem + 2 * A_STAGE;   // [2][BN][ROW_B]
-    const T* const in = static_cast<const T*>(a.in);
-    const T* const wgt = static_cast<const T*>(a.wgt);
-
-    // ---- XCD-aware tile assignment (bijective for any block count) ------------------------------
-    const int nblocks = a.tiles_m * a.tiles_n;
-    const int bid = blockIdx.x;
-    const int q = nblocks >> 3, r8 = nblocks & 7;
-    const int xcd = bid & 7, local = bid >> 3;
-    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + local;
-    const int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
-    const int m0 = mt * BM, n0 = nt * BN;
-
-    const int t = threadIdx.x;
-    const int kq = t & 7, r0 = t >> 3;
-
-    // ---- per-thread A rows: output pixel → input window origin ----------------------------------
-    long a_off[AP];
-    int ih0[AP], iw0[AP];
-    bool a_ok[AP];
-    const int ohw = a.OH * a.OW;
-#pragma unroll
-    for (int p = 0; p < AP; ++p) {
-        const int m = m0 + r0 + RPT * p;
-        a_ok[p] = m < a.M;
-        const int mm = a_ok[p] ? m : 0;
-        const int b = mm / ohw, rem = mm - b * ohw;
-        const int oh = rem / a.OW, ow = rem - oh * a.OW;
-        ih0[p] = oh * a.stride - a.padH;
-        iw0[p] = ow * a.stride - a.padW;
-        a_off[p] = (long)b * a.in_sB + (long)ih0[p] * a.in_sH + (long)iw0[p] * a.in_sW + kq * EPV;
-#ifdef MRCNN_DBG_HOTLOAD
-        a_off[p] = (long)(1 - a.padH) * a.in_sH + (long)(1 - a.padW) * a.in_sW + kq * EPV + p * 64;   // every row hits the same lines
-        ih0[p] = 1; iw0[p] = 1;
-#endif
-    }
-#ifdef MRCNN_DBG_HOTLOAD
-    const T* const wbase = wgt + kq * EPV;
-#else
-    const T* const wbase = wgt + (size_t)(n0 + r0) * a.Ktot + kq * EPV;
-#endif
-
-    const int cin_tiles = a.Cin / BK;
-    const int KT = a.KH * a.KW * cin_tiles;
-
-    // Register staging of the next K tile, in NAMED registers: with an array (lambda or not) hipcc
-    // (ROCm 7.2) left the B half in scratch memory for the 128-wide variant, which put a vmcnt(0) +
-    // scratch round trip between the global loads and the MFMAs and serialised the pipeline.
-    static_assert(AP <= 4 && BP <= 4, "staging registers are spelled out for <= 4 A rows / <= 4 B rows per thread");
-    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = make_uint4(0u, 0u, 0u, 0u);
-    int kh = 0, kw = 0, ct = 0;      // position of the NEXT tile to load
-#define MRCNN_LD_A(P)                                                                                          \
-    if constexpr (AP > P) {                                                                                    \
-        const int ih = ih0[P] + kh, iw = iw0[P] + kw;                                                          \
-        const bool ok = a_ok[P] && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;               \
-        ra##P = ok ? *reinterpret_cast<const uint4*>(in + a_off[P] + tap_off) : make_uint4(0u, 0u, 0u, 0u);    \
-    }
-#define MRCNN_LD_B(P) \
-    if constexpr (BP > P) rb##P = *reinterpret_cast<const uint4*>(wbase + (size_t)(RPT * P) * a.Ktot + (size_t)kt_next * BK);
-#define MRCNN_LOAD_TILE(KT_)                                                                                   \
-    {                                                                                                          \
-        const long tap_off = (long)kh * a.in_sH + (long)kw * a.in_sW + ct * BK;                                \
-        const int kt_next = (KT_);                                                                             \
-        MRCNN_LD_A(0) MRCNN_LD_A(1) MRCNN_LD_A(2) MRCNN_LD_A(3)                                                \
-        MRCNN_LD_B(0) MRCNN_LD_B(1) MRCNN_LD_B(2) MRCNN_LD_B(3)                                                \
-        if (++ct == cin_tiles) { ct = 0; if (++kw == a.KW) { kw = 0; ++kh; } }                                 \
-    }
-#define MRCNN_ST_A(P) if constexpr (AP > P) *reinterpret_cast<uint4*>(sa + (RPT * P) * ROW_B) = ra##P;
-#define MRCNN_ST_B(P) if constexpr (BP > P) *reinterpret_cast<uint4*>(sb + (RPT * P) * ROW_B) = rb##P;
-#define MRCNN_STORE_TILE(BUF_)                                                                                 \
-    {                                                                                                          \
-        unsigned char* const sa = As + (BUF_) * A_STAGE + r0 * ROW_B + kq * 16;                                \
-        unsigned char* const sb = Bs + (BUF_) * B_STAGE + r0 * ROW_B + kq * 16;                                \
-        MRCNN_ST_A(0) MRCNN_ST_A(1) MRCNN_ST_A(2) MRCNN_ST_A(3)                                                \
-        MRCNN_ST_B(0) MRCNN_ST_B(1) MRCNN_ST_B(2) MRCNN_ST_B(3)                                                \
-    }
-
-    const int wave = t >> 6, lane = t & 63;
-    const int wm = wave / WN, wn = wave - wm * WN;
-    const int l31 = lane & 31, kk = lane >> 5;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    // Pipeline: tile k+1 sits in registers while tile k is computed from LDS.  The registers are
-    // written to the other LDS buffer at the TOP of step k (that buffer was last read in step k-1,
-    // which every wave left through the barrier) and immediately re-used for the global loads of
-    // tile k+2, so neither the vmcnt wait nor the ds_writes sit between the last MFMA of a step
-    // and its barrier.
-    MRCNN_LOAD_TILE(0)
-    MRCNN_STORE_TILE(0)
-    if (KT > 1) MRCNN_LOAD_TILE(1)
-    __syncthreads();
-
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-#ifndef MRCNN_DBG_NOLOAD
-        if (kt + 1 < KT) MRCNN_STORE_TILE(buf ^ 1)
-        if (kt + 2 < KT) MRCNN_LOAD_TILE(kt + 2)
-#endif
-        const unsigned char* as = As + buf * A_STAGE + (wm * TM * 32 + l31) * ROW_B + kk * 16;
-        const unsigned char* bs = Bs + buf * B_STAGE + (wn * TN * 32 + l31) * ROW_B + kk * 16;
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
-            uint4 av[TM], bv[TN];
-#ifdef MRCNN_DBG_NOLDS
-#pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = make_uint4(kt + i, t4, lane, 1u);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = make_uint4(kt + j, t4 + 1, lane, 2u);
-#else
-#pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const uint4*>(as + i * 32 * ROW_B + t4 * 32);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const uint4*>(bs + j * 32 * ROW_B + t4 * 32);
-#endif
-            if constexpr (sizeof(T) == 4) {
-                // fp32: lane kk owns k = 8*t4 + 4*kk + {0..3} — the same permutation of K on both
-                // operands, so one ds_read_b128 feeds four MFMA steps; consecutive MFMAs go to
-                // different accumulators.
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) {
-                            const uint32_t au = c == 0 ? av[i].x : c == 1 ? av[i].y : c == 2 ? av[i].z : av[i].w;
-                            const uint32_t bu = c == 0 ? bv[j].x : c == 1 ? bv[j].y : c == 2 ? bv[j].z : bv[j].w;
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(au), __uint_as_float(bu), acc[i][j], 0, 0, 0);
-                        }
-            } else {
-                // fp16: lane kk owns k = 16*t4 + 8*kk + {0..7}: one ds_read_b128 = one MFMA operand
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[i]), __builtin_bit_cast(f16x8, bv[j]),
-                                                                           acc[i][j], 0, 0, 0);
-            }
-        }
-#ifndef MRCNN_DBG_NOBAR
-        __syncthreads();
-#endif
-    }
-
-#undef MRCNN_LOAD_TILE
-#undef MRCNN_STORE_TILE
-#undef MRCNN_LD_A
-#undef MRCNN_LD_B
-#undef MRCNN_ST_A
-#undef MRCNN_ST_B
-    conv_epilogue<T, BN, TM, TN, WM, WN, C_ROW>(a, acc, smem, m0, n0);
-}
-
 // ------------------------------------------------------------------------------------------------
-// Variant with direct global→LDS staging (global_load_lds_dwordx4): no VGPR round trip, no ds_write,
-// no address/register traffic between the loads and the MFMAs — the register-staged loop above loses
-// 13 % (fp32) / 40 % (fp16) of the MFMA rate to that path even with cache-hot loads.
+// The implicit-GEMM kernel.  T = float   : v_mfma_f32_32x32x2_f32  (exact fp32, 157.3 TFLOP/s peak), K tile = 32
+//                            T = _Float16: v_mfma_f32_32x32x16_f16 (fp32 accumulate, ~2.5 PFLOP/s peak), K tile = 64
+// Operands are staged global→LDS directly (global_load_lds_dwordx4): no VGPR round trip, no ds_write,
+// no address/register traffic between the loads and the MFMAs — a register-staged loop (round-1
+// history) lost 13 % (fp32) / 40 % (fp16) of the MFMA rate to that path even with
+// cache-hot loads.
 //   * LDS rows are unpadded 128-B K runs (the DMA writes wave-uniform base + lane×16, so rows cannot
 //     be padded); bank conflicts are removed by an XOR swizzle instead: 16-B chunk c of row r lives
 //     at chunk position c ^ ((r >> 1) & 7).  The permutation is applied to the per-lane SOURCE
@@ -396,7 +214,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma(const ConvArgs a)
 //   * two LDS buffers: the DMA of tile k+1 is issued right after the barrier that retired buffer
 //     (k+1)&1 and lands while tile k is being multiplied; one vmcnt(0) + barrier per K step.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BN, int TM, int TN, int WM, int WN, int STAGES = 2>
+template <typename T, int BN, int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs a)
 {
     constexpr int BM = WM * TM * 32;
@@ -411,9 +229,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
     constexpr int ROWB = 128;
     constexpr int A_STAGE = BM * ROWB, B_STAGE = BN * ROWB;
     constexpr int C_ROW = BN;                                   // fp32 C tile, unpadded
-    static_assert(STAGES == 2 || STAGES == 3, "ring depth");
-    constexpr int NLOADS = AP + BP;                              // DMA instructions per tile per thread
-    constexpr int SMEM_OPS = STAGES * (A_STAGE + B_STAGE);
+    constexpr int SMEM_OPS = 2 * (A_STAGE + B_STAGE);   // two operand buffers
     constexpr int SMEM = SMEM_OPS > BM * C_ROW * 4 ? SMEM_OPS : BM * C_ROW * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     const T* const in = static_cast<const T*>(a.in);
@@ -464,11 +280,13 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
     // store it must order against every later ds_read and drains it with vmcnt(0) at the top of the
     // step, which makes the copy synchronous.  In asm the compiler does not count it, so the waits
     // are placed by hand (M0 = wave-uniform LDS byte address; lane i's 16 B land at M0 + 16 i).
-    static_assert(AP <= 4 && BP <= 2, "per-row DMA state is spelled out for <= 4 A rows / <= 2 B rows");
+    static_assert(AP <= 4 && BP <= 4, "per-row DMA state is spelled out for <= 4 A rows / <= 4 B rows");
     const T *pa0 = zero, *pa1 = zero, *pa2 = zero, *pa3 = zero;
     unsigned sa0 = 0, sa1 = 0, sa2 = 0, sa3 = 0;
     const unsigned vb0 = (unsigned)(((size_t)r0 * a.Ktot + kq * EPV) * sizeof(T));
     const unsigned vb1 = (unsigned)(((size_t)(r0 + RPT) * a.Ktot + kq * EPV) * sizeof(T));
+    const unsigned vb2 = (unsigned)(((size_t)(r0 + 2 * RPT) * a.Ktot + kq * EPV) * sizeof(T));
+    const unsigned vb3 = (unsigned)(((size_t)(r0 + 3 * RPT) * a.Ktot + kq * EPV) * sizeof(T));
     const T* sb = wgt + (size_t)n0 * a.Ktot;                 // uniform
     int kh = 0, kw = 0, ct = 0;
 #define MRCNN_SET_TAP(P)                                                                                       \
@@ -486,10 +304,12 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
 #define MRCNN_DMA_TILE(KT_, BUF_)                                                                              \
     {                                                                                                          \
         const unsigned da = lds0 + (BUF_) * A_STAGE + wrow * ROWB;                                             \
-        const unsigned db = lds0 + STAGES * A_STAGE + (BUF_) * B_STAGE + wrow * ROWB;                          \
+        const unsigned db = lds0 + 2 * A_STAGE + (BUF_) * B_STAGE + wrow * ROWB;                               \
         MRCNN_DMA_A(0) MRCNN_DMA_A(1) MRCNN_DMA_A(2) MRCNN_DMA_A(3)                                            \
         MRCNN_GLDS_S(vb0, sb, db);                                                                             \
         if constexpr (BP > 1) MRCNN_GLDS_S(vb1, sb, db + RPT * ROWB);                                          \
+        if constexpr (BP > 2) MRCNN_GLDS_S(vb2, sb, db + 2 * RPT * ROWB);                                      \
+        if constexpr (BP > 3) MRCNN_GLDS_S(vb3, sb, db + 3 * RPT * ROWB);                                      \
         sb += BK;                                                                                              \
         if (++ct == cin_tiles) {                                                                               \
             ct = 0;                                                                                            \
@@ -511,20 +331,16 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    // STAGES == 2: the DMA of tile k+1 is issued at the top of step k and must land within the step.
-    // STAGES == 3: two tiles in flight — tile k+2 is issued at the top of step k and only tile k+1 is
-    // waited for (counted vmcnt: the NLOADS most recent DMAs may stay outstanding across the barrier).
     MRCNN_DMA_TILE(0, 0)
-    if (STAGES == 3 && KT > 1) MRCNN_DMA_TILE(1, 1)
-    if (STAGES == 3 && KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();          // tile 0 is in LDS
 
-    // One K step on buffer BUF; the DMA of tile KTV + STAGES - 1 goes to buffer NBUF.  BUF / NBUF are
-    // compile-time constants in the 2-stage path (loop unrolled by two), so every LDS offset folds
-    // into an instruction immediate and the four swizzled lane addresses are loop-invariant.
+    // One K step on buffer BUF; the DMA of tile KTV + 1 is issued at the top of the step into buffer
+    // NBUF and must land within the step.  BUF / NBUF are compile-time constants (loop unrolled by
+    // two), so every LDS offset folds into an instruction immediate and the four swizzled lane
+    // addresses are loop-invariant.
     const unsigned char* const la = smem + (wm * TM * 32 + l31) * ROWB;
-    const unsigned char* const lb = smem + STAGES * A_STAGE + (wn * TN * 32 + l31) * ROWB;
+    const unsigned char* const lb = smem + 2 * A_STAGE + (wn * TN * 32 + l31) * ROWB;
     const int co0 = ((0 + kk) ^ swz) << 4, co1 = ((2 + kk) ^ swz) << 4, co2 = ((4 + kk) ^ swz) << 4, co3 = ((6 + kk) ^ swz) << 4;
 #define MRCNN_KGROUP(BUF, CO)                                                                                  \
     {                                                                                                          \
@@ -548,27 +364,15 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
     }
 #define MRCNN_STEP(BUF, NBUF, KTV)                                                                             \
     {                                                                                                          \
-        const bool more = (KTV) + STAGES - 1 < KT;                                                             \
-        if (more) MRCNN_DMA_TILE((KTV) + STAGES - 1, NBUF)                                                     \
+        if ((KTV) + 1 < KT) MRCNN_DMA_TILE((KTV) + 1, NBUF)                                                    \
         MRCNN_KGROUP(BUF, co0) MRCNN_KGROUP(BUF, co1) MRCNN_KGROUP(BUF, co2) MRCNN_KGROUP(BUF, co3)            \
         /* tile KTV+1 must have landed before the barrier hands its buffer over */                             \
-        if (STAGES == 3 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");                 \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
         __syncthreads(); /* ... and every wave is done reading BUF */                                          \
     }
-    if constexpr (STAGES == 2) {
-        for (int kt = 0; kt < KT; kt += 2) {
-            MRCNN_STEP(0, 1, kt)
-            if (kt + 1 < KT) MRCNN_STEP(1, 0, kt + 1)
-        }
-    } else {
-        int buf = 0;
-        for (int kt = 0; kt < KT; ++kt) {
-            int nbuf = buf + STAGES - 1;
-            if (nbuf >= STAGES) nbuf -= STAGES;
-            MRCNN_STEP(buf, nbuf, kt)
-            if (++buf == STAGES) buf = 0;
-        }
+    for (int kt = 0; kt < KT; kt += 2) {
+        MRCNN_STEP(0, 1, kt)
+        if (kt + 1 < KT) MRCNN_STEP(1, 0, kt + 1)
     }
 #undef MRCNN_STEP
 #undef MRCNN_KGROUP
@@ -623,28 +427,13 @@ int conv_n_tile(int Cout)
 }
 
 template <typename T>
-static void conv_launch(hipStream_t s, const ConvArgs& a, int bn, int bm)
+static void conv_launch(hipStream_t s, const ConvArgs& a, int bn)
 {
+    // 8 waves as 4 (M) × 2 (N): 128×128 block tile, 32×64 per wave; narrower N tiles keep 128 rows.
     const dim3 grid(a.tiles_m * a.tiles_n);
-#ifndef MRCNN_TALL_STAGES
-#define MRCNN_TALL_STAGES 3
-#endif
-    if (bm == 256) {
-        hipLaunchKernelGGL((k_conv_mfma_glds<T, 128, 2, 2, 4, 2, MRCNN_TALL_STAGES>), grid, dim3(512), 0, s, a);
-        return;
-    }
-#ifndef MRCNN_GLDS_STAGING
-#define MRCNN_GLDS_STAGING 1
-#endif
-#if MRCNN_GLDS_STAGING
     if (bn == 128) hipLaunchKernelGGL((k_conv_mfma_glds<T, 128, 1, 2, 4, 2>), grid, dim3(512), 0, s, a);
     else if (bn == 64) hipLaunchKernelGGL((k_conv_mfma_glds<T, 64, 1, 1, 4, 2>), grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL((k_conv_mfma_glds<T, 32, 1, 1, 4, 1>), grid, dim3(256), 0, s, a);
-#else
-    if (bn == 128) hipLaunchKernelGGL((k_conv_mfma<T, 128, 1, 2, 4, 2>), grid, dim3(512), 0, s, a);
-    else if (bn == 64) hipLaunchKernelGGL((k_conv_mfma<T, 64, 1, 1, 4, 2>), grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((k_conv_mfma<T, 32, 1, 1, 4, 1>), grid, dim3(256), 0, s, a);
-#endif
 }
 
 void conv_forward(hipStream_t s, const ConvDesc& d)
@@ -678,16 +467,9 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     // the chip under-filled (< 2 blocks per CU) — C5, the top FPN levels and the small RPN levels.
     const int bn_max = conv_n_tile(a.ncols);
     MRCNN_REQUIRE(d.Npad % bn_max == 0 && d.Npad >= a.ncols, MRCNN_ERR_SHAPE, "conv: Npad %d incompatible with tile %d", d.Npad, bn_max);
-#ifndef MRCNN_TALL_TILE
-#define MRCNN_TALL_TILE 0
-#endif
-    // 256×128 "tall" tile (one block per CU, 1.33× the arithmetic intensity of 128×128): selected by
-    // MRCNN_TALL_TILE (1 = fp16 only, 2 = both dtypes) for layers with enough rows to fill the chip.
-    int bm = BM_DEFAULT;
-    if (MRCNN_TALL_TILE && bn_max == 128 && (half || MRCNN_TALL_TILE == 2) && (long)((a.M + 255) / 256) * (d.Npad / 128) >= 512) bm = 256;
-    a.tiles_m = (a.M + bm - 1) / bm;
+    a.tiles_m = (a.M + BM_DEFAULT - 1) / BM_DEFAULT;
     int bn = bn_max;
-    while (bm == BM_DEFAULT && bn > 32 && (long)a.tiles_m * (d.Npad / bn) < 512) bn >>= 1;
+    while (bn > 32 && (long)a.tiles_m * (d.Npad / bn) < 512) bn >>= 1;
     const size_t out_es = a.out_f32 ? 4 : 2;
     auto al = [](const void* p, size_t n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
     a.vec_ok = a.ncols % 4 == 0 && d.out2 == nullptr && d.out_sP % 4 == 0 && d.out_sB % 4 == 0 && al(d.out, 4 * out_es) &&
@@ -697,8 +479,8 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     a.tiles_n = d.Npad / bn;
     ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
     const int e0 = prof ? prof_event(prof, s) : 0;
-    if (half) conv_launch<_Float16>(s, a, bn, bm);
-    else conv_launch<float>(s, a, bn, bm);
+    if (half) conv_launch<_Float16>(s, a, bn);
+    else conv_launch<float>(s, a, bn);
     if (prof) {
         const int e1 = prof_event(prof, s);
         const double k = d.algo_k > 0 ? d.algo_k : a.Ktot;
