@@ -199,6 +199,14 @@ MRCNN_API int mrcnn_model_stage_ms(mrcnn_model* model, const char* stage, float*
 MRCNN_API int mrcnn_model_conv_profile_enable(mrcnn_model* model, int on);
 MRCNN_API int mrcnn_model_conv_profile_get(mrcnn_model* model, int tile, int64_t* launches, double* total_ms,
                                            double* total_flops);
+/* The same totals broken down by GEMM shape (M = images*OH*OW, N = output columns, K = taps*Cin): writes at
+ * most `capacity` records, *count = number of distinct shapes seen (call with capacity 0 to size the buffer). */
+typedef struct mrcnn_conv_shape_stat {
+    int32_t M, N, K, tile;
+    int64_t launches;
+    double total_ms, total_flops;
+} mrcnn_conv_shape_stat;
+MRCNN_API int mrcnn_model_conv_profile_shapes(mrcnn_model* model, mrcnn_conv_shape_stat* out, int capacity, int* count);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution micro-benchmark hook (bench.py roofline leg): runs one convolution of the trunk's

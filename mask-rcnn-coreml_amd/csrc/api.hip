@@ -651,6 +651,21 @@ extern "C" int mrcnn_model_conv_profile_get(mrcnn_model* model, int tile, int64_
         *launches = sl.launches; *total_ms = sl.ms; *total_flops = sl.flops;
     });
 }
+extern "C" int mrcnn_model_conv_profile_shapes(mrcnn_model* model, mrcnn_conv_shape_stat* out, int capacity, int* count)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model && count && (out || capacity == 0) && capacity >= 0, MRCNN_ERR_INVALID, "bad argument");
+        HIP_CHECK(hipStreamSynchronize(model->m.stream));
+        model->m.conv_profile.collect();
+        const auto& shapes = model->m.conv_profile.by_shape;
+        *count = (int)shapes.size();
+        int i = 0;
+        for (const auto& kv : shapes) {
+            if (i >= capacity) break;
+            out[i++] = {kv.first.M, kv.first.N, kv.first.K, kv.first.tile, (int64_t)kv.second.launches, kv.second.ms, kv.second.flops};
+        }
+    });
+}
 
 // ================================================================================================
 // convolution micro-benchmark (bench.py roofline leg)

@@ -1,5 +1,7 @@
 // kernels.h — host-side launchers of the gfx950 kernels (one namespace, no torch, no templates in the API).
 #pragma once
+#include <map>
+#include <tuple>
 #include <vector>
 
 #include "common.h"
@@ -120,7 +122,9 @@ struct ConvProfile {
     struct Slot { long launches = 0; double ms = 0, flops = 0; };
     Slot by_tile[3];                 // 0: 128x128, 1: 128x64, 2: 128x32
     std::vector<hipEvent_t> pool;
-    struct Pending { int tile; double flops; int e0, e1; };
+    struct Shape { int M, N, K, tile; bool operator<(const Shape& o) const { return std::tie(M, N, K, tile) < std::tie(o.M, o.N, o.K, o.tile); } };
+    std::map<Shape, Slot> by_shape;  // per GEMM shape (M = images·OH·OW, N = output columns, K = taps·Cin)
+    struct Pending { int tile; double flops; int e0, e1; Shape shape; };
     std::vector<Pending> pending;
     int used = 0;
     bool active = false;

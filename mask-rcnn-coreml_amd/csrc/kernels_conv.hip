@@ -389,6 +389,7 @@ void conv_set_profiler(ConvProfile* p) { g_prof = p; }
 void ConvProfile::reset()
 {
     for (auto& s : by_tile) s = Slot();
+    by_shape.clear();
     pending.clear();
     used = 0;
 }
@@ -400,6 +401,8 @@ void ConvProfile::collect()
         by_tile[pd.tile].launches += 1;
         by_tile[pd.tile].ms += ms;
         by_tile[pd.tile].flops += pd.flops;
+        Slot& sh = by_shape[pd.shape];
+        sh.launches += 1; sh.ms += ms; sh.flops += pd.flops;
     }
     pending.clear();
     used = 0;
@@ -484,7 +487,8 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     if (prof) {
         const int e1 = prof_event(prof, s);
         const double k = d.algo_k > 0 ? d.algo_k : a.Ktot;
-        prof->pending.push_back({bn == 128 ? 0 : (bn == 64 ? 1 : 2), 2.0 * (double)a.M * (double)a.ncols * k, e0, e1});
+        const int tile = bn == 128 ? 0 : (bn == 64 ? 1 : 2);
+        prof->pending.push_back({tile, 2.0 * (double)a.M * (double)a.ncols * k, e0, e1, {a.M, a.ncols, a.Ktot, tile}});
     }
     HIP_CHECK(hipGetLastError());
 }

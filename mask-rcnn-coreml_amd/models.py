@@ -129,6 +129,15 @@ class MaskRCNN(_Model):
             out[name] = (int(n.value), float(ms.value), float(fl.value))
         return out
 
+    def conv_profile_shapes(self):
+        """[(M, N, K, tile, launches, total_ms, total_algorithmic_flops)] per distinct GEMM shape."""
+        L = _lib.lib()
+        n = C.c_int(0)
+        _lib.check(L.mrcnn_model_conv_profile_shapes(self._h, None, 0, C.byref(n)))
+        buf = (_lib.ConvShapeStat * max(n.value, 1))()
+        _lib.check(L.mrcnn_model_conv_profile_shapes(self._h, buf, n.value, C.byref(n)))
+        return [(r.M, r.N, r.K, r.tile, r.launches, r.total_ms, r.total_flops) for r in buf[:n.value]]
+
     def enable_timing(self, on: bool = True):
         _lib.check(_lib.lib().mrcnn_model_enable_timing(self._h, int(on)))
 
