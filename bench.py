@@ -13,7 +13,7 @@ Weights are seeded synthetic weights of the exact architecture ("forced full loa
 100 detections per image, so no data-dependent stage idles); there is no network for checkpoints.
 
 Rank 0 prints ONE JSON line with, besides the contract fields:
-  roofline     — dominant kernel k_conv_mfma_glds<float,128,1,2,4,2> (fp32 MFMA implicit-GEMM conv): its
+  roofline     — dominant kernel k_conv_mfma_glds<float,128,1,2,4,2,2> (fp32 MFMA implicit-GEMM conv): its
                  ALGORITHMIC flops per launch ÷ its average launch duration, both measured live with HIP
                  events on the launching stream over the timed region; peak = 157.3 TFLOP/s (dense fp32 MFMA)
   cpu_baseline — the oracle (torch-CPU fp32 network + the C restatement of the custom layers) timed on this
@@ -144,7 +144,7 @@ def main():
                 achieved = flops / (ms * 1e-3) / 1e12
                 peak = PEAK_FP16_MFMA_TFLOPS if args.dtype == "f16" else PEAK_FP32_MFMA_TFLOPS
                 out["roofline"] = {
-                    "kernel": f"k_conv_mfma_glds<{'_Float16' if args.dtype == 'f16' else 'float'},128,1,2,4,2>", "bound": "mfma",
+                    "kernel": f"k_conv_mfma_glds<{'_Float16' if args.dtype == 'f16' else 'float'},128,1,2,4,2,2>", "bound": "mfma",
                     "achieved": round(achieved, 2),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "traffic": pmc_traffic() if args.dtype == "f32" else None,

@@ -214,7 +214,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
 //   * two LDS buffers: the DMA of tile k+1 is issued right after the barrier that retired buffer
 //     (k+1)&1 and lands while tile k is being multiplied; one vmcnt(0) + barrier per K step.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BN, int TM, int TN, int WM, int WN>
+template <typename T, int BN, int TM, int TN, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs a)
 {
     constexpr int BM = WM * TM * 32;
@@ -229,7 +229,9 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
     constexpr int ROWB = 128;
     constexpr int A_STAGE = BM * ROWB, B_STAGE = BN * ROWB;
     constexpr int C_ROW = BN;                                   // fp32 C tile, unpadded
-    constexpr int SMEM_OPS = 2 * (A_STAGE + B_STAGE);   // two operand buffers
+    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
+    constexpr int NLOADS = AP + BP;                             // DMA instructions per tile per thread
+    constexpr int SMEM_OPS = STAGES * (A_STAGE + B_STAGE);      // ring of operand buffers
     constexpr int SMEM = SMEM_OPS > BM * C_ROW * 4 ? SMEM_OPS : BM * C_ROW * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     const T* const in = static_cast<const T*>(a.in);
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
 #define MRCNN_DMA_TILE(KT_, BUF_)                                                                              \
     {                                                                                                          \
         const unsigned da = lds0 + (BUF_) * A_STAGE + wrow * ROWB;                                             \
-        const unsigned db = lds0 + 2 * A_STAGE + (BUF_) * B_STAGE + wrow * ROWB;                               \
+        const unsigned db = lds0 + STAGES * A_STAGE + (BUF_) * B_STAGE + wrow * ROWB;                          \
         MRCNN_DMA_A(0) MRCNN_DMA_A(1) MRCNN_DMA_A(2) MRCNN_DMA_A(3)                                            \
         MRCNN_GLDS_S(vb0, sb, db);                                                                             \
         if constexpr (BP > 1) MRCNN_GLDS_S(vb1, sb, db + RPT * ROWB);                                          \
@@ -331,51 +333,71 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+    // Ring of STAGES operand buffers, STAGES-1 tiles in flight: tile k+STAGES-1 is issued at the top of
+    // step k, and only tile k+1 has to have landed at the end of it — counted vmcnt lets the
+    // NLOADS·(STAGES-2) most recent DMAs stay outstanding across the barrier.  STAGES = 2 for the
+    // 128-wide tile (a step is 2048 MFMA cycles per wave, longer than the DMA latency); the narrow
+    // tiles run on under-filled grids with short steps and use deeper rings.
     MRCNN_DMA_TILE(0, 0)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (STAGES > 2 && KT > 1) MRCNN_DMA_TILE(1, 1)
+    if (STAGES > 3 && KT > 2) MRCNN_DMA_TILE(2, 2)
+    if (KT - 1 >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS * (STAGES - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();          // tile 0 is in LDS
 
-    // One K step on buffer BUF; the DMA of tile KTV + 1 is issued at the top of the step into buffer
-    // NBUF and must land within the step.  BUF / NBUF are compile-time constants (loop unrolled by
-    // two), so every LDS offset folds into an instruction immediate and the four swizzled lane
+    // One K step on buffer BUF; the DMA of tile KTV + STAGES - 1 goes to buffer NBUF (the one retired
+    // by the previous step's barrier).  BUF / NBUF are compile-time constants (loop unrolled by
+    // STAGES), so every LDS offset folds into an instruction immediate and the four swizzled lane
     // addresses are loop-invariant.
     const unsigned char* const la = smem + (wm * TM * 32 + l31) * ROWB;
-    const unsigned char* const lb = smem + 2 * A_STAGE + (wn * TN * 32 + l31) * ROWB;
+    const unsigned char* const lb = smem + STAGES * A_STAGE + (wn * TN * 32 + l31) * ROWB;
     const int co0 = ((0 + kk) ^ swz) << 4, co1 = ((2 + kk) ^ swz) << 4, co2 = ((4 + kk) ^ swz) << 4, co3 = ((6 + kk) ^ swz) << 4;
-#define MRCNN_KGROUP(BUF, CO)                                                                                  \
+    // Operand fetch for the four 32-B K groups of a step is issued up front, ahead of the first MFMA:
+    // LDS returns in order, so the waits count down (lgkmcnt) and the reads of group g+1.. are in
+    // flight under the MFMAs of group g — needed when a SIMD holds a single wave (narrow tiles on
+    // under-filled grids), free otherwise.
+#define MRCNN_KLOAD(G, BUF, CO)                                                                                \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) av[G][i] = *reinterpret_cast<const uint4*>(la + (BUF) * A_STAGE + i * 32 * ROWB + (CO)); \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) bv[G][j] = *reinterpret_cast<const uint4*>(lb + (BUF) * B_STAGE + j * 32 * ROWB + (CO));
+#define MRCNN_KMATH(G)                                                                                         \
     {                                                                                                          \
-        uint4 av[TM], bv[TN];                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const uint4*>(la + (BUF) * A_STAGE + i * 32 * ROWB + (CO)); \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const uint4*>(lb + (BUF) * B_STAGE + j * 32 * ROWB + (CO)); \
         if constexpr (sizeof(T) == 4) {                                                                        \
             _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                      \
                 _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
                     _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                           \
-                        const uint32_t au = c == 0 ? av[i].x : c == 1 ? av[i].y : c == 2 ? av[i].z : av[i].w;  \
-                        const uint32_t bu = c == 0 ? bv[j].x : c == 1 ? bv[j].y : c == 2 ? bv[j].z : bv[j].w;  \
+                        const uint32_t au = c == 0 ? av[G][i].x : c == 1 ? av[G][i].y : c == 2 ? av[G][i].z : av[G][i].w;  \
+                        const uint32_t bu = c == 0 ? bv[G][j].x : c == 1 ? bv[G][j].y : c == 2 ? bv[G][j].z : bv[G][j].w;  \
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(au), __uint_as_float(bu), acc[i][j], 0, 0, 0); \
                     }                                                                                          \
         } else {                                                                                               \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                     \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[i]),       \
-                                                                       __builtin_bit_cast(f16x8, bv[j]), acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[G][i]),    \
+                                                                       __builtin_bit_cast(f16x8, bv[G][j]), acc[i][j], 0, 0, 0); \
         }                                                                                                      \
     }
 #define MRCNN_STEP(BUF, NBUF, KTV)                                                                             \
     {                                                                                                          \
-        if ((KTV) + 1 < KT) MRCNN_DMA_TILE((KTV) + 1, NBUF)                                                    \
-        MRCNN_KGROUP(BUF, co0) MRCNN_KGROUP(BUF, co1) MRCNN_KGROUP(BUF, co2) MRCNN_KGROUP(BUF, co3)            \
+        const bool more = (KTV) + STAGES - 1 < KT;                                                             \
+        if (more) MRCNN_DMA_TILE((KTV) + STAGES - 1, NBUF)                                                     \
+        uint4 av[4][TM], bv[4][TN];                                                                            \
+        MRCNN_KLOAD(0, BUF, co0) MRCNN_KLOAD(1, BUF, co1) MRCNN_KLOAD(2, BUF, co2) MRCNN_KLOAD(3, BUF, co3)    \
+        if constexpr (BN < 128) __builtin_amdgcn_sched_barrier(0); /* keep the reads ahead of the MFMAs */     \
+        MRCNN_KMATH(0) MRCNN_KMATH(1) MRCNN_KMATH(2) MRCNN_KMATH(3)                                            \
         /* tile KTV+1 must have landed before the barrier hands its buffer over */                             \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS * (STAGES - 2)) : "memory");                 \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
         __syncthreads(); /* ... and every wave is done reading BUF */                                          \
     }
-    for (int kt = 0; kt < KT; kt += 2) {
-        MRCNN_STEP(0, 1, kt)
+    for (int kt = 0; kt < KT; kt += STAGES) {
+        MRCNN_STEP(0, STAGES - 1, kt)
         if (kt + 1 < KT) MRCNN_STEP(1, 0, kt + 1)
+        if constexpr (STAGES > 2) { if (kt + 2 < KT) MRCNN_STEP(2, 1, kt + 2) }
+        if constexpr (STAGES > 3) { if (kt + 3 < KT) MRCNN_STEP(3, 2, kt + 3) }
     }
 #undef MRCNN_STEP
-#undef MRCNN_KGROUP
+#undef MRCNN_KMATH
+#undef MRCNN_KLOAD
 #undef MRCNN_DMA_TILE
 #undef MRCNN_DMA_A
 #undef MRCNN_GLDS_V
@@ -434,9 +456,15 @@ static void conv_launch(hipStream_t s, const ConvArgs& a, int bn)
 {
     // 8 waves as 4 (M) × 2 (N): 128×128 block tile, 32×64 per wave; narrower N tiles keep 128 rows.
     const dim3 grid(a.tiles_m * a.tiles_n);
-    if (bn == 128) hipLaunchKernelGGL((k_conv_mfma_glds<T, 128, 1, 2, 4, 2>), grid, dim3(512), 0, s, a);
-    else if (bn == 64) hipLaunchKernelGGL((k_conv_mfma_glds<T, 64, 1, 1, 4, 2>), grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((k_conv_mfma_glds<T, 32, 1, 1, 4, 1>), grid, dim3(256), 0, s, a);
+#ifndef MRCNN_RING64
+#define MRCNN_RING64 3
+#endif
+#ifndef MRCNN_RING32
+#define MRCNN_RING32 4
+#endif
+    if (bn == 128) hipLaunchKernelGGL((k_conv_mfma_glds<T, 128, 1, 2, 4, 2, 2>), grid, dim3(512), 0, s, a);
+    else if (bn == 64) hipLaunchKernelGGL((k_conv_mfma_glds<T, 64, 1, 1, 4, 2, MRCNN_RING64>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((k_conv_mfma_glds<T, 32, 1, 1, 4, 1, MRCNN_RING32>), grid, dim3(256), 0, s, a);
 }
 
 void conv_forward(hipStream_t s, const ConvDesc& d)
