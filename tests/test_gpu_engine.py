@@ -287,3 +287,51 @@ def test_engine_full_size_one_image(pkg, orc, tmp_path_factory, weights_mod):
     # the synthetic "forced full load" weights must actually load the data-dependent stages
     assert int(m.read_tensor("keep_count", 0)[0]) == cfg.max_proposals
     assert int((d0[:, 5] > 0).sum()) == cfg.max_detections
+
+
+def test_engine_lifecycle_streams_and_handles(pkg, small_model):
+    """Handles are independent and leak-free: load/destroy cycles give the HBM back, two live handles do not
+    disturb each other, and a handle moved onto the caller's stream (mrcnn_model_set_stream + predict_async,
+    the torch-interop path of bench.py) gives the results of the synchronous call."""
+    import gc
+    import torch
+    il = __import__("importlib")
+    models, L = il.import_module("mask-rcnn-coreml_amd.models"), il.import_module("mask-rcnn-coreml_amd._lib")
+    d, cfg = small_model
+    images = rand_images(3, cfg.image_height, cfg.image_width, seed=13)
+    m1 = models.load_maskrcnn(d, max_batch=3)
+    det_ref, mask_ref = m1.predict(images)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        m = models.load_maskrcnn(d, max_batch=3)
+        det, mask = m.predict(images)
+        np.testing.assert_array_equal(det, det_ref)
+        del m
+        gc.collect()
+    torch.cuda.synchronize()
+    assert abs(torch.cuda.mem_get_info()[0] - free0) < 32 << 20, "model handles leak device memory"
+    L.lib().mrcnn_model_destroy(None)                        # NULL is a no-op, like free()
+
+    # two live handles with different arenas, interleaved calls
+    m2 = models.load_maskrcnn(d, max_batch=1)
+    for b in range(3):
+        d2, k2 = m2.predict(images[b:b + 1])
+        d1, k1 = m1.predict(images[::-1].copy())
+        np.testing.assert_array_equal(d2[0], det_ref[b])
+        np.testing.assert_array_equal(k2[0], mask_ref[b])
+        np.testing.assert_array_equal(d1[::-1], det_ref)
+
+    # the caller's stream: enqueue-only predict ordered after work the caller queued on that stream
+    st = torch.cuda.Stream()
+    m1.set_stream(st.cuda_stream)
+    with torch.cuda.stream(st):
+        img_d = torch.from_numpy(images).cuda(non_blocking=True)     # H2D queued on st, predict must see it
+        det_d = torch.full((3, m1.max_detections, 6), float("nan"), device="cuda")
+        mask_d = torch.full((3, m1.max_detections, m1.mask_size, m1.mask_size), float("nan"), device="cuda")
+        m1.predict_into(img_d, det_d, mask_d, sync=False)
+        total = det_d[:, :, 5].sum()                                 # consumer queued behind predict on st
+    st.synchronize()
+    np.testing.assert_array_equal(det_d.cpu().numpy(), det_ref)
+    np.testing.assert_array_equal(mask_d.cpu().numpy(), mask_ref)
+    assert float(total) == float(det_ref[:, :, 5].astype(np.float32).sum(dtype=np.float32)) or abs(float(total) - det_ref[:, :, 5].sum()) < 1e-3
