@@ -152,6 +152,14 @@ MRCNN_API void mrcnn_model_destroy(mrcnn_model* model);
 /* Use an existing hipStream_t (e.g. torch's current stream) instead of the model's own. */
 MRCNN_API int mrcnn_model_set_stream(mrcnn_model* model, void* hip_stream);
 
+/* Optional hipGraph replay of predict's launch sequence (captured on the second call at a given batch size;
+ * ~200 launches per image batch).  Off by default (measured neutral on MI355X); on = 1 enables it,
+ * on = 0 switches back to plain stream launches and frees the captured graphs; the environment variable
+ * MRCNN_GRAPH=1 sets the default for new handles.  Replay is bypassed automatically while stage timing or the conv
+ * profile is enabled, and when the caller is itself capturing the stream (the launches then join the caller's
+ * graph).  mrcnn_model_get_int keys "graph_enabled" / "graph_launches" report the state. */
+MRCNN_API int mrcnn_model_enable_graph(mrcnn_model* model, int on);
+
 /* MaskRCNN.prediction(image:) — input `image` (task.py:70-75): RGB 8-bit, H×W = the model's
  * input_image_shape, interleaved (B,H,W,3).  The per-channel mean is subtracted on the GPU.
  * Outputs: `detections` (B, maxDetections, 6) rows (y1,x1,y2,x2,classId,score) normalized,
@@ -194,7 +202,9 @@ MRCNN_API int mrcnn_model_stage_ms(mrcnn_model* model, const char* stage, float*
 
 /* Live per-kernel profile of the convolution family during predict (bench.py roofline leg): when
  * enabled every conv launch is bracketed by HIP events on the model's stream.  tile: 0 = the
- * 128x128 kernel (dominant), 1 = 128x64, 2 = 128x32.  Totals accumulate since enable/reset;
+ * 128x128 kernel (dominant), 1 = 128x64, 2 = 128x32.  enable(1) opens a measurement window (totals reset);
+ * enable(0) closes it and the totals stay readable — the events cost ~2 % (fp32) / ~13 % (fp16) of a step,
+ * so bench.py opens the window for the first steps of its timed region only.
  * total_flops is ALGORITHMIC work (2*M*N*K of the convolution, padding excluded). */
 MRCNN_API int mrcnn_model_conv_profile_enable(mrcnn_model* model, int on);
 MRCNN_API int mrcnn_model_conv_profile_get(mrcnn_model* model, int tile, int64_t* launches, double* total_ms,

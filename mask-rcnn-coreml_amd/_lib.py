@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "mrcnn_model_load", "mrcnn_model_destroy", "mrcnn_model_set_stream", "mrcnn_maskrcnn_predict",
     "mrcnn_maskrcnn_predict_async", "mrcnn_classifier_predict", "mrcnn_mask_predict", "mrcnn_model_get_int",
     "mrcnn_model_read_tensor", "mrcnn_model_enable_timing", "mrcnn_model_stage_ms", "mrcnn_bench_conv",
-    "mrcnn_model_conv_profile_enable", "mrcnn_model_conv_profile_get", "mrcnn_model_conv_profile_shapes", "mrcnn_bench_conv_dtype",
+    "mrcnn_model_conv_profile_enable", "mrcnn_model_conv_profile_get", "mrcnn_model_conv_profile_shapes", "mrcnn_model_enable_graph", "mrcnn_bench_conv_dtype",
     "mrcnn_detections_decode", "mrcnn_mask_to_u8", "mrcnn_paste_masks", "mrcnn_generate_anchors", "mrcnn_letterbox_geometry", "mrcnn_letterbox_rgb",
 ]
 
@@ -111,6 +111,7 @@ def lib():
     L.mrcnn_model_stage_ms.argtypes = [vp, cp, f32p]
     L.mrcnn_model_conv_profile_enable.argtypes = [vp, C.c_int]
     L.mrcnn_model_conv_profile_get.argtypes = [vp, C.c_int, i64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.mrcnn_model_enable_graph.argtypes = [vp, C.c_int]
     L.mrcnn_model_conv_profile_shapes.argtypes = [vp, C.POINTER(ConvShapeStat), C.c_int, C.POINTER(C.c_int)]
     L.mrcnn_bench_conv.argtypes = [C.c_int] * 8 + [f32p, C.POINTER(C.c_double)]
     L.mrcnn_bench_conv_dtype.argtypes = [C.c_int] * 9 + [f32p, C.POINTER(C.c_double)]

@@ -519,6 +519,18 @@ extern "C" int mrcnn_model_set_stream(mrcnn_model* model, void* hip_stream)
     });
 }
 
+extern "C" int mrcnn_model_enable_graph(mrcnn_model* model, int on)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model, MRCNN_ERR_INVALID, "null model");
+        model->m.use_graph = on != 0;
+        if (!on) {
+            HIP_CHECK(hipStreamSynchronize(model->m.stream));
+            model->m.drop_graphs();
+        }
+    });
+}
+
 extern "C" int mrcnn_maskrcnn_predict(mrcnn_model* model, const uint8_t* rgb, int batch, int height, int width, int memspace,
                                       float* detections, float* masks)
 {
@@ -603,6 +615,8 @@ extern "C" int mrcnn_model_get_int(mrcnn_model* model, const char* key, int64_t*
         else if (k == "pre_nms_max_proposals") *value = m.pre_nms;
         else if (k == "pre_nms_count") *value = m.K;
         else if (k == "mask_size") *value = 2 * m.mask_pool;
+        else if (k == "graph_launches") *value = m.graph_launches;
+        else if (k == "graph_enabled") *value = m.use_graph ? 1 : 0;
         else *value = m.file.get_int(k);
     });
 }
@@ -637,8 +651,14 @@ extern "C" int mrcnn_model_conv_profile_enable(mrcnn_model* model, int on)
 {
     return guarded([&] {
         MRCNN_REQUIRE(model, MRCNN_ERR_INVALID, "null model");
-        model->m.conv_profile.active = on != 0;
-        model->m.conv_profile.reset();
+        ConvProfile& cp = model->m.conv_profile;
+        if (on) {
+            cp.reset();                                  // a new measurement window
+        } else if (cp.active) {
+            HIP_CHECK(hipStreamSynchronize(model->m.stream));
+            cp.collect();                                // keep the totals readable after the window closes
+        }
+        cp.active = on != 0;
     });
 }
 extern "C" int mrcnn_model_conv_profile_get(mrcnn_model* model, int tile, int64_t* launches, double* total_ms, double* total_flops)

@@ -142,11 +142,23 @@ struct Model {
     MaskSelectWorkspace msel_ws;
     StageTimer timer;
     ConvProfile conv_profile;
+    // Optional: the ~200 launches of one predict captured once per batch size and replayed as a hipGraph
+    // (the pipeline is static: every data-dependent count lives in device memory).  Off by default —
+    // measured neutral on MI355X (the runtime already keeps the queue full; the gaps
+    // between kernels are the GPU's own dispatch) — on with mrcnn_model_enable_graph / MRCNN_GRAPH=1.
+    // Bypassed while stage timing / the conv profiler record events between launches and when the
+    // caller is itself capturing the stream.
+    struct GraphSlot { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int eager_runs = 0; };
+    std::map<int, GraphSlot> graphs;
+    bool use_graph = false;
+    long graph_launches = 0;
 
     ~Model();
     void load(int kind, const std::string& path, int max_batch, int dtype);
     void build_maskrcnn();
     void predict(const uint8_t* rgb, int batch, int h, int w, int memspace, float* det, float* masks, bool sync);
+    void enqueue_pipeline(hipStream_t s, int batch);    // d_rgb → detections / mask_out, launches only
+    void drop_graphs();
     void read_tensor(const std::string& name, int image, float* dst, int64_t cap, int64_t* count);
 };
 

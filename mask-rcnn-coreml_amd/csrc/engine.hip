@@ -511,8 +511,18 @@ StageTimer::~StageTimer()
 // ------------------------------------------------------------------------------------------------
 // Model
 // ------------------------------------------------------------------------------------------------
+void Model::drop_graphs()
+{
+    for (auto& kv : graphs) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    graphs.clear();
+}
+
 Model::~Model()
 {
+    drop_graphs();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
 
@@ -537,6 +547,7 @@ void Model::load(int kind_, const std::string& path, int max_batch_, int dtype_)
                   file.get_string("kind").c_str(), want);
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     own_stream = true;
+    if (const char* e = getenv("MRCNN_GRAPH")) use_graph = atoi(e) != 0;
     nc = (int)file.get_int("num_classes");
     if (kind == MRCNN_MODEL_CLASSIFIER) { cls_head.load(file, max_batch, dtype); return; }
     if (kind == MRCNN_MODEL_MASK) { mask_head.load(file, max_batch, dtype); return; }
@@ -795,6 +806,48 @@ void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, f
     hipStream_t s = stream;
     const size_t img_bytes = (size_t)batch * H * W * 3;
     HIP_CHECK(hipMemcpyAsync(d_rgb, rgb, img_bytes, memspace == MRCNN_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+
+    hipStreamCaptureStatus caller_capture = hipStreamCaptureStatusNone;
+    if (use_graph) HIP_CHECK(hipStreamIsCapturing(s, &caller_capture));
+    const bool plain = !use_graph || timer.enabled || conv_profile.active || caller_capture != hipStreamCaptureStatusNone;
+    if (plain) {
+        enqueue_pipeline(s, batch);
+    } else {
+        GraphSlot& g = graphs[batch];
+        if (!g.exec && g.eager_runs++ == 0) {
+            enqueue_pipeline(s, batch);              // first call at this batch size: also runs the one-time host set-up
+        } else {
+            if (!g.exec) {
+                HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                try {
+                    enqueue_pipeline(s, batch);
+                } catch (...) {
+                    hipGraph_t dead = nullptr;
+                    (void)hipStreamEndCapture(s, &dead);
+                    if (dead) (void)hipGraphDestroy(dead);
+                    throw;
+                }
+                HIP_CHECK(hipStreamEndCapture(s, &g.graph));
+                HIP_CHECK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+            }
+            HIP_CHECK(hipGraphLaunch(g.exec, s));
+            ++graph_launches;
+        }
+    }
+
+    const int HW = 4 * mask_pool * mask_pool;
+    const hipMemcpyKind back = memspace == MRCNN_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    HIP_CHECK(hipMemcpyAsync(det_out, detections, (size_t)batch * max_det * 6 * 4, back, s));
+    HIP_CHECK(hipMemcpyAsync(masks_out, mask_out, (size_t)batch * max_det * HW * 4, back, s));
+    if (sync) {
+        HIP_CHECK(hipStreamSynchronize(s));
+        timer.finish();
+        if (conv_profile.active) conv_profile.collect();
+    }
+}
+
+void Model::enqueue_pipeline(hipStream_t s, int batch)
+{
     timer.begin(s);
     conv_set_profiler(conv_profile.active ? &conv_profile : nullptr);
     for (auto& op : trunk_ops) op(s, batch);
@@ -832,15 +885,7 @@ void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, f
                         mask_head.final_w.as<float>(), mask_head.final_b.as<float>(), nc, detections, (long)max_det * 6, 6, max_det,
                         batch, msel_ws, mask_out, (long)max_det * HW, HW, dtype);
     timer.mark(s, "TimeDistributedMask-Eval");
-    const hipMemcpyKind back = memspace == MRCNN_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    HIP_CHECK(hipMemcpyAsync(det_out, detections, (size_t)batch * max_det * 6 * 4, back, s));
-    HIP_CHECK(hipMemcpyAsync(masks_out, mask_out, (size_t)batch * max_det * HW * 4, back, s));
     conv_set_profiler(nullptr);
-    if (sync) {
-        HIP_CHECK(hipStreamSynchronize(s));
-        timer.finish();
-        if (conv_profile.active) conv_profile.collect();
-    }
 }
 
 void Model::read_tensor(const std::string& name, int image, float* dst, int64_t cap, int64_t* count)

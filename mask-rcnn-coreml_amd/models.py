@@ -46,6 +46,10 @@ class _Model:
         _lib.check(_lib.lib().mrcnn_model_get_int(self._h, key.encode(), C.byref(v)))
         return int(v.value)
 
+    def enable_graph(self, on: bool = True):
+        """hipGraph replay of predict's launch sequence (default off; see mrcnn_model_enable_graph)."""
+        _lib.check(_lib.lib().mrcnn_model_enable_graph(self._h, int(on)))
+
     def set_stream(self, hip_stream: int):
         _lib.check(_lib.lib().mrcnn_model_set_stream(self._h, C.c_void_p(hip_stream)))
 

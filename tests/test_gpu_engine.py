@@ -335,3 +335,32 @@ def test_engine_lifecycle_streams_and_handles(pkg, small_model):
     np.testing.assert_array_equal(det_d.cpu().numpy(), det_ref)
     np.testing.assert_array_equal(mask_d.cpu().numpy(), mask_ref)
     assert float(total) == float(det_ref[:, :, 5].astype(np.float32).sum(dtype=np.float32)) or abs(float(total) - det_ref[:, :, 5].sum()) < 1e-3
+
+
+def test_engine_graph_replay_matches_stream_launches(pkg, small_model):
+    """Opt-in hipGraph replay: captured on the second call per batch size, identical results, bypassed (not broken)
+    while the profilers record events, and droppable."""
+    models = __import__("importlib").import_module("mask-rcnn-coreml_amd.models")
+    d, cfg = small_model
+    m = models.load_maskrcnn(d, max_batch=2)
+    assert m.get_int("graph_enabled") == 0
+    imgs = [rand_images(b, cfg.image_height, cfg.image_width, seed=30 + b) for b in (1, 2)]
+    ref = [m.predict(i) for i in imgs]
+    m.enable_graph(True)
+    for rep in range(3):                                  # eager, capture + launch, launch
+        for i, r in zip(imgs, ref):
+            det, mask = m.predict(i)
+            np.testing.assert_array_equal(det, r[0])
+            np.testing.assert_array_equal(mask, r[1])
+    assert m.get_int("graph_launches") == 4               # 2 batch sizes × (rep 1, rep 2)
+    m.enable_timing(True)                                 # events between launches: replay is bypassed
+    det, _ = m.predict(imgs[1])
+    np.testing.assert_array_equal(det, ref[1][0])
+    assert m.get_int("graph_launches") == 4 and m.stage_ms()["Trunk"] > 0
+    m.enable_timing(False)
+    m.predict(imgs[1])
+    assert m.get_int("graph_launches") == 5
+    m.enable_graph(False)
+    det, mask = m.predict(imgs[0])
+    np.testing.assert_array_equal(det, ref[0][0])
+    assert m.get_int("graph_launches") == 5 and m.get_int("graph_enabled") == 0
