@@ -13,7 +13,7 @@ Weights are seeded synthetic weights of the exact architecture ("forced full loa
 100 detections per image, so no data-dependent stage idles); there is no network for checkpoints.
 
 Rank 0 prints ONE JSON line with, besides the contract fields:
-  roofline     — dominant kernel k_conv_mfma_glds<float,128,1,2,4,2,2> (fp32 MFMA implicit-GEMM conv): its
+  roofline     — dominant kernel k_conv_mfma_glds<float,float,128,1,2,4,2,2> (fp32 MFMA implicit-GEMM conv): its
                  ALGORITHMIC flops per launch ÷ its average launch duration, both measured live with HIP
                  events on the launching stream inside the timed region (the first --event-steps steps of it:
                  bracketing every launch drains the queue between kernels and costs ~2 % of a step);
@@ -48,9 +48,10 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
     ap.add_argument("--arch", default="resnet101")
     ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f32s"],
                     help="compute dtype of the convolutions: f32 = exact-fp32 MFMA (default, the parity baseline); "
-                         "f16 = fp16 MFMA with fp32 accumulation (BASELINE configs[3])")
+                         "f16 = fp16 MFMA with fp32 accumulation (BASELINE configs[3]); f32s = fp32 tensors, every "
+                         "convolution as two fp16 MFMA passes over a hi/lo split of its activations (fp32-grade results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=3)
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
@@ -150,9 +151,11 @@ def main():
             all_fl = sum(v[2] for v in prof.values())
             if launches:
                 achieved = flops / (ms * 1e-3) / 1e12
-                peak = PEAK_FP16_MFMA_TFLOPS if args.dtype == "f16" else PEAK_FP32_MFMA_TFLOPS
+                # f32s executes two fp16 MFMA flops per algorithmic flop: its ceiling is half the fp16 peak
+                peak = {"f32": PEAK_FP32_MFMA_TFLOPS, "f16": PEAK_FP16_MFMA_TFLOPS, "f32s": PEAK_FP16_MFMA_TFLOPS / 2}[args.dtype]
+                ktypes = {"f32": "float,float", "f16": "_Float16,_Float16", "f32s": "float,_Float16"}[args.dtype]
                 out["roofline"] = {
-                    "kernel": f"k_conv_mfma_glds<{'_Float16' if args.dtype == 'f16' else 'float'},128,1,2,4,2,2>", "bound": "mfma",
+                    "kernel": f"k_conv_mfma_glds<{ktypes},128,1,2,4,2,2>", "bound": "mfma",
                     "achieved": round(achieved, 2),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "traffic": pmc_traffic() if args.dtype == "f32" else None,

@@ -50,7 +50,10 @@ MRCNN_API int mrcnn_device_count(void);
  * strides[0] or strides[2] and the raw data pointer (e.g. ProposalLayer.swift:179,
  * TimeDistributedClassifierLayer.swift:63, PyramidROIAlignLayer.swift:124).
  * --------------------------------------------------------------------------------------------- */
-typedef enum { MRCNN_F32 = 0, MRCNN_F64 = 1, MRCNN_F16 = 2, MRCNN_U8 = 3, MRCNN_I32 = 4 } mrcnn_dtype;
+typedef enum {
+    MRCNN_F32 = 0, MRCNN_F64 = 1, MRCNN_F16 = 2, MRCNN_U8 = 3, MRCNN_I32 = 4,
+    MRCNN_F32S = 5   /* compute mode only (mrcnn_model_load): fp32 tensors, fp16 filters, split-fp16 MFMA — see there */
+} mrcnn_dtype;
 typedef enum { MRCNN_HOST = 0, MRCNN_DEVICE = 1 } mrcnn_memspace;
 
 typedef struct {
@@ -144,8 +147,12 @@ typedef struct mrcnn_model mrcnn_model;
  * (the reference re-loads the sub-models on every evaluate, TimeDistributedClassifierLayer.swift:41 —
  * deliberately not reproduced).  max_batch sizes the activation arena (images per predict call).
  * compute_dtype: MRCNN_F32 (exact-fp32 MFMA, fp32 activations — the default and the parity
- * baseline) or MRCNN_F16 (fp16 activations and filters, fp32 accumulate, fp32 box path and outputs:
- * BASELINE configs[3]). */
+ * baseline), MRCNN_F16 (fp16 activations and filters, fp32 accumulate, fp32 box path and outputs:
+ * BASELINE configs[3]) or MRCNN_F32S (everything stays fp32 in memory; each convolution runs as TWO fp16
+ * MFMA passes over a hi/lo split of its fp32 activations against the fp16 filters the artefact stores
+ * (task.py:90), fp32 accumulate: products are exact, the split carries 22 of the 24 significand bits —
+ * fp32-grade results at several times the fp32-MFMA rate.  Requires fp16-representable filters, which is
+ * what the converter writes; an artefact with genuine fp32 filters is refused in this mode). */
 MRCNN_API int mrcnn_model_load(int kind, const char* path, int max_batch, int compute_dtype,
                                mrcnn_model** out_model);
 MRCNN_API void mrcnn_model_destroy(mrcnn_model* model);

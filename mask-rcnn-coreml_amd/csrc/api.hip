@@ -501,7 +501,8 @@ extern "C" int mrcnn_model_load(int kind, const char* path, int max_batch, int c
     return guarded([&] {
         MRCNN_REQUIRE(path && out_model, MRCNN_ERR_INVALID, "null argument");
         MRCNN_REQUIRE(kind >= 0 && kind <= 2, MRCNN_ERR_INVALID, "unknown model kind %d", kind);
-        MRCNN_REQUIRE(compute_dtype == MRCNN_F32 || compute_dtype == MRCNN_F16, MRCNN_ERR_UNSUPPORTED, "compute dtype %d not available (MRCNN_F32 or MRCNN_F16)", compute_dtype);
+        MRCNN_REQUIRE(compute_dtype == MRCNN_F32 || compute_dtype == MRCNN_F16 || compute_dtype == MRCNN_F32S, MRCNN_ERR_UNSUPPORTED,
+                      "compute dtype %d not available (MRCNN_F32, MRCNN_F16 or MRCNN_F32S)", compute_dtype);
         std::unique_ptr<mrcnn_model> h(new mrcnn_model);
         h->m.load(kind, path, max_batch, compute_dtype);
         *out_model = h.release();
@@ -605,7 +606,7 @@ extern "C" int mrcnn_model_get_int(mrcnn_model* model, const char* key, int64_t*
         const std::string k = key;
         if (k == "num_classes") *value = m.nc;
         else if (k == "max_batch") *value = m.max_batch;
-        else if (k == "compute_dtype") *value = m.dtype;
+        else if (k == "compute_dtype") *value = m.mode;
         else if (m.kind != MRCNN_MODEL_MASKRCNN) *value = m.file.get_int(k);
         else if (k == "image_height") *value = m.H;
         else if (k == "image_width") *value = m.W;
@@ -702,7 +703,9 @@ extern "C" int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout
     return guarded([&] {
         require_gpu();
         MRCNN_REQUIRE(avg_ms && flops && iters >= 1 && (ksize == 1 || ksize == 3) && cin % 64 == 0, MRCNN_ERR_INVALID, "bad bench_conv arguments");
-        const size_t es = dtype == MRCNN_F16 ? 2 : 4;
+        MRCNN_REQUIRE(dtype == MRCNN_F32 || dtype == MRCNN_F16 || dtype == MRCNN_F32S, MRCNN_ERR_UNSUPPORTED, "bench_conv: dtype %d", dtype);
+        const size_t es = dtype == MRCNN_F16 ? 2 : 4;             // activations
+        const size_t ws = dtype == MRCNN_F32 ? 4 : 2;             // filters
         const int pad = ksize / 2;
         const int oh = (h + 2 * pad - ksize) / stride + 1, ow = (w + 2 * pad - ksize) / stride + 1;
         const int bn = conv_n_tile(cout), npad = (cout + bn - 1) / bn * bn;
@@ -712,26 +715,27 @@ extern "C" int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout
         std::vector<float> hs(npad, 1.f), hb(npad, 0.f);
         // random operands in [-1,1) (weights scaled); for fp16 the bit patterns are generated directly
         const size_t pat = 1 << 20;
-        std::vector<unsigned char> hin(pat * es), hw(n_w * es);
-        auto fill = [&](unsigned char* dst, size_t n, float scale) {
+        std::vector<unsigned char> hin(pat * es), hw(n_w * ws);
+        auto fill = [&](unsigned char* dst, size_t n, float scale, size_t esz) {
             for (size_t i = 0; i < n; ++i) {
                 const float v = U(rng) * scale;
-                if (es == 4) memcpy(dst + i * 4, &v, 4);
+                if (esz == 4) memcpy(dst + i * 4, &v, 4);
                 else { const _Float16 hv = (_Float16)v; memcpy(dst + i * 2, &hv, 2); }
             }
         };
-        fill(hin.data(), pat, 1.f);
-        fill(hw.data(), n_w, 0.05f);
-        DevBuf din(n_in * es), dw(n_w * es), ds(npad * 4), db(npad * 4), dout(n_out * es);
+        fill(hin.data(), pat, 1.f, es);
+        fill(hw.data(), n_w, 0.05f, ws);
+        DevBuf din(n_in * es), dw(n_w * ws), ds(npad * 4), db(npad * 4), dout(n_out * es);
         for (size_t off = 0; off < n_in; off += pat) {
             const size_t c = n_in - off < pat ? n_in - off : pat;
             HIP_CHECK(hipMemcpy((char*)din.p + off * es, hin.data(), c * es, hipMemcpyHostToDevice));
         }
-        HIP_CHECK(hipMemcpy(dw.p, hw.data(), n_w * es, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dw.p, hw.data(), n_w * ws, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(ds.p, hs.data(), npad * 4, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(db.p, hb.data(), npad * 4, hipMemcpyHostToDevice));
         ConvDesc d;
-        d.dtype = dtype;
+        d.dtype = dtype == MRCNN_F32S ? MRCNN_F32 : dtype;
+        d.wdtype = dtype == MRCNN_F32 ? MRCNN_F32 : MRCNN_F16;
         d.in = din.p; d.B = batch; d.H = h; d.W = w; d.Cin = cin;
         d.in_sW = cin; d.in_sH = (long)w * cin; d.in_sB = (long)h * w * cin;
         d.wgt = dw.p; d.KH = d.KW = ksize; d.stride = stride; d.padH = d.padW = pad;

@@ -35,10 +35,15 @@ struct MrcwFile {
 };
 
 // ---- packed convolution weights on the device ----------------------------------------------------
+// compute mode (mrcnn_model_load's compute_dtype) → element type of activations / of filters
+inline int mode_act(int mode) { return mode == MRCNN_F32S ? MRCNN_F32 : mode; }
+inline int mode_wgt(int mode) { return mode == MRCNN_F32 ? MRCNN_F32 : MRCNN_F16; }
+
 struct PackedConv {
-    DevBuf wgt, scale, shift;     // wgt in the compute dtype; scale/shift always fp32
+    DevBuf wgt, scale, shift;     // wgt in `wdtype`; scale/shift always fp32
     int Cin = 0, Cout = 0, KH = 1, KW = 1, Npad = 0;
-    int dtype = MRCNN_F32;
+    int dtype = MRCNN_F32;        // activations
+    int wdtype = MRCNN_F32;       // filters (fp16 with fp32 activations = split mode, MRCNN_F32S)
 };
 
 struct Tensor4 {   // dense NHWC activation (element type = the model's compute dtype)
@@ -76,7 +81,8 @@ struct ClassifierHead {
     DevBuf arena;
     void *h1 = nullptr, *h2 = nullptr, *stage_in = nullptr;           // compute dtype
     float *lb = nullptr, *probs = nullptr, *bbox = nullptr, *cls6 = nullptr;
-    void load(const MrcwFile& f, int capacity_rows, int dtype);
+    int mode = MRCNN_F32;          // compute mode the head was loaded with (MRCNN_F32 | MRCNN_F16 | MRCNN_F32S)
+    void load(const MrcwFile& f, int capacity_rows, int mode);
     // pooled: n rows of pool*pool*C elements in (h,w,c) order, contiguous, compute dtype.
     void forward(hipStream_t s, const void* pooled_nhwc, int n, float* cls6_out, long cls6_stride);
 };
@@ -89,7 +95,8 @@ struct MaskHead {
     DevBuf arena;
     void *t0 = nullptr, *t1 = nullptr, *feat = nullptr, *stage_in = nullptr;   // compute dtype
     float* full = nullptr;
-    void load(const MrcwFile& f, int capacity_rows, int dtype);
+    int mode = MRCNN_F32;          // compute mode the head was loaded with (MRCNN_F32 | MRCNN_F16 | MRCNN_F32S)
+    void load(const MrcwFile& f, int capacity_rows, int mode);
     // pooled: n rows of 14*14*C NHWC → feat (n, 28*28, C) = ReLU(deconv)
     void forward_features(hipStream_t s, const void* pooled_nhwc, int n);
     // feat → all-class sigmoid masks, NHWC (n, 784, nc) in `full`
@@ -110,7 +117,8 @@ struct StageTimer {
 struct Model {
     int kind = 0;
     int max_batch = 1;
-    int dtype = MRCNN_F32;      // compute dtype of activations / filters
+    int mode = MRCNN_F32;       // compute mode: MRCNN_F32 | MRCNN_F16 | MRCNN_F32S
+    int dtype = MRCNN_F32;      // element type of the activations = mode_act(mode)
     MrcwFile file;
     hipStream_t stream = nullptr;
     bool own_stream = false;

@@ -205,11 +205,18 @@ static uint16_t float_to_half(float f)   // round to nearest even
 }
 
 // filter weights in the compute dtype (the artefact stores fp16, so the fp16 path is lossless)
-static void upload_w(DevBuf& d, const std::vector<float>& h, int dtype)
+static void upload_w(DevBuf& d, const std::vector<float>& h, int dtype, bool must_be_exact = false, const char* what = "")
 {
     if (dtype != MRCNN_F16) { upload(d, h); return; }
     std::vector<uint16_t> hh(h.size());
-    for (size_t i = 0; i < h.size(); ++i) hh[i] = float_to_half(h[i]);
+    for (size_t i = 0; i < h.size(); ++i) {
+        hh[i] = float_to_half(h[i]);
+        if (must_be_exact) {
+            const _Float16 back = __builtin_bit_cast(_Float16, hh[i]);
+            MRCNN_REQUIRE((float)back == h[i], MRCNN_ERR_UNSUPPORTED,
+                          "%s: filter value %.9g is not fp16-representable; MRCNN_F32S needs the fp16 filters the converter writes", what, h[i]);
+        }
+    }
     d.alloc(hh.size() * 2);
     HIP_CHECK(hipMemcpy(d.p, hh.data(), hh.size() * 2, hipMemcpyHostToDevice));
 }
@@ -244,7 +251,7 @@ PackedConv pack_conv_oihw(const MrcwFile& f, const std::string& conv, const std:
     const int O = t.dims[0], I = t.dims[1], KH = t.dims[2], KW = t.dims[3];
     const std::vector<float> k = f.floats(conv + "/kernel");
     PackedConv pc;
-    pc.dtype = dtype;
+    pc.dtype = mode_act(dtype); pc.wdtype = mode_wgt(dtype);
     pc.Cin = I; pc.Cout = O; pc.KH = KH; pc.KW = KW;
     const int bn_tile = conv_n_tile(O);
     pc.Npad = (O + bn_tile - 1) / bn_tile * bn_tile;
@@ -254,7 +261,7 @@ PackedConv pack_conv_oihw(const MrcwFile& f, const std::string& conv, const std:
             for (int y = 0; y < KH; ++y)
                 for (int x = 0; x < KW; ++x)
                     w[(((size_t)o * KH + y) * KW + x) * I + i] = k[(((size_t)o * I + i) * KH + y) * KW + x];
-    upload_w(pc.wgt, w, dtype);
+    upload_w(pc.wgt, w, pc.wdtype, pc.wdtype != pc.dtype, "MRCNN_F32S");
     std::vector<float> sc, sh;
     fold_bn(f, conv, bn, O, pc.Npad, sc, sh);
     upload(pc.scale, sc);
@@ -271,8 +278,9 @@ static PackedConv pack_conv1(const MrcwFile& f, int dtype)
     MRCNN_REQUIRE(t.dims.size() == 4 && t.dims[1] == 3 && t.dims[2] == 7 && t.dims[3] == 7, MRCNN_ERR_IO, "conv1/kernel must be [O,3,7,7]");
     const int O = t.dims[0];
     const std::vector<float> k = f.floats("conv1/kernel");
+    if (dtype == MRCNN_F32S) dtype = MRCNN_F32;     // the stem (1 % of the work, K = 147) stays on the fp32 MFMA
     PackedConv pc;
-    pc.dtype = dtype;
+    pc.dtype = dtype; pc.wdtype = dtype;
     const int px = dtype == MRCNN_F16 ? 8 : 4;      // channels per staged pixel (NHWC8 / NHWC4): 16 B either way
     const int row = 8 * px;                         // one kernel row = 7 taps padded to 8 pixels = 128 B
     pc.Cin = row; pc.Cout = O; pc.KH = 7; pc.KW = 1;
@@ -284,7 +292,7 @@ static PackedConv pack_conv1(const MrcwFile& f, int dtype)
             for (int y = 0; y < 7; ++y)
                 for (int x = 0; x < 7; ++x)
                     w[((size_t)o * 7 + y) * row + x * px + ci] = k[(((size_t)o * 3 + ci) * 7 + y) * 7 + x];
-    upload_w(pc.wgt, w, dtype);
+    upload_w(pc.wgt, w, pc.wdtype, pc.wdtype != pc.dtype, "MRCNN_F32S");
     std::vector<float> sc, sh;
     fold_bn(f, "conv1", "bn_conv1", O, pc.Npad, sc, sh);
     upload(pc.scale, sc);
@@ -296,7 +304,7 @@ static PackedConv pack_conv1(const MrcwFile& f, int dtype)
 static PackedConv pack_stacked_1x1(const MrcwFile& f, const std::vector<std::string>& names, int dtype)
 {
     PackedConv pc;
-    pc.dtype = dtype;
+    pc.dtype = mode_act(dtype); pc.wdtype = mode_wgt(dtype);
     int O = 0, I = -1;
     for (auto& n : names) {
         const MrcwTensor& t = f.tensor(n + "/kernel");
@@ -317,7 +325,7 @@ static PackedConv pack_stacked_1x1(const MrcwFile& f, const std::vector<std::str
         for (size_t o = 0; o < b.size(); ++o) { sc[o0 + o] = 1.f; sh[o0 + o] = b[o]; }
         o0 += (int)b.size();
     }
-    upload_w(pc.wgt, w, dtype);
+    upload_w(pc.wgt, w, pc.wdtype, pc.wdtype != pc.dtype, "MRCNN_F32S");
     upload(pc.scale, sc);
     upload(pc.shift, sh);
     return pc;
@@ -331,7 +339,7 @@ static PackedConv pack_deconv2(const MrcwFile& f, const std::string& name, int d
     const int I = t.dims[0], O = t.dims[1];
     const std::vector<float> k = f.floats(name + "/kernel"), b = f.floats(name + "/bias");
     PackedConv pc;
-    pc.dtype = dtype;
+    pc.dtype = mode_act(dtype); pc.wdtype = mode_wgt(dtype);
     pc.Cin = I; pc.Cout = O; pc.KH = pc.KW = 1;
     pc.Npad = 4 * O;
     MRCNN_REQUIRE(pc.Npad % conv_n_tile(pc.Npad) == 0, MRCNN_ERR_SHAPE, "%s: 4*O must be a multiple of the N tile", name.c_str());
@@ -341,7 +349,7 @@ static PackedConv pack_deconv2(const MrcwFile& f, const std::string& name, int d
             for (int i = 0; i < I; ++i) w[((size_t)qd * O + o) * I + i] = k[(((size_t)i * O + o) * 2 + (qd >> 1)) * 2 + (qd & 1)];
             sh[(size_t)qd * O + o] = b[o];
         }
-    upload_w(pc.wgt, w, dtype);
+    upload_w(pc.wgt, w, pc.wdtype, pc.wdtype != pc.dtype, "MRCNN_F32S");
     upload(pc.scale, sc);
     upload(pc.shift, sh);
     return pc;
@@ -352,7 +360,7 @@ void run_conv_dense(hipStream_t s, const PackedConv& pc, const void* in, int B, 
                     int pad, int act, const void* res, int out_f32)
 {
     ConvDesc d;
-    d.dtype = pc.dtype; d.out_f32 = out_f32;
+    d.dtype = pc.dtype; d.wdtype = pc.wdtype; d.out_f32 = out_f32;
     d.in = in; d.B = B; d.H = H; d.W = W; d.Cin = pc.Cin;
     d.in_sW = pc.Cin; d.in_sH = (long)W * pc.Cin; d.in_sB = (long)H * W * pc.Cin;
     d.wgt = pc.wgt.p; d.KH = pc.KH; d.KW = pc.KW; d.stride = stride; d.padH = d.padW = pad;
@@ -373,14 +381,15 @@ void ClassifierHead::load(const MrcwFile& f, int capacity_rows, int dtype_)
 {
     nc = (int)f.get_int("num_classes");
     cap = capacity_rows;
-    dtype = dtype_;
+    mode = dtype_;
+    dtype = mode_act(mode);
     const MrcwTensor& k1 = f.tensor("mrcnn_class_conv1/kernel");
     MRCNN_REQUIRE(k1.dims.size() == 4, MRCNN_ERR_IO, "mrcnn_class_conv1/kernel must be 4-D");
     C = k1.dims[1]; pool = k1.dims[2];
-    fc1 = pack_conv_oihw(f, "mrcnn_class_conv1", "mrcnn_class_bn1", dtype);    // [1024][7][7][256] == rows of the NHWC pooled vector
+    fc1 = pack_conv_oihw(f, "mrcnn_class_conv1", "mrcnn_class_bn1", mode);    // [1024][7][7][256] == rows of the NHWC pooled vector
     fc1.Cin = fc1.Cin * fc1.KH * fc1.KW; fc1.KH = fc1.KW = 1;           // as an inner product over K = 12544
-    fc2 = pack_conv_oihw(f, "mrcnn_class_conv2", "mrcnn_class_bn2", dtype);
-    fc3 = pack_stacked_1x1(f, {"mrcnn_class_logits", "mrcnn_bbox_fc"}, dtype);
+    fc2 = pack_conv_oihw(f, "mrcnn_class_conv2", "mrcnn_class_bn2", mode);
+    fc3 = pack_stacked_1x1(f, {"mrcnn_class_logits", "mrcnn_bbox_fc"}, mode);
     MRCNN_REQUIRE(fc3.Cout == 5 * nc, MRCNN_ERR_IO, "classifier output size %d != 5*num_classes", fc3.Cout);
     Arena ar;
     for (int pass = 0; pass < 2; ++pass) {
@@ -416,12 +425,13 @@ void MaskHead::load(const MrcwFile& f, int capacity_rows, int dtype_)
 {
     nc = (int)f.get_int("num_classes");
     cap = capacity_rows;
-    dtype = dtype_;
+    mode = dtype_;
+    dtype = mode_act(mode);
     for (int i = 0; i < 4; ++i)
-        conv[i] = pack_conv_oihw(f, "mrcnn_mask_conv" + std::to_string(i + 1), "mrcnn_mask_bn" + std::to_string(i + 1), dtype);
+        conv[i] = pack_conv_oihw(f, "mrcnn_mask_conv" + std::to_string(i + 1), "mrcnn_mask_bn" + std::to_string(i + 1), mode);
     C = conv[0].Cin;
-    deconv = pack_deconv2(f, "mrcnn_mask_deconv", dtype);
-    final_full = pack_conv_oihw(f, "mrcnn_mask", "", dtype);
+    deconv = pack_deconv2(f, "mrcnn_mask_deconv", mode);
+    final_full = pack_conv_oihw(f, "mrcnn_mask", "", mode);
     upload(final_w, f.floats("mrcnn_mask/kernel"));
     upload(final_b, f.floats("mrcnn_mask/bias"));
     const size_t hw = (size_t)pool * pool;
@@ -450,6 +460,7 @@ void MaskHead::forward_features(hipStream_t s, const void* pooled_nhwc, int n)
     d.dtype = dtype;
     d.in = t1; d.B = n; d.H = pool; d.W = pool; d.Cin = deconv.Cin;
     d.in_sW = deconv.Cin; d.in_sH = (long)pool * deconv.Cin; d.in_sB = (long)pool * pool * deconv.Cin;
+    d.wdtype = deconv.wdtype;
     d.wgt = deconv.wgt.p; d.scale = deconv.scale.as<float>(); d.shift = deconv.shift.as<float>();
     d.OH = pool; d.OW = pool; d.Cout = Co; d.Npad = deconv.Npad;
     d.deconv2 = 1; d.act = ACT_RELU;
@@ -466,6 +477,7 @@ void MaskHead::forward_full(hipStream_t s, int n)
     d.dtype = dtype; d.out_f32 = 1;
     d.in = feat; d.B = n; d.H = P2; d.W = P2; d.Cin = final_full.Cin;
     d.in_sW = d.Cin; d.in_sH = (long)P2 * d.Cin; d.in_sB = (long)P2 * P2 * d.Cin;
+    d.wdtype = final_full.wdtype;
     d.wgt = final_full.wgt.p; d.scale = final_full.scale.as<float>(); d.shift = final_full.shift.as<float>();
     d.OH = P2; d.OW = P2; d.Cout = nc; d.Npad = final_full.Npad;
     d.act = ACT_SIGMOID;
@@ -539,7 +551,8 @@ void Model::load(int kind_, const std::string& path, int max_batch_, int dtype_)
 {
     require_gpu();
     kind = kind_;
-    dtype = dtype_;
+    mode = dtype_;
+    dtype = mode_act(mode);
     max_batch = max_batch_ > 0 ? max_batch_ : 1;
     file.load(path);
     const char* want = kind == MRCNN_MODEL_MASKRCNN ? "MaskRCNN" : kind == MRCNN_MODEL_CLASSIFIER ? "Classifier" : "Mask";
@@ -549,8 +562,8 @@ void Model::load(int kind_, const std::string& path, int max_batch_, int dtype_)
     own_stream = true;
     if (const char* e = getenv("MRCNN_GRAPH")) use_graph = atoi(e) != 0;
     nc = (int)file.get_int("num_classes");
-    if (kind == MRCNN_MODEL_CLASSIFIER) { cls_head.load(file, max_batch, dtype); return; }
-    if (kind == MRCNN_MODEL_MASK) { mask_head.load(file, max_batch, dtype); return; }
+    if (kind == MRCNN_MODEL_CLASSIFIER) { cls_head.load(file, max_batch, mode); return; }
+    if (kind == MRCNN_MODEL_MASK) { mask_head.load(file, max_batch, mode); return; }
     build_maskrcnn();
 }
 
@@ -609,16 +622,16 @@ void Model::build_maskrcnn()
     {
         MrcwFile cf; cf.load(cp);
         MRCNN_REQUIRE(cf.get_string("kind") == "Classifier", MRCNN_ERR_IO, "'%s' is not a Classifier artefact", cp);
-        cls_head.load(cf, max_batch * max_prop, dtype);
+        cls_head.load(cf, max_batch * max_prop, mode);
         MRCNN_REQUIRE(cls_head.nc == nc, MRCNN_ERR_IO, "Classifier num_classes %d != %d", cls_head.nc, nc);
         MrcwFile mf; mf.load(mp);
         MRCNN_REQUIRE(mf.get_string("kind") == "Mask", MRCNN_ERR_IO, "'%s' is not a Mask artefact", mp);
-        mask_head.load(mf, max_batch * max_det, dtype);
+        mask_head.load(mf, max_batch * max_det, mode);
         MRCNN_REQUIRE(mask_head.nc == nc, MRCNN_ERR_IO, "Mask num_classes %d != %d", mask_head.nc, nc);
     }
 
     // ---- trunk weights ----------------------------------------------------------------------------
-    convs["conv1"] = pack_conv1(f, dtype);
+    convs["conv1"] = pack_conv1(f, mode);
     std::vector<std::vector<std::string>> blocks(6);
     {
         const int n4 = arch == "resnet101" ? 22 : 5;
@@ -631,12 +644,12 @@ void Model::build_maskrcnn()
     for (int st = 2; st <= 5; ++st)
         for (auto& b : blocks[st]) {
             const std::string p = std::to_string(st) + b;
-            for (const char* br : {"2a", "2b", "2c"}) convs["res" + p + "_branch" + br] = pack_conv_oihw(f, "res" + p + "_branch" + br, "bn" + p + "_branch" + br, dtype);
-            if (b == "a") convs["res" + p + "_branch1"] = pack_conv_oihw(f, "res" + p + "_branch1", "bn" + p + "_branch1", dtype);
+            for (const char* br : {"2a", "2b", "2c"}) convs["res" + p + "_branch" + br] = pack_conv_oihw(f, "res" + p + "_branch" + br, "bn" + p + "_branch" + br, mode);
+            if (b == "a") convs["res" + p + "_branch1"] = pack_conv_oihw(f, "res" + p + "_branch1", "bn" + p + "_branch1", mode);
         }
     for (const char* n : {"fpn_c5p5", "fpn_c4p4", "fpn_c3p3", "fpn_c2p2", "fpn_p2", "fpn_p3", "fpn_p4", "fpn_p5", "rpn_conv_shared"})
-        convs[n] = pack_conv_oihw(f, n, "", dtype);
-    convs["rpn_heads"] = pack_stacked_1x1(f, {"rpn_class_raw", "rpn_bbox_pred"}, dtype);
+        convs[n] = pack_conv_oihw(f, n, "", mode);
+    convs["rpn_heads"] = pack_stacked_1x1(f, {"rpn_class_raw", "rpn_bbox_pred"}, mode);
     MRCNN_REQUIRE(convs["rpn_heads"].Cout == 6 * na, MRCNN_ERR_IO, "RPN head width %d != 6*anchors_per_location", convs["rpn_heads"].Cout);
 
     // ---- activation plan (pass 0 sizes the arena, pass 1 binds pointers and records the ops) ------
@@ -657,6 +670,7 @@ void Model::build_maskrcnn()
             d.dtype = dt;
             d.in = in.p; d.H = in.H; d.W = in.W; d.Cin = pc->Cin;
             d.in_sW = in.C; d.in_sH = (long)in.W * in.C; d.in_sB = in.sB();
+            d.wdtype = pc->wdtype;
             d.wgt = pc->wgt.p; d.KH = pc->KH; d.KW = pc->KW; d.stride = stride; d.padH = d.padW = pad;
             d.scale = pc->scale.as<float>(); d.shift = pc->shift.as<float>();
             d.OH = out.H; d.OW = out.W; d.Cout = pc->Cout; d.Npad = pc->Npad;
@@ -685,6 +699,7 @@ void Model::build_maskrcnn()
             d.dtype = dt;
             d.in = x0; d.H = Hp; d.W = Wp; d.Cin = 8 * pxc;
             d.in_sW = pxc; d.in_sH = (long)Wp * pxc; d.in_sB = (long)Hp * Wp * pxc;
+            d.wdtype = pc->wdtype;
             d.wgt = pc->wgt.p; d.KH = 7; d.KW = 1; d.stride = 2; d.padH = d.padW = 0;
             d.scale = pc->scale.as<float>(); d.shift = pc->shift.as<float>();
             d.OH = c1.H; d.OW = c1.W; d.Cout = pc->Cout; d.Npad = pc->Npad;
@@ -750,6 +765,7 @@ void Model::build_maskrcnn()
             d.dtype = dt;
             d.in = src.p; d.H = fh[l]; d.W = fw[l]; d.Cin = 256;
             d.in_sW = (long)sub * src.C; d.in_sH = (long)sub * src.W * src.C; d.in_sB = src.sB();
+            d.wdtype = pc->wdtype;
             d.wgt = pc->wgt.p; d.KH = 3; d.KW = 3; d.stride = 1; d.padH = d.padW = 1;
             d.scale = pc->scale.as<float>(); d.shift = pc->shift.as<float>();
             d.OH = fh[l]; d.OW = fw[l]; d.Cout = 512; d.Npad = pc->Npad;
@@ -760,6 +776,7 @@ void Model::build_maskrcnn()
             e.dtype = dt; e.out_f32 = 1;      // the box path consumes fp32 (ProposalLayer.swift:108-109)
             e.in = rpn_feat; e.H = fh[l]; e.W = fw[l]; e.Cin = 512;
             e.in_sW = 512; e.in_sH = (long)fw[l] * 512; e.in_sB = (long)fh[l] * fw[l] * 512;
+            e.wdtype = hc->wdtype;
             e.wgt = hc->wgt.p; e.scale = hc->scale.as<float>(); e.shift = hc->shift.as<float>();
             e.OH = fh[l]; e.OW = fw[l]; e.Cout = hc->Cout; e.Npad = hc->Npad;
             e.out = rpn_logits + lvl_off[l] * 2; e.out_sP = 2 * na; e.out_sB = (long)A * 2;
@@ -881,6 +898,9 @@ void Model::enqueue_pipeline(hipStream_t s, int batch)
     const int HW = 4 * mask_pool * mask_pool;
     mask_valid_rows_forward(s, pooled_mask, (long)max_det * mrow, mrow, mrow, max_det, batch, msel_ws, dtype);
     mask_head.forward_features(s, pooled_mask, batch * max_det);
+    // Rows the reference's mask layer never writes (an invalid row below the kept count,
+    // TimeDistributedMaskLayer.swift:58-89) hold whatever Core ML's buffer held; here they are defined: zero.
+    HIP_CHECK(hipMemsetAsync(mask_out, 0, (size_t)batch * max_det * HW * sizeof(float), s));
     mask_select_forward(s, mask_head.feat, (long)max_det * HW * mask_head.deconv.Cout, HW, mask_head.deconv.Cout,
                         mask_head.final_w.as<float>(), mask_head.final_b.as<float>(), nc, detections, (long)max_det * 6, 6, max_det,
                         batch, msel_ws, mask_out, (long)max_det * HW, HW, dtype);

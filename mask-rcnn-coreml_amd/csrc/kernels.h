@@ -86,6 +86,9 @@ struct ConvDesc {
     // element type of activations / filters / residual: MRCNN_F32 or MRCNN_F16 (fp32 accumulate)
     int dtype = MRCNN_F32;
     int out_f32 = 0;             // with MRCNN_F16: store the output(s) as fp32
+    // element type of the filters; -1 = same as dtype.  (dtype F32, wdtype F16) selects the split mode:
+    // fp32 tensors, each convolution as two fp16 MFMA passes over a hi/lo split of the activations.
+    int wdtype = -1;
     // input NHWC (channel stride 1), arbitrary outer strides in elements
     const void* in = nullptr;
     int B = 0, H = 0, W = 0, Cin = 0;

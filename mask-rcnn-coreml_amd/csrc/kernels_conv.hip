@@ -198,6 +198,25 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
     }
 }
 
+// fp32 → (hi, lo) fp16 pair with hi + lo = a to ~2^-22 relative: hi = a rounded toward zero to fp16,
+// lo = (a - hi) rounded toward zero to fp16 (a - hi is exact in fp32; for |a| below ~1e-2 lo lands in the
+// fp16 subnormals, whose 2^-24 absolute step is far under the fp32 rounding noise of the sums it feeds).
+// fp16 × fp16 products are exact in the MFMA's fp32 accumulate, so hi·w + lo·w reproduces the fp32 product
+// a·w for fp16-exact filters w.  |a| must stay below 65504 (as in any fp16 GPU path of the reference).
+__device__ __forceinline__ void split_hi_lo(const uint4 u0, const uint4 u1, f16x8& hi, f16x8& lo)
+{
+    const float a[8] = {__uint_as_float(u0.x), __uint_as_float(u0.y), __uint_as_float(u0.z), __uint_as_float(u0.w),
+                        __uint_as_float(u1.x), __uint_as_float(u1.y), __uint_as_float(u1.z), __uint_as_float(u1.w)};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const auto h2 = __builtin_amdgcn_cvt_pkrtz(a[2 * p], a[2 * p + 1]);
+        const float r0 = a[2 * p] - (float)h2[0], r1 = a[2 * p + 1] - (float)h2[1];
+        const auto l2 = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+        hi[2 * p] = (_Float16)h2[0]; hi[2 * p + 1] = (_Float16)h2[1];
+        lo[2 * p] = (_Float16)l2[0]; lo[2 * p + 1] = (_Float16)l2[1];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // The implicit-GEMM kernel.  T = float   : v_mfma_f32_32x32x2_f32  (exact fp32, 157.3 TFLOP/s peak), K tile = 32
 //                            T = _Float16: v_mfma_f32_32x32x16_f16 (fp32 accumulate, ~2.5 PFLOP/s peak), K tile = 64
@@ -214,9 +233,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
 //   * two LDS buffers: the DMA of tile k+1 is issued right after the barrier that retired buffer
 //     (k+1)&1 and lands while tile k is being multiplied; one vmcnt(0) + barrier per K step.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BN, int TM, int TN, int WM, int WN, int STAGES>
+template <typename T, typename TW, int BN, int TM, int TN, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs a)
 {
+    // SPLIT: fp32 activations × fp16 filters as two fp16 MFMA passes over a hi/lo split of the activations
+    constexpr bool SPLIT = sizeof(T) == 4 && sizeof(TW) == 2;
+    static_assert(sizeof(T) == sizeof(TW) || SPLIT, "operand types");
     constexpr int BM = WM * TM * 32;
     static_assert(WN * TN * 32 == BN, "tile shape");
     constexpr int EPV = Elem<T>::EPV;
@@ -224,18 +246,20 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
     constexpr int NT = WM * WN * 64;
     constexpr int RPT = NT / 8;
     constexpr int AP = BM / RPT;
-    constexpr int BP = BN / RPT;
+    constexpr int BP = SPLIT ? 1 : BN / RPT;                    // SPLIT: 64-B filter rows, one DMA per thread of the first BN/16 waves
     static_assert(AP >= 1 && BP >= 1 && AP <= 4 && BP <= 4 && RPT % 16 == 0, "staging shape");
+    static_assert(!SPLIT || BN * 4 <= NT, "split mode: the filter tile is staged by one DMA per thread");
     constexpr int ROWB = 128;
-    constexpr int A_STAGE = BM * ROWB, B_STAGE = BN * ROWB;
+    constexpr int BROWB = SPLIT ? 64 : 128;                     // bytes of one filter row per K step
+    constexpr int A_STAGE = BM * ROWB, B_STAGE = BN * BROWB;
     constexpr int C_ROW = BN;                                   // fp32 C tile, unpadded
     static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
-    constexpr int NLOADS = AP + BP;                             // DMA instructions per tile per thread
+    constexpr int NLOADS = SPLIT ? AP : AP + BP;                // DMA instructions per tile per thread (SPLIT: waves past BN/16 issue no filter DMA)
     constexpr int SMEM_OPS = STAGES * (A_STAGE + B_STAGE);      // ring of operand buffers
     constexpr int SMEM = SMEM_OPS > BM * C_ROW * 4 ? SMEM_OPS : BM * C_ROW * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     const T* const in = static_cast<const T*>(a.in);
-    const T* const wgt = static_cast<const T*>(a.wgt);
+    const TW* const wgt = static_cast<const TW*>(a.wgt);
     const T* const zero = static_cast<const T*>(a.zero_page);
 
     const int nblocks = a.tiles_m * a.tiles_n;
@@ -285,11 +309,15 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
     static_assert(AP <= 4 && BP <= 4, "per-row DMA state is spelled out for <= 4 A rows / <= 4 B rows");
     const T *pa0 = zero, *pa1 = zero, *pa2 = zero, *pa3 = zero;
     unsigned sa0 = 0, sa1 = 0, sa2 = 0, sa3 = 0;
-    const unsigned vb0 = (unsigned)(((size_t)r0 * a.Ktot + kq * EPV) * sizeof(T));
+    // SPLIT: thread t stages 16 B (8 fp16 channels) of filter row t>>2; chunk c of row r sits at position c ^ ((r>>2)&3)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool wave_has_b = !SPLIT || wave_u < BN / 16;
+    const unsigned vb0 = SPLIT ? (unsigned)(((size_t)(t >> 2) * a.Ktot + (((t & 3) ^ ((t >> 4) & 3)) << 3)) * sizeof(TW))
+                               : (unsigned)(((size_t)r0 * a.Ktot + kq * EPV) * sizeof(T));
     const unsigned vb1 = (unsigned)(((size_t)(r0 + RPT) * a.Ktot + kq * EPV) * sizeof(T));
     const unsigned vb2 = (unsigned)(((size_t)(r0 + 2 * RPT) * a.Ktot + kq * EPV) * sizeof(T));
     const unsigned vb3 = (unsigned)(((size_t)(r0 + 3 * RPT) * a.Ktot + kq * EPV) * sizeof(T));
-    const T* sb = wgt + (size_t)n0 * a.Ktot;                 // uniform
+    const TW* sb = wgt + (size_t)n0 * a.Ktot;                // uniform
     int kh = 0, kw = 0, ct = 0;
 #define MRCNN_SET_TAP(P)                                                                                       \
     if constexpr (AP > P) {                                                                                    \
@@ -306,9 +334,9 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
 #define MRCNN_DMA_TILE(KT_, BUF_)                                                                              \
     {                                                                                                          \
         const unsigned da = lds0 + (BUF_) * A_STAGE + wrow * ROWB;                                             \
-        const unsigned db = lds0 + STAGES * A_STAGE + (BUF_) * B_STAGE + wrow * ROWB;                          \
+        const unsigned db = lds0 + STAGES * A_STAGE + (BUF_) * B_STAGE + (SPLIT ? wave_u * 1024 : wrow * ROWB); \
         MRCNN_DMA_A(0) MRCNN_DMA_A(1) MRCNN_DMA_A(2) MRCNN_DMA_A(3)                                            \
-        MRCNN_GLDS_S(vb0, sb, db);                                                                             \
+        if (wave_has_b) MRCNN_GLDS_S(vb0, sb, db);                                                             \
         if constexpr (BP > 1) MRCNN_GLDS_S(vb1, sb, db + RPT * ROWB);                                          \
         if constexpr (BP > 2) MRCNN_GLDS_S(vb2, sb, db + 2 * RPT * ROWB);                                      \
         if constexpr (BP > 3) MRCNN_GLDS_S(vb3, sb, db + 3 * RPT * ROWB);                                      \
@@ -326,12 +354,16 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
     const int swz = (l31 >> 1) & 7;
 
     f32x16 acc[TM][TN];
+    f32x16 accl[SPLIT ? TM : 1][SPLIT ? TN : 1];       // SPLIT: the lo-part products
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+            for (int e = 0; e < 16; ++e) {
+                acc[i][j][e] = 0.0f;
+                if constexpr (SPLIT) accl[i][j][e] = 0.0f;
+            }
 
     // Ring of STAGES operand buffers, STAGES-1 tiles in flight: tile k+STAGES-1 is issued at the top of
     // step k, and only tile k+1 has to have landed at the end of it — counted vmcnt lets the
@@ -350,15 +382,26 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
     // STAGES), so every LDS offset folds into an instruction immediate and the four swizzled lane
     // addresses are loop-invariant.
     const unsigned char* const la = smem + (wm * TM * 32 + l31) * ROWB;
-    const unsigned char* const lb = smem + STAGES * A_STAGE + (wn * TN * 32 + l31) * ROWB;
+    const unsigned char* const lb = smem + STAGES * A_STAGE + (wn * TN * 32 + l31) * BROWB;
     const int co0 = ((0 + kk) ^ swz) << 4, co1 = ((2 + kk) ^ swz) << 4, co2 = ((4 + kk) ^ swz) << 4, co3 = ((6 + kk) ^ swz) << 4;
     // Operand fetch for the four 32-B K groups of a step is issued up front, ahead of the first MFMA:
     // LDS returns in order, so the waits count down (lgkmcnt) and the reads of group g+1.. are in
     // flight under the MFMAs of group g — needed when a SIMD holds a single wave (narrow tiles on
     // under-filled grids), free otherwise.
+    // SPLIT: a step is 32 channels = two fp16 MFMA K groups; lane kk of group g owns channels
+    // [8(2g+kk), +8): two fp32 chunks of the activation row, one fp16 chunk of the filter row.
+    const int swzb = (l31 >> 2) & 3;
+    const int cb0 = ((0 + kk) ^ swzb) << 4, cb1 = ((2 + kk) ^ swzb) << 4;
+    const int ca0 = ((0 + 2 * kk) ^ swz) << 4, ca1 = ((1 + 2 * kk) ^ swz) << 4, ca2 = ((4 + 2 * kk) ^ swz) << 4, ca3 = ((5 + 2 * kk) ^ swz) << 4;
 #define MRCNN_KLOAD(G, BUF, CO)                                                                                \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) av[G][i] = *reinterpret_cast<const uint4*>(la + (BUF) * A_STAGE + i * 32 * ROWB + (CO)); \
     _Pragma("unroll") for (int j = 0; j < TN; ++j) bv[G][j] = *reinterpret_cast<const uint4*>(lb + (BUF) * B_STAGE + j * 32 * ROWB + (CO));
+#define MRCNN_KLOAD_SPLIT(G, BUF, CA, CA1, CB)                                                                 \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                           \
+        av[2 * G][i] = *reinterpret_cast<const uint4*>(la + (BUF) * A_STAGE + i * 32 * ROWB + (CA));           \
+        av[2 * G + 1][i] = *reinterpret_cast<const uint4*>(la + (BUF) * A_STAGE + i * 32 * ROWB + (CA1));      \
+    }                                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) bv[G][j] = *reinterpret_cast<const uint4*>(lb + (BUF) * B_STAGE + j * 32 * BROWB + (CB));
 #define MRCNN_KMATH(G)                                                                                         \
     {                                                                                                          \
         if constexpr (sizeof(T) == 4) {                                                                        \
@@ -376,14 +419,30 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
                                                                        __builtin_bit_cast(f16x8, bv[G][j]), acc[i][j], 0, 0, 0); \
         }                                                                                                      \
     }
+#define MRCNN_KMATH_SPLIT(G)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                           \
+        f16x8 hi, lo;                                                                                          \
+        split_hi_lo(av[2 * G][i], av[2 * G + 1][i], hi, lo);                                                   \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                       \
+            const f16x8 bw = __builtin_bit_cast(f16x8, bv[G][j]);                                              \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, bw, acc[i][j], 0, 0, 0);                    \
+            accl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo, bw, accl[i][j], 0, 0, 0);                  \
+        }                                                                                                      \
+    }
 #define MRCNN_STEP(BUF, NBUF, KTV)                                                                             \
     {                                                                                                          \
         const bool more = (KTV) + STAGES - 1 < KT;                                                             \
         if (more) MRCNN_DMA_TILE((KTV) + STAGES - 1, NBUF)                                                     \
         uint4 av[4][TM], bv[4][TN];                                                                            \
-        MRCNN_KLOAD(0, BUF, co0) MRCNN_KLOAD(1, BUF, co1) MRCNN_KLOAD(2, BUF, co2) MRCNN_KLOAD(3, BUF, co3)    \
-        if constexpr (BN < 128) __builtin_amdgcn_sched_barrier(0); /* keep the reads ahead of the MFMAs */     \
-        MRCNN_KMATH(0) MRCNN_KMATH(1) MRCNN_KMATH(2) MRCNN_KMATH(3)                                            \
+        if constexpr (SPLIT) {                                                                                 \
+            MRCNN_KLOAD_SPLIT(0, BUF, ca0, ca1, cb0) MRCNN_KLOAD_SPLIT(1, BUF, ca2, ca3, cb1)                  \
+            if constexpr (BN < 128) __builtin_amdgcn_sched_barrier(0);                                         \
+            MRCNN_KMATH_SPLIT(0) MRCNN_KMATH_SPLIT(1)                                                          \
+        } else {                                                                                               \
+            MRCNN_KLOAD(0, BUF, co0) MRCNN_KLOAD(1, BUF, co1) MRCNN_KLOAD(2, BUF, co2) MRCNN_KLOAD(3, BUF, co3) \
+            if constexpr (BN < 128) __builtin_amdgcn_sched_barrier(0); /* keep the reads ahead of the MFMAs */ \
+            MRCNN_KMATH(0) MRCNN_KMATH(1) MRCNN_KMATH(2) MRCNN_KMATH(3)                                        \
+        }                                                                                                      \
         /* tile KTV+1 must have landed before the barrier hands its buffer over */                             \
         if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS * (STAGES - 2)) : "memory");                 \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
@@ -396,13 +455,21 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
         if constexpr (STAGES > 3) { if (kt + 3 < KT) MRCNN_STEP(3, 2, kt + 3) }
     }
 #undef MRCNN_STEP
+#undef MRCNN_KMATH_SPLIT
 #undef MRCNN_KMATH
+#undef MRCNN_KLOAD_SPLIT
 #undef MRCNN_KLOAD
 #undef MRCNN_DMA_TILE
 #undef MRCNN_DMA_A
 #undef MRCNN_GLDS_V
 #undef MRCNN_GLDS_S
 #undef MRCNN_SET_TAP
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] += accl[i][j];
+    }
     conv_epilogue<T, BN, TM, TN, WM, WN, C_ROW>(a, acc, smem, m0, n0);
 }
 
@@ -451,7 +518,7 @@ int conv_n_tile(int Cout)
     return 32;
 }
 
-template <typename T>
+template <typename T, typename TW>
 static void conv_launch(hipStream_t s, const ConvArgs& a, int bn)
 {
     // 8 waves as 4 (M) × 2 (N): 128×128 block tile, 32×64 per wave; narrower N tiles keep 128 rows.
@@ -462,15 +529,18 @@ static void conv_launch(hipStream_t s, const ConvArgs& a, int bn)
 #ifndef MRCNN_RING32
 #define MRCNN_RING32 4
 #endif
-    if (bn == 128) hipLaunchKernelGGL((k_conv_mfma_glds<T, 128, 1, 2, 4, 2, 2>), grid, dim3(512), 0, s, a);
-    else if (bn == 64) hipLaunchKernelGGL((k_conv_mfma_glds<T, 64, 1, 1, 4, 2, MRCNN_RING64>), grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((k_conv_mfma_glds<T, 32, 1, 1, 4, 1, MRCNN_RING32>), grid, dim3(256), 0, s, a);
+    if (bn == 128) hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 128, 1, 2, 4, 2, 2>), grid, dim3(512), 0, s, a);
+    else if (bn == 64) hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 64, 1, 1, 4, 2, MRCNN_RING64>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 32, 1, 1, 4, 1, MRCNN_RING32>), grid, dim3(256), 0, s, a);
 }
 
 void conv_forward(hipStream_t s, const ConvDesc& d)
 {
     const bool half = d.dtype == MRCNN_F16;
+    const int wdtype = d.wdtype < 0 ? d.dtype : d.wdtype;
+    const bool split = d.dtype == MRCNN_F32 && wdtype == MRCNN_F16;       // fp32 activations, fp16 filters: two-pass fp16 MFMA
     MRCNN_REQUIRE(d.dtype == MRCNN_F32 || half, MRCNN_ERR_UNSUPPORTED, "conv: dtype %d", d.dtype);
+    MRCNN_REQUIRE(wdtype == d.dtype || split, MRCNN_ERR_UNSUPPORTED, "conv: activation dtype %d with filter dtype %d", d.dtype, wdtype);
     const int bk = half ? 64 : 32, es = half ? 2 : 4;
     MRCNN_REQUIRE(d.Cin % bk == 0, MRCNN_ERR_SHAPE, "conv: Cin %d not a multiple of %d", d.Cin, bk);
     ConvArgs a;
@@ -510,8 +580,9 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     a.tiles_n = d.Npad / bn;
     ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
     const int e0 = prof ? prof_event(prof, s) : 0;
-    if (half) conv_launch<_Float16>(s, a, bn);
-    else conv_launch<float>(s, a, bn);
+    if (half) conv_launch<_Float16, _Float16>(s, a, bn);
+    else if (split) conv_launch<float, _Float16>(s, a, bn);
+    else conv_launch<float, float>(s, a, bn);
     if (prof) {
         const int e1 = prof_event(prof, s);
         const double k = d.algo_k > 0 ? d.algo_k : a.Ktot;

@@ -19,7 +19,7 @@ import numpy as np
 from . import _lib
 from .config import MaskRCNNConfig
 
-DTYPES = {"f32": _lib.F32, "f16": _lib.F16}
+DTYPES = {"f32": _lib.F32, "f16": _lib.F16, "f32s": _lib.F32S}   # f32s: fp32 tensors, split-fp16 MFMA convolutions
 STAGES = ["Trunk", "Proposal-Eval", "PyramidROIAlign-Eval", "TimeDistributedClassifierLayer-Eval", "Detection-Eval",
           "PyramidROIAlign-Eval-Mask", "TimeDistributedMask-Eval"]
 

@@ -289,6 +289,71 @@ def test_engine_full_size_one_image(pkg, orc, tmp_path_factory, weights_mod):
     assert int((d0[:, 5] > 0).sum()) == cfg.max_detections
 
 
+def test_engine_f32s_split_mode(pkg, orc, small_model, weights_mod, tmp_path):
+    """MRCNN_F32S: fp32 tensors, convolutions as two fp16 MFMA passes over a hi/lo split of the activations.
+    Same staged parity as the fp32 engine AT THE SAME fp32 TOLERANCES, per-image batch independence, agreement
+    with the exact-fp32 engine to a few 1e-6, and refusal of artefacts whose filters are not fp16-representable."""
+    from oracle.network import load_oracle_model
+    models = __import__("importlib").import_module("mask-rcnn-coreml_amd.models")
+    d, cfg = small_model
+    om = load_oracle_model(d)
+    B = 3
+    images = rand_images(B, cfg.image_height, cfg.image_width, seed=1)
+    m = models.load_maskrcnn(d, max_batch=B, compute_dtype="f32s")
+    assert m.get_int("compute_dtype") == 5
+    det, mask = m.predict(images)
+    trunk = om.trunk(images)
+    for b in range(B):
+        d_b, m_b = _check_stages(pkg, orc, om, m, cfg, images, b, True, trunk)          # fp32 tolerances
+        np.testing.assert_array_equal(det[b], d_b)
+        np.testing.assert_array_equal(mask[b].reshape(cfg.max_detections, -1), m_b)
+    d1, m1 = m.predict(images[2:3])
+    np.testing.assert_array_equal(d1[0], det[2])
+    np.testing.assert_array_equal(m1[0], mask[2])
+    # against the exact-fp32 engine: the pyramid after ~50 convolutions agrees to ~3e-6 of its range
+    m32 = models.load_maskrcnn(d, max_batch=B)
+    m32.predict(images)
+    for name in ("P2", "P3", "P4", "P5", "rpn_deltas"):
+        x, y = m32.read_tensor(name, 1), m.read_tensor(name, 1)
+        assert _rel(y, x) < 2e-5, name
+    # and to the oracle it is as close as the fp32 engine is (both sit at summation-order noise)
+    pyr = trunk[0]
+    h, w = cfg.feature_shapes()[0]
+    e32 = _rel(_nhwc_to_chw(m32.read_tensor("P2", 1), h, w, 256), pyr[0][1])
+    e32s = _rel(_nhwc_to_chw(m.read_tensor("P2", 1), h, w, 256), pyr[0][1])
+    assert e32s < max(4 * e32, 2e-5), (e32, e32s)
+    # genuine fp32 filters cannot be split exactly: refused with a message, never silently rounded
+    bad = tmp_path / "fp32w"
+    bad.mkdir()
+    for kind in ("MaskRCNN", "Classifier", "Mask"):
+        meta, tensors = weights_mod.read_mrcw(os.path.join(d, f"{kind}.mrcw"))
+        t32 = {k: v.astype(np.float32) for k, v in tensors.items()}
+        if kind == "MaskRCNN":
+            t32["res2a_branch2a/kernel"] = t32["res2a_branch2a/kernel"] * np.float32(1.0001)
+        weights_mod.write_mrcw(str(bad / f"{kind}.mrcw"), meta, t32)
+    __import__("importlib").import_module("mask-rcnn-coreml_amd.anchors").write_anchors_bin(str(bad / "anchors.bin"), cfg)
+    models.load_maskrcnn(str(bad), max_batch=1)                                           # fine in fp32
+    with pytest.raises(Exception, match="not fp16-representable"):
+        models.load_maskrcnn(str(bad), max_batch=1, compute_dtype="f32s")
+    pkg.MaskRCNNConfig.defaultConfig().anchorsURL = os.path.join(d, "anchors.bin")
+
+
+def test_engine_f32s_full_size(pkg, orc, tmp_path_factory, weights_mod):
+    """BASELINE configs[1] shapes (R101, 1024², 81 classes) in split mode, batch 2: staged parity at fp32 tolerances."""
+    from oracle.network import load_oracle_model
+    models = __import__("importlib").import_module("mask-rcnn-coreml_amd.models")
+    d, cfg = make_model_dir(tmp_path_factory, pkg, weights_mod, "full32s", architecture="resnet101")
+    om = load_oracle_model(d)
+    m = models.load_maskrcnn(d, max_batch=2, compute_dtype="f32s")
+    images = rand_images(2, 1024, 1024, seed=1)
+    m.predict(images)
+    trunk = om.trunk(images[:1])
+    d0, _ = _check_stages(pkg, orc, om, m, cfg, images, 0, True, trunk)
+    _check_stages(pkg, orc, om, m, cfg, images, 1, False)
+    assert int(m.read_tensor("keep_count", 0)[0]) == cfg.max_proposals
+    assert int((d0[:, 5] > 0).sum()) == cfg.max_detections
+
+
 def test_engine_lifecycle_streams_and_handles(pkg, small_model):
     """Handles are independent and leak-free: load/destroy cycles give the HBM back, two live handles do not
     disturb each other, and a handle moved onto the caller's stream (mrcnn_model_set_stream + predict_async,

@@ -1,0 +1,22 @@
+import importlib, os, sys, numpy as np, tempfile
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("mask-rcnn-coreml_amd")
+models = importlib.import_module("mask-rcnn-coreml_amd.models")
+weights = importlib.import_module("mask-rcnn-coreml_amd.weights")
+cfg = pkg.ModelConfig(architecture="resnet50", input_image_shape=(128, 128, 3), num_classes=21, pre_nms_max_proposals=300, max_proposals=64, max_detections=16)
+d = tempfile.mkdtemp()
+weights.save_synthetic_models(d, cfg, seed=0)
+img = np.random.default_rng(1).integers(0, 256, (3, 128, 128, 3), dtype=np.uint8)
+names = ("P2", "P3", "P4", "P5", "rpn_probs", "rpn_deltas", "rois", "pooled", "cls_probs", "cls_bbox", "cls6", "detections", "pooled_mask", "mask")
+for dt in ("f32", "f32s"):
+    m3 = models.load_maskrcnn(d, max_batch=3, compute_dtype=dt)
+    m1 = models.load_maskrcnn(d, max_batch=1, compute_dtype=dt)
+    m3.predict(img)
+    for b in range(3):
+        m1.predict(img[b:b + 1])
+        diffs = []
+        for n in names:
+            x, y = m3.read_tensor(n, b), m1.read_tensor(n, 0)
+            if not np.array_equal(x, y):
+                diffs.append((n, int((x != y).sum()), float(np.abs(x - y).max())))
+        print(dt, "image", b, "differing taps:", diffs)
