@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=3)
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
+    ap.add_argument("--no-other-modes", action="store_true",
+                    help="skip the short extra timed loops of the other compute modes (reported under other_modes, N = 1 only)")
     ap.add_argument("--event-steps", type=int, default=3,
                     help="conv launches are bracketed by HIP events during the first N steps of the timed region "
                          "(the events cost ~2 %% of an fp32 step, ~13 %% of an fp16 one); 0 = all steps")
@@ -168,6 +170,26 @@ def main():
                                          "survey_gflop_per_image": GFLOP_PER_IMAGE_SURVEY,
                                          "share_of_step_time": round(all_ms / (1e3 * elapsed * ev_steps / args.steps), 4)},
                 }
+        if n_gpus == 1 and not args.no_other_modes:
+            # the same workload in the engine's other compute modes (same images, same weights): not the headline value
+            out["other_modes"] = {}
+            for mode in ("f32", "f32s", "f16"):
+                if mode == args.dtype:
+                    continue
+                mm = models.load_maskrcnn(model_dir, max_batch=B, compute_dtype=mode)
+                for _ in range(2):
+                    mm.predict_into(images, det, mask, sync=True)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    mm.predict_into(images, det, mask, sync=True)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / 5
+                out["other_modes"][mode] = {"value": round(B / dt, 1), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3), "steps": 5,
+                                            "note": {"f32": "exact-fp32 MFMA", "f16": "fp16 tensors + fp16 MFMA (BASELINE configs[3])",
+                                                     "f32s": "fp32 tensors, two fp16 MFMA passes over a hi/lo split of the activations "
+                                                             "(fp32-grade: parity-tested at the fp32 tolerances)"}[mode]}
+                del mm
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model_dir, cfg, args)
         print(json.dumps(out), flush=True)

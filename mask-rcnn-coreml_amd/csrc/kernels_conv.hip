@@ -207,14 +207,19 @@ __device__ __forceinline__ void split_hi_lo(const uint4 u0, const uint4 u1, f16x
 {
     const float a[8] = {__uint_as_float(u0.x), __uint_as_float(u0.y), __uint_as_float(u0.z), __uint_as_float(u0.w),
                         __uint_as_float(u1.x), __uint_as_float(u1.y), __uint_as_float(u1.z), __uint_as_float(u1.w)};
+    uint32_t hw[4], lw[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const auto h2 = __builtin_amdgcn_cvt_pkrtz(a[2 * p], a[2 * p + 1]);
-        const float r0 = a[2 * p] - (float)h2[0], r1 = a[2 * p + 1] - (float)h2[1];
-        const auto l2 = __builtin_amdgcn_cvt_pkrtz(r0, r1);
-        hi[2 * p] = (_Float16)h2[0]; hi[2 * p + 1] = (_Float16)h2[1];
-        lo[2 * p] = (_Float16)l2[0]; lo[2 * p + 1] = (_Float16)l2[1];
+        const uint32_t h2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a[2 * p], a[2 * p + 1]));
+        // r = a - hi in ONE mixed-precision FMA (fp16 half of h2 × -1.0 + a): saves the widening conversion
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h2), "v"(a[2 * p]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h2), "v"(a[2 * p + 1]));
+        hw[p] = h2;
+        lw[p] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r0, r1));
     }
+    hi = __builtin_bit_cast(f16x8, uint4{hw[0], hw[1], hw[2], hw[3]});
+    lo = __builtin_bit_cast(f16x8, uint4{lw[0], lw[1], lw[2], lw[3]});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -529,7 +534,11 @@ static void conv_launch(hipStream_t s, const ConvArgs& a, int bn)
 #ifndef MRCNN_RING32
 #define MRCNN_RING32 4
 #endif
-    if (bn == 128) hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 128, 1, 2, 4, 2, 2>), grid, dim3(512), 0, s, a);
+#ifndef MRCNN_RING128S
+#define MRCNN_RING128S 3    /* split mode: a step is 8 MFMAs per wave, two tiles in flight (+2 %) */
+#endif
+    constexpr int R128 = (sizeof(T) == 4 && sizeof(TW) == 2) ? MRCNN_RING128S : 2;
+    if (bn == 128) hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 128, 1, 2, 4, 2, R128>), grid, dim3(512), 0, s, a);
     else if (bn == 64) hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 64, 1, 1, 4, 2, MRCNN_RING64>), grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 32, 1, 1, 4, 1, MRCNN_RING32>), grid, dim3(256), 0, s, a);
 }

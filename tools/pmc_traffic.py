@@ -36,7 +36,7 @@ def per_kernel(d, counter, match):
 
 def main():
     fd, wd, out = sys.argv[1:4]
-    match = sys.argv[4] if len(sys.argv) > 4 else "k_conv_mfma_glds<float, 128"
+    match = sys.argv[4] if len(sys.argv) > 4 else "k_conv_mfma_glds<float, float, 128"
     f_avg, n, name, f_whole = per_kernel(fd, "FETCH_SIZE", match)
     w_avg, n2, _, w_whole = per_kernel(wd, "WRITE_SIZE", match)
     json.dump({"kernel": name, "launches_sampled": n,
