@@ -278,10 +278,9 @@ static PackedConv pack_conv1(const MrcwFile& f, int dtype)
     MRCNN_REQUIRE(t.dims.size() == 4 && t.dims[1] == 3 && t.dims[2] == 7 && t.dims[3] == 7, MRCNN_ERR_IO, "conv1/kernel must be [O,3,7,7]");
     const int O = t.dims[0];
     const std::vector<float> k = f.floats("conv1/kernel");
-    if (dtype == MRCNN_F32S) dtype = MRCNN_F32;     // the stem (1 % of the work, K = 147) stays on the fp32 MFMA
     PackedConv pc;
-    pc.dtype = dtype; pc.wdtype = dtype;
-    const int px = dtype == MRCNN_F16 ? 8 : 4;      // channels per staged pixel (NHWC8 / NHWC4): 16 B either way
+    pc.dtype = mode_act(dtype); pc.wdtype = mode_wgt(dtype);
+    const int px = pc.dtype == MRCNN_F16 ? 8 : 4;   // channels per staged pixel (NHWC8 / NHWC4): 16 B either way
     const int row = 8 * px;                         // one kernel row = 7 taps padded to 8 pixels = 128 B
     pc.Cin = row; pc.Cout = O; pc.KH = 7; pc.KW = 1;
     const int bn_tile = conv_n_tile(O);
