@@ -359,16 +359,12 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
     const int swz = (l31 >> 1) & 7;
 
     f32x16 acc[TM][TN];
-    f32x16 accl[SPLIT ? TM : 1][SPLIT ? TN : 1];       // SPLIT: the lo-part products
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                acc[i][j][e] = 0.0f;
-                if constexpr (SPLIT) accl[i][j][e] = 0.0f;
-            }
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     // Ring of STAGES operand buffers, STAGES-1 tiles in flight: tile k+STAGES-1 is issued at the top of
     // step k, and only tile k+1 has to have landed at the end of it — counted vmcnt lets the
@@ -428,11 +424,10 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
     _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                           \
         f16x8 hi, lo;                                                                                          \
         split_hi_lo(av[2 * G][i], av[2 * G + 1][i], hi, lo);                                                   \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                       \
-            const f16x8 bw = __builtin_bit_cast(f16x8, bv[G][j]);                                              \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, bw, acc[i][j], 0, 0, 0);                    \
-            accl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo, bw, accl[i][j], 0, 0, 0);                  \
-        }                                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                         \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, __builtin_bit_cast(f16x8, bv[G][j]), acc[i][j], 0, 0, 0); \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                         \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo, __builtin_bit_cast(f16x8, bv[G][j]), acc[i][j], 0, 0, 0); \
     }
 #define MRCNN_STEP(BUF, NBUF, KTV)                                                                             \
     {                                                                                                          \
@@ -469,12 +464,6 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
 #undef MRCNN_GLDS_V
 #undef MRCNN_GLDS_S
 #undef MRCNN_SET_TAP
-    if constexpr (SPLIT) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] += accl[i][j];
-    }
     conv_epilogue<T, BN, TM, TN, WM, WN, C_ROW>(a, acc, smem, m0, n0);
 }
 
