@@ -69,130 +69,140 @@ template <> __device__ __forceinline__ void store4<_Float16>(_Float16* p, float4
 
 // Epilogue shared by the conv kernels: accumulators → LDS (fp32 C tile) → full-row vector stores with
 // fused scale/shift (BN + bias), residual, activation, column split / 2×2 scatter.
-template <typename T, int BN, int TM, int TN, int WM, int WN, int C_ROW>
+// CPASS = 1: the whole BM×BN tile is staged at once; CPASS = WN (tiles whose fp32 C tile would not fit
+// beside a second block: 128×256): one pass per wave column, BM × TN·32 columns each.
+template <typename T, int BN, int TM, int TN, int WM, int WN, int CPASS>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned char* smem, int m0, int n0)
 {
+    static_assert(CPASS == 1 || CPASS == WN, "column passes");
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32;
+    constexpr int CW = BN / CPASS;     // columns staged per pass = row length of the LDS C tile
     const int t = threadIdx.x;
     const int wave = t >> 6, lane = t & 63;
     const int wm = wave / WN, wn = wave - wm * WN;
     const int l31 = lane & 31, kk = lane >> 5;
     const int ohw = a.OH * a.OW;
-    // ---- epilogue: accumulators → LDS → full-row vector stores ----------------------------------
+    // ---- accumulators → LDS → full-row vector stores ---------------------------------------------
     // (the loop's final barrier guarantees nobody still reads the operand buffers)
-    constexpr int TPR = BN / 4;       // threads per output row (4 columns each)
+    constexpr int TPR = CW / 4;       // threads per output row (4 columns each)
     constexpr int RPP = NT / TPR;     // rows per pass
     constexpr int NPASS = BM / RPP;
     const int c4 = t % TPR, rr = t / TPR;
-    const int n = n0 + c4 * 4;
-    const bool col_ok = n < a.ncols;
     const bool dense_out = a.out_sB == (long)ohw * a.out_sP;
     const bool dense_res = a.res_sB == (long)ohw * a.res_sW && a.res_shift == 0;
     const bool need_bp = !dense_out || a.out2 != nullptr || a.deconv2 || (a.res && !dense_res);
     const bool need_yx = a.deconv2 || (a.res && a.res_shift);
     const T* const res = static_cast<const T*>(a.res);
+    float* const Cs = reinterpret_cast<float*>(smem);
 
-    // Residual / scale / shift are fetched BEFORE the accumulators are staged through LDS: `res` and
-    // `out` may alias as far as the compiler knows, so inside the store loop every residual load would
-    // wait behind the previous store (16 serialized HBM round trips per thread on the branch2c layers).
-    float4 rv[NPASS];
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.vec_ok && col_ok) {
-        if (a.scale) sc = *reinterpret_cast<const float4*>(a.scale + n);
-        if (a.shift) sh = *reinterpret_cast<const float4*>(a.shift + n);
-        if (res) {
+#pragma unroll
+    for (int h = 0; h < CPASS; ++h) {
+        const int n = n0 + h * CW + c4 * 4;
+        const bool col_ok = n < a.ncols;
+        // Residual / scale / shift are fetched BEFORE the accumulators are staged through LDS: `res` and
+        // `out` may alias as far as the compiler knows, so inside the store loop every residual load would
+        // wait behind the previous store (16 serialized HBM round trips per thread on the branch2c layers).
+        float4 rv[NPASS];
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.vec_ok && col_ok) {
+            if (a.scale) sc = *reinterpret_cast<const float4*>(a.scale + n);
+            if (a.shift) sh = *reinterpret_cast<const float4*>(a.shift + n);
+            if (res) {
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const int m = m0 + rr + ps * RPP;
+                    rv[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (m < a.M) {
+                        long ro;
+                        if (dense_res) ro = (long)m * a.res_sW;
+                        else {
+                            const int b = m / ohw, pix = m - b * ohw;
+                            if (a.res_shift) {
+                                const int oh = pix / a.OW, ow = pix - oh * a.OW;
+                                ro = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
+                            } else ro = (long)b * a.res_sB + (long)pix * a.res_sW;
+                        }
+                        rv[ps] = load4<T>(res + ro + n);
+                    }
+                }
+            }
+        }
+
+        if (h > 0) __syncthreads();            // the previous pass has been read out of the C tile
+        if (CPASS == 1 || wn == h) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+                        Cs[row * CW + (CPASS == 1 ? wn * TN * 32 : 0) + j * 32 + l31] = acc[i][j][e];
+                    }
+        }
+        __syncthreads();
+
+        if (!col_ok) continue;
+        if (a.vec_ok) {
+            const int qd = a.deconv2 ? n / a.Cout : 0;
+            const int co = a.deconv2 ? n - qd * a.Cout : n;
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
-                const int m = m0 + rr + ps * RPP;
-                rv[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m < a.M) {
-                    long ro;
-                    if (dense_res) ro = (long)m * a.res_sW;
-                    else {
-                        const int b = m / ohw, pix = m - b * ohw;
-                        if (a.res_shift) {
-                            const int oh = pix / a.OW, ow = pix - oh * a.OW;
-                            ro = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
-                        } else ro = (long)b * a.res_sB + (long)pix * a.res_sW;
-                    }
-                    rv[ps] = load4<T>(res + ro + n);
+                const int r = rr + ps * RPP;
+                const int m = m0 + r;
+                if (m >= a.M) break;
+                int b = 0, pix = m, oh = 0, ow = 0;
+                if (need_bp) { b = m / ohw; pix = m - b * ohw; }
+                if (need_yx) { oh = pix / a.OW; ow = pix - oh * a.OW; }
+                float4 v = *reinterpret_cast<const float4*>(&Cs[r * CW + c4 * 4]);
+                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                if (res) { v.x += rv[ps].x; v.y += rv[ps].y; v.z += rv[ps].z; v.w += rv[ps].w; }
+                if (a.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                else if (a.act == ACT_SIGMOID) {
+                    v.x = 1.0f / (1.0f + expf(-v.x)); v.y = 1.0f / (1.0f + expf(-v.y));
+                    v.z = 1.0f / (1.0f + expf(-v.z)); v.w = 1.0f / (1.0f + expf(-v.w));
                 }
-            }
-        }
-    }
-
-    float* const Cs = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
-                Cs[row * C_ROW + wn * TN * 32 + j * 32 + l31] = acc[i][j][e];
-            }
-    __syncthreads();
-
-    if (!col_ok) return;
-    if (a.vec_ok) {
-        const int qd = a.deconv2 ? n / a.Cout : 0;
-        const int co = a.deconv2 ? n - qd * a.Cout : n;
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            const int r = rr + ps * RPP;
-            const int m = m0 + r;
-            if (m >= a.M) break;
-            int b = 0, pix = m, oh = 0, ow = 0;
-            if (need_bp) { b = m / ohw; pix = m - b * ohw; }
-            if (need_yx) { oh = pix / a.OW; ow = pix - oh * a.OW; }
-            float4 v = *reinterpret_cast<const float4*>(&Cs[r * C_ROW + c4 * 4]);
-            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-            if (res) { v.x += rv[ps].x; v.y += rv[ps].y; v.z += rv[ps].z; v.w += rv[ps].w; }
-            if (a.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            else if (a.act == ACT_SIGMOID) {
-                v.x = 1.0f / (1.0f + expf(-v.x)); v.y = 1.0f / (1.0f + expf(-v.y));
-                v.z = 1.0f / (1.0f + expf(-v.z)); v.w = 1.0f / (1.0f + expf(-v.w));
-            }
-            long o;
-            if (a.deconv2) o = (long)b * a.out_sB + (long)(2 * oh + (qd >> 1)) * a.out_sH + (long)(2 * ow + (qd & 1)) * a.out_sW + co;
-            else o = (dense_out ? (long)m * a.out_sP : (long)b * a.out_sB + (long)pix * a.out_sP) + n;
-            if (a.out_f32) store4<float>(static_cast<float*>(a.out) + o, v);
-            else store4<T>(static_cast<T*>(a.out) + o, v);
-        }
-    } else {
-        for (int r = rr; r < BM; r += RPP) {
-            const int m = m0 + r;
-            if (m >= a.M) break;
-            const int b = m / ohw, pix = m - b * ohw;
-            const int oh = pix / a.OW, ow = pix - oh * a.OW;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int nn = n + c;
-                if (nn >= a.ncols) break;
-                float v = Cs[r * C_ROW + c4 * 4 + c];
-                v = v * (a.scale ? a.scale[nn] : 1.0f) + (a.shift ? a.shift[nn] : 0.0f);
-                if (res) {
-                    long ro;
-                    if (a.res_shift) ro = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
-                    else ro = (long)b * a.res_sB + (long)pix * a.res_sW;
-                    v += (float)res[ro + nn];
-                }
-                if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
-                else if (a.act == ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
                 long o;
-                void* dst = a.out;
-                if (a.deconv2) {
-                    const int qd = nn / a.Cout, co = nn - qd * a.Cout;
-                    o = (long)b * a.out_sB + (long)(2 * oh + (qd >> 1)) * a.out_sH + (long)(2 * ow + (qd & 1)) * a.out_sW + co;
-                } else if (a.out2 && nn >= a.n_split) {
-                    dst = a.out2;
-                    o = (long)b * a.out2_sB + (long)pix * a.out2_sP + (nn - a.n_split);
-                } else {
-                    o = (long)b * a.out_sB + (long)pix * a.out_sP + nn;
+                if (a.deconv2) o = (long)b * a.out_sB + (long)(2 * oh + (qd >> 1)) * a.out_sH + (long)(2 * ow + (qd & 1)) * a.out_sW + co;
+                else o = (dense_out ? (long)m * a.out_sP : (long)b * a.out_sB + (long)pix * a.out_sP) + n;
+                if (a.out_f32) store4<float>(static_cast<float*>(a.out) + o, v);
+                else store4<T>(static_cast<T*>(a.out) + o, v);
+            }
+        } else {
+            for (int r = rr; r < BM; r += RPP) {
+                const int m = m0 + r;
+                if (m >= a.M) break;
+                const int b = m / ohw, pix = m - b * ohw;
+                const int oh = pix / a.OW, ow = pix - oh * a.OW;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int nn = n + c;
+                    if (nn >= a.ncols) break;
+                    float v = Cs[r * CW + c4 * 4 + c];
+                    v = v * (a.scale ? a.scale[nn] : 1.0f) + (a.shift ? a.shift[nn] : 0.0f);
+                    if (res) {
+                        long ro;
+                        if (a.res_shift) ro = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
+                        else ro = (long)b * a.res_sB + (long)pix * a.res_sW;
+                        v += (float)res[ro + nn];
+                    }
+                    if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
+                    else if (a.act == ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                    long o;
+                    void* dst = a.out;
+                    if (a.deconv2) {
+                        const int qd = nn / a.Cout, co = nn - qd * a.Cout;
+                        o = (long)b * a.out_sB + (long)(2 * oh + (qd >> 1)) * a.out_sH + (long)(2 * ow + (qd & 1)) * a.out_sW + co;
+                    } else if (a.out2 && nn >= a.n_split) {
+                        dst = a.out2;
+                        o = (long)b * a.out2_sB + (long)pix * a.out2_sP + (nn - a.n_split);
+                    } else {
+                        o = (long)b * a.out_sB + (long)pix * a.out_sP + nn;
+                    }
+                    if (a.out_f32) static_cast<float*>(dst)[o] = v;
+                    else static_cast<T*>(dst)[o] = (T)v;
                 }
-                if (a.out_f32) static_cast<float*>(dst)[o] = v;
-                else static_cast<T*>(dst)[o] = (T)v;
             }
         }
     }
@@ -251,17 +261,18 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
     constexpr int NT = WM * WN * 64;
     constexpr int RPT = NT / 8;
     constexpr int AP = BM / RPT;
-    constexpr int BP = SPLIT ? 1 : BN / RPT;                    // SPLIT: 64-B filter rows, one DMA per thread of the first BN/16 waves
+    constexpr int BP = SPLIT ? (BN * 4 > NT ? BN * 4 / NT : 1) : BN / RPT;   // SPLIT: 64-B filter rows, 16 B per thread and DMA
     static_assert(AP >= 1 && BP >= 1 && AP <= 4 && BP <= 4 && RPT % 16 == 0, "staging shape");
-    static_assert(!SPLIT || BN * 4 <= NT, "split mode: the filter tile is staged by one DMA per thread");
+    static_assert(!SPLIT || BP <= 2, "split mode: the filter tile is staged by at most two DMAs per thread");
     constexpr int ROWB = 128;
     constexpr int BROWB = SPLIT ? 64 : 128;                     // bytes of one filter row per K step
     constexpr int A_STAGE = BM * ROWB, B_STAGE = BN * BROWB;
-    constexpr int C_ROW = BN;                                   // fp32 C tile, unpadded
+    constexpr int CPASS = BM * BN * 4 > 64 * 1024 ? WN : 1;    // column passes of the epilogue (fp32 C tile of at most 64 KB)
+    constexpr int C_BYTES = BM * (BN / CPASS) * 4;
     static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
     constexpr int NLOADS = SPLIT ? AP : AP + BP;                // DMA instructions per tile per thread (SPLIT: waves past BN/16 issue no filter DMA)
     constexpr int SMEM_OPS = STAGES * (A_STAGE + B_STAGE);      // ring of operand buffers
-    constexpr int SMEM = SMEM_OPS > BM * C_ROW * 4 ? SMEM_OPS : BM * C_ROW * 4;
+    constexpr int SMEM = SMEM_OPS > C_BYTES ? SMEM_OPS : C_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     const T* const in = static_cast<const T*>(a.in);
     const TW* const wgt = static_cast<const TW*>(a.wgt);
@@ -316,10 +327,11 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
     unsigned sa0 = 0, sa1 = 0, sa2 = 0, sa3 = 0;
     // SPLIT: thread t stages 16 B (8 fp16 channels) of filter row t>>2; chunk c of row r sits at position c ^ ((r>>2)&3)
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const bool wave_has_b = !SPLIT || wave_u < BN / 16;
+    const bool wave_has_b = !SPLIT || BN * 4 >= NT || wave_u < BN / 16;
     const unsigned vb0 = SPLIT ? (unsigned)(((size_t)(t >> 2) * a.Ktot + (((t & 3) ^ ((t >> 4) & 3)) << 3)) * sizeof(TW))
                                : (unsigned)(((size_t)r0 * a.Ktot + kq * EPV) * sizeof(T));
-    const unsigned vb1 = (unsigned)(((size_t)(r0 + RPT) * a.Ktot + kq * EPV) * sizeof(T));
+    const unsigned vb1 = SPLIT ? vb0 + (unsigned)((size_t)(NT / 4) * a.Ktot * sizeof(TW))
+                               : (unsigned)(((size_t)(r0 + RPT) * a.Ktot + kq * EPV) * sizeof(T));
     const unsigned vb2 = (unsigned)(((size_t)(r0 + 2 * RPT) * a.Ktot + kq * EPV) * sizeof(T));
     const unsigned vb3 = (unsigned)(((size_t)(r0 + 3 * RPT) * a.Ktot + kq * EPV) * sizeof(T));
     const TW* sb = wgt + (size_t)n0 * a.Ktot;                // uniform
@@ -342,7 +354,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
         const unsigned db = lds0 + STAGES * A_STAGE + (BUF_) * B_STAGE + (SPLIT ? wave_u * 1024 : wrow * ROWB); \
         MRCNN_DMA_A(0) MRCNN_DMA_A(1) MRCNN_DMA_A(2) MRCNN_DMA_A(3)                                            \
         if (wave_has_b) MRCNN_GLDS_S(vb0, sb, db);                                                             \
-        if constexpr (BP > 1) MRCNN_GLDS_S(vb1, sb, db + RPT * ROWB);                                          \
+        if constexpr (BP > 1) MRCNN_GLDS_S(vb1, sb, db + (SPLIT ? NT * 16 : RPT * ROWB));                      \
         if constexpr (BP > 2) MRCNN_GLDS_S(vb2, sb, db + 2 * RPT * ROWB);                                      \
         if constexpr (BP > 3) MRCNN_GLDS_S(vb3, sb, db + 3 * RPT * ROWB);                                      \
         sb += BK;                                                                                              \
@@ -464,7 +476,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
 #undef MRCNN_GLDS_V
 #undef MRCNN_GLDS_S
 #undef MRCNN_SET_TAP
-    conv_epilogue<T, BN, TM, TN, WM, WN, C_ROW>(a, acc, smem, m0, n0);
+    conv_epilogue<T, BN, TM, TN, WM, WN, CPASS>(a, acc, smem, m0, n0);
 }
 
 static thread_local ConvProfile* g_prof = nullptr;
@@ -527,6 +539,17 @@ static void conv_launch(hipStream_t s, const ConvArgs& a, int bn)
 #define MRCNN_RING128S 3    /* split mode: a step is 8 MFMAs per wave, two tiles in flight (+2 %) */
 #endif
     constexpr int R128 = (sizeof(T) == 4 && sizeof(TW) == 2) ? MRCNN_RING128S : 2;
+#ifndef MRCNN_SPLIT_WIDE
+#define MRCNN_SPLIT_WIDE 0
+#endif
+#if MRCNN_SPLIT_WIDE
+    if constexpr (sizeof(T) == 4 && sizeof(TW) == 2) {
+        // Experiment kept behind a switch (measured neutral): 128×256 block, 32×128 per wave — the
+        // hi/lo conversion of an activation fragment feeds eight MFMAs instead of four, 0.75 LDS reads per MFMA
+        // instead of 1, a third less L2→LDS traffic per flop, but 168 VGPRs = one block per CU.
+        if (bn == 256) { hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 256, 1, 4, 4, 2, 2>), grid, dim3(512), 0, s, a); return; }
+    }
+#endif
     if (bn == 128) hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 128, 1, 2, 4, 2, R128>), grid, dim3(512), 0, s, a);
     else if (bn == 64) hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 64, 1, 1, 4, 2, MRCNN_RING64>), grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 32, 1, 1, 4, 1, MRCNN_RING32>), grid, dim3(256), 0, s, a);
@@ -568,6 +591,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     MRCNN_REQUIRE(d.Npad % bn_max == 0 && d.Npad >= a.ncols, MRCNN_ERR_SHAPE, "conv: Npad %d incompatible with tile %d", d.Npad, bn_max);
     a.tiles_m = (a.M + BM_DEFAULT - 1) / BM_DEFAULT;
     int bn = bn_max;
+    if (MRCNN_SPLIT_WIDE && split && bn_max == 128 && d.Npad % 256 == 0 && (long)a.tiles_m * (d.Npad / 256) >= 512) bn = 256;
     while (bn > 32 && (long)a.tiles_m * (d.Npad / bn) < 512) bn >>= 1;
     const size_t out_es = a.out_f32 ? 4 : 2;
     auto al = [](const void* p, size_t n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
@@ -584,7 +608,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     if (prof) {
         const int e1 = prof_event(prof, s);
         const double k = d.algo_k > 0 ? d.algo_k : a.Ktot;
-        const int tile = bn == 128 ? 0 : (bn == 64 ? 1 : 2);
+        const int tile = bn == 128 ? 0 : (bn == 64 ? 1 : (bn == 32 ? 2 : 3));
         prof->pending.push_back({tile, 2.0 * (double)a.M * (double)a.ncols * k, e0, e1, {a.M, a.ncols, a.Ktot, tile}});
     }
     HIP_CHECK(hipGetLastError());
