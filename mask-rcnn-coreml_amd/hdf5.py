@@ -75,6 +75,8 @@ class Group:
         return k in self._links
 
     def __getitem__(self, path: str):
+        if path.count("/") > 64:
+            raise KeyError(path)
         node = self
         for part in [p for p in path.split("/") if p]:
             if not isinstance(node, Group) or part not in node._links:
@@ -83,11 +85,13 @@ class Group:
             node = node._f._object(node._links[part], child)
         return node
 
-    def visit_datasets(self) -> Iterator[Dataset]:
+    def visit_datasets(self, _depth: int = 0) -> Iterator[Dataset]:
+        if _depth > 32:
+            raise HDF5FormatError(f"{self.name}: groups nested deeper than 32 levels (link cycle in a corrupt file?)")
         for k in self._links:
             o = self[k]
             if isinstance(o, Group):
-                yield from o.visit_datasets()
+                yield from o.visit_datasets(_depth + 1)
             else:
                 yield o
 
@@ -137,6 +141,8 @@ class File(Group):
     def _messages(self, addr: int) -> List[Tuple[int, int, int]]:
         """[(type, absolute file position of the body, size)] of a version-1 object header."""
         p = self._base + addr
+        if p < 0 or p + 16 > len(self._buf):
+            raise HDF5FormatError(f"object header address {addr:#x} beyond end of file")
         if self._buf[p:p + 4] == b"OHDR":
             raise HDF5FormatError("version-2 object header (libver='latest') not supported")
         if self._buf[p] != 1:
@@ -145,7 +151,11 @@ class File(Group):
         hdr_size = self._uint(p + 8, 4)
         blocks = [(p + 16, hdr_size)]
         out = []
+        seen_blocks = 0
         while blocks and len(out) < n_msgs:
+            seen_blocks += 1
+            if seen_blocks > 4096:
+                raise HDF5FormatError("object header continuation chain too long (corrupt file?)")
             q, size = blocks.pop(0)
             end = q + size
             while q + 8 <= end and len(out) < n_msgs:
@@ -156,6 +166,13 @@ class File(Group):
                 out.append((mtype, body, msize))
                 q = body + msize
         return out
+
+    @staticmethod
+    def _find(msgs, mtype: int, name: str) -> int:
+        for t, body, _ in msgs:
+            if t == mtype:
+                return body
+        raise HDF5FormatError(f"{name}: object header lacks message {mtype:#06x}")
 
     def _object(self, addr: int, name: str):
         if addr in self._cache:
@@ -172,13 +189,13 @@ class File(Group):
                 k, v = self._attribute(body)
                 attrs[k] = v
         if 0x0011 in types:
-            body = next(b for t, b, _ in msgs if t == 0x0011)
+            body = self._find(msgs, 0x0011, name)
             links = self._group_links(self._off(body), self._off(body + self._O))
             obj: object = Group(self, name, links, attrs)
         elif 0x0008 in types:
-            shape = self._dataspace(next(b for t, b, _ in msgs if t == 0x0001))
-            dt = self._datatype(next(b for t, b, _ in msgs if t == 0x0003))[0]
-            layout = self._layout(next(b for t, b, _ in msgs if t == 0x0008), name)
+            shape = self._dataspace(self._find(msgs, 0x0001, name))
+            dt = self._datatype(self._find(msgs, 0x0003, name))[0]
+            layout = self._layout(self._find(msgs, 0x0008, name), name)
             obj = Dataset(self, name, shape, dt, layout)
             obj.attrs = attrs
         else:
@@ -201,8 +218,12 @@ class File(Group):
         self._btree_walk(btree, heap_data, links)
         return links
 
-    def _btree_walk(self, addr: int, heap_data: int, links: Dict[str, int]) -> None:
+    def _btree_walk(self, addr: int, heap_data: int, links: Dict[str, int], depth: int = 0) -> None:
+        if depth > 16:
+            raise HDF5FormatError("group B-tree deeper than 16 levels (corrupt file?)")
         p = self._base + addr
+        if p < 0 or p + 8 > len(self._buf):
+            raise HDF5FormatError(f"B-tree node address {addr:#x} beyond end of file")
         sig = self._buf[p:p + 4]
         if sig == b"TREE":
             if self._buf[p + 4] != 0:
@@ -211,7 +232,7 @@ class File(Group):
             q = p + 8 + 2 * self._O
             for i in range(n):
                 q += self._L                                  # key i
-                self._btree_walk(self._off(q), heap_data, links)
+                self._btree_walk(self._off(q), heap_data, links, depth + 1)
                 q += self._O
         elif sig == b"SNOD":
             n = self._uint(p + 6, 2)

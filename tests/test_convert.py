@@ -6,6 +6,7 @@ import gzip
 import importlib
 import json
 import os
+import struct
 import subprocess
 
 import numpy as np
@@ -70,6 +71,22 @@ def test_hdf5_reader_rejects_what_it_does_not_parse(hdf5, tmp_path, tiny_h5):
     p.write_bytes(bytes(open(tiny_h5, "rb").read()[:4096]))   # truncated file: addresses beyond EOF
     with pytest.raises((hdf5.HDF5FormatError, ValueError, IndexError)):
         hdf5.read_keras_weights(str(p))
+    # corrupted metadata never hangs or crashes the interpreter: a clean exception, or (for flips that land in
+    # unused bytes / dataset payload) a normal read
+    good = open(tiny_h5, "rb").read()
+    rng = np.random.default_rng(5)
+    outcomes = {"ok": 0, "rejected": 0}
+    for trial in range(60):
+        raw = bytearray(good)
+        for pos in rng.integers(0, min(len(raw), 200_000), 8):
+            raw[pos] ^= 1 << int(rng.integers(0, 8))
+        p.write_bytes(bytes(raw))
+        try:
+            hdf5.read_keras_weights(str(p))
+            outcomes["ok"] += 1
+        except (hdf5.HDF5FormatError, ValueError, IndexError, KeyError, UnicodeDecodeError, OverflowError, struct.error, RecursionError, MemoryError):
+            outcomes["rejected"] += 1
+    assert outcomes["ok"] + outcomes["rejected"] == 60
 
 
 def _keras_checkpoint(conv, models):
