@@ -55,12 +55,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=3)
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group and run the all-gather leg even at world size 1 (self-test of the N > 1 path)")
     ap.add_argument("--no-other-modes", action="store_true",
                     help="skip the short extra timed loops of the other compute modes (reported under other_modes, N = 1 only)")
     ap.add_argument("--event-steps", type=int, default=3,
                     help="conv launches are bracketed by HIP events during the first N steps of the timed region "
                          "(the events cost ~2 %% of an fp32 step, ~13 %% of an fp16 one); 0 = all steps")
     args = ap.parse_args()
+
+    # stdout carries the ONE JSON line and nothing else: libraries that print there (RCCL's version banner on the
+    # first communicator) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -73,9 +81,14 @@ def main():
     n_gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29517")
+        if world > 1:
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
 
     pkg = importlib.import_module("mask-rcnn-coreml_amd")
     models = importlib.import_module("mask-rcnn-coreml_amd.models")
@@ -93,7 +106,7 @@ def main():
     images = torch.from_numpy(rng.integers(0, 256, (B, args.size, args.size, 3), dtype=np.uint8)).to(dev)
     det = torch.empty((B, m.max_detections, 6), dtype=torch.float32, device=dev)
     mask = torch.empty((B, m.max_detections, m.mask_size, m.mask_size), dtype=torch.float32, device=dev)
-    gather = dmod.DetectionGather(B, m.max_detections, m.mask_size, world, dev) if world > 1 else None
+    gather = dmod.DetectionGather(B, m.max_detections, m.mask_size, world, dev) if use_dist else None
 
     def step():
         m.predict_into(images, det, mask, sync=True)       # returns after the model's stream has drained
@@ -109,7 +122,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -122,7 +135,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -192,8 +205,9 @@ def main():
                 del mm
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model_dir, cfg, args)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
