@@ -152,7 +152,10 @@ typedef struct mrcnn_model mrcnn_model;
  * MFMA passes over a hi/lo split of its fp32 activations against the fp16 filters the artefact stores
  * (task.py:90), fp32 accumulate: products are exact, the split carries 22 of the 24 significand bits —
  * fp32-grade results at several times the fp32-MFMA rate.  Requires fp16-representable filters, which is
- * what the converter writes; an artefact with genuine fp32 filters is refused in this mode). */
+ * what the converter writes; an artefact with genuine fp32 filters is refused in this mode).
+ * In MRCNN_F16 and MRCNN_F32S every convolution watches its outputs: if one leaves the fp16 range (|v| >= 65504,
+ * which the next layer could not read), the synchronous predict fails with MRCNN_ERR_UNSUPPORTED instead of
+ * returning saturated results (mrcnn_model_get_int key "range_overflows" counts such calls). */
 MRCNN_API int mrcnn_model_load(int kind, const char* path, int max_batch, int compute_dtype,
                                mrcnn_model** out_model);
 MRCNN_API void mrcnn_model_destroy(mrcnn_model* model);

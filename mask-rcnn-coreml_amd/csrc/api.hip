@@ -616,6 +616,7 @@ extern "C" int mrcnn_model_get_int(mrcnn_model* model, const char* key, int64_t*
         else if (k == "pre_nms_max_proposals") *value = m.pre_nms;
         else if (k == "pre_nms_count") *value = m.K;
         else if (k == "mask_size") *value = 2 * m.mask_pool;
+        else if (k == "range_overflows") *value = m.range_overflows;
         else if (k == "graph_launches") *value = m.graph_launches;
         else if (k == "graph_enabled") *value = m.use_graph ? 1 : 0;
         else *value = m.file.get_int(k);

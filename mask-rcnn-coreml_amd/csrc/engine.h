@@ -159,6 +159,8 @@ struct Model {
     struct GraphSlot { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int eager_runs = 0; };
     std::map<int, GraphSlot> graphs;
     bool use_graph = false;
+    DevBuf range_flag;          // 4 B: set by the conv epilogues in MRCNN_F16 / MRCNN_F32S when an activation leaves the fp16 range
+    long range_overflows = 0;   // predicts that tripped it
     long graph_launches = 0;
 
     ~Model();

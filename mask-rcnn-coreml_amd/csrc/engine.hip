@@ -560,6 +560,8 @@ void Model::load(int kind_, const std::string& path, int max_batch_, int dtype_)
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     own_stream = true;
     if (const char* e = getenv("MRCNN_GRAPH")) use_graph = atoi(e) != 0;
+    range_flag.alloc(sizeof(int));
+    HIP_CHECK(hipMemset(range_flag.p, 0, sizeof(int)));
     nc = (int)file.get_int("num_classes");
     if (kind == MRCNN_MODEL_CLASSIFIER) { cls_head.load(file, max_batch, mode); return; }
     if (kind == MRCNN_MODEL_MASK) { mask_head.load(file, max_batch, mode); return; }
@@ -859,11 +861,23 @@ void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, f
         HIP_CHECK(hipStreamSynchronize(s));
         timer.finish();
         if (conv_profile.active) conv_profile.collect();
+        if (mode != MRCNN_F32) {
+            int tripped = 0;
+            HIP_CHECK(hipMemcpy(&tripped, range_flag.p, sizeof(int), hipMemcpyDeviceToHost));
+            if (tripped) {
+                ++range_overflows;
+                fail(MRCNN_ERR_UNSUPPORTED, "an activation left the fp16 range (|v| >= 65504) in compute mode %s: the results of this call are "
+                     "not valid; load the model with MRCNN_F32", mode == MRCNN_F16 ? "MRCNN_F16" : "MRCNN_F32S");
+            }
+        }
     }
 }
 
 void Model::enqueue_pipeline(hipStream_t s, int batch)
 {
+    int* const rflag = mode != MRCNN_F32 ? range_flag.as<int>() : nullptr;
+    if (rflag) HIP_CHECK(hipMemsetAsync(rflag, 0, sizeof(int), s));
+    conv_set_range_flag(rflag);
     timer.begin(s);
     conv_set_profiler(conv_profile.active ? &conv_profile : nullptr);
     for (auto& op : trunk_ops) op(s, batch);
@@ -905,6 +919,7 @@ void Model::enqueue_pipeline(hipStream_t s, int batch)
                         batch, msel_ws, mask_out, (long)max_det * HW, HW, dtype);
     timer.mark(s, "TimeDistributedMask-Eval");
     conv_set_profiler(nullptr);
+    conv_set_range_flag(nullptr);
 }
 
 void Model::read_tensor(const std::string& name, int image, float* dst, int64_t cap, int64_t* count)

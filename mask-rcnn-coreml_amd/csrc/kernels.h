@@ -136,6 +136,9 @@ struct ConvProfile {
     ~ConvProfile();
 };
 void conv_set_profiler(ConvProfile* p);   // thread-local; nullptr disables
+// While set (thread-local), every conv launch ORs 1 into *device_flag when one of its outputs leaves the fp16
+// range (|v| >= 65504, inf or NaN): the watchdog of the fp16-MFMA modes, whose next layer reads it through fp16.
+void conv_set_range_flag(int* device_flag);
 // Picks the tile shape from Cout; returns the N tile it will use so that callers can pad weights.
 int conv_n_tile(int Cout);
 void conv_forward(hipStream_t s, const ConvDesc& d);

@@ -43,6 +43,7 @@ struct ConvArgs {
     int vec_ok;          // epilogue may use vector stores / residual loads
     int out_f32;         // store fp32 even when the activations are fp16 (RPN outputs, class logits, masks)
     const void* zero_page;   // >= 16 B of zeros in HBM: source of out-of-image taps for the DMA variant
+    int* range_flag;         // optional: set to 1 when an output leaves the fp16 range (|v| >= 65504 or NaN)
 };
 
 static constexpr int BM_DEFAULT = 128;   // rows of the block tile = WM*TM*32
@@ -95,6 +96,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
     const bool need_yx = a.deconv2 || (a.res && a.res_shift);
     const T* const res = static_cast<const T*>(a.res);
     float* const Cs = reinterpret_cast<float*>(smem);
+    bool out_of_range = false;       // fp16-range watch for the modes whose next layer reads this output through fp16
 
 #pragma unroll
     for (int h = 0; h < CPASS; ++h) {
@@ -163,6 +165,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
                     v.x = 1.0f / (1.0f + expf(-v.x)); v.y = 1.0f / (1.0f + expf(-v.y));
                     v.z = 1.0f / (1.0f + expf(-v.z)); v.w = 1.0f / (1.0f + expf(-v.w));
                 }
+                out_of_range |= !(fabsf(v.x) < 65504.0f) | !(fabsf(v.y) < 65504.0f) | !(fabsf(v.z) < 65504.0f) | !(fabsf(v.w) < 65504.0f);
                 long o;
                 if (a.deconv2) o = (long)b * a.out_sB + (long)(2 * oh + (qd >> 1)) * a.out_sH + (long)(2 * ow + (qd & 1)) * a.out_sW + co;
                 else o = (dense_out ? (long)m * a.out_sP : (long)b * a.out_sB + (long)pix * a.out_sP) + n;
@@ -189,6 +192,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
                     }
                     if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
                     else if (a.act == ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                    out_of_range |= !(fabsf(v) < 65504.0f);
                     long o;
                     void* dst = a.out;
                     if (a.deconv2) {
@@ -206,6 +210,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
             }
         }
     }
+    if (a.range_flag && out_of_range) atomicOr(a.range_flag, 1);
 }
 
 // fp32 → (hi, lo) fp16 pair with hi + lo = a to ~2^-22 relative: hi = a rounded toward zero to fp16,
@@ -481,6 +486,8 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
 
 static thread_local ConvProfile* g_prof = nullptr;
 void conv_set_profiler(ConvProfile* p) { g_prof = p; }
+static thread_local int* g_range_flag = nullptr;
+void conv_set_range_flag(int* device_flag) { g_range_flag = device_flag; }
 void ConvProfile::reset()
 {
     for (auto& s : by_tile) s = Slot();
@@ -585,6 +592,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
         HIP_CHECK(hipMemset(zero_page, 0, 256));
     }
     a.zero_page = zero_page;
+    a.range_flag = g_range_flag;
     // Tile choice: the widest N tile the packed weights allow, narrowed while the grid would leave
     // the chip under-filled (< 2 blocks per CU) — C5, the top FPN levels and the small RPN levels.
     const int bn_max = conv_n_tile(a.ncols);

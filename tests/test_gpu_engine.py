@@ -338,6 +338,35 @@ def test_engine_f32s_split_mode(pkg, orc, small_model, weights_mod, tmp_path):
     pkg.MaskRCNNConfig.defaultConfig().anchorsURL = os.path.join(d, "anchors.bin")
 
 
+def test_engine_fp16_range_watchdog(pkg, small_model, weights_mod, tmp_path):
+    """Activations beyond the fp16 range: exact in MRCNN_F32, refused (not silently saturated) in MRCNN_F32S / MRCNN_F16."""
+    models = __import__("importlib").import_module("mask-rcnn-coreml_amd.models")
+    d, cfg = small_model
+    hot = tmp_path / "hot"
+    hot.mkdir()
+    for kind in ("MaskRCNN", "Classifier", "Mask"):
+        meta, tensors = weights_mod.read_mrcw(os.path.join(d, f"{kind}.mrcw"))
+        t = dict(tensors)
+        if kind == "MaskRCNN":                       # the stem's BatchNorm now multiplies by 2^12: C1 reaches ~1e5
+            t["bn_conv1/gamma"] = (t["bn_conv1/gamma"].astype(np.float32) * 4096).astype(np.float16)
+        weights_mod.write_mrcw(str(hot / f"{kind}.mrcw"), meta, t)
+    __import__("importlib").import_module("mask-rcnn-coreml_amd.anchors").write_anchors_bin(str(hot / "anchors.bin"), cfg)
+    images = rand_images(1, cfg.image_height, cfg.image_width, seed=2)
+    m32 = models.load_maskrcnn(str(hot), max_batch=1)
+    det, _ = m32.predict(images)
+    assert np.isfinite(det).all() and m32.get_int("range_overflows") == 0
+    for mode in ("f32s", "f16"):
+        m = models.load_maskrcnn(str(hot), max_batch=1, compute_dtype=mode)
+        with pytest.raises(Exception, match="left the fp16 range"):
+            m.predict(images)
+        assert m.get_int("range_overflows") == 1
+    # the same handles are fine on in-range weights
+    ok = models.load_maskrcnn(d, max_batch=1, compute_dtype="f32s")
+    ok.predict(images)
+    assert ok.get_int("range_overflows") == 0
+    pkg.MaskRCNNConfig.defaultConfig().anchorsURL = os.path.join(d, "anchors.bin")
+
+
 def test_engine_f32s_full_size(pkg, orc, tmp_path_factory, weights_mod):
     """BASELINE configs[1] shapes (R101, 1024², 81 classes) in split mode, batch 2: staged parity at fp32 tolerances."""
     from oracle.network import load_oracle_model
