@@ -170,7 +170,7 @@ def main():
                 peak = {"f32": PEAK_FP32_MFMA_TFLOPS, "f16": PEAK_FP16_MFMA_TFLOPS, "f32s": PEAK_FP16_MFMA_TFLOPS / 2}[args.dtype]
                 ktypes = {"f32": "float,float", "f16": "_Float16,_Float16", "f32s": "float,_Float16"}[args.dtype]
                 out["roofline"] = {
-                    "kernel": f"k_conv_mfma_glds<{ktypes},128,1,2,4,2,2>", "bound": "mfma",
+                    "kernel": f"k_conv_mfma_glds<{ktypes},128,1,2,4,2,{3 if args.dtype == 'f32s' else 2}>", "bound": "mfma",
                     "achieved": round(achieved, 2),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "traffic": pmc_traffic() if args.dtype == "f32" else None,
