@@ -338,6 +338,38 @@ def test_engine_f32s_split_mode(pkg, orc, small_model, weights_mod, tmp_path):
     pkg.MaskRCNNConfig.defaultConfig().anchorsURL = os.path.join(d, "anchors.bin")
 
 
+@pytest.mark.parametrize("mode", ["f32", "f32s", "f16"])
+def test_engine_sparse_outcomes(pkg, orc, weights_mod, tmp_path, mode):
+    """Plain He-init weights (no forced load): the RPN soft-max sits near 0.5, NMS keeps fewer than maxProposals, almost no
+    row passes the 0.7 score filter — the zero-padding / short-count paths of every stage, and a black image on top."""
+    from oracle.network import load_oracle_model
+    models = __import__("importlib").import_module("mask-rcnn-coreml_amd.models")
+    cfg = pkg.ModelConfig(architecture="resnet50", input_image_shape=(128, 128, 3), num_classes=21, pre_nms_max_proposals=300,
+                          max_proposals=64, max_detections=16)
+    d = str(tmp_path)
+    weights_mod.save_synthetic_models(d, cfg, seed=4, forced_load=False)
+    om = load_oracle_model(d)
+    images = rand_images(3, 128, 128, seed=8)
+    images[2] = 0                                                        # black frame
+    m = models.load_maskrcnn(d, max_batch=3, compute_dtype=mode)
+    det, mask = m.predict(images)
+    trunk = om.trunk(images)
+    counts = []
+    for b in range(3):
+        d_b, m_b = _check_stages(pkg, orc, om, m, cfg, images, b, True, trunk, f16=(mode == "f16"))
+        np.testing.assert_array_equal(det[b], d_b)
+        np.testing.assert_array_equal(mask[b].reshape(cfg.max_detections, -1), m_b)
+        n = int((d_b[:, 5] > 0).sum())
+        counts.append(n)
+        assert (d_b[n:] == 0).all() and (m_b[n:] == 0).all()             # zero padding after the last detection
+    assert min(counts) < cfg.max_detections, counts                     # the short-count path was taken
+    # a second call on other images must not inherit rows from this one
+    det2, mask2 = m.predict(images[::-1].copy())
+    np.testing.assert_array_equal(det2[::-1], det)
+    np.testing.assert_array_equal(mask2[::-1], mask)
+    pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None
+
+
 def test_engine_fp16_range_watchdog(pkg, small_model, weights_mod, tmp_path):
     """Activations beyond the fp16 range: exact in MRCNN_F32, refused (not silently saturated) in MRCNN_F32S / MRCNN_F16."""
     models = __import__("importlib").import_module("mask-rcnn-coreml_amd.models")
