@@ -490,3 +490,36 @@ def test_engine_graph_replay_matches_stream_launches(pkg, small_model):
     det, mask = m.predict(imgs[0])
     np.testing.assert_array_equal(det, ref[0][0])
     assert m.get_int("graph_launches") == 5 and m.get_int("graph_enabled") == 0
+
+
+def test_engine_joins_a_callers_graph_capture(pkg, small_model):
+    """A caller that captures its own stream (here: torch.cuda.graph) gets predict_async's launches recorded into ITS graph:
+    replaying that graph on new input reproduces the eager results."""
+    import torch
+    models = __import__("importlib").import_module("mask-rcnn-coreml_amd.models")
+    d, cfg = small_model
+    m = models.load_maskrcnn(d, max_batch=2)
+    imgs_a = rand_images(2, cfg.image_height, cfg.image_width, seed=41)
+    imgs_b = rand_images(2, cfg.image_height, cfg.image_width, seed=42)
+    ref_a, ref_b = m.predict(imgs_a), m.predict(imgs_b)           # also the one-time host set-up, outside any capture
+    st = torch.cuda.Stream()
+    m.set_stream(st.cuda_stream)
+    img_d = torch.from_numpy(imgs_a).cuda()
+    det_d = torch.zeros((2, m.max_detections, 6), device="cuda")
+    mask_d = torch.zeros((2, m.max_detections, m.mask_size, m.mask_size), device="cuda")
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=st):
+        m.predict_into(img_d, det_d, mask_d, sync=False)
+    det_d.zero_(); mask_d.zero_()
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(det_d.cpu().numpy(), ref_a[0])
+    np.testing.assert_array_equal(mask_d.cpu().numpy(), ref_a[1])
+    img_d.copy_(torch.from_numpy(imgs_b).cuda())
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(det_d.cpu().numpy(), ref_b[0])
+    np.testing.assert_array_equal(mask_d.cpu().numpy(), ref_b[1])
