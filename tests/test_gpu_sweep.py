@@ -117,3 +117,41 @@ def test_pyramid_roi_align_sweep(pkg, orc):
         np.testing.assert_array_equal(out.reshape(want.shape), want, err_msg=f"seed {seed}: C={C} sizes={sizes} n={n} pool={pool}")
         levels_seen |= set(np.unique(orc.roi_levels(rois, img_w, img_h)).tolist())
     assert levels_seen >= {-1, 0, 1, 2, 3}
+
+
+def test_engine_config_sweep(pkg, orc, weights_mod, tmp_path_factory):
+    """The fused engine on a dozen seeded small configurations — non-square inputs, class counts 2..81, proposal / detection
+    budgets from tiny to larger than the anchor count allows, loaded and sparse weights, batch 1..3, all three compute modes —
+    each through the full staged parity of test_gpu_engine (index / box stages bit-exact on the GPU's taps)."""
+    import importlib
+    from oracle.network import load_oracle_model
+    from test_gpu_engine import _check_stages
+    models = importlib.import_module("mask-rcnn-coreml_amd.models")
+    rng = np.random.default_rng(77)
+    seen_modes = set()
+    for case in range(12):
+        h = int(rng.choice([128, 192, 256]))
+        w = int(rng.choice([128, 192, 256]))
+        kw = dict(architecture="resnet50", input_image_shape=(h, w, 3), num_classes=int(rng.choice([2, 5, 21, 81])),
+                  pre_nms_max_proposals=int(rng.choice([50, 300, 6000])), max_proposals=int(rng.choice([16, 64, 200])),
+                  max_detections=int(rng.choice([4, 16, 100])))
+        cfg = pkg.ModelConfig(**kw)
+        d = str(tmp_path_factory.mktemp(f"sweep{case}"))
+        weights_mod.save_synthetic_models(d, cfg, seed=100 + case, forced_load=bool(case % 3))
+        mode = ("f32", "f32s", "f16")[case % 3]
+        seen_modes.add(mode)
+        B = 1 + case % 3
+        om = load_oracle_model(d)
+        m = models.load_maskrcnn(d, max_batch=B, compute_dtype=mode)
+        images = np.random.default_rng(200 + case).integers(0, 256, (B, h, w, 3), dtype=np.uint8)
+        det, mask = m.predict(images)
+        trunk = om.trunk(images)
+        for b in range(B):
+            try:
+                d_b, m_b = _check_stages(pkg, orc, om, m, cfg, images, b, True, trunk, f16=(mode == "f16"))
+            except AssertionError as e:
+                raise AssertionError(f"case {case}: {kw} mode={mode} batch={B} image={b}: {e}") from e
+            np.testing.assert_array_equal(det[b], d_b)
+            np.testing.assert_array_equal(mask[b].reshape(cfg.max_detections, -1), m_b)
+        del m
+    assert seen_modes == {"f32", "f32s", "f16"}
