@@ -441,12 +441,7 @@ void proposal_forward(hipStream_t s, const ProposalWorkspace& ws, const float* p
     const size_t sort_lds = (size_t)ws.Kpad * 8;
     MRCNN_REQUIRE(sort_lds <= 160 * 1024 - 1024, MRCNN_ERR_UNSUPPORTED,
                   "preNMSMaxProposals %d exceeds the in-LDS sort capacity (max 16384)", K);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_decode, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_nms_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        attr_set = true;
-    }
+    boxes_one_time_init();
     const float4 stdv = make_float4(std4[0], std4[1], std4[2], std4[3]);
     hipLaunchKernelGGL(k_sort_decode, dim3(B), dim3(1024), sort_lds, s, ws.cand, K, ws.Kpad, deltas, deltas_sB, anchors,
                        stdv, ws.topk_idx, ws.boxes);
@@ -606,12 +601,7 @@ void detection_forward(hipStream_t s, const DetectionWorkspace& ws, const float*
     const long boxes_sB = (long)N * 4, mask_sB = (long)N * ws.W;
     hipLaunchKernelGGL(k_nms_mask, dim3(ws.W, ws.W, B), dim3(64), 0, s, ws.boxes, boxes_sB, ws.cls, (long)N, ws.count, 0,
                        nms_thr, ws.nms_mask, mask_sB, ws.W);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_nms_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_det_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-        attr_set = true;
-    }
+    boxes_one_time_init();
     const size_t scan_lds = (size_t)N * 8;
     MRCNN_REQUIRE(scan_lds <= 64 * 1024, MRCNN_ERR_UNSUPPORTED, "DetectionLayer: too many regions (%d)", N);
     hipLaunchKernelGGL(k_nms_scan, dim3(B), dim3(256), scan_lds, s, ws.boxes, boxes_sB, ws.cls, (long)N, ws.count, 0,
@@ -619,6 +609,18 @@ void detection_forward(hipStream_t s, const DetectionWorkspace& ws, const float*
     hipLaunchKernelGGL(k_det_finalize, dim3(B), dim3(1024), (size_t)ws.Npad * 8, s, ws.boxes, ws.score, ws.cls, ws.keep_idx,
                        ws.keep_count, N, ws.Npad, ws.max_det, out, out_sB, row_stride);
     HIP_CHECK(hipGetLastError());
+}
+
+// Large dynamic-LDS opt-ins of the box kernels, once per process (also called at model / layer creation so that the first
+// predict may already run inside a caller's stream capture).
+void boxes_one_time_init()
+{
+    static bool done = false;
+    if (done) return;
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_decode, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_nms_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_det_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    done = true;
 }
 
 }  // namespace mrcnn

@@ -484,6 +484,19 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
     conv_epilogue<T, BN, TM, TN, WM, WN, CPASS>(a, acc, smem, m0, n0);
 }
 
+// 256 B of zeros in HBM, one per process (one device per process): allocated by kernels_one_time_init() at model / layer
+// creation so that no allocation can fall inside a caller's stream capture; lazily here as a fallback.
+static void* conv_zero_page()
+{
+    static void* zero_page = nullptr;
+    if (!zero_page) {
+        HIP_CHECK(hipMalloc(&zero_page, 256));
+        HIP_CHECK(hipMemset(zero_page, 0, 256));
+    }
+    return zero_page;
+}
+void conv_one_time_init() { (void)conv_zero_page(); }
+
 static thread_local ConvProfile* g_prof = nullptr;
 void conv_set_profiler(ConvProfile* p) { g_prof = p; }
 static thread_local int* g_range_flag = nullptr;
@@ -586,12 +599,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     a.M = (int)M;
     a.res_shift = d.res_shift; a.act = d.act; a.n_split = d.n_split; a.deconv2 = d.deconv2;
     a.out_f32 = (!half || d.out_f32) ? 1 : 0;
-    static void* zero_page = nullptr;     // one per process (single device per process)
-    if (!zero_page) {
-        HIP_CHECK(hipMalloc(&zero_page, 256));
-        HIP_CHECK(hipMemset(zero_page, 0, 256));
-    }
-    a.zero_page = zero_page;
+    a.zero_page = conv_zero_page();
     a.range_flag = g_range_flag;
     // Tile choice: the widest N tile the packed weights allow, narrowed while the grid would leave
     // the chip under-filled (< 2 blocks per CU) — C5, the top FPN levels and the small RPN levels.
