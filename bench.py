@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
     ap.add_argument("--arch", default="resnet101")
     ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f32s"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f32s", "f32x3"],
                     help="compute dtype of the convolutions: f32 = exact-fp32 MFMA (default, the parity baseline); "
                          "f16 = fp16 MFMA with fp32 accumulation (BASELINE configs[3]); f32s = fp32 tensors, every "
                          "convolution as two fp16 MFMA passes over a hi/lo split of its activations (fp32-grade results)")
@@ -167,10 +167,11 @@ def main():
             if launches:
                 achieved = flops / (ms * 1e-3) / 1e12
                 # f32s executes two fp16 MFMA flops per algorithmic flop: its ceiling is half the fp16 peak
-                peak = {"f32": PEAK_FP32_MFMA_TFLOPS, "f16": PEAK_FP16_MFMA_TFLOPS, "f32s": PEAK_FP16_MFMA_TFLOPS / 2}[args.dtype]
-                ktypes = {"f32": "float,float", "f16": "_Float16,_Float16", "f32s": "float,_Float16"}[args.dtype]
+                peak = {"f32": PEAK_FP32_MFMA_TFLOPS, "f16": PEAK_FP16_MFMA_TFLOPS, "f32s": PEAK_FP16_MFMA_TFLOPS / 2,
+                        "f32x3": PEAK_FP16_MFMA_TFLOPS / 3}[args.dtype]
+                ktypes = {"f32": "float,float", "f16": "_Float16,_Float16", "f32s": "float,_Float16", "f32x3": "float,_Float16"}[args.dtype]
                 out["roofline"] = {
-                    "kernel": f"k_conv_mfma_glds<{ktypes},128,1,2,4,2,{3 if args.dtype == 'f32s' else 2}>", "bound": "mfma",
+                    "kernel": f"k_conv_mfma_glds<{ktypes},128,1,2,4,2,{'3,2' if args.dtype == 'f32s' else '3,3' if args.dtype == 'f32x3' else '2,2'}>", "bound": "mfma",
                     "achieved": round(achieved, 2),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "traffic": pmc_traffic() if args.dtype == "f32" else None,
@@ -186,7 +187,7 @@ def main():
         if n_gpus == 1 and not args.no_other_modes:
             # the same workload in the engine's other compute modes (same images, same weights): not the headline value
             out["other_modes"] = {}
-            for mode in ("f32", "f32s", "f16"):
+            for mode in ("f32", "f32x3", "f32s", "f16"):
                 if mode == args.dtype:
                     continue
                 mm = models.load_maskrcnn(model_dir, max_batch=B, compute_dtype=mode)
@@ -201,7 +202,9 @@ def main():
                 out["other_modes"][mode] = {"value": round(B / dt, 1), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3), "steps": 5,
                                             "note": {"f32": "exact-fp32 MFMA", "f16": "fp16 tensors + fp16 MFMA (BASELINE configs[3])",
                                                      "f32s": "fp32 tensors, two fp16 MFMA passes over a hi/lo split of the activations "
-                                                             "(fp32-grade: parity-tested at the fp32 tolerances)"}[mode]}
+                                                             "(fp32-grade: parity-tested at the fp32 tolerances)",
+                                                     "f32x3": "fp32 tensors, three fp16 MFMA passes over an exact three-part split of the "
+                                                              "activations (every product equals the fp32 product)"}[mode]}
                 del mm
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model_dir, cfg, args)

@@ -52,7 +52,8 @@ MRCNN_API int mrcnn_device_count(void);
  * --------------------------------------------------------------------------------------------- */
 typedef enum {
     MRCNN_F32 = 0, MRCNN_F64 = 1, MRCNN_F16 = 2, MRCNN_U8 = 3, MRCNN_I32 = 4,
-    MRCNN_F32S = 5   /* compute mode only (mrcnn_model_load): fp32 tensors, fp16 filters, split-fp16 MFMA — see there */
+    MRCNN_F32S = 5,  /* compute mode only (mrcnn_model_load): fp32 tensors, fp16 filters, split-fp16 MFMA — see there */
+    MRCNN_F32X3 = 6  /* compute mode only: as MRCNN_F32S with a three-part split (all 24 significand bits: exact products) */
 } mrcnn_dtype;
 typedef enum { MRCNN_HOST = 0, MRCNN_DEVICE = 1 } mrcnn_memspace;
 
@@ -152,7 +153,9 @@ typedef struct mrcnn_model mrcnn_model;
  * MFMA passes over a hi/lo split of its fp32 activations against the fp16 filters the artefact stores
  * (task.py:90), fp32 accumulate: products are exact, the split carries 22 of the 24 significand bits —
  * fp32-grade results at several times the fp32-MFMA rate.  Requires fp16-representable filters, which is
- * what the converter writes; an artefact with genuine fp32 filters is refused in this mode).
+ * what the converter writes; an artefact with genuine fp32 filters is refused in this mode).  MRCNN_F32X3 is the same
+ * with THREE parts: every activation in [0.5, 65504) is represented exactly (2^-24 absolute below), so each product
+ * equals the fp32 product — three MFMA passes instead of two.
  * In MRCNN_F16 and MRCNN_F32S every convolution watches its outputs: if one leaves the fp16 range (|v| >= 65504,
  * which the next layer could not read), the synchronous predict fails with MRCNN_ERR_UNSUPPORTED instead of
  * returning saturated results (mrcnn_model_get_int key "range_overflows" counts such calls). */

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MRCNN_HIP_LIB") or os.path.join(_HERE, "libmaskrcnn_hip.so")   # override: A/B builds
 
 MRCNN_OK = 0
-F32, F64, F16, U8, I32, F32S = 0, 1, 2, 3, 4, 5
+F32, F64, F16, U8, I32, F32S, F32X3 = 0, 1, 2, 3, 4, 5, 6
 HOST, DEVICE = 0, 1
 PARAM_INT, PARAM_DOUBLE, PARAM_STRING = 0, 1, 2
 MODEL_MASKRCNN, MODEL_CLASSIFIER, MODEL_MASK = 0, 1, 2

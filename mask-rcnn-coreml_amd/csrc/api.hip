@@ -501,8 +501,8 @@ extern "C" int mrcnn_model_load(int kind, const char* path, int max_batch, int c
     return guarded([&] {
         MRCNN_REQUIRE(path && out_model, MRCNN_ERR_INVALID, "null argument");
         MRCNN_REQUIRE(kind >= 0 && kind <= 2, MRCNN_ERR_INVALID, "unknown model kind %d", kind);
-        MRCNN_REQUIRE(compute_dtype == MRCNN_F32 || compute_dtype == MRCNN_F16 || compute_dtype == MRCNN_F32S, MRCNN_ERR_UNSUPPORTED,
-                      "compute dtype %d not available (MRCNN_F32, MRCNN_F16 or MRCNN_F32S)", compute_dtype);
+        MRCNN_REQUIRE(compute_dtype == MRCNN_F32 || compute_dtype == MRCNN_F16 || compute_dtype == MRCNN_F32S || compute_dtype == MRCNN_F32X3,
+                      MRCNN_ERR_UNSUPPORTED, "compute dtype %d not available (MRCNN_F32, MRCNN_F16, MRCNN_F32S or MRCNN_F32X3)", compute_dtype);
         std::unique_ptr<mrcnn_model> h(new mrcnn_model);
         h->m.load(kind, path, max_batch, compute_dtype);
         *out_model = h.release();
@@ -704,7 +704,7 @@ extern "C" int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout
     return guarded([&] {
         require_gpu();
         MRCNN_REQUIRE(avg_ms && flops && iters >= 1 && (ksize == 1 || ksize == 3) && cin % 64 == 0, MRCNN_ERR_INVALID, "bad bench_conv arguments");
-        MRCNN_REQUIRE(dtype == MRCNN_F32 || dtype == MRCNN_F16 || dtype == MRCNN_F32S, MRCNN_ERR_UNSUPPORTED, "bench_conv: dtype %d", dtype);
+        MRCNN_REQUIRE(dtype == MRCNN_F32 || dtype == MRCNN_F16 || dtype == MRCNN_F32S || dtype == MRCNN_F32X3, MRCNN_ERR_UNSUPPORTED, "bench_conv: dtype %d", dtype);
         const size_t es = dtype == MRCNN_F16 ? 2 : 4;             // activations
         const size_t ws = dtype == MRCNN_F32 ? 4 : 2;             // filters
         const int pad = ksize / 2;
@@ -735,8 +735,8 @@ extern "C" int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout
         HIP_CHECK(hipMemcpy(ds.p, hs.data(), npad * 4, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(db.p, hb.data(), npad * 4, hipMemcpyHostToDevice));
         ConvDesc d;
-        d.dtype = dtype == MRCNN_F32S ? MRCNN_F32 : dtype;
-        d.wdtype = dtype == MRCNN_F32 ? MRCNN_F32 : MRCNN_F16;
+        d.dtype = (dtype == MRCNN_F32S || dtype == MRCNN_F32X3) ? MRCNN_F32 : dtype;
+        d.wdtype = dtype == MRCNN_F32 ? MRCNN_F32 : (dtype == MRCNN_F32X3 ? MRCNN_F32X3 : MRCNN_F16);
         d.in = din.p; d.B = batch; d.H = h; d.W = w; d.Cin = cin;
         d.in_sW = cin; d.in_sH = (long)w * cin; d.in_sB = (long)h * w * cin;
         d.wgt = dw.p; d.KH = d.KW = ksize; d.stride = stride; d.padH = d.padW = pad;

@@ -36,8 +36,9 @@ struct MrcwFile {
 
 // ---- packed convolution weights on the device ----------------------------------------------------
 // compute mode (mrcnn_model_load's compute_dtype) → element type of activations / of filters
-inline int mode_act(int mode) { return mode == MRCNN_F32S ? MRCNN_F32 : mode; }
-inline int mode_wgt(int mode) { return mode == MRCNN_F32 ? MRCNN_F32 : MRCNN_F16; }
+// (filters of MRCNN_F32X3 are fp16 too; the value MRCNN_F32X3 on the filter side only tags the three-part split)
+inline int mode_act(int mode) { return (mode == MRCNN_F32S || mode == MRCNN_F32X3) ? MRCNN_F32 : mode; }
+inline int mode_wgt(int mode) { return mode == MRCNN_F32 ? MRCNN_F32 : (mode == MRCNN_F32X3 ? MRCNN_F32X3 : MRCNN_F16); }
 
 struct PackedConv {
     DevBuf wgt, scale, shift;     // wgt in `wdtype`; scale/shift always fp32

@@ -207,7 +207,7 @@ static uint16_t float_to_half(float f)   // round to nearest even
 // filter weights in the compute dtype (the artefact stores fp16, so the fp16 path is lossless)
 static void upload_w(DevBuf& d, const std::vector<float>& h, int dtype, bool must_be_exact = false, const char* what = "")
 {
-    if (dtype != MRCNN_F16) { upload(d, h); return; }
+    if (dtype != MRCNN_F16 && dtype != MRCNN_F32X3) { upload(d, h); return; }
     std::vector<uint16_t> hh(h.size());
     for (size_t i = 0; i < h.size(); ++i) {
         hh[i] = float_to_half(h[i]);
@@ -261,7 +261,7 @@ PackedConv pack_conv_oihw(const MrcwFile& f, const std::string& conv, const std:
             for (int y = 0; y < KH; ++y)
                 for (int x = 0; x < KW; ++x)
                     w[(((size_t)o * KH + y) * KW + x) * I + i] = k[(((size_t)o * I + i) * KH + y) * KW + x];
-    upload_w(pc.wgt, w, pc.wdtype, pc.wdtype != pc.dtype, "MRCNN_F32S");
+    upload_w(pc.wgt, w, pc.wdtype, pc.wdtype != pc.dtype, "MRCNN_F32S / MRCNN_F32X3");
     std::vector<float> sc, sh;
     fold_bn(f, conv, bn, O, pc.Npad, sc, sh);
     upload(pc.scale, sc);
@@ -291,7 +291,7 @@ static PackedConv pack_conv1(const MrcwFile& f, int dtype)
             for (int y = 0; y < 7; ++y)
                 for (int x = 0; x < 7; ++x)
                     w[((size_t)o * 7 + y) * row + x * px + ci] = k[(((size_t)o * 3 + ci) * 7 + y) * 7 + x];
-    upload_w(pc.wgt, w, pc.wdtype, pc.wdtype != pc.dtype, "MRCNN_F32S");
+    upload_w(pc.wgt, w, pc.wdtype, pc.wdtype != pc.dtype, "MRCNN_F32S / MRCNN_F32X3");
     std::vector<float> sc, sh;
     fold_bn(f, "conv1", "bn_conv1", O, pc.Npad, sc, sh);
     upload(pc.scale, sc);
@@ -324,7 +324,7 @@ static PackedConv pack_stacked_1x1(const MrcwFile& f, const std::vector<std::str
         for (size_t o = 0; o < b.size(); ++o) { sc[o0 + o] = 1.f; sh[o0 + o] = b[o]; }
         o0 += (int)b.size();
     }
-    upload_w(pc.wgt, w, pc.wdtype, pc.wdtype != pc.dtype, "MRCNN_F32S");
+    upload_w(pc.wgt, w, pc.wdtype, pc.wdtype != pc.dtype, "MRCNN_F32S / MRCNN_F32X3");
     upload(pc.scale, sc);
     upload(pc.shift, sh);
     return pc;
@@ -348,7 +348,7 @@ static PackedConv pack_deconv2(const MrcwFile& f, const std::string& name, int d
             for (int i = 0; i < I; ++i) w[((size_t)qd * O + o) * I + i] = k[(((size_t)i * O + o) * 2 + (qd >> 1)) * 2 + (qd & 1)];
             sh[(size_t)qd * O + o] = b[o];
         }
-    upload_w(pc.wgt, w, pc.wdtype, pc.wdtype != pc.dtype, "MRCNN_F32S");
+    upload_w(pc.wgt, w, pc.wdtype, pc.wdtype != pc.dtype, "MRCNN_F32S / MRCNN_F32X3");
     upload(pc.scale, sc);
     upload(pc.shift, sh);
     return pc;
@@ -869,7 +869,7 @@ void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, f
             if (tripped) {
                 ++range_overflows;
                 fail(MRCNN_ERR_UNSUPPORTED, "an activation left the fp16 range (|v| >= 65504) in compute mode %s: the results of this call are "
-                     "not valid; load the model with MRCNN_F32", mode == MRCNN_F16 ? "MRCNN_F16" : "MRCNN_F32S");
+                     "not valid; load the model with MRCNN_F32", mode == MRCNN_F16 ? "MRCNN_F16" : (mode == MRCNN_F32S ? "MRCNN_F32S" : "MRCNN_F32X3"));
             }
         }
     }

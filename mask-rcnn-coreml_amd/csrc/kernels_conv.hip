@@ -237,6 +237,31 @@ __device__ __forceinline__ void split_hi_lo(const uint4 u0, const uint4 u1, f16x
     lo = __builtin_bit_cast(f16x8, uint4{lw[0], lw[1], lw[2], lw[3]});
 }
 
+// Three-part variant (MRCNN_F32X3): hi + mid + lo carries all 24 significand bits — exact for 0.5 <= |a| < 65504, and to
+// 2^-24 absolute below (where the last part reaches the fp16 subnormal step): the fp32 product a·w is reproduced exactly.
+__device__ __forceinline__ void split_hi_mid_lo(const uint4 u0, const uint4 u1, f16x8& hi, f16x8& mid, f16x8& lo)
+{
+    const float a[8] = {__uint_as_float(u0.x), __uint_as_float(u0.y), __uint_as_float(u0.z), __uint_as_float(u0.w),
+                        __uint_as_float(u1.x), __uint_as_float(u1.y), __uint_as_float(u1.z), __uint_as_float(u1.w)};
+    uint32_t hw[4], mw[4], lw[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const uint32_t h2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a[2 * p], a[2 * p + 1]));
+        float r0, r1, q0, q1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h2), "v"(a[2 * p]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h2), "v"(a[2 * p + 1]));
+        const uint32_t m2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(q0) : "v"(m2), "v"(r0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(q1) : "v"(m2), "v"(r1));
+        hw[p] = h2;
+        mw[p] = m2;
+        lw[p] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(q0, q1));
+    }
+    hi = __builtin_bit_cast(f16x8, uint4{hw[0], hw[1], hw[2], hw[3]});
+    mid = __builtin_bit_cast(f16x8, uint4{mw[0], mw[1], mw[2], mw[3]});
+    lo = __builtin_bit_cast(f16x8, uint4{lw[0], lw[1], lw[2], lw[3]});
+}
+
 // ------------------------------------------------------------------------------------------------
 // The implicit-GEMM kernel.  T = float   : v_mfma_f32_32x32x2_f32  (exact fp32, 157.3 TFLOP/s peak), K tile = 32
 //                            T = _Float16: v_mfma_f32_32x32x16_f16 (fp32 accumulate, ~2.5 PFLOP/s peak), K tile = 64
@@ -253,11 +278,12 @@ __device__ __forceinline__ void split_hi_lo(const uint4 u0, const uint4 u1, f16x
 //   * two LDS buffers: the DMA of tile k+1 is issued right after the barrier that retired buffer
 //     (k+1)&1 and lands while tile k is being multiplied; one vmcnt(0) + barrier per K step.
 // ------------------------------------------------------------------------------------------------
-template <typename T, typename TW, int BN, int TM, int TN, int WM, int WN, int STAGES>
+template <typename T, typename TW, int BN, int TM, int TN, int WM, int WN, int STAGES, int PARTS = 2>
 __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs a)
 {
-    // SPLIT: fp32 activations × fp16 filters as two fp16 MFMA passes over a hi/lo split of the activations
+    // SPLIT: fp32 activations × fp16 filters as PARTS (2 or 3) fp16 MFMA passes over a split of the activations
     constexpr bool SPLIT = sizeof(T) == 4 && sizeof(TW) == 2;
+    static_assert(PARTS == 2 || PARTS == 3, "split parts");
     static_assert(sizeof(T) == sizeof(TW) || SPLIT, "operand types");
     constexpr int BM = WM * TM * 32;
     static_assert(WN * TN * 32 == BN, "tile shape");
@@ -439,12 +465,17 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
     }
 #define MRCNN_KMATH_SPLIT(G)                                                                                   \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                           \
-        f16x8 hi, lo;                                                                                          \
-        split_hi_lo(av[2 * G][i], av[2 * G + 1][i], hi, lo);                                                   \
+        f16x8 hi, lo, lo2;                                                                                     \
+        if constexpr (PARTS == 3) split_hi_mid_lo(av[2 * G][i], av[2 * G + 1][i], hi, lo, lo2);                \
+        else split_hi_lo(av[2 * G][i], av[2 * G + 1][i], hi, lo);                                              \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                         \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, __builtin_bit_cast(f16x8, bv[G][j]), acc[i][j], 0, 0, 0); \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                         \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo, __builtin_bit_cast(f16x8, bv[G][j]), acc[i][j], 0, 0, 0); \
+        if constexpr (PARTS == 3) {                                                                            \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo2, __builtin_bit_cast(f16x8, bv[G][j]), acc[i][j], 0, 0, 0); \
+        }                                                                                                      \
     }
 #define MRCNN_STEP(BUF, NBUF, KTV)                                                                             \
     {                                                                                                          \
@@ -544,7 +575,7 @@ int conv_n_tile(int Cout)
     return 32;
 }
 
-template <typename T, typename TW>
+template <typename T, typename TW, int PARTS = 2>
 static void conv_launch(hipStream_t s, const ConvArgs& a, int bn)
 {
     // 8 waves as 4 (M) × 2 (N): 128×128 block tile, 32×64 per wave; narrower N tiles keep 128 rows.
@@ -570,16 +601,17 @@ static void conv_launch(hipStream_t s, const ConvArgs& a, int bn)
         if (bn == 256) { hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 256, 1, 4, 4, 2, 2>), grid, dim3(512), 0, s, a); return; }
     }
 #endif
-    if (bn == 128) hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 128, 1, 2, 4, 2, R128>), grid, dim3(512), 0, s, a);
-    else if (bn == 64) hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 64, 1, 1, 4, 2, MRCNN_RING64>), grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 32, 1, 1, 4, 1, MRCNN_RING32>), grid, dim3(256), 0, s, a);
+    if (bn == 128) hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 128, 1, 2, 4, 2, R128, PARTS>), grid, dim3(512), 0, s, a);
+    else if (bn == 64) hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 64, 1, 1, 4, 2, MRCNN_RING64, PARTS>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 32, 1, 1, 4, 1, MRCNN_RING32, PARTS>), grid, dim3(256), 0, s, a);
 }
 
 void conv_forward(hipStream_t s, const ConvDesc& d)
 {
     const bool half = d.dtype == MRCNN_F16;
     const int wdtype = d.wdtype < 0 ? d.dtype : d.wdtype;
-    const bool split = d.dtype == MRCNN_F32 && wdtype == MRCNN_F16;       // fp32 activations, fp16 filters: two-pass fp16 MFMA
+    // fp32 activations, fp16 filters: two-pass (wdtype F16) or exact three-pass (wdtype F32X3, a filter-side tag) fp16 MFMA
+    const bool split = d.dtype == MRCNN_F32 && (wdtype == MRCNN_F16 || wdtype == MRCNN_F32X3);
     MRCNN_REQUIRE(d.dtype == MRCNN_F32 || half, MRCNN_ERR_UNSUPPORTED, "conv: dtype %d", d.dtype);
     MRCNN_REQUIRE(wdtype == d.dtype || split, MRCNN_ERR_UNSUPPORTED, "conv: activation dtype %d with filter dtype %d", d.dtype, wdtype);
     const int bk = half ? 64 : 32, es = half ? 2 : 4;
@@ -619,7 +651,8 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
     const int e0 = prof ? prof_event(prof, s) : 0;
     if (half) conv_launch<_Float16, _Float16>(s, a, bn);
-    else if (split) conv_launch<float, _Float16>(s, a, bn);
+    else if (split && wdtype == MRCNN_F32X3) conv_launch<float, _Float16, 3>(s, a, bn);
+    else if (split) conv_launch<float, _Float16, 2>(s, a, bn);
     else conv_launch<float, float>(s, a, bn);
     if (prof) {
         const int e1 = prof_event(prof, s);

@@ -19,7 +19,7 @@ import numpy as np
 from . import _lib
 from .config import MaskRCNNConfig
 
-DTYPES = {"f32": _lib.F32, "f16": _lib.F16, "f32s": _lib.F32S}   # f32s: fp32 tensors, split-fp16 MFMA convolutions
+DTYPES = {"f32": _lib.F32, "f16": _lib.F16, "f32s": _lib.F32S, "f32x3": _lib.F32X3}   # f32s / f32x3: fp32 tensors, 2- / 3-part split-fp16 MFMA
 STAGES = ["Trunk", "Proposal-Eval", "PyramidROIAlign-Eval", "TimeDistributedClassifierLayer-Eval", "Detection-Eval",
           "PyramidROIAlign-Eval-Mask", "TimeDistributedMask-Eval"]
 

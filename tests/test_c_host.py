@@ -54,7 +54,7 @@ def test_c_host_builds_and_fails_loudly_without_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", ["f32", "f16", "f32s"])
+@pytest.mark.parametrize("dtype", ["f32", "f16", "f32s", "f32x3"])
 def test_c_host_matches_python_mirror(pkg, small_model, tmp_path, dtype):
     models = importlib.import_module("mask-rcnn-coreml_amd.models")
     ev = importlib.import_module("mask-rcnn-coreml_amd.evaluate")

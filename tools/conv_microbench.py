@@ -21,7 +21,7 @@ SHAPES = [  # (name, batch, h, w, cin, cout, k, stride)
     ("RPN 3x3 256->512 @128", 8, 128, 128, 256, 512, 3, 1),
 ]
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-dtype = {"f32": L.F32, "f16": L.F16, "f32s": L.F32S}[sys.argv[2] if len(sys.argv) > 2 else "f32"]
+dtype = {"f32": L.F32, "f16": L.F16, "f32s": L.F32S, "f32x3": L.F32X3}[sys.argv[2] if len(sys.argv) > 2 else "f32"]
 for name, b, h, w, ci, co, k, s in SHAPES:
     ms, fl = C.c_float(0), C.c_double(0)
     L.check(lib.mrcnn_bench_conv_dtype(b, h, w, ci, co, k, s, iters, dtype, C.byref(ms), C.byref(fl)))
