@@ -1,0 +1,52 @@
+"""bench.py's output contract, on a reduced workload so it runs in seconds: exactly one JSON line on stdout carrying the
+driver's fields plus the `roofline` and `cpu_baseline` objects (and `other_modes`), also through torch.distributed.run with the
+RCCL leg forced at world size 1."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--arch", "resnet50", "--size", "256", "--batch", "2", "--steps", "3", "--warmup", "1", "--cpu-images", "1"]
+
+
+def _check(line, n_gpus=1, steps=3, warmup=1):
+    j = json.loads(line)
+    for k, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                   ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
+        assert isinstance(j[k], typ), k
+    assert j["metric"].startswith("images/sec") and j["unit"] == "images/s" and j["higher_is_better"] is True
+    assert j["n_gpus"] == n_gpus and j["steps"] == steps and j["warmup"] == warmup and j["scaling"] == "weak"
+    assert j["vs_baseline"] is None and j["data"] == "synthetic" and "workload" in j["config"] and "model" not in j["config"]
+    assert abs(j["value"] - n_gpus * 2 * 1e3 / j["ms_per_step"]) / j["value"] < 1e-2            # whole-job images per second
+    r = j["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and 0 < r["frac"] < 1
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r and r["kernel"].startswith("k_conv_mfma_glds<")
+    return j
+
+
+def test_bench_json_contract():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                                   # ONE line on stdout
+    j = _check(lines[0])
+    c = j["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["unit"] == "images/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert c["value"] < j["value"]
+    assert set(j["other_modes"]) == {"f32x3", "f32s", "f16"} and all(v["value"] > 0 for v in j["other_modes"].values())
+
+
+def test_bench_under_torchrun_with_rccl_leg():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--no-cpu-baseline",
+           "--no-other-modes"] + SMALL
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                                   # RCCL's banner must not reach stdout
+    j = _check(lines[0])
+    assert "cpu_baseline" not in j and "other_modes" not in j
