@@ -354,3 +354,43 @@ def test_evaluate_harness(pkg, small_model):
     lb = E.letterbox(dict(images)[3], cfg.image_height, cfg.image_width)
     want = rp.detections_to_pb(m.prediction(lb)["detections"])
     assert results[2].detections == want and (results[2].width, results[2].height) == (160 - 21, 120)
+
+
+def test_layers_with_strided_and_device_arrays(pkg, orc):
+    """The MLMultiArray conventions the layers rely on: a row stride wider than the row (rois taken from (n,6) detection
+    rows, exactly how the mask branch feeds PyramidROIAlign, task.py:44-55) and arrays that already live on the GPU."""
+    import torch
+    rng = np.random.default_rng(31)
+    C, sizes, n, pool = 16, (32, 16, 8, 4), 40, 14
+    fm = _pyramid(rng, C, sizes)
+    det = np.zeros((n, 6), dtype=np.float32)
+    y1 = rng.random(n) * 0.6; x1 = rng.random(n) * 0.6
+    det[:, 0], det[:, 1], det[:, 2], det[:, 3] = y1, x1, y1 + rng.random(n) * 0.4, x1 + rng.random(n) * 0.4
+    det[:, 4] = rng.integers(1, 5, n); det[:, 5] = rng.random(n)
+    det[30:] = 0                                                          # zero-padded tail of a detections array
+    ML = pkg.MLMultiArray
+    layer = pkg.PyramidROIAlignLayer({"poolSize": pool, "imageWidth": 512, "imageHeight": 512})
+    want = orc.pyramid_roi_align(np.ascontiguousarray(det[:, :4]), fm, pool, 512, 512)
+    # host, strided rows: shape says 4 columns, stride says 6
+    out = np.full((n, 1, C, pool, pool), np.float32(np.nan), dtype=np.float32)
+    layer.evaluate([ML(det, shape=(n, 1, 4, 1, 1), strides=(6, 6, 1, 1, 1))] + [ML(f) for f in fm], [ML(out)])
+    np.testing.assert_array_equal(out.reshape(want.shape), want)
+    assert (out[30:] == 0).all()
+    # device-resident inputs and output, used in place
+    det_d = torch.from_numpy(det).cuda()
+    fm_d = [torch.from_numpy(f).cuda() for f in fm]
+    out_d = torch.full((n, 1, C, pool, pool), float("nan"), device="cuda")
+    layer.evaluate([ML(det_d, shape=(n, 1, 4, 1, 1), strides=(6, 6, 1, 1, 1))] + [ML(f) for f in fm_d], [ML(out_d)])
+    np.testing.assert_array_equal(out_d.cpu().numpy().reshape(want.shape), want)
+    # DetectionLayer writing into rows of a wider output array (row stride 8), device memory
+    rois = np.ascontiguousarray(det[:, :4])
+    cls = _cls6(rng, n, 5)
+    dl = pkg.DetectionLayer({"maxDetections": 12})
+    wide = torch.full((12, 8), -1.0, device="cuda")
+    dl.evaluate([ML(torch.from_numpy(rois).cuda()), ML(torch.from_numpy(cls).cuda())], [ML(wide, shape=(12, 1, 6, 1, 1), strides=(8, 8, 1, 1, 1))])
+    got = wide.cpu().numpy()
+    np.testing.assert_array_equal(got[:, :6], orc.detection_layer(rois, cls, 12, 0.7, 0.3))
+    nd = int((got[:, 5] > 0).sum())
+    assert 0 < nd < 12
+    assert (got[:nd, 6:] == -1).all()             # kept rows: only 6 floats written (DetectionLayer.swift:217-224)
+    assert (got[nd:] == 0).all()                  # padding rows: zeroed over the whole row stride (padTailWithZeros, :229-231)
