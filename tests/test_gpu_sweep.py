@@ -45,11 +45,15 @@ def _proposal_case(pkg, anchors_mod, orc, tmp_path, seed):
         deltas[rng.integers(0, A, 50), 2] = 1000.0    # expf(200) = inf → inf-sized box → clipped to the window
         deltas[rng.integers(0, A, 50), 3] = -1000.0   # expf(-200) = 0 → zero width
     params = dict(cfg.proposal_layer_params(), preNMSMaxProposals=pre, maxProposals=maxp, nmsIOUThreshold=thr)
+    std = (0.1, 0.1, 0.2, 0.2)
+    if seed % 4 == 3:                                 # bboxStdDev_* from the parameter dictionary (ProposalLayer.swift:70-80)
+        std = tuple(float(np.float32(v)) for v in rng.choice([0.05, 0.1, 0.2, 0.5], 4))
+        params.update({"bboxStdDev_count": 4, **{f"bboxStdDev_{i}": std[i] for i in range(4)}})
     stride = int(rng.choice([4, 4, 5, 8]))
     out = np.full((maxp, stride), np.float32(-3.0), dtype=np.float32)
     pkg.ProposalLayer(params).evaluate([ML(probs), ML(deltas)], [ML(out, shape=(maxp, 1, stride, 1, 1))])
     want = np.full((maxp, stride), np.float32(-3.0), dtype=np.float32)
-    want = orc.proposal_layer(probs, deltas, anchors, pre, maxp, thr, out_stride=stride, out=want)
+    want = orc.proposal_layer(probs, deltas, anchors, pre, maxp, thr, std=std, out_stride=stride, out=want)
     np.testing.assert_array_equal(out, want, err_msg=f"seed {seed}: {h}x{w} A={A} pre={pre} maxp={maxp} thr={thr} mode={mode}")
     return int((np.abs(want[:, :4]).sum(1) > 0).sum())
 
@@ -81,11 +85,12 @@ def test_detection_layer_sweep(pkg, orc):
         if n > 4:
             rois[1] = 0                               # padding ROI
             rois[2] = [0.9, 0.9, 0.1, 0.1]            # inverted ROI
-        params = {"bboxStdDev_count": 4, "bboxStdDev_0": 0.1, "bboxStdDev_1": 0.1, "bboxStdDev_2": 0.2, "bboxStdDev_3": 0.2,
+        std = (0.1, 0.1, 0.2, 0.2) if seed % 5 else tuple(float(np.float32(v)) for v in rng.choice([0.05, 0.1, 0.3], 4))
+        params = {"bboxStdDev_count": 4, "bboxStdDev_0": std[0], "bboxStdDev_1": std[1], "bboxStdDev_2": std[2], "bboxStdDev_3": std[3],
                   "maxDetections": maxd, "scoreThreshold": sthr, "nmsIOUThreshold": nthr}
         out = np.full((maxd, 6), np.float32(np.nan), dtype=np.float32)
         pkg.DetectionLayer(params).evaluate([ML(rois), ML(cls)], [ML(out)])
-        want = orc.detection_layer(rois, cls, maxd, sthr, nthr)
+        want = orc.detection_layer(rois, cls, maxd, sthr, nthr, std=std)
         np.testing.assert_array_equal(out, want, err_msg=f"seed {seed}: n={n} nc={nc} maxd={maxd} score>={sthr} iou>{nthr}")
         seen_counts.append(int((want[:, 5] > 0).sum()))
     assert max(seen_counts) >= 50 and min(seen_counts) == 0      # loaded and empty outcomes both occurred
