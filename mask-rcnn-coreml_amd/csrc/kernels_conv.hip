@@ -68,6 +68,21 @@ template <> __device__ __forceinline__ void store4<_Float16>(_Float16* p, float4
     *reinterpret_cast<f16x4*>(p) = h;
 }
 
+// 8 consecutive fp16 values as one 16-B access (the fp16 epilogue moves 8 columns per thread)
+__device__ __forceinline__ void load8h(const _Float16* p, float4& lo, float4& hi)
+{
+    const f16x8 h = *reinterpret_cast<const f16x8*>(p);
+    lo = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    hi = make_float4((float)h[4], (float)h[5], (float)h[6], (float)h[7]);
+}
+__device__ __forceinline__ void store8h(_Float16* p, const float4 lo, const float4 hi)
+{
+    f16x8 h;
+    h[0] = (_Float16)lo.x; h[1] = (_Float16)lo.y; h[2] = (_Float16)lo.z; h[3] = (_Float16)lo.w;
+    h[4] = (_Float16)hi.x; h[5] = (_Float16)hi.y; h[6] = (_Float16)hi.z; h[7] = (_Float16)hi.w;
+    *reinterpret_cast<f16x8*>(p) = h;
+}
+
 // Epilogue shared by the conv kernels: accumulators → LDS (fp32 C tile) → full-row vector stores with
 // fused scale/shift (BN + bias), residual, activation, column split / 2×2 scatter.
 // CPASS = 1: the whole BM×BN tile is staged at once; CPASS = WN (tiles whose fp32 C tile would not fit
@@ -86,7 +101,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
     const int ohw = a.OH * a.OW;
     // ---- accumulators → LDS → full-row vector stores ---------------------------------------------
     // (the loop's final barrier guarantees nobody still reads the operand buffers)
-    constexpr int TPR = CW / 4;       // threads per output row (4 columns each)
+    constexpr int CPT = sizeof(T) == 2 ? 8 : 4;   // columns per thread: 16 B of the activation type
+    constexpr int NV = CPT / 4;                   // float4 groups per thread
+    constexpr int TPR = CW / CPT;     // threads per output row
     constexpr int RPP = NT / TPR;     // rows per pass
     constexpr int NPASS = BM / RPP;
     const int c4 = t % TPR, rr = t / TPR;
@@ -100,21 +117,27 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
 
 #pragma unroll
     for (int h = 0; h < CPASS; ++h) {
-        const int n = n0 + h * CW + c4 * 4;
+        const int n = n0 + h * CW + c4 * CPT;
         const bool col_ok = n < a.ncols;
         // Residual / scale / shift are fetched BEFORE the accumulators are staged through LDS: `res` and
         // `out` may alias as far as the compiler knows, so inside the store loop every residual load would
         // wait behind the previous store (16 serialized HBM round trips per thread on the branch2c layers).
-        float4 rv[NPASS];
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 rv[NPASS][NV];
+        float4 sc[NV], sh[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) { sc[q] = make_float4(1.f, 1.f, 1.f, 1.f); sh[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
         if (a.vec_ok && col_ok) {
-            if (a.scale) sc = *reinterpret_cast<const float4*>(a.scale + n);
-            if (a.shift) sh = *reinterpret_cast<const float4*>(a.shift + n);
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                if (a.scale) sc[q] = *reinterpret_cast<const float4*>(a.scale + n + 4 * q);
+                if (a.shift) sh[q] = *reinterpret_cast<const float4*>(a.shift + n + 4 * q);
+            }
             if (res) {
 #pragma unroll
                 for (int ps = 0; ps < NPASS; ++ps) {
                     const int m = m0 + rr + ps * RPP;
-                    rv[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) rv[ps][q] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (m < a.M) {
                         long ro;
                         if (dense_res) ro = (long)m * a.res_sW;
@@ -125,7 +148,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
                                 ro = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
                             } else ro = (long)b * a.res_sB + (long)pix * a.res_sW;
                         }
-                        rv[ps] = load4<T>(res + ro + n);
+                        if constexpr (CPT == 8) load8h(reinterpret_cast<const _Float16*>(res) + ro + n, rv[ps][0], rv[ps][NV - 1]);
+                        else rv[ps][0] = load4<T>(res + ro + n);
                     }
                 }
             }
@@ -157,20 +181,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
                 int b = 0, pix = m, oh = 0, ow = 0;
                 if (need_bp) { b = m / ohw; pix = m - b * ohw; }
                 if (need_yx) { oh = pix / a.OW; ow = pix - oh * a.OW; }
-                float4 v = *reinterpret_cast<const float4*>(&Cs[r * CW + c4 * 4]);
-                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-                if (res) { v.x += rv[ps].x; v.y += rv[ps].y; v.z += rv[ps].z; v.w += rv[ps].w; }
-                if (a.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                else if (a.act == ACT_SIGMOID) {
-                    v.x = 1.0f / (1.0f + expf(-v.x)); v.y = 1.0f / (1.0f + expf(-v.y));
-                    v.z = 1.0f / (1.0f + expf(-v.z)); v.w = 1.0f / (1.0f + expf(-v.w));
+                float4 v[NV];
+#pragma unroll
+                for (int q = 0; q < NV; ++q) {
+                    float4 x = *reinterpret_cast<const float4*>(&Cs[r * CW + c4 * CPT + 4 * q]);
+                    x.x = x.x * sc[q].x + sh[q].x; x.y = x.y * sc[q].y + sh[q].y; x.z = x.z * sc[q].z + sh[q].z; x.w = x.w * sc[q].w + sh[q].w;
+                    if (res) { x.x += rv[ps][q].x; x.y += rv[ps][q].y; x.z += rv[ps][q].z; x.w += rv[ps][q].w; }
+                    if (a.act == ACT_RELU) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+                    else if (a.act == ACT_SIGMOID) {
+                        x.x = 1.0f / (1.0f + expf(-x.x)); x.y = 1.0f / (1.0f + expf(-x.y));
+                        x.z = 1.0f / (1.0f + expf(-x.z)); x.w = 1.0f / (1.0f + expf(-x.w));
+                    }
+                    out_of_range = out_of_range || !(fabsf(x.x) < 65504.0f) || !(fabsf(x.y) < 65504.0f) || !(fabsf(x.z) < 65504.0f) || !(fabsf(x.w) < 65504.0f);
+                    v[q] = x;
                 }
-                out_of_range = out_of_range || !(fabsf(v.x) < 65504.0f) || !(fabsf(v.y) < 65504.0f) || !(fabsf(v.z) < 65504.0f) || !(fabsf(v.w) < 65504.0f);
                 long o;
                 if (a.deconv2) o = (long)b * a.out_sB + (long)(2 * oh + (qd >> 1)) * a.out_sH + (long)(2 * ow + (qd & 1)) * a.out_sW + co;
                 else o = (dense_out ? (long)m * a.out_sP : (long)b * a.out_sB + (long)pix * a.out_sP) + n;
-                if (a.out_f32) store4<float>(static_cast<float*>(a.out) + o, v);
-                else store4<T>(static_cast<T*>(a.out) + o, v);
+                if (a.out_f32) {
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) store4<float>(static_cast<float*>(a.out) + o + 4 * q, v[q]);
+                } else if constexpr (CPT == 8) store8h(reinterpret_cast<_Float16*>(a.out) + o, v[0], v[NV - 1]);
+                else store4<T>(static_cast<T*>(a.out) + o, v[0]);
             }
         } else {
             for (int r = rr; r < BM; r += RPP) {
@@ -179,10 +211,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
                 const int b = m / ohw, pix = m - b * ohw;
                 const int oh = pix / a.OW, ow = pix - oh * a.OW;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < CPT; ++c) {
                     const int nn = n + c;
                     if (nn >= a.ncols) break;
-                    float v = Cs[r * CW + c4 * 4 + c];
+                    float v = Cs[r * CW + c4 * CPT + c];
                     v = v * (a.scale ? a.scale[nn] : 1.0f) + (a.shift ? a.shift[nn] : 0.0f);
                     if (res) {
                         long ro;
@@ -643,10 +675,11 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     while (bn > 32 && (long)a.tiles_m * (d.Npad / bn) < 512) bn >>= 1;
     const size_t out_es = a.out_f32 ? 4 : 2;
     auto al = [](const void* p, size_t n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
-    a.vec_ok = a.ncols % 4 == 0 && d.out2 == nullptr && d.out_sP % 4 == 0 && d.out_sB % 4 == 0 && al(d.out, 4 * out_es) &&
+    const int cpt = half ? 8 : 4;        // columns per epilogue thread: 16 B of the activation type
+    a.vec_ok = a.ncols % cpt == 0 && d.out2 == nullptr && d.out_sP % cpt == 0 && d.out_sB % cpt == 0 && al(d.out, 16) &&
                (!d.scale || al(d.scale, 16)) && (!d.shift || al(d.shift, 16)) &&
-               (!d.res || (d.res_sW % 4 == 0 && d.res_sH % 4 == 0 && d.res_sB % 4 == 0 && al(d.res, 4 * (size_t)es))) &&
-               (!d.deconv2 || (d.Cout % 4 == 0 && d.out_sH % 4 == 0 && d.out_sW % 4 == 0));
+               (!d.res || (d.res_sW % cpt == 0 && d.res_sH % cpt == 0 && d.res_sB % cpt == 0 && al(d.res, 16))) &&
+               (!d.deconv2 || (d.Cout % cpt == 0 && d.out_sH % cpt == 0 && d.out_sW % cpt == 0));
     a.tiles_n = d.Npad / bn;
     ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
     const int e0 = prof ? prof_event(prof, s) : 0;
