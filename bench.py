@@ -53,7 +53,11 @@ def main():
                          "f16 = fp16 MFMA with fp32 accumulation (BASELINE configs[3]); f32s = fp32 tensors, every "
                          "convolution as two fp16 MFMA passes over a hi/lo split of its activations (fp32-grade results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=3)
+    ap.add_argument("--cpu-images", type=int, default=5,
+                    help="timed oracle images after 1 warm-up (SURVEY.md §8d / EvaluateCommand.swift:165: 5 images)")
+    ap.add_argument("--e2e-images", type=int, default=16,
+                    help="images on which HIP predict is compared end to end with the CPU oracle's predict (parity_e2e); the "
+                         "warm-up and timed images of the cpu_baseline leg are the first of them; 0 = skip")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run the all-gather leg even at world size 1 (self-test of the N > 1 path)")
@@ -184,6 +188,20 @@ def main():
                                          "survey_gflop_per_image": GFLOP_PER_IMAGE_SURVEY,
                                          "share_of_step_time": round(all_ms / (1e3 * elapsed * ev_steps / args.steps), 4)},
                 }
+        # images of the end-to-end parity leg (the oracle sees the same ones): seed 1 stream, after this rank's bench batch
+        n_e2e = 0 if (n_gpus != 1 or args.no_cpu_baseline) else max(args.e2e_images, 0)
+        e2e_imgs = rng.integers(0, 256, (max(n_e2e, 1 + args.cpu_images), args.size, args.size, 3), dtype=np.uint8)
+        e2e_pred = {}
+
+        def hip_predict_all(model):
+            dd, kk = [], []
+            for i in range(0, n_e2e, B):
+                d_, k_ = model.predict(e2e_imgs[i:min(i + B, n_e2e)])
+                dd.append(d_); kk.append(k_)
+            return np.concatenate(dd), np.concatenate(kk)
+
+        if n_e2e:
+            e2e_pred[args.dtype] = hip_predict_all(m)
         if n_gpus == 1 and not args.no_other_modes:
             # the same workload in the engine's other compute modes (same images, same weights): not the headline value
             out["other_modes"] = {}
@@ -191,6 +209,8 @@ def main():
                 if mode == args.dtype:
                     continue
                 mm = models.load_maskrcnn(model_dir, max_batch=B, compute_dtype=mode)
+                if n_e2e:
+                    e2e_pred[mode] = hip_predict_all(mm)
                 for _ in range(2):
                     mm.predict_into(images, det, mask, sync=True)
                 torch.cuda.synchronize()
@@ -207,7 +227,9 @@ def main():
                                                               "activations (every product equals the fp32 product)"}[mode]}
                 del mm
         if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model_dir, cfg, args)
+            out["cpu_baseline"], oracle_pred = cpu_baseline(model_dir, cfg, args, e2e_imgs)
+            if n_e2e:
+                out["parity_e2e"] = parity_e2e(e2e_pred, oracle_pred, n_e2e)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
@@ -227,25 +249,86 @@ def pmc_traffic():
         return None
 
 
-def cpu_baseline(model_dir, cfg, args):
-    """The oracle on host cores: 1 warm-up image, then `cpu_images` images, wall clock around predict
-    only, model load excluded (EvaluateCommand.swift:146-179); median ms/image → images/s."""
+def host_cores():
+    """(physical, logical) core counts of the host."""
+    logical = os.cpu_count() or 1
+    physical = None
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False)
+    except Exception:
+        pass
+    if not physical:
+        try:
+            seen = set()
+            phys = core = None
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        seen.add((phys, core))
+                    phys = core = None
+            physical = len(seen) or None
+        except Exception:
+            physical = None
+    return int(physical or logical), int(logical)
+
+
+def cpu_baseline(model_dir, cfg, args, imgs):
+    """The oracle on host cores, to the reference's protocol (EvaluateCommand.swift:146-179): model load
+    excluded, 1 warm-up image, then `cpu_images` images one at a time, wall clock around predict only; median
+    ms/image → images/s.  Threads pinned to the physical core count.  The remaining images (up to --e2e-images)
+    are predicted untimed: their outputs are the checker side of parity_e2e."""
     import numpy as np
     import torch
     from oracle.network import load_oracle_model
+    physical, logical = host_cores()
+    torch.set_num_threads(physical)
+    os.environ["OMP_NUM_THREADS"] = str(physical)
     om = load_oracle_model(model_dir, cfg)
-    rng = np.random.default_rng(1)
-    imgs = rng.integers(0, 256, (1 + args.cpu_images, args.size, args.size, 3), dtype=np.uint8)
-    om.predict(imgs[:1])
-    ts = []
-    for i in range(args.cpu_images):
+    dets, masks, ts = [], [], []
+    n_total = max(1 + args.cpu_images, args.e2e_images if args.e2e_images > 0 else 0)
+    for i in range(min(n_total, imgs.shape[0])):
         t0 = time.perf_counter()
-        om.predict(imgs[1 + i:2 + i])
-        ts.append(time.perf_counter() - t0)
+        d, k = om.predict(imgs[i:i + 1])
+        dt = time.perf_counter() - t0
+        if 1 <= i <= args.cpu_images:
+            ts.append(dt)
+        dets.append(d[0]); masks.append(k[0])
     med = float(np.median(ts))
-    return {"value": round(1.0 / med, 4), "unit": "images/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"{args.cpu_images} images of the same workload after 1 warm-up, batch 1, median "
-                      f"{round(med * 1e3, 1)} ms/image; torch-CPU fp32 network (oneDNN) + C restatement of the custom layers"}
+    rec = {"value": round(1.0 / med, 4), "unit": "images/s", "cores": int(torch.get_num_threads()), "physical_cores": physical,
+           "logical_cores": logical, "kind": "port",
+           "sample": f"{len(ts)} images of the same workload after 1 warm-up, batch 1, median {round(med * 1e3, 1)} ms/image "
+                     f"(min {round(min(ts) * 1e3, 1)}, max {round(max(ts) * 1e3, 1)}); torch-CPU fp32 network (oneDNN, "
+                     f"{int(torch.get_num_threads())} threads = physical cores) + C restatement of the custom layers (1 thread)"}
+    return rec, (np.stack(dets), np.stack(masks))
+
+
+def parity_e2e(hip_pred, oracle_pred, n):
+    """HIP predict vs the CPU oracle's predict on the same n images, per compute mode: share of detections with the
+    same class id and a box within 1e-4 (order-insensitive), and how far scores / masks of matched detections differ.
+    Differences come from the convolutions' summation order (fp32 modes) or precision (f16) moving a score across a
+    threshold / a neighbour in the NMS order; every stage is bit-exact on equal inputs (tests/)."""
+    import numpy as np
+    ev = importlib.import_module("mask-rcnn-coreml_amd.evaluate")
+    od, ok = oracle_pred
+    out = {"images": int(n), "box_tol": 1e-4, "modes": {}}
+    for mode, (hd, hk) in hip_pred.items():
+        tot_m = tot_d = same = 0
+        identical = 0
+        ds = dm = 0.0
+        for i in range(n):
+            a = ev.detection_agreement(hd[i], od[i], 1e-4, hk[i], ok[i])
+            tot_m += a["matched"]; tot_d += max(a["n_a"], a["n_b"]); same += a["same_row"]
+            identical += int(a["matched"] == max(a["n_a"], a["n_b"]))
+            ds = max(ds, a["max_score_diff"]); dm = max(dm, a["max_mask_diff"])
+        out["modes"][mode] = {"detections": int(tot_d), "matched": int(tot_m), "fraction": round(tot_m / max(tot_d, 1), 4),
+                              "same_rank": int(same), "images_fully_matched": int(identical),
+                              "max_score_diff": float(np.float32(ds)), "max_mask_diff": float(np.float32(dm))}
+    return out
 
 
 if __name__ == "__main__":

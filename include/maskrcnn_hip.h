@@ -192,8 +192,10 @@ MRCNN_API int mrcnn_classifier_predict(mrcnn_model* model, const float* feature_
 MRCNN_API int mrcnn_mask_predict(mrcnn_model* model, const float* feature_map, int n, int memspace,
                                  float* masks);
 
-/* Introspection (integers from the artefact's metadata): "num_classes", "image_height",
- * "image_width", "max_proposals", "max_detections", "num_anchors", "pre_nms_max_proposals". */
+/* Introspection: "num_classes", "image_height", "image_width", "max_proposals", "max_detections", "num_anchors",
+ * "pre_nms_max_proposals", "pre_nms_count" (= min(num_anchors, pre_nms_max_proposals)), "mask_size" (side of the
+ * square masks predict returns: 2 × the mask pool size = 28), "max_batch", "compute_dtype", "range_overflows",
+ * "graph_enabled", "graph_launches"; any other key is looked up in the artefact's integer metadata. */
 MRCNN_API int mrcnn_model_get_int(mrcnn_model* model, const char* key, int64_t* value);
 
 /* Debug taps for parity tests: copies a named intermediate of the last predict (image b) to a host
@@ -201,9 +203,27 @@ MRCNN_API int mrcnn_model_get_int(mrcnn_model* model, const char* key, int64_t* 
  * "rpn_deltas" (A,4), "P2".."P5" (H,W,256 NHWC), "topk_idx" (int32 stored as float-exact values),
  * "boxes_sorted" (n,4), "rois" (maxProposals,4), "pooled" (maxProposals,7,7,256 NHWC),
  * "cls_probs" (maxProposals,nc), "cls_bbox" (maxProposals,nc*4), "cls6" (maxProposals,6),
- * "detections" (maxDetections,6), "pooled_mask" (maxDetections,14,14,256 NHWC), "mask" (maxDetections,784). */
+ * "detections" (maxDetections,6), "pooled_mask" (maxDetections,14,14,256 NHWC), "mask" (maxDetections,784),
+ * "keep_count" (1), "mask_row_flags" (maxDetections: the mask layer's removeZeros predicate per detection row). */
 MRCNN_API int mrcnn_model_read_tensor(mrcnn_model* model, const char* name, int image_index,
                                       float* host_dst, int64_t capacity, int64_t* count);
+
+/* fp16-range watchdog for the enqueue-only path: mrcnn_maskrcnn_predict reports an activation that left the fp16
+ * range (MRCNN_F16 / MRCNN_F32S / MRCNN_F32X3) as MRCNN_ERR_UNSUPPORTED when it synchronises; _predict_async cannot.
+ * Call this after the stream work of an async predict has been ordered before the caller's consumer: it
+ * synchronises the model's stream and sets *tripped = 1 when the LAST predict's results are not valid
+ * (counted in "range_overflows" like the synchronous path).  Always 0 in MRCNN_F32. */
+MRCNN_API int mrcnn_model_check_range(mrcnn_model* model, int* tripped);
+
+/* PyramidROIAlign (PyramidROIAlignLayer.swift:79-181) on the engine's own layout: four NHWC maps (H_l, W_l, C),
+ * dtype MRCNN_F32 or MRCNN_F16; rois rows (y1,x1,y2,x2,...) of `roi_stride` floats; out (n_rois, pool, pool, C)
+ * in the maps' dtype.  row_flags (optional, n_rois int32): the removeZeros predicate the mask layer applies to a
+ * pooled row (TimeDistributedClassifierLayer.swift:116-127: kept iff every element != 0) evaluated on the fp32
+ * samples BEFORE the store rounds them — in fp16 a tiny non-zero sample would otherwise flush to zero and drop a
+ * valid detection.  This is what the fused engine uses; the stand-alone MLCustomLayer entry takes CHW fp32. */
+MRCNN_API int mrcnn_roi_align_nhwc(const void* const maps[4], const int heights[4], const int widths[4], int channels,
+                                   int dtype, const float* rois, int64_t roi_stride, int n_rois, int pool,
+                                   double image_w, double image_h, int memspace, void* out, int32_t* row_flags);
 
 /* Per-stage GPU time of the last predict in milliseconds (HIP events on the model's stream).
  * Stage names mirror the reference's os_signpost intervals (ProposalLayer.swift:105-194 etc.):
@@ -241,6 +261,18 @@ MRCNN_API int mrcnn_bench_conv(int batch, int h, int w, int cin, int cout, int k
 /* Same with an explicit element type (MRCNN_F32 | MRCNN_F16, fp32 accumulate). */
 MRCNN_API int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout, int ksize, int stride,
                                      int iters, int dtype, float* avg_ms, double* flops);
+
+/* One convolution of the engine's kernel family on caller (host) data — the unit the parity tests of the kernels use:
+ * in (B,H,W,Cin) NHWC fp32, filters (Cout, k, k, Cin) fp32 (k = 1 | 3, 'same' padding k/2), optional per-channel
+ * scale/shift (folded BatchNorm + bias), optional residual (B,OH,OW,Cout), act 0 none | 1 ReLU | 2 sigmoid;
+ * dtype = compute mode (inputs are converted to it on the host, round-to-nearest); out (B,OH,OW,Cout) fp32
+ * (the unrounded epilogue result).  mrcnn_debug_set switches kernel-selection policy knobs for A/B tests
+ * ("conv_pp" 0|1: the 256-row ping-pong fp16 kernels; "conv_pp_min_tiles", "conv_pp_min_kt"): every choice must give
+ * bit-identical results — the tile shape depends on the batch size and per-image results must not. */
+MRCNN_API int mrcnn_conv2d_nhwc(const float* in, int batch, int h, int w, int cin, const float* filters, int cout,
+                                int ksize, int stride, const float* scale, const float* shift, const float* residual,
+                                int act, int dtype, float* out);
+MRCNN_API int mrcnn_debug_set(const char* key, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * Result decoding — Detection.detectionsFromFeatureValue (Sources/Mask-RCNN-CoreML/

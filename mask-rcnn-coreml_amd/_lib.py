@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = [
     "mrcnn_model_read_tensor", "mrcnn_model_enable_timing", "mrcnn_model_stage_ms", "mrcnn_bench_conv",
     "mrcnn_model_conv_profile_enable", "mrcnn_model_conv_profile_get", "mrcnn_model_conv_profile_shapes", "mrcnn_model_enable_graph", "mrcnn_bench_conv_dtype",
     "mrcnn_detections_decode", "mrcnn_mask_to_u8", "mrcnn_paste_masks", "mrcnn_generate_anchors", "mrcnn_letterbox_geometry", "mrcnn_letterbox_rgb",
+    "mrcnn_model_check_range", "mrcnn_roi_align_nhwc", "mrcnn_conv2d_nhwc", "mrcnn_debug_set",
 ]
 
 
@@ -122,6 +123,11 @@ def lib():
     L.mrcnn_letterbox_rgb.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int]
     L.mrcnn_generate_anchors.argtypes = [C.c_int, C.c_int, vp, C.c_int64, i64p]
     L.mrcnn_paste_masks.argtypes = [vp, C.c_int64, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp]
+    L.mrcnn_conv2d_nhwc.argtypes = [vp] + [C.c_int] * 4 + [vp] + [C.c_int] * 3 + [vp, vp, vp, C.c_int, C.c_int, vp]
+    L.mrcnn_debug_set.argtypes = [cp, C.c_int]
+    L.mrcnn_model_check_range.argtypes = [vp, ip]
+    L.mrcnn_roi_align_nhwc.argtypes = [C.POINTER(vp), ip, ip, C.c_int, C.c_int, vp, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double,
+                                       C.c_int, vp, vp]
     _lib = L
     return L
 

@@ -308,6 +308,7 @@ struct ClassifierLayerImpl : mrcnn_layer {
         const long row = (long)C * ph * pw;
         DevBuf ti;
         const float* chw = stage_rows(in[0].data, in[0].memspace, n, row, in[0].strides[0], ti);
+        std::lock_guard<std::mutex> lk(model->eval_mu);   // the head's scratch is shared by every layer instance
         nchw_to_nhwc_forward(st.s, chw, n, C, ph, pw, hd.stage_in, hd.dtype);
         hd.forward(st.s, hd.stage_in, (int)n, hd.cls6, 6);
         HIP_CHECK(hipStreamSynchronize(st.s));
@@ -410,6 +411,7 @@ struct MaskLayerImpl : mrcnn_layer {
         ws.flags = ws_buf.as<int32_t>();
         ws.mapping = ws.flags + det_count;
         ws.kept = ws.mapping + det_count;
+        std::lock_guard<std::mutex> lk(model->eval_mu);   // the head's scratch is shared by every layer instance
         mask_valid_rows_forward(st.s, chw, 0, row, row, (int)D, 1, ws, MRCNN_F32);          // removeZeros:true (:52)
         nchw_to_nhwc_forward(st.s, chw, D, C, ph, pw, hd.stage_in, hd.dtype);
         hd.forward_features(st.s, hd.stage_in, (int)D);
@@ -632,6 +634,65 @@ extern "C" int mrcnn_model_read_tensor(mrcnn_model* model, const char* name, int
     });
 }
 
+extern "C" int mrcnn_model_check_range(mrcnn_model* model, int* tripped)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model && tripped, MRCNN_ERR_INVALID, "null argument");
+        Model& m = model->m;
+        *tripped = 0;
+        if (m.mode == MRCNN_F32 || !m.range_flag.p) return;           // exact-fp32 mode has no fp16 hand-over to watch
+        HIP_CHECK(hipStreamSynchronize(m.stream));
+        int t = 0;
+        HIP_CHECK(hipMemcpy(&t, m.range_flag.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (t) ++m.range_overflows;
+        *tripped = t ? 1 : 0;
+    });
+}
+
+// PyramidROIAlign on the engine's own layout (NHWC maps, fp32 or fp16) with the mask layer's removeZeros predicate
+extern "C" int mrcnn_roi_align_nhwc(const void* const maps[4], const int heights[4], const int widths[4], int channels, int dtype,
+                                    const float* rois, int64_t roi_stride, int n_rois, int pool, double image_w, double image_h,
+                                    int memspace, void* out, int32_t* row_flags)
+{
+    return guarded([&] {
+        require_gpu();
+        MRCNN_REQUIRE(maps && heights && widths && rois && out, MRCNN_ERR_INVALID, "null argument");
+        MRCNN_REQUIRE(dtype == MRCNN_F32 || dtype == MRCNN_F16, MRCNN_ERR_UNSUPPORTED, "roi_align_nhwc: dtype %d", dtype);
+        MRCNN_REQUIRE(n_rois >= 0 && pool >= 1 && channels >= 4 && channels % 4 == 0 && roi_stride >= 4, MRCNN_ERR_INVALID, "bad roi_align_nhwc argument");
+        if (n_rois == 0) return;
+        const size_t es = dtype == MRCNN_F16 ? 2 : 4;
+        Stream st;
+        DevBuf tm[4], tr, to, tf;
+        PyramidMaps pm;
+        for (int l = 0; l < 4; ++l) {
+            MRCNN_REQUIRE(maps[l] && heights[l] > 0 && widths[l] > 0, MRCNN_ERR_INVALID, "roi_align_nhwc: level %d missing", l);
+            const size_t bytes = (size_t)heights[l] * widths[l] * channels * es;
+            const void* p = maps[l];
+            if (memspace != MRCNN_DEVICE) {
+                tm[l].alloc(bytes);
+                HIP_CHECK(hipMemcpy(tm[l].p, maps[l], bytes, hipMemcpyHostToDevice));
+                p = tm[l].p;
+            }
+            pm.data[l] = p; pm.H[l] = heights[l]; pm.W[l] = widths[l]; pm.sB[l] = 0;
+        }
+        const float* r = stage_rows(rois, memspace, n_rois, roi_stride, roi_stride, tr);
+        const long row = (long)pool * pool * channels;
+        void* o = out;
+        int32_t* f = row_flags;
+        if (memspace != MRCNN_DEVICE) {
+            to.alloc((size_t)n_rois * row * es);
+            o = to.p;
+            if (row_flags) { tf.alloc((size_t)n_rois * 4); f = tf.as<int32_t>(); }
+        }
+        roi_align_forward(st.s, pm, channels, 1, r, 0, roi_stride, n_rois, 1, pool, image_w, image_h, o, 0, row, dtype, f);
+        HIP_CHECK(hipStreamSynchronize(st.s));
+        if (memspace != MRCNN_DEVICE) {
+            HIP_CHECK(hipMemcpy(out, to.p, (size_t)n_rois * row * es, hipMemcpyDeviceToHost));
+            if (row_flags) HIP_CHECK(hipMemcpy(row_flags, tf.p, (size_t)n_rois * 4, hipMemcpyDeviceToHost));
+        }
+    });
+}
+
 extern "C" int mrcnn_model_enable_timing(mrcnn_model* model, int on)
 {
     return guarded([&] {
@@ -666,7 +727,7 @@ extern "C" int mrcnn_model_conv_profile_enable(mrcnn_model* model, int on)
 extern "C" int mrcnn_model_conv_profile_get(mrcnn_model* model, int tile, int64_t* launches, double* total_ms, double* total_flops)
 {
     return guarded([&] {
-        MRCNN_REQUIRE(model && launches && total_ms && total_flops && tile >= 0 && tile < 4, MRCNN_ERR_INVALID, "bad argument");
+        MRCNN_REQUIRE(model && launches && total_ms && total_flops && tile >= 0 && tile < 6, MRCNN_ERR_INVALID, "bad argument");
         HIP_CHECK(hipStreamSynchronize(model->m.stream));
         model->m.conv_profile.collect();
         const auto& sl = model->m.conv_profile.by_tile[tile];
@@ -758,6 +819,72 @@ extern "C" int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout
         (void)hipEventDestroy(e1);
         *avg_ms = ms / iters;
         *flops = 2.0 * (double)batch * oh * ow * (double)cout * ksize * ksize * cin;
+    });
+}
+
+// ================================================================================================
+// One convolution of the engine's kernel family on caller data (parity tests of the kernels themselves: every tile
+// shape / pipeline variant must give bit-identical results, since the choice depends on the batch size)
+// ================================================================================================
+extern "C" int mrcnn_debug_set(const char* key, int value)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(key, MRCNN_ERR_INVALID, "null key");
+        MRCNN_REQUIRE(conv_debug_set(key, value), MRCNN_ERR_INVALID, "unknown debug key '%s'", key);
+    });
+}
+
+extern "C" int mrcnn_conv2d_nhwc(const float* in, int batch, int h, int w, int cin, const float* filters, int cout, int ksize, int stride,
+                                 const float* scale, const float* shift, const float* residual, int act, int dtype, float* out)
+{
+    return guarded([&] {
+        require_gpu();
+        MRCNN_REQUIRE(in && filters && out && batch >= 1 && h >= 1 && w >= 1 && cout >= 1 && (ksize == 1 || ksize == 3) && stride >= 1,
+                      MRCNN_ERR_INVALID, "bad conv2d_nhwc argument");
+        MRCNN_REQUIRE(dtype == MRCNN_F32 || dtype == MRCNN_F16 || dtype == MRCNN_F32S || dtype == MRCNN_F32X3, MRCNN_ERR_UNSUPPORTED, "conv2d_nhwc: dtype %d", dtype);
+        const int adt = dtype == MRCNN_F16 ? MRCNN_F16 : MRCNN_F32;
+        const int wdt = dtype == MRCNN_F32 ? MRCNN_F32 : (dtype == MRCNN_F32X3 ? MRCNN_F32X3 : MRCNN_F16);
+        MRCNN_REQUIRE(cin % (adt == MRCNN_F16 ? 64 : 32) == 0, MRCNN_ERR_SHAPE, "conv2d_nhwc: Cin %d not a multiple of the K tile", cin);
+        const int pad = ksize / 2;
+        const int oh = (h + 2 * pad - ksize) / stride + 1, ow = (w + 2 * pad - ksize) / stride + 1;
+        const int bn = conv_n_tile(cout), npad = (cout + bn - 1) / bn * bn;
+        const size_t n_in = (size_t)batch * h * w * cin, kk = (size_t)ksize * ksize * cin, n_out = (size_t)batch * oh * ow * cout;
+        auto to_dev = [&](const float* src, size_t n, size_t n_alloc, bool half, DevBuf& d) {
+            if (half) {
+                std::vector<_Float16> t(n_alloc, (_Float16)0.f);
+                for (size_t i = 0; i < n; ++i) t[i] = (_Float16)src[i];
+                d.alloc(n_alloc * 2);
+                HIP_CHECK(hipMemcpy(d.p, t.data(), n_alloc * 2, hipMemcpyHostToDevice));
+            } else {
+                std::vector<float> t(n_alloc, 0.f);
+                memcpy(t.data(), src, n * 4);
+                d.alloc(n_alloc * 4);
+                HIP_CHECK(hipMemcpy(d.p, t.data(), n_alloc * 4, hipMemcpyHostToDevice));
+            }
+        };
+        DevBuf din, dw, ds, db, dres, dout;
+        to_dev(in, n_in, n_in, adt == MRCNN_F16, din);
+        to_dev(filters, (size_t)cout * kk, (size_t)npad * kk, wdt != MRCNN_F32, dw);
+        std::vector<float> hs(npad, 0.f), hb(npad, 0.f);
+        for (int o = 0; o < cout; ++o) { hs[o] = scale ? scale[o] : 1.f; hb[o] = shift ? shift[o] : 0.f; }
+        ds.alloc((size_t)npad * 4); db.alloc((size_t)npad * 4);
+        HIP_CHECK(hipMemcpy(ds.p, hs.data(), (size_t)npad * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(db.p, hb.data(), (size_t)npad * 4, hipMemcpyHostToDevice));
+        if (residual) to_dev(residual, n_out, n_out, adt == MRCNN_F16, dres);
+        dout.alloc(n_out * 4);
+        ConvDesc d;
+        d.dtype = adt; d.wdtype = wdt; d.out_f32 = 1;
+        d.in = din.p; d.B = batch; d.H = h; d.W = w; d.Cin = cin;
+        d.in_sW = cin; d.in_sH = (long)w * cin; d.in_sB = (long)h * w * cin;
+        d.wgt = dw.p; d.KH = d.KW = ksize; d.stride = stride; d.padH = d.padW = pad;
+        d.scale = ds.as<float>(); d.shift = db.as<float>();
+        d.OH = oh; d.OW = ow; d.Cout = cout; d.Npad = npad;
+        d.out = dout.p; d.out_sP = cout; d.out_sB = (long)oh * ow * cout; d.act = act;
+        if (residual) { d.res = dres.p; d.res_sB = d.out_sB; d.res_sW = cout; d.res_sH = (long)ow * cout; }
+        Stream st;
+        conv_forward(st.s, d);
+        HIP_CHECK(hipStreamSynchronize(st.s));
+        HIP_CHECK(hipMemcpy(out, dout.p, n_out * 4, hipMemcpyDeviceToHost));
     });
 }
 

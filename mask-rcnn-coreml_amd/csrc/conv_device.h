@@ -1,0 +1,230 @@
+// conv_device.h — device-side pieces shared by the convolution kernels (kernels_conv.hip: the 128-row tiles of every
+// compute mode; kernels_conv_pp.hip: the 256-row ping-pong fp16 tiles): launch arguments, 16-B load/store helpers and the
+// fused epilogue.  Private to libmaskrcnn_hip.so.
+#pragma once
+#include "kernels.h"
+
+namespace mrcnn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+    const void* in; const void* wgt; const float* scale; const float* shift; const void* res;
+    void* out; void* out2;
+    long in_sB, in_sH, in_sW;
+    long res_sB, res_sH, res_sW;
+    long out_sB, out_sP, out_sH, out_sW;
+    long out2_sB, out2_sP;
+    int B, H, W, Cin, KH, KW, stride, padH, padW;
+    int OH, OW, Cout, ncols, Ktot, M;
+    int res_shift, act, n_split, deconv2;
+    int tiles_m, tiles_n;
+    int vec_ok;          // epilogue may use vector stores / residual loads
+    int out_f32;         // store fp32 even when the activations are fp16 (RPN outputs, class logits, masks)
+    const void* zero_page;   // >= 16 B of zeros in HBM: source of out-of-image taps for the DMA variant
+    int* range_flag;         // optional: set to 1 when an output leaves the fp16 range (|v| >= 65504 or NaN)
+    int dbg;                 // ablation switches of the ping-pong kernels (measurement only; 0 in production)
+};
+
+static constexpr int BM_DEFAULT = 128;   // rows of the block tile = WM*TM*32
+
+template <typename T> struct Elem;
+template <> struct Elem<float> { static constexpr int EPV = 4; };        // elements per 16-B vector
+template <> struct Elem<_Float16> { static constexpr int EPV = 8; };
+
+template <typename T> __device__ __forceinline__ float4 load4(const T* p);
+template <> __device__ __forceinline__ float4 load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 load4<_Float16>(const _Float16* p)
+{
+    const f16x4 h = *reinterpret_cast<const f16x4*>(p);
+    return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, float4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+template <> __device__ __forceinline__ void store4<_Float16>(_Float16* p, float4 v)
+{
+    f16x4 h;
+    h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+    *reinterpret_cast<f16x4*>(p) = h;
+}
+
+// 8 consecutive fp16 values as one 16-B access (the fp16 epilogue moves 8 columns per thread)
+__device__ __forceinline__ void load8h(const _Float16* p, float4& lo, float4& hi)
+{
+    const f16x8 h = *reinterpret_cast<const f16x8*>(p);
+    lo = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    hi = make_float4((float)h[4], (float)h[5], (float)h[6], (float)h[7]);
+}
+__device__ __forceinline__ void store8h(_Float16* p, const float4 lo, const float4 hi)
+{
+    f16x8 h;
+    h[0] = (_Float16)lo.x; h[1] = (_Float16)lo.y; h[2] = (_Float16)lo.z; h[3] = (_Float16)lo.w;
+    h[4] = (_Float16)hi.x; h[5] = (_Float16)hi.y; h[6] = (_Float16)hi.z; h[7] = (_Float16)hi.w;
+    *reinterpret_cast<f16x8*>(p) = h;
+}
+
+// Epilogue shared by the conv kernels: accumulators → LDS (fp32 C tile) → full-row vector stores with
+// fused scale/shift (BN + bias), residual, activation, column split / 2×2 scatter.
+// CPASS = 1: the whole BM×BN tile is staged at once; CPASS = WN (tiles whose fp32 C tile would not fit
+// beside a second block: 128×256): one pass per wave column, BM × TN·32 columns each.
+template <typename T, int BN, int TM, int TN, int WM, int WN, int CPASS>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned char* smem, int m0, int n0)
+{
+    static_assert(CPASS == 1 || CPASS == WN, "column passes");
+    constexpr int NT = WM * WN * 64;
+    constexpr int BM = WM * TM * 32;
+    constexpr int CW = BN / CPASS;     // columns staged per pass = row length of the LDS C tile
+    const int t = threadIdx.x;
+    const int wave = t >> 6, lane = t & 63;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int ohw = a.OH * a.OW;
+    // ---- accumulators → LDS → full-row vector stores ---------------------------------------------
+    // (the loop's final barrier guarantees nobody still reads the operand buffers)
+    constexpr int CPT = sizeof(T) == 2 ? 8 : 4;   // columns per thread: 16 B of the activation type
+    constexpr int NV = CPT / 4;                   // float4 groups per thread
+    constexpr int TPR = CW / CPT;     // threads per output row
+    constexpr int RPP = NT / TPR;     // rows per pass
+    constexpr int NPASS = BM / RPP;
+    const int c4 = t % TPR, rr = t / TPR;
+    const bool dense_out = a.out_sB == (long)ohw * a.out_sP;
+    const bool dense_res = a.res_sB == (long)ohw * a.res_sW && a.res_shift == 0;
+    const bool need_bp = !dense_out || a.out2 != nullptr || a.deconv2 || (a.res && !dense_res);
+    const bool need_yx = a.deconv2 || (a.res && a.res_shift);
+    const T* const res = static_cast<const T*>(a.res);
+    float* const Cs = reinterpret_cast<float*>(smem);
+    bool out_of_range = false;       // fp16-range watch for the modes whose next layer reads this output through fp16
+
+#pragma unroll
+    for (int h = 0; h < CPASS; ++h) {
+        const int n = n0 + h * CW + c4 * CPT;
+        const bool col_ok = n < a.ncols;
+        // Residual / scale / shift are fetched BEFORE the accumulators are staged through LDS: `res` and
+        // `out` may alias as far as the compiler knows, so inside the store loop every residual load would
+        // wait behind the previous store (16 serialized HBM round trips per thread on the branch2c layers).
+        float4 rv[NPASS][NV];
+        float4 sc[NV], sh[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) { sc[q] = make_float4(1.f, 1.f, 1.f, 1.f); sh[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        if (a.vec_ok && col_ok) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                if (a.scale) sc[q] = *reinterpret_cast<const float4*>(a.scale + n + 4 * q);
+                if (a.shift) sh[q] = *reinterpret_cast<const float4*>(a.shift + n + 4 * q);
+            }
+            if (res) {
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const int m = m0 + rr + ps * RPP;
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) rv[ps][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (m < a.M) {
+                        long ro;
+                        if (dense_res) ro = (long)m * a.res_sW;
+                        else {
+                            const int b = m / ohw, pix = m - b * ohw;
+                            if (a.res_shift) {
+                                const int oh = pix / a.OW, ow = pix - oh * a.OW;
+                                ro = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
+                            } else ro = (long)b * a.res_sB + (long)pix * a.res_sW;
+                        }
+                        if constexpr (CPT == 8) load8h(reinterpret_cast<const _Float16*>(res) + ro + n, rv[ps][0], rv[ps][NV - 1]);
+                        else rv[ps][0] = load4<T>(res + ro + n);
+                    }
+                }
+            }
+        }
+
+        if (h > 0) __syncthreads();            // the previous pass has been read out of the C tile
+        if (CPASS == 1 || wn == h) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+                        Cs[row * CW + (CPASS == 1 ? wn * TN * 32 : 0) + j * 32 + l31] = acc[i][j][e];
+                    }
+        }
+        __syncthreads();
+
+        if (!col_ok) continue;
+        if (a.vec_ok) {
+            const int qd = a.deconv2 ? n / a.Cout : 0;
+            const int co = a.deconv2 ? n - qd * a.Cout : n;
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int r = rr + ps * RPP;
+                const int m = m0 + r;
+                if (m >= a.M) break;
+                int b = 0, pix = m, oh = 0, ow = 0;
+                if (need_bp) { b = m / ohw; pix = m - b * ohw; }
+                if (need_yx) { oh = pix / a.OW; ow = pix - oh * a.OW; }
+                float4 v[NV];
+#pragma unroll
+                for (int q = 0; q < NV; ++q) {
+                    float4 x = *reinterpret_cast<const float4*>(&Cs[r * CW + c4 * CPT + 4 * q]);
+                    x.x = x.x * sc[q].x + sh[q].x; x.y = x.y * sc[q].y + sh[q].y; x.z = x.z * sc[q].z + sh[q].z; x.w = x.w * sc[q].w + sh[q].w;
+                    if (res) { x.x += rv[ps][q].x; x.y += rv[ps][q].y; x.z += rv[ps][q].z; x.w += rv[ps][q].w; }
+                    if (a.act == ACT_RELU) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+                    else if (a.act == ACT_SIGMOID) {
+                        x.x = 1.0f / (1.0f + expf(-x.x)); x.y = 1.0f / (1.0f + expf(-x.y));
+                        x.z = 1.0f / (1.0f + expf(-x.z)); x.w = 1.0f / (1.0f + expf(-x.w));
+                    }
+                    out_of_range = out_of_range || !(fabsf(x.x) < 65504.0f) || !(fabsf(x.y) < 65504.0f) || !(fabsf(x.z) < 65504.0f) || !(fabsf(x.w) < 65504.0f);
+                    v[q] = x;
+                }
+                long o;
+                if (a.deconv2) o = (long)b * a.out_sB + (long)(2 * oh + (qd >> 1)) * a.out_sH + (long)(2 * ow + (qd & 1)) * a.out_sW + co;
+                else o = (dense_out ? (long)m * a.out_sP : (long)b * a.out_sB + (long)pix * a.out_sP) + n;
+                if (a.out_f32) {
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) store4<float>(static_cast<float*>(a.out) + o + 4 * q, v[q]);
+                } else if constexpr (CPT == 8) store8h(reinterpret_cast<_Float16*>(a.out) + o, v[0], v[NV - 1]);
+                else store4<T>(static_cast<T*>(a.out) + o, v[0]);
+            }
+        } else {
+            for (int r = rr; r < BM; r += RPP) {
+                const int m = m0 + r;
+                if (m >= a.M) break;
+                const int b = m / ohw, pix = m - b * ohw;
+                const int oh = pix / a.OW, ow = pix - oh * a.OW;
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) {
+                    const int nn = n + c;
+                    if (nn >= a.ncols) break;
+                    float v = Cs[r * CW + c4 * CPT + c];
+                    v = v * (a.scale ? a.scale[nn] : 1.0f) + (a.shift ? a.shift[nn] : 0.0f);
+                    if (res) {
+                        long ro;
+                        if (a.res_shift) ro = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
+                        else ro = (long)b * a.res_sB + (long)pix * a.res_sW;
+                        v += (float)res[ro + nn];
+                    }
+                    if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
+                    else if (a.act == ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                    out_of_range |= !(fabsf(v) < 65504.0f);
+                    long o;
+                    void* dst = a.out;
+                    if (a.deconv2) {
+                        const int qd = nn / a.Cout, co = nn - qd * a.Cout;
+                        o = (long)b * a.out_sB + (long)(2 * oh + (qd >> 1)) * a.out_sH + (long)(2 * ow + (qd & 1)) * a.out_sW + co;
+                    } else if (a.out2 && nn >= a.n_split) {
+                        dst = a.out2;
+                        o = (long)b * a.out2_sB + (long)pix * a.out2_sP + (nn - a.n_split);
+                    } else {
+                        o = (long)b * a.out_sB + (long)pix * a.out_sP + nn;
+                    }
+                    if (a.out_f32) static_cast<float*>(dst)[o] = v;
+                    else static_cast<T*>(dst)[o] = (T)v;
+                }
+            }
+        }
+    }
+    if (a.range_flag && out_of_range) atomicOr(a.range_flag, 1);
+}
+
+}  // namespace mrcnn

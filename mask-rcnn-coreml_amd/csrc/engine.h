@@ -2,6 +2,7 @@
 #pragma once
 #include <functional>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <vector>
@@ -163,6 +164,9 @@ struct Model {
     DevBuf range_flag;          // 4 B: set by the conv epilogues in MRCNN_F16 / MRCNN_F32S when an activation leaves the fp16 range
     long range_overflows = 0;   // predicts that tripped it
     long graph_launches = 0;
+    // Held by the stand-alone TimeDistributed*Layer plugins around stage → forward → unstage: every layer instance
+    // shares the cached sub-model's head scratch (stage_in, h1/h2, cls6, feat, full) but launches on its own stream.
+    std::mutex eval_mu;
 
     ~Model();
     void load(int kind, const std::string& path, int max_batch, int dtype);

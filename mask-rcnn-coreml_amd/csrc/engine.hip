@@ -906,12 +906,13 @@ void Model::enqueue_pipeline(hipStream_t s, int batch)
     timer.mark(s, "Detection-Eval");
     // PyramidROIAlign (mask) on the detections' boxes
     const long mrow = (long)mask_pool * mask_pool * 256;
+    // ... which also evaluates the mask layer's removeZeros predicate on the fp32 samples (before an fp16 store rounds them)
     roi_align_forward(s, maps, 256, 1, detections, (long)max_det * 6, 6, max_det, batch, mask_pool, roi_img_w, roi_img_h, pooled_mask,
-                      (long)max_det * mrow, mrow, dtype);
+                      (long)max_det * mrow, mrow, dtype, msel_ws.flags);
     timer.mark(s, "PyramidROIAlign-Eval-Mask");
     // TimeDistributedMask
     const int HW = 4 * mask_pool * mask_pool;
-    mask_valid_rows_forward(s, pooled_mask, (long)max_det * mrow, mrow, mrow, max_det, batch, msel_ws, dtype);
+    mask_valid_rows_forward(s, nullptr, (long)max_det * mrow, mrow, mrow, max_det, batch, msel_ws, dtype);
     mask_head.forward_features(s, pooled_mask, batch * max_det);
     // Rows the reference's mask layer never writes (an invalid row below the kept count,
     // TimeDistributedMaskLayer.swift:58-89) hold whatever Core ML's buffer held; here they are defined: zero.
@@ -944,6 +945,15 @@ void Model::read_tensor(const std::string& name, int image, float* dst, int64_t 
         if (count) *count = n;
         MRCNN_REQUIRE(dst && cap >= n, MRCNN_ERR_SHAPE, "tensor '%s' needs %ld floats", name.c_str(), n);
         HIP_CHECK(hipMemcpy(dst, prop_ws.boxes + (size_t)image * n, (size_t)n * 4, hipMemcpyDeviceToHost));
+        return;
+    }
+    if (name == "mask_row_flags") {
+        const long n = max_det;
+        if (count) *count = n;
+        MRCNN_REQUIRE(dst && cap >= n, MRCNN_ERR_SHAPE, "tensor '%s' needs %ld floats", name.c_str(), n);
+        std::vector<int32_t> tmp((size_t)n);
+        HIP_CHECK(hipMemcpy(tmp.data(), msel_ws.flags + (size_t)image * n, (size_t)n * 4, hipMemcpyDeviceToHost));
+        for (long i = 0; i < n; ++i) dst[i] = (float)tmp[(size_t)i];
         return;
     }
     if (name == "keep_count") {

@@ -69,7 +69,8 @@ struct PyramidMaps {
 // dtype: element type of the maps and of the output (MRCNN_F16 only with layout_nhwc = 1).
 void roi_align_forward(hipStream_t s, const PyramidMaps& maps, int C, int layout_nhwc, const float* rois,
                        long rois_sB, long roi_stride, int n_rois, int B, int pool, double image_w,
-                       double image_h, void* out, long out_sB, long out_row_stride, int dtype);
+                       double image_h, void* out, long out_sB, long out_row_stride, int dtype,
+                       int32_t* row_flags = nullptr);   // NHWC only: [B][n_rois] 1 iff every fp32 sample of the row != 0
 
 // `.scaleFit` letterbox of an RGB8 image into an H×W canvas (content nh×nw at offset (py,px)).
 void letterbox_forward(hipStream_t s, const uint8_t* src, int h, int w, uint8_t* dst, int H, int W, int nh, int nw, int py, int px);
@@ -123,7 +124,7 @@ struct ConvDesc {
 // has been synchronised) folds the elapsed times into per-tile-shape totals.
 struct ConvProfile {
     struct Slot { long launches = 0; double ms = 0, flops = 0; };
-    Slot by_tile[4];                 // 0: 128x128, 1: 128x64, 2: 128x32, 3: 128x256 (split mode)
+    Slot by_tile[6];                 // 0: 128x128, 1: 128x64, 2: 128x32, 3: 128x256 (split mode), 4 / 5: 256x256 / 256x128 ping-pong (fp16)
     std::vector<hipEvent_t> pool;
     struct Shape { int M, N, K, tile; bool operator<(const Shape& o) const { return std::tie(M, N, K, tile) < std::tie(o.M, o.N, o.K, o.tile); } };
     std::map<Shape, Slot> by_shape;  // per GEMM shape (M = images·OH·OW, N = output columns, K = taps·Cin)
@@ -145,6 +146,8 @@ void conv_set_range_flag(int* device_flag);
 // Picks the tile shape from Cout; returns the N tile it will use so that callers can pad weights.
 int conv_n_tile(int Cout);
 void conv_forward(hipStream_t s, const ConvDesc& d);
+// Test / measurement switches of the kernel choice ("conv_pp" 0|1, "conv_pp_min_tiles", "conv_pp_min_kt"); false = unknown key.
+bool conv_debug_set(const char* key, int value);
 
 // uint8 RGB (B,H,W,3) → fp32 (B, H+2*pad, W+2*pad, 4) minus mean, zero border, channel 3 = 0.
 void preprocess_forward(hipStream_t s, const uint8_t* rgb, int B, int H, int W, int pad, const float mean[3],
@@ -173,6 +176,8 @@ struct MaskSelectWorkspace {
     int32_t* kept = nullptr;       // [B]
 };
 // flags/mapping of MultiArrayBatchProvider(removeZeros:true): pooled (B, D, row_len) contiguous rows.
+// pooled == nullptr: ws.flags already holds the predicate (written by roi_align_forward's row_flags from the fp32
+// samples — the fused engine path, also in fp16 mode where the stored rows are rounded); only the compaction runs.
 void mask_valid_rows_forward(hipStream_t s, const void* pooled, long pooled_sB, long row_stride, long row_len,
                              int D, int B, const MaskSelectWorkspace& ws, int dtype);
 // feat (B, D, HW, C) = ReLU(deconv) NHWC; w (nc, C), bias (nc); detections rows det_stride;

@@ -17,6 +17,8 @@
 //     the diagonal word with ballot/readlane, then the block ORs the kept rows into the removed
 //     set.  Early exit at maxProposals kept.
 // Compiled with -ffp-contract=off (see device_math.h).
+#include <mutex>
+
 #include "device_math.h"
 #include "kernels.h"
 
@@ -297,10 +299,12 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes
         const int gj = cb * 64 + j;
         if (gj <= i || gj >= n) continue;
         if (cls && ccls[j] != mycls) continue;
-        // exact float pre-test: disjoint (or merely touching) boxes have intersection 0, hence IoU 0
+        // exact float pre-test: disjoint (or merely touching) boxes have intersection 0, hence IoU 0 — which is
+        // "not suppressed" only for a non-negative threshold (IOU() == 0 > thr holds for a caller-supplied thr < 0)
         const float4 o = cbox[j];
-        if (fminf(fmaxf(o.x, o.z), fmaxf(me.x, me.z)) <= fmaxf(fminf(o.x, o.z), fminf(me.x, me.z)) ||
-            fminf(fmaxf(o.y, o.w), fmaxf(me.y, me.w)) <= fmaxf(fminf(o.y, o.w), fminf(me.y, me.w)))
+        if (thr >= 0.0f &&
+            (fminf(fmaxf(o.x, o.z), fmaxf(me.x, me.z)) <= fmaxf(fminf(o.x, o.z), fminf(me.x, me.z)) ||
+             fminf(fmaxf(o.y, o.w), fmaxf(me.y, me.w)) <= fmaxf(fminf(o.y, o.w), fminf(me.y, me.w))))
             continue;
         if (iou_yxyx(o, me) > thr) bits |= 1ull << j;           // IOU(anchorA = candidate, anchorB = selected)
     }
@@ -615,12 +619,17 @@ void detection_forward(hipStream_t s, const DetectionWorkspace& ws, const float*
 // predict may already run inside a caller's stream capture).
 void boxes_one_time_init()
 {
-    static bool done = false;
-    if (done) return;
+    // per device (the attribute lives on the device's code object) and safe against concurrent first callers
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev >= 0 && dev < 64 && done[dev]) return;
     HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_decode, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_nms_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_det_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-    done = true;
+    if (dev >= 0 && dev < 64) done[dev] = true;
 }
 
 }  // namespace mrcnn

@@ -21,229 +21,11 @@
 //     outputs (RPN class + bbox from one GEMM) or 2×2 scatter (transposed conv);
 //   * XCD-aware block→tile map: the 8 XCDs get contiguous runs of tiles, N-tiles of one M-tile
 //     adjacent, so an A tile is fetched into one XCD's L2 once.
-#include "kernels.h"
+#include <mutex>
+
+#include "conv_device.h"
 
 namespace mrcnn {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-
-struct ConvArgs {
-    const void* in; const void* wgt; const float* scale; const float* shift; const void* res;
-    void* out; void* out2;
-    long in_sB, in_sH, in_sW;
-    long res_sB, res_sH, res_sW;
-    long out_sB, out_sP, out_sH, out_sW;
-    long out2_sB, out2_sP;
-    int B, H, W, Cin, KH, KW, stride, padH, padW;
-    int OH, OW, Cout, ncols, Ktot, M;
-    int res_shift, act, n_split, deconv2;
-    int tiles_m, tiles_n;
-    int vec_ok;          // epilogue may use vector stores / residual loads
-    int out_f32;         // store fp32 even when the activations are fp16 (RPN outputs, class logits, masks)
-    const void* zero_page;   // >= 16 B of zeros in HBM: source of out-of-image taps for the DMA variant
-    int* range_flag;         // optional: set to 1 when an output leaves the fp16 range (|v| >= 65504 or NaN)
-};
-
-static constexpr int BM_DEFAULT = 128;   // rows of the block tile = WM*TM*32
-
-template <typename T> struct Elem;
-template <> struct Elem<float> { static constexpr int EPV = 4; };        // elements per 16-B vector
-template <> struct Elem<_Float16> { static constexpr int EPV = 8; };
-
-template <typename T> __device__ __forceinline__ float4 load4(const T* p);
-template <> __device__ __forceinline__ float4 load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
-template <> __device__ __forceinline__ float4 load4<_Float16>(const _Float16* p)
-{
-    const f16x4 h = *reinterpret_cast<const f16x4*>(p);
-    return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
-}
-template <typename T> __device__ __forceinline__ void store4(T* p, float4 v);
-template <> __device__ __forceinline__ void store4<float>(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-template <> __device__ __forceinline__ void store4<_Float16>(_Float16* p, float4 v)
-{
-    f16x4 h;
-    h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
-    *reinterpret_cast<f16x4*>(p) = h;
-}
-
-// 8 consecutive fp16 values as one 16-B access (the fp16 epilogue moves 8 columns per thread)
-__device__ __forceinline__ void load8h(const _Float16* p, float4& lo, float4& hi)
-{
-    const f16x8 h = *reinterpret_cast<const f16x8*>(p);
-    lo = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
-    hi = make_float4((float)h[4], (float)h[5], (float)h[6], (float)h[7]);
-}
-__device__ __forceinline__ void store8h(_Float16* p, const float4 lo, const float4 hi)
-{
-    f16x8 h;
-    h[0] = (_Float16)lo.x; h[1] = (_Float16)lo.y; h[2] = (_Float16)lo.z; h[3] = (_Float16)lo.w;
-    h[4] = (_Float16)hi.x; h[5] = (_Float16)hi.y; h[6] = (_Float16)hi.z; h[7] = (_Float16)hi.w;
-    *reinterpret_cast<f16x8*>(p) = h;
-}
-
-// Epilogue shared by the conv kernels: accumulators → LDS (fp32 C tile) → full-row vector stores with
-// fused scale/shift (BN + bias), residual, activation, column split / 2×2 scatter.
-// CPASS = 1: the whole BM×BN tile is staged at once; CPASS = WN (tiles whose fp32 C tile would not fit
-// beside a second block: 128×256): one pass per wave column, BM × TN·32 columns each.
-template <typename T, int BN, int TM, int TN, int WM, int WN, int CPASS>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], unsigned char* smem, int m0, int n0)
-{
-    static_assert(CPASS == 1 || CPASS == WN, "column passes");
-    constexpr int NT = WM * WN * 64;
-    constexpr int BM = WM * TM * 32;
-    constexpr int CW = BN / CPASS;     // columns staged per pass = row length of the LDS C tile
-    const int t = threadIdx.x;
-    const int wave = t >> 6, lane = t & 63;
-    const int wm = wave / WN, wn = wave - wm * WN;
-    const int l31 = lane & 31, kk = lane >> 5;
-    const int ohw = a.OH * a.OW;
-    // ---- accumulators → LDS → full-row vector stores ---------------------------------------------
-    // (the loop's final barrier guarantees nobody still reads the operand buffers)
-    constexpr int CPT = sizeof(T) == 2 ? 8 : 4;   // columns per thread: 16 B of the activation type
-    constexpr int NV = CPT / 4;                   // float4 groups per thread
-    constexpr int TPR = CW / CPT;     // threads per output row
-    constexpr int RPP = NT / TPR;     // rows per pass
-    constexpr int NPASS = BM / RPP;
-    const int c4 = t % TPR, rr = t / TPR;
-    const bool dense_out = a.out_sB == (long)ohw * a.out_sP;
-    const bool dense_res = a.res_sB == (long)ohw * a.res_sW && a.res_shift == 0;
-    const bool need_bp = !dense_out || a.out2 != nullptr || a.deconv2 || (a.res && !dense_res);
-    const bool need_yx = a.deconv2 || (a.res && a.res_shift);
-    const T* const res = static_cast<const T*>(a.res);
-    float* const Cs = reinterpret_cast<float*>(smem);
-    bool out_of_range = false;       // fp16-range watch for the modes whose next layer reads this output through fp16
-
-#pragma unroll
-    for (int h = 0; h < CPASS; ++h) {
-        const int n = n0 + h * CW + c4 * CPT;
-        const bool col_ok = n < a.ncols;
-        // Residual / scale / shift are fetched BEFORE the accumulators are staged through LDS: `res` and
-        // `out` may alias as far as the compiler knows, so inside the store loop every residual load would
-        // wait behind the previous store (16 serialized HBM round trips per thread on the branch2c layers).
-        float4 rv[NPASS][NV];
-        float4 sc[NV], sh[NV];
-#pragma unroll
-        for (int q = 0; q < NV; ++q) { sc[q] = make_float4(1.f, 1.f, 1.f, 1.f); sh[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
-        if (a.vec_ok && col_ok) {
-#pragma unroll
-            for (int q = 0; q < NV; ++q) {
-                if (a.scale) sc[q] = *reinterpret_cast<const float4*>(a.scale + n + 4 * q);
-                if (a.shift) sh[q] = *reinterpret_cast<const float4*>(a.shift + n + 4 * q);
-            }
-            if (res) {
-#pragma unroll
-                for (int ps = 0; ps < NPASS; ++ps) {
-                    const int m = m0 + rr + ps * RPP;
-#pragma unroll
-                    for (int q = 0; q < NV; ++q) rv[ps][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (m < a.M) {
-                        long ro;
-                        if (dense_res) ro = (long)m * a.res_sW;
-                        else {
-                            const int b = m / ohw, pix = m - b * ohw;
-                            if (a.res_shift) {
-                                const int oh = pix / a.OW, ow = pix - oh * a.OW;
-                                ro = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
-                            } else ro = (long)b * a.res_sB + (long)pix * a.res_sW;
-                        }
-                        if constexpr (CPT == 8) load8h(reinterpret_cast<const _Float16*>(res) + ro + n, rv[ps][0], rv[ps][NV - 1]);
-                        else rv[ps][0] = load4<T>(res + ro + n);
-                    }
-                }
-            }
-        }
-
-        if (h > 0) __syncthreads();            // the previous pass has been read out of the C tile
-        if (CPASS == 1 || wn == h) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
-                        Cs[row * CW + (CPASS == 1 ? wn * TN * 32 : 0) + j * 32 + l31] = acc[i][j][e];
-                    }
-        }
-        __syncthreads();
-
-        if (!col_ok) continue;
-        if (a.vec_ok) {
-            const int qd = a.deconv2 ? n / a.Cout : 0;
-            const int co = a.deconv2 ? n - qd * a.Cout : n;
-#pragma unroll
-            for (int ps = 0; ps < NPASS; ++ps) {
-                const int r = rr + ps * RPP;
-                const int m = m0 + r;
-                if (m >= a.M) break;
-                int b = 0, pix = m, oh = 0, ow = 0;
-                if (need_bp) { b = m / ohw; pix = m - b * ohw; }
-                if (need_yx) { oh = pix / a.OW; ow = pix - oh * a.OW; }
-                float4 v[NV];
-#pragma unroll
-                for (int q = 0; q < NV; ++q) {
-                    float4 x = *reinterpret_cast<const float4*>(&Cs[r * CW + c4 * CPT + 4 * q]);
-                    x.x = x.x * sc[q].x + sh[q].x; x.y = x.y * sc[q].y + sh[q].y; x.z = x.z * sc[q].z + sh[q].z; x.w = x.w * sc[q].w + sh[q].w;
-                    if (res) { x.x += rv[ps][q].x; x.y += rv[ps][q].y; x.z += rv[ps][q].z; x.w += rv[ps][q].w; }
-                    if (a.act == ACT_RELU) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
-                    else if (a.act == ACT_SIGMOID) {
-                        x.x = 1.0f / (1.0f + expf(-x.x)); x.y = 1.0f / (1.0f + expf(-x.y));
-                        x.z = 1.0f / (1.0f + expf(-x.z)); x.w = 1.0f / (1.0f + expf(-x.w));
-                    }
-                    out_of_range = out_of_range || !(fabsf(x.x) < 65504.0f) || !(fabsf(x.y) < 65504.0f) || !(fabsf(x.z) < 65504.0f) || !(fabsf(x.w) < 65504.0f);
-                    v[q] = x;
-                }
-                long o;
-                if (a.deconv2) o = (long)b * a.out_sB + (long)(2 * oh + (qd >> 1)) * a.out_sH + (long)(2 * ow + (qd & 1)) * a.out_sW + co;
-                else o = (dense_out ? (long)m * a.out_sP : (long)b * a.out_sB + (long)pix * a.out_sP) + n;
-                if (a.out_f32) {
-#pragma unroll
-                    for (int q = 0; q < NV; ++q) store4<float>(static_cast<float*>(a.out) + o + 4 * q, v[q]);
-                } else if constexpr (CPT == 8) store8h(reinterpret_cast<_Float16*>(a.out) + o, v[0], v[NV - 1]);
-                else store4<T>(static_cast<T*>(a.out) + o, v[0]);
-            }
-        } else {
-            for (int r = rr; r < BM; r += RPP) {
-                const int m = m0 + r;
-                if (m >= a.M) break;
-                const int b = m / ohw, pix = m - b * ohw;
-                const int oh = pix / a.OW, ow = pix - oh * a.OW;
-#pragma unroll
-                for (int c = 0; c < CPT; ++c) {
-                    const int nn = n + c;
-                    if (nn >= a.ncols) break;
-                    float v = Cs[r * CW + c4 * CPT + c];
-                    v = v * (a.scale ? a.scale[nn] : 1.0f) + (a.shift ? a.shift[nn] : 0.0f);
-                    if (res) {
-                        long ro;
-                        if (a.res_shift) ro = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
-                        else ro = (long)b * a.res_sB + (long)pix * a.res_sW;
-                        v += (float)res[ro + nn];
-                    }
-                    if (a.act == ACT_RELU) v = fmaxf(v, 0.0f);
-                    else if (a.act == ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
-                    out_of_range |= !(fabsf(v) < 65504.0f);
-                    long o;
-                    void* dst = a.out;
-                    if (a.deconv2) {
-                        const int qd = nn / a.Cout, co = nn - qd * a.Cout;
-                        o = (long)b * a.out_sB + (long)(2 * oh + (qd >> 1)) * a.out_sH + (long)(2 * ow + (qd & 1)) * a.out_sW + co;
-                    } else if (a.out2 && nn >= a.n_split) {
-                        dst = a.out2;
-                        o = (long)b * a.out2_sB + (long)pix * a.out2_sP + (nn - a.n_split);
-                    } else {
-                        o = (long)b * a.out_sB + (long)pix * a.out_sP + nn;
-                    }
-                    if (a.out_f32) static_cast<float*>(dst)[o] = v;
-                    else static_cast<T*>(dst)[o] = (T)v;
-                }
-            }
-        }
-    }
-    if (a.range_flag && out_of_range) atomicOr(a.range_flag, 1);
-}
 
 // fp32 → (hi, lo) fp16 pair with hi + lo = a to ~2^-22 relative: hi = a rounded toward zero to fp16,
 // lo = (a - hi) rounded toward zero to fp16 (a - hi is exact in fp32; for |a| below ~1e-2 lo lands in the
@@ -547,16 +329,21 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
     conv_epilogue<T, BN, TM, TN, WM, WN, CPASS>(a, acc, smem, m0, n0);
 }
 
-// 256 B of zeros in HBM, one per process (one device per process): allocated by kernels_one_time_init() at model / layer
-// creation so that no allocation can fall inside a caller's stream capture; lazily here as a fallback.
+// 256 B of zeros in HBM, one per device: allocated by conv_one_time_init() at model / layer creation so that no
+// allocation can fall inside a caller's stream capture; lazily here as a fallback.
 static void* conv_zero_page()
 {
-    static void* zero_page = nullptr;
-    if (!zero_page) {
-        HIP_CHECK(hipMalloc(&zero_page, 256));
-        HIP_CHECK(hipMemset(zero_page, 0, 256));
+    static std::mutex mu;
+    static void* zero_page[64] = {};
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    MRCNN_REQUIRE(dev >= 0 && dev < 64, MRCNN_ERR_HIP, "device ordinal %d out of range", dev);
+    std::lock_guard<std::mutex> lk(mu);
+    if (!zero_page[dev]) {
+        HIP_CHECK(hipMalloc(&zero_page[dev], 256));
+        HIP_CHECK(hipMemset(zero_page[dev], 0, 256));
     }
-    return zero_page;
+    return zero_page[dev];
 }
 void conv_one_time_init() { (void)conv_zero_page(); }
 
@@ -638,6 +425,31 @@ static void conv_launch(hipStream_t s, const ConvArgs& a, int bn)
     else hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 32, 1, 1, 4, 1, MRCNN_RING32, PARTS>), grid, dim3(256), 0, s, a);
 }
 
+void conv_pp_launch(hipStream_t s, const ConvArgs& a, int bn);   // kernels_conv_pp.hip
+
+// Run-time switches of the tile choice (A/B measurements through the micro-benchmark hook; defaults = the shipped policy)
+static int env_int(const char* name, int dflt)
+{
+    const char* e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+struct PpPolicy { int on, min_tiles, min_kt, dbg; };
+static PpPolicy& pp_policy()
+{
+    static PpPolicy p = {env_int("MRCNN_PP", 1), env_int("MRCNN_PP_MIN_TILES", 256), env_int("MRCNN_PP_MIN_KT", 4), env_int("MRCNN_PP_DBG", 0)};
+    return p;
+}
+bool conv_debug_set(const char* key, int value)
+{
+    const std::string k = key;
+    if (k == "conv_pp") pp_policy().on = value;
+    else if (k == "conv_pp_min_tiles") pp_policy().min_tiles = value;
+    else if (k == "conv_pp_min_kt") pp_policy().min_kt = value;
+    else if (k == "conv_pp_dbg") pp_policy().dbg = value;
+    else return false;
+    return true;
+}
+
 void conv_forward(hipStream_t s, const ConvDesc& d)
 {
     const bool half = d.dtype == MRCNN_F16;
@@ -665,6 +477,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     a.out_f32 = (!half || d.out_f32) ? 1 : 0;
     a.zero_page = conv_zero_page();
     a.range_flag = g_range_flag;
+    a.dbg = pp_policy().dbg;
     // Tile choice: the widest N tile the packed weights allow, narrowed while the grid would leave
     // the chip under-filled (< 2 blocks per CU) — C5, the top FPN levels and the small RPN levels.
     const int bn_max = conv_n_tile(a.ncols);
@@ -681,16 +494,23 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
                (!d.res || (d.res_sW % cpt == 0 && d.res_sH % cpt == 0 && d.res_sB % cpt == 0 && al(d.res, 16))) &&
                (!d.deconv2 || (d.Cout % cpt == 0 && d.out_sH % cpt == 0 && d.out_sW % cpt == 0));
     a.tiles_n = d.Npad / bn;
+    // fp16 layers with a large GEMM: the 256-row ping-pong kernel (kernels_conv_pp.hip), one block per CU
+    int pp_bn = 0;
+    if (half && pp_policy().on && d.Cin % 64 == 0 && a.Ktot / 64 >= pp_policy().min_kt && d.Npad % 256 == 0 &&
+        (long)((a.M + 255) / 256) * (d.Npad / 256) >= pp_policy().min_tiles)
+        pp_bn = 256;
+    if (pp_bn) { a.tiles_m = (a.M + 255) / 256; a.tiles_n = d.Npad / pp_bn; }
     ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
     const int e0 = prof ? prof_event(prof, s) : 0;
-    if (half) conv_launch<_Float16, _Float16>(s, a, bn);
+    if (pp_bn) conv_pp_launch(s, a, pp_bn);
+    else if (half) conv_launch<_Float16, _Float16>(s, a, bn);
     else if (split && wdtype == MRCNN_F32X3) conv_launch<float, _Float16, 3>(s, a, bn);
     else if (split) conv_launch<float, _Float16, 2>(s, a, bn);
     else conv_launch<float, float>(s, a, bn);
     if (prof) {
         const int e1 = prof_event(prof, s);
         const double k = d.algo_k > 0 ? d.algo_k : a.Ktot;
-        const int tile = bn == 128 ? 0 : (bn == 64 ? 1 : (bn == 32 ? 2 : 3));
+        const int tile = pp_bn == 256 ? 4 : (pp_bn == 128 ? 5 : (bn == 128 ? 0 : (bn == 64 ? 1 : (bn == 32 ? 2 : 3))));
         prof->pending.push_back({tile, 2.0 * (double)a.M * (double)a.ncols * k, e0, e1, {a.M, a.ncols, a.Ktot, tile}});
     }
     HIP_CHECK(hipGetLastError());
@@ -958,7 +778,8 @@ void mask_valid_rows_forward(hipStream_t s, const void* pooled, long pooled_sB, 
                              int B, const MaskSelectWorkspace& ws, int dtype)
 {
     if (D <= 0 || B <= 0) return;
-    if (dtype == MRCNN_F16)
+    if (!pooled) { /* flags come from the ROIAlign kernel */ }
+    else if (dtype == MRCNN_F16)
         hipLaunchKernelGGL(k_mask_row_flags<_Float16>, dim3(D, B), dim3(256), 0, s, (const _Float16*)pooled, pooled_sB, row_stride, row_len, D, ws.flags);
     else hipLaunchKernelGGL(k_mask_row_flags<float>, dim3(D, B), dim3(256), 0, s, (const float*)pooled, pooled_sB, row_stride, row_len, D, ws.flags);
     hipLaunchKernelGGL(k_mask_row_compact, dim3(B), dim3(64), 0, s, ws.flags, D, ws.mapping, ws.kept);

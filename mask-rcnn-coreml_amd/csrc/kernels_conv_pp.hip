@@ -1,0 +1,246 @@
+// kernels_conv_pp.hip — the deep-pipelined fp16 implicit-GEMM convolution of the trunk's large layers on gfx950:
+// 256-row block tiles, 8 waves in two groups that PING-PONG between "issue loads" and "issue MFMAs".
+//
+// Same contract as k_conv_mfma_glds (kernels_conv.hip; reference layers: the 3×3 / 1×1 convolutions of
+// MaskRCNN.mlmodel / Mask.mlmodel, Sources/maskrcnn/Python/Conversion/task.py:69-104): NHWC fp16 activations, filters
+// packed [cout][tap][cin] fp16, out[m][n] = Σ_k A[m][k]·Wt[n][k] in fp32 (v_mfma_f32_32x32x16_f16), the fused epilogue of
+// conv_device.h.  What changes is the main loop, built for the regime the round-1 profile showed the 128×128 kernel
+// to be in (MFMA issue 55 %, clock 1.49 GHz — LDS→VGPR and L2→LDS bytes per flop, one vmcnt(0)+barrier per K step):
+//
+//   * block tile 256 × BN (BN = 256 or 128), K tile 64 (one 128-B run per operand row), 8 waves: wave tile 128×64
+//     (BN = 256: 2×4 waves) or 64×64 (BN = 128: 4×2 waves) → 0.75 / 1.0 ds_read_b128 per MFMA (was 1.5) and half /
+//     two thirds of the global→LDS bytes per flop of the 128×128 tile;
+//   * a K tile is consumed in PHASES of 8 MFMAs (one 32-row slab of the wave tile × all its columns × K = 64); the B
+//     fragments of the whole K tile are read once (phase 0) and stay in registers;
+//   * the two wave groups (waves 0-3 / 4-7 = one wave of each per SIMD) run ONE BARRIER APART: while group 0 issues
+//     the 8 MFMAs of a phase (256 matrix-pipe cycles, s_setprio 1), group 1 issues its LDS fragment reads and its
+//     share of the global→LDS DMA for a later K tile, then they swap — the matrix pipe of every SIMD always has one
+//     wave feeding it;
+//   * operands arrive by global_load_lds_dwordx4 (16 B per lane, XOR-swizzled source chunks, zero page for padding
+//     taps — as in kernels_conv.hip) 1½–2 K tiles ahead; vmcnt is COUNTED (one `s_waitcnt vmcnt(6)` per K tile, never
+//     0 in steady state): the DMAs stay in flight across the barriers.
+//
+// LDS hazards are excluded by construction, not by observation.  With "slot" = the interval between two consecutive
+// barrier rendezvous, group 0 runs L(ph) in slot 2·ph and M(ph) in slot 2·ph+1 of a K tile, group 1 one slot later:
+//   RAW  a DMA is visible to a ds_read only after the issuing wave's covering vmcnt AND a barrier the reader passed
+//        afterwards: every wave waits for K tile kt+1 at the end of its LAST L phase of K tile kt (group 1: the slot
+//        right before group 0's first read of kt+1);
+//   WAR  the last reader of slab ph of K tile kt is group 1, whose reads are issued in slot 2ph+1 and retired by its
+//        lgkmcnt(0) at the top of slot 2ph+2: the slab's LDS rows may be overwritten by DMAs issued from slot 2ph+3
+//        on.  BN = 256 (two K-tile buffers, 128 KB): slab ph of tile kt+2 is issued in L(ph+2) of tile kt (slabs 2, 3
+//        in L(0), L(1) of tile kt+1) — slot 2ph+4 at the earliest; the B tile (read only in phase 0) in L(2), L(3).
+//        BN = 128 (three buffers, 144 KB): tile kt+2 goes to the buffer of tile kt-1, whose last read retired two
+//        slots before the first issue.
+#include "conv_device.h"
+
+namespace mrcnn {
+
+#define PP_GLDS_V(SRC, DST)                                                                                    \
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(SRC), "s"(DST) : "memory", "m0");
+#define PP_GLDS_S(VOFF, SBASE, DST)                                                                            \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(VOFF), "s"(SBASE), "s"(DST) : "memory", "m0");
+#define PP_DSR(DSTV, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DSTV) : "v"(ADDR), "n"(OFF));
+#define PP_BARRIER asm volatile("s_barrier" ::: "memory");
+#define PP_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#define PP_MFMA(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, C_, 0, 0, 0);
+
+// Source of one staged activation row P for the tap (KH_, KW_) and byte offset KOFF_ (tap + channel tile, wave-uniform):
+// the row's pixel run, or the zero page when the tap falls outside the image (zero padding) / the row is beyond M.
+// Rebuilt at every issue from 3 registers per row (64-bit pixel base, packed 16-bit (ih0, iw0)): ~10 VALU in a load
+// phase instead of 7 live registers per row — the kernel's budget is 256 registers with a 128-register accumulator.
+#define PP_SRC_A(P, KH_, KW_, KOFF_)                                                                           \
+    ({                                                                                                         \
+        const int ih = (int)(short)(ihw[P] & 0xffff) + (KH_), iw = (ihw[P] >> 16) + (KW_);                     \
+        const bool ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;                          \
+        ok ? reinterpret_cast<const T*>(reinterpret_cast<const char*>(pbase[P]) + (KOFF_)) : zero;             \
+    })
+
+// ================================================================================================================
+// BN = 256: 2 (M) × 4 (N) waves, wave tile 128 × 64 = acc[4][2], four phases per K tile, two K-tile buffers.
+// ================================================================================================================
+__global__ __launch_bounds__(512) void k_conv_f16_pp256(const ConvArgs a)
+{
+    using T = _Float16;
+    constexpr int BM = 256, BN = 256, BK = 64, ROWB = 128;
+    constexpr int A_STAGE = BM * ROWB, B_STAGE = BN * ROWB, B_BASE = 2 * A_STAGE;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_STAGE + B_STAGE)];     // 128 KB; the epilogue reuses it
+    const T* const in = static_cast<const T*>(a.in);
+    const T* const wgt = static_cast<const T*>(a.wgt);
+    const T* const zero = static_cast<const T*>(a.zero_page);
+
+    // XCD-aware bijective block → tile map (the N tiles of one M tile adjacent, contiguous runs per XCD)
+    const int nblocks = a.tiles_m * a.tiles_n;
+    const int bid = blockIdx.x;
+    const int q8 = nblocks >> 3, r8 = nblocks & 7;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+    const int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 2, wc = wave & 3;                  // wave row (= ping-pong group) / wave column
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
+
+    // ---- staging: slab p (p = 0..3) of the A tile = rows {wr·128 + p·32 + 0..31 : wr = 0, 1}; one DMA per thread and slab:
+    //      wave w stages rows (w>>2)·128 + p·32 + (w&3)·8 + 0..7 (1 KB, lane-linear); chunk c of row r sits at c ^ ((r>>1)&7).
+    const int srow = (wave & 3) * 8 + (lane >> 3);
+    const int kq = (lane & 7) ^ ((srow >> 1) & 7);
+    const int ohw = a.OH * a.OW;
+    const T* pbase[4];       // pixel of tap (0, 0), channel chunk kq, of the row this thread stages in slab p
+    int ihw[4];              // (ih0 & 0xffff) | (iw0 << 16): input coordinates of tap (0, 0)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int m = m0 + wr * 128 + p * 32 + srow;
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
+        const int b = mm / ohw, rem = mm - b * ohw;
+        const int oh = rem / a.OW, ow = rem - oh * a.OW;
+        const int ih0 = oh * a.stride - a.padH, iw0 = ow * a.stride - a.padW;
+        ihw[p] = ((ok ? ih0 : -32768) & 0xffff) | (iw0 << 16);      // a row beyond M never passes the bounds test
+        pbase[p] = in + ((long)b * a.in_sB + (long)ih0 * a.in_sH + (long)iw0 * a.in_sW + kq * 8);
+    }
+    const int cin_tiles = a.Cin / BK;
+    const int KT = a.KH * a.KW * cin_tiles;
+    // measurement-only ablations (a.dbg = 0 in production): 1 no s_setprio, 2 no group stagger, 4 no DMA in the main
+    // loop, 8 no fragment reads, 16 no MFMAs
+    const bool dbg_noprio = a.dbg & 1, dbg_nostagger = a.dbg & 2, dbg_nodma = a.dbg & 4, dbg_nords = a.dbg & 8, dbg_nomma = a.dbg & 16;
+    // two issue streams (wave-uniform scalar state): slabs 0, 1 (+ the filter tile) run one K tile ahead of slabs 2, 3
+    int ct01 = 0, kh01 = 0, kw01 = 0, ct23 = 0, kh23 = 0, kw23 = 0;
+    long ko01 = 0, ko23 = 0;                   // byte offset of the stream's current K tile from the tap-(0,0) pixel
+    const long tapW = a.in_sW * (long)sizeof(T), tapH = a.in_sH * (long)sizeof(T);
+#define PP_ADV(CT_, KH_, KW_, KO_)                                                                             \
+    {                                                                                                          \
+        KO_ += BK * (long)sizeof(T);                                                                           \
+        if (++CT_ == cin_tiles) {                                                                              \
+            CT_ = 0;                                                                                           \
+            if (++KW_ == a.KW) { KW_ = 0; ++KH_; }                                                             \
+            KO_ = KH_ * tapH + KW_ * tapW;                                                                     \
+        }                                                                                                      \
+    }
+#define PP_ADV01 PP_ADV(ct01, kh01, kw01, ko01)
+#define PP_ADV23 PP_ADV(ct23, kh23, kw23, ko23)
+    // filter tile: 256 rows = four DMAs per thread (rows p·64 + wave·8 + lane>>3): one scalar base + lane offset + p·bstr
+    const unsigned vb = (unsigned)(((size_t)(wave * 8 + (lane >> 3)) * a.Ktot + kq * 8) * sizeof(T));
+    const T* sb = wgt + (size_t)n0 * a.Ktot;                             // wave-uniform, advances one K tile per issue round
+    const unsigned bstr = (unsigned)((size_t)64 * a.Ktot * sizeof(T));    // byte distance of the four 64-row groups
+    const unsigned dA = lds0 + (wr * 128 + (wave & 3) * 8) * ROWB;      // + buf·A_STAGE + p·4096
+    const unsigned dB = lds0 + B_BASE + wave * 8 * ROWB;                // + buf·B_STAGE + p·8192
+#define PP_ISSUE_A01(P, BUF) { const T* src_ = PP_SRC_A(P, kh01, kw01, ko01); PP_GLDS_V(src_, dA + (BUF) * A_STAGE + (P) * 4096); }
+#define PP_ISSUE_A23(P, BUF) { const T* src_ = PP_SRC_A(P, kh23, kw23, ko23); PP_GLDS_V(src_, dA + (BUF) * A_STAGE + (P) * 4096); }
+#define PP_ISSUE_B(P, BUF) PP_GLDS_S(vb + (P) * bstr, sb, dB + (BUF) * B_STAGE + (P) * 8192);
+
+    // ---- fragment reads: lane (l31, kk) of K group g reads chunk 2g+kk of row l31 of its slab
+    const int l31 = lane & 31, kk = lane >> 5, swz = (l31 >> 1) & 7;
+    const unsigned ra_base = lds0 + (wr * 128 + l31) * ROWB;
+    const unsigned rb_base = lds0 + B_BASE + (wc * 64 + l31) * ROWB;
+    const unsigned c0 = ((0 + kk) ^ swz) << 4, c1 = ((2 + kk) ^ swz) << 4, c2 = ((4 + kk) ^ swz) << 4, c3 = ((6 + kk) ^ swz) << 4;
+    const unsigned ra0 = ra_base + c0, ra1 = ra_base + c1, ra2 = ra_base + c2, ra3 = ra_base + c3;
+    const unsigned rb0 = rb_base + c0, rb1 = rb_base + c1, rb2 = rb_base + c2, rb3 = rb_base + c3;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    f16x8 fa0, fa1, fa2, fa3;                                      // A fragments of the current phase (4 K groups)
+    f16x8 fb00, fb01, fb10, fb11, fb20, fb21, fb30, fb31;          // B fragments of the current K tile (K group, column tile)
+
+    // ---- prologue: K tile 0 completely, of K tile 1 the part the steady state has in flight at a tile boundary
+    PP_ISSUE_A01(0, 0) PP_ISSUE_A01(1, 0) PP_ISSUE_A23(2, 0) PP_ISSUE_A23(3, 0)
+    PP_ISSUE_B(0, 0) PP_ISSUE_B(1, 0) PP_ISSUE_B(2, 0) PP_ISSUE_B(3, 0)
+    sb += BK;
+    PP_ADV01 PP_ADV23
+    if (KT > 1) {
+        PP_ISSUE_A01(0, 1) PP_ISSUE_B(0, 1) PP_ISSUE_B(1, 1)
+        PP_ISSUE_A01(1, 1) PP_ISSUE_B(2, 1) PP_ISSUE_B(3, 1)
+        sb += BK;
+        PP_ADV01
+        PP_VMCNT(6)
+    } else {
+        PP_VMCNT(0)
+    }
+    PP_BARRIER
+    if (wr == 1 && !dbg_nostagger) PP_BARRIER          // group 1 runs one barrier behind group 0 from here on
+
+#define PP_RD_A(PH, BUF)                                                                                       \
+    PP_DSR(fa0, ra0, (BUF) * A_STAGE + (PH) * 4096) PP_DSR(fa1, ra1, (BUF) * A_STAGE + (PH) * 4096)            \
+    PP_DSR(fa2, ra2, (BUF) * A_STAGE + (PH) * 4096) PP_DSR(fa3, ra3, (BUF) * A_STAGE + (PH) * 4096)
+#define PP_RD_B(BUF)                                                                                           \
+    PP_DSR(fb00, rb0, (BUF) * B_STAGE) PP_DSR(fb01, rb0, (BUF) * B_STAGE + 4096)                               \
+    PP_DSR(fb10, rb1, (BUF) * B_STAGE) PP_DSR(fb11, rb1, (BUF) * B_STAGE + 4096)                               \
+    PP_DSR(fb20, rb2, (BUF) * B_STAGE) PP_DSR(fb21, rb2, (BUF) * B_STAGE + 4096)                               \
+    PP_DSR(fb30, rb3, (BUF) * B_STAGE) PP_DSR(fb31, rb3, (BUF) * B_STAGE + 4096)
+// the wait names every fragment as read-write: nothing that consumes one can be scheduled above it
+#define PP_WAIT_A asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa0), "+v"(fa1), "+v"(fa2), "+v"(fa3)::"memory");
+#define PP_WAIT_AB                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                        \
+                 : "+v"(fa0), "+v"(fa1), "+v"(fa2), "+v"(fa3), "+v"(fb00), "+v"(fb01), "+v"(fb10), "+v"(fb11), "+v"(fb20), "+v"(fb21), \
+                   "+v"(fb30), "+v"(fb31)::"memory");
+#define PP_MATH(PH)                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    if (!dbg_noprio) __builtin_amdgcn_s_setprio(1);                                                            \
+    if (!dbg_nomma) {                                                                                          \
+    PP_MFMA(fa0, fb00, acc[PH][0]) PP_MFMA(fa0, fb01, acc[PH][1]) PP_MFMA(fa1, fb10, acc[PH][0]) PP_MFMA(fa1, fb11, acc[PH][1]) \
+    PP_MFMA(fa2, fb20, acc[PH][0]) PP_MFMA(fa2, fb21, acc[PH][1]) PP_MFMA(fa3, fb30, acc[PH][0]) PP_MFMA(fa3, fb31, acc[PH][1]) \
+    }                                                                                                          \
+    __builtin_amdgcn_s_setprio(0);                                                                             \
+    __builtin_amdgcn_sched_barrier(0);
+
+    // One K tile on buffer BUF (compile-time): four L/M phase pairs.  has1 / has2: K tiles kt+1 / kt+2 exist.
+#define PP_KTILE(KTV, BUF)                                                                                     \
+    {                                                                                                          \
+        const bool has1 = (KTV) + 1 < KT && !dbg_nodma, has2 = (KTV) + 2 < KT && !dbg_nodma;                   \
+        /* phase 0: slab 0 + the whole B tile; DMA: slab 2 of tile kt+1 */                                     \
+        if (!dbg_nords) { PP_RD_A(0, BUF) PP_RD_B(BUF) }                                                       \
+        if (has1) PP_ISSUE_A23(2, (BUF) ^ 1)                                                                     \
+        PP_BARRIER PP_WAIT_AB PP_MATH(0) PP_BARRIER                                                            \
+        /* phase 1: DMA: slab 3 of tile kt+1 */                                                                \
+        if (!dbg_nords) { PP_RD_A(1, BUF) }                                                                    \
+        if (has1) { PP_ISSUE_A23(3, (BUF) ^ 1) PP_ADV23 }                                                        \
+        PP_BARRIER PP_WAIT_A PP_MATH(1) PP_BARRIER                                                             \
+        /* phase 2: DMA: slab 0 and filter rows 0-127 of tile kt+2 (over this tile's own buffer) */            \
+        if (!dbg_nords) { PP_RD_A(2, BUF) }                                                                    \
+        if (has2) { PP_ISSUE_A01(0, BUF) PP_ISSUE_B(0, BUF) PP_ISSUE_B(1, BUF) }                       \
+        PP_BARRIER PP_WAIT_A PP_MATH(2) PP_BARRIER                                                             \
+        /* phase 3: DMA: slab 1 and filter rows 128-255 of tile kt+2; then tile kt+1 must have landed */       \
+        if (!dbg_nords) { PP_RD_A(3, BUF) }                                                                    \
+        if (has2) {                                                                                            \
+            PP_ISSUE_A01(1, BUF) PP_ISSUE_B(2, BUF) PP_ISSUE_B(3, BUF)                                 \
+            sb += BK;                                                        \
+            PP_ADV01                                                                                           \
+            PP_VMCNT(6)                                                                                        \
+        } else {                                                                                               \
+            PP_VMCNT(0)                                                                                        \
+        }                                                                                                      \
+        PP_BARRIER PP_WAIT_A PP_MATH(3) PP_BARRIER                                                             \
+    }
+    for (int kt = 0; kt < KT; kt += 2) {
+        PP_KTILE(kt, 0)
+        if (kt + 1 < KT) PP_KTILE(kt + 1, 1)
+    }
+    if (wr == 0 && !dbg_nostagger) PP_BARRIER          // re-join: every wave's last fragment read has retired behind this rendezvous
+#undef PP_KTILE
+#undef PP_MATH
+#undef PP_WAIT_AB
+#undef PP_WAIT_A
+#undef PP_RD_B
+#undef PP_RD_A
+#undef PP_ISSUE_B
+#undef PP_ISSUE_A23
+#undef PP_ISSUE_A01
+#undef PP_ADV23
+#undef PP_ADV01
+    conv_epilogue<T, BN, 4, 2, 2, 4, 4>(a, acc, smem, m0, n0);
+}
+
+void conv_pp_launch(hipStream_t s, const ConvArgs& a, int bn)
+{
+    const dim3 grid(a.tiles_m * a.tiles_n);
+    MRCNN_REQUIRE(bn == 256, MRCNN_ERR_UNSUPPORTED, "conv_pp: N tile %d", bn);
+    hipLaunchKernelGGL(k_conv_f16_pp256, grid, dim3(512), 0, s, a);
+}
+
+}  // namespace mrcnn

@@ -91,7 +91,8 @@ template <> __device__ __forceinline__ void st4<_Float16>(_Float16* p, float4 v)
 template <typename T>
 __global__ __launch_bounds__(256) void k_roi_align_nhwc(PyramidMaps maps, int C, const float* __restrict__ rois,
                                                         long rois_sB, long roi_stride, int P, double ratio,
-                                                        T* __restrict__ out, long out_sB, long out_row_stride)
+                                                        T* __restrict__ out, long out_sB, long out_row_stride,
+                                                        int32_t* __restrict__ row_flags)
 {
     const int roi = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
     const RoiGeom g = roi_geom(rois + (size_t)b * rois_sB + (size_t)roi * roi_stride, ratio);
@@ -100,8 +101,13 @@ __global__ __launch_bounds__(256) void k_roi_align_nhwc(PyramidMaps maps, int C,
     const int total = P * P * C4;
     if (g.level < 0) {
         for (int e = t; e < total; e += 256) st4<T>(o + (size_t)e * 4, make_float4(0, 0, 0, 0));
+        if (row_flags && t == 0) row_flags[(size_t)b * gridDim.x + roi] = 0;
         return;
     }
+    // removeZeros predicate of the mask layer (TimeDistributedClassifierLayer.swift:116-127: a row is kept iff every
+    // element != 0), evaluated on the fp32 samples BEFORE the store rounds them — the decision the reference's fp32
+    // pipeline takes; an fp16 store would flush |v| < 3e-8 to zero and drop a valid detection.
+    int all_nonzero = 1;
     const int H = maps.H[g.level], W = maps.W[g.level];
     const T* m = static_cast<const T*>(maps.data[g.level]) + (size_t)b * maps.sB[g.level];
     for (int e = t; e < total; e += 256) {
@@ -119,7 +125,12 @@ __global__ __launch_bounds__(256) void k_roi_align_nhwc(PyramidMaps maps, int C,
             v.z = bilerp(tl.z, tr.z, bl.z, br.z, s.lx, s.ly);
             v.w = bilerp(tl.w, tr.w, bl.w, br.w, s.lx, s.ly);
         }
+        all_nonzero &= (v.x != 0.0f && v.y != 0.0f && v.z != 0.0f && v.w != 0.0f) ? 1 : 0;
         st4<T>(o + ((size_t)pt * C4 + cq) * 4, v);
+    }
+    if (row_flags) {                                   // wave-uniform branch: kernel argument
+        all_nonzero = __syncthreads_and(all_nonzero);
+        if (t == 0) row_flags[(size_t)b * gridDim.x + roi] = all_nonzero;
     }
 }
 
@@ -154,18 +165,19 @@ __global__ __launch_bounds__(256) void k_roi_align_nchw(PyramidMaps maps, int C,
 
 void roi_align_forward(hipStream_t s, const PyramidMaps& maps, int C, int layout_nhwc, const float* rois,
                        long rois_sB, long roi_stride, int n_rois, int B, int pool, double image_w,
-                       double image_h, void* out, long out_sB, long out_row_stride, int dtype)
+                       double image_h, void* out, long out_sB, long out_row_stride, int dtype, int32_t* row_flags)
 {
     if (n_rois <= 0 || B <= 0) return;
+    MRCNN_REQUIRE(!row_flags || layout_nhwc, MRCNN_ERR_INVALID, "ROIAlign: row flags are produced by the NHWC kernel only");
     const double ratio = 224.0 / sqrt(image_w * image_h);    // PyramidROIAlignLayer.swift:98,357
     if (layout_nhwc) {
         MRCNN_REQUIRE(C % 4 == 0, MRCNN_ERR_SHAPE, "ROIAlign: channel count %d not a multiple of 4", C);
         if (dtype == MRCNN_F16)
             hipLaunchKernelGGL(k_roi_align_nhwc<_Float16>, dim3(n_rois, B), dim3(256), 0, s, maps, C, rois, rois_sB, roi_stride, pool,
-                               ratio, (_Float16*)out, out_sB, out_row_stride);
+                               ratio, (_Float16*)out, out_sB, out_row_stride, row_flags);
         else
             hipLaunchKernelGGL(k_roi_align_nhwc<float>, dim3(n_rois, B), dim3(256), 0, s, maps, C, rois, rois_sB, roi_stride, pool,
-                               ratio, (float*)out, out_sB, out_row_stride);
+                               ratio, (float*)out, out_sB, out_row_stride, row_flags);
     } else {
         MRCNN_REQUIRE(dtype == MRCNN_F32, MRCNN_ERR_UNSUPPORTED, "ROIAlign: the CHW layout is fp32 only");
         hipLaunchKernelGGL(k_roi_align_nchw, dim3(n_rois, B), dim3(256), 0, s, maps, C, rois, rois_sB, roi_stride, pool,

@@ -39,9 +39,49 @@ def unletterbox_boxes(detections: np.ndarray, h: int, w: int, H: int, W: int) ->
     """Normalized (y1,x1,y2,x2) in the letterboxed frame → normalized in the source image (host arithmetic)."""
     nh, nw, py, px = letterbox_geometry(h, w, H, W)
     d = np.array(detections, dtype=np.float64, copy=True)
-    d[:, [0, 2]] = np.clip((d[:, [0, 2]] * H - py) / nh, 0.0, 1.0)
-    d[:, [1, 3]] = np.clip((d[:, [1, 3]] * W - px) / nw, 0.0, 1.0)
+    # The engine's normalized coordinates follow Matterport's norm_boxes (anchors.py, k_paste_masks):
+    # pixel = norm * (size - 1), far edge + 1.  Denormalize in the letterboxed frame, remove the padding, scale the
+    # content back to the source size, renormalize with (size - 1) and the far edge - 1.
+    sy, sx = h / nh, w / nw
+    y1 = (d[:, 0] * (H - 1) - py) * sy
+    x1 = (d[:, 1] * (W - 1) - px) * sx
+    y2 = (d[:, 2] * (H - 1) + 1.0 - py) * sy
+    x2 = (d[:, 3] * (W - 1) + 1.0 - px) * sx
+    hy, wx = max(h - 1, 1), max(w - 1, 1)
+    d[:, 0] = np.clip(y1 / hy, 0.0, 1.0)
+    d[:, 1] = np.clip(x1 / wx, 0.0, 1.0)
+    d[:, 2] = np.clip((y2 - 1.0) / hy, 0.0, 1.0)
+    d[:, 3] = np.clip((x2 - 1.0) / wx, 0.0, 1.0)
     return d
+
+
+def detection_agreement(det_a: np.ndarray, det_b: np.ndarray, box_tol: float = 1e-4, masks_a=None, masks_b=None) -> dict:
+    """End-to-end agreement of two engines' outputs for ONE image: det_* (n,6) rows (y1,x1,y2,x2,classId,score),
+    zero-padded.  A row of A is matched to at most one row of B with the SAME class id and every box coordinate
+    within `box_tol` (order-insensitive: scores that differ in the last bits may swap neighbours).  Returns counts,
+    the matched fraction over max(nA, nB), the largest score difference over matched pairs and — when the 28×28
+    masks are given — the largest mask difference over matched pairs."""
+    a = np.asarray(det_a, dtype=np.float32)
+    b = np.asarray(det_b, dtype=np.float32)
+    ia = np.flatnonzero(a[:, 5] > 0)
+    ib = np.flatnonzero(b[:, 5] > 0)
+    used = np.zeros(len(ib), dtype=bool)
+    matched, same_row, dscore, dmask = 0, 0, 0.0, 0.0
+    for i in ia:
+        ok = (~used) & (b[ib, 4] == a[i, 4]) & (np.abs(b[ib, :4] - a[i, :4]).max(axis=1) <= box_tol)
+        js = np.flatnonzero(ok)
+        if js.size == 0:
+            continue
+        j = js[np.argmin(np.abs(b[ib[js], 5] - a[i, 5]))]
+        used[j] = True
+        matched += 1
+        same_row += int(ib[j] == i)
+        dscore = max(dscore, float(abs(b[ib[j], 5] - a[i, 5])))
+        if masks_a is not None and masks_b is not None:
+            dmask = max(dmask, float(np.abs(np.asarray(masks_a[i], np.float32) - np.asarray(masks_b[ib[j]], np.float32)).max()))
+    denom = max(len(ia), len(ib))
+    return {"n_a": int(len(ia)), "n_b": int(len(ib)), "matched": int(matched), "same_row": int(same_row),
+            "fraction": (matched / denom) if denom else 1.0, "max_score_diff": dscore, "max_mask_diff": dmask}
 
 
 def evaluate(model: MaskRCNN, images: Iterable[Tuple[int, np.ndarray]], dataset_id: str = "coco",

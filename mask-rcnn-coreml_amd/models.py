@@ -110,6 +110,13 @@ class MaskRCNN(_Model):
         else:
             _lib.check(_lib.lib().mrcnn_maskrcnn_predict_async(self._h, images.data_ptr(), B, H, W, det.data_ptr(), mask.data_ptr()))
 
+    def check_range(self) -> bool:
+        """After predict_into(sync=False): synchronises the model's stream and reports whether the last predict left
+        the fp16 range (its results are then not valid) — the async counterpart of the error predict() raises."""
+        t = C.c_int(0)
+        _lib.check(_lib.lib().mrcnn_model_check_range(self._h, C.byref(t)))
+        return bool(t.value)
+
     # -- parity / profiling hooks -------------------------------------------------------------------
     def read_tensor(self, name: str, image_index: int = 0) -> np.ndarray:
         cnt = C.c_int64(0)

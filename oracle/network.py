@@ -31,8 +31,8 @@ BN_EPS = weights_mod.BN_EPS
 
 
 class _W:
-    def __init__(self, tensors):
-        self.t = {k: torch.from_numpy(np.asarray(v, dtype=np.float32).copy()) for k, v in tensors.items()}
+    def __init__(self, tensors, dtype=torch.float32):
+        self.t = {k: torch.from_numpy(np.asarray(v, dtype=np.float32).copy()).to(dtype) for k, v in tensors.items()}
 
     def conv(self, x, name, stride=1, padding=0):
         return F.conv2d(x, self.t[f"{name}/kernel"], self.t[f"{name}/bias"], stride=stride, padding=padding)
@@ -116,6 +116,20 @@ class OracleMaskRCNN:
             probs, deltas = self.rpn(pyr)
         return [p.numpy() for p in pyr[:4]], probs.numpy(), deltas.numpy()
 
+    def trunk_fp64(self, images_u8):
+        """The same graph evaluated in float64 (weights are the fp16-exact values widened): the ground truth that the
+        fp32 engines' summation-order / split-precision errors are measured against."""
+        w32 = self.w
+        try:
+            self.w = _W({k: v.numpy() for k, v in w32.t.items()}, torch.float64)
+            with torch.no_grad():
+                x = self.preprocess(images_u8).to(torch.float64)
+                pyr = self.fpn(self.backbone(x))
+                probs, deltas = self.rpn(pyr)
+            return [p.numpy() for p in pyr[:4]], probs.numpy(), deltas.numpy()
+        finally:
+            self.w = w32
+
     # ---- Classifier.mlmodel / Mask.mlmodel -----------------------------------------------------
     def classifier_model(self, fmap):
         """feature_map (n,256,7,7) → probabilities (n,nc), bounding_boxes (n, nc*4)."""
@@ -163,8 +177,10 @@ class OracleMaskRCNN:
         return orc.detection_layer(rois, cls6, c.max_detections, c.detection_min_confidence,
                                    c.detection_nms_threshold, c.bounding_box_std_dev)
 
-    def masks(self, pooled_mask, detections, out=None):
-        mapping = orc.mask_valid_rows(pooled_mask)
+    def masks(self, pooled_mask, detections, out=None, valid_from=None):
+        """valid_from: the rows the removeZeros predicate is evaluated on when they differ from what the mask model is
+        fed (fp16 engine: the predicate sees the fp32 samples, the model their fp16 rounding)."""
+        mapping = orc.mask_valid_rows(pooled_mask if valid_from is None else valid_from)
         m = self.mask_model(pooled_mask[mapping])
         if out is None:
             out = np.zeros((detections.shape[0], m.shape[2] * m.shape[3] if m.size else 784), np.float32)

@@ -1,0 +1,95 @@
+"""Kernel-level parity of the convolution family through mrcnn_conv2d_nhwc (C ABI).
+
+The tile shape / pipeline variant a layer runs on depends on its GEMM size, i.e. on the batch: the 256-row ping-pong
+fp16 kernels (kernels_conv_pp.hip) take over from the 128-row kernel once the grid fills the chip.  Per-image results
+must not depend on the batch, so both kernels have to produce BIT-IDENTICAL outputs on the same data — checked here
+directly, layer shape by layer shape (incl. ragged M, zero padding on every border, residual, stride 2, 1×1 and 3×3,
+K tiles from 2 up), next to a torch-CPU fp32 reference within the fp16-operand tolerance.
+"""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+L = importlib.import_module("mask-rcnn-coreml_amd._lib")
+
+
+def conv(x, w, k, stride, scale=None, shift=None, res=None, act=1, dtype="f16"):
+    B, H, W, Ci = x.shape
+    Co = w.shape[0]
+    pad = k // 2
+    oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = np.empty((B, oh, ow, Co), np.float32)
+    keep = [None if a is None else np.ascontiguousarray(a, np.float32) for a in (x, w, scale, shift, res)]
+    ptr = [None if a is None else a.ctypes.data for a in keep]
+    L.check(L.lib().mrcnn_conv2d_nhwc(ptr[0], B, H, W, Ci, ptr[1], Co, k, stride, ptr[2], ptr[3], ptr[4], act,
+                                      {"f32": L.F32, "f16": L.F16, "f32s": L.F32S, "f32x3": L.F32X3}[dtype], out.ctypes.data))
+    return out
+
+
+def torch_ref(x, w, k, stride, scale, shift, res, act):
+    import torch
+    import torch.nn.functional as F
+    h = lambda a: torch.from_numpy(np.asarray(a, np.float32).astype(np.float16).astype(np.float32))
+    y = F.conv2d(h(x).permute(0, 3, 1, 2), h(w).permute(0, 3, 1, 2), stride=stride, padding=k // 2)
+    y = y * torch.from_numpy(scale)[None, :, None, None] + torch.from_numpy(shift)[None, :, None, None]
+    if res is not None:
+        y = y + h(res).permute(0, 3, 1, 2)
+    if act == 1:
+        y = F.relu(y)
+    return y.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+SHAPES = [  # B, H, W, Cin, Cout, k, stride, residual
+    (2, 64, 64, 256, 256, 3, 1, False),      # M = 8192 = 32 tiles of 256, K = 36 tiles: every border of the zero padding
+    (1, 72, 56, 128, 256, 3, 1, False),      # M = 4032: ragged last M tile (4032 = 15.75 × 256), non-square image
+    (2, 48, 48, 256, 512, 1, 1, True),       # 1×1 with residual, two N tiles, K = 4 tiles (the minimum the policy admits)
+    (1, 96, 96, 64, 256, 3, 2, False),       # stride 2, Cin = 64 (one channel tile per tap: a tap change every K tile)
+    (3, 40, 40, 320, 256, 1, 1, False),      # odd K-tile count (5)
+    (1, 33, 47, 192, 300, 3, 1, True),       # Cout not a multiple of the tile (Npad 384 → the 128-row kernel on both sides)
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_pingpong_kernel_equals_128row_kernel_bitwise(shape):
+    B, H, W, Ci, Co, k, stride, with_res = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal((B, H, W, Ci), np.float32)
+    w = (rng.standard_normal((Co, k, k, Ci), np.float32) * np.float32(1.0 / np.sqrt(k * k * Ci)))
+    scale = (0.5 + rng.random(Co)).astype(np.float32)
+    shift = rng.standard_normal(Co).astype(np.float32) * np.float32(0.1)
+    oh, ow = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    res = rng.standard_normal((B, oh, ow, Co), np.float32) if with_res else None
+    lib = L.lib()
+    try:
+        L.check(lib.mrcnn_debug_set(b"conv_pp", 0))
+        y0 = conv(x, w, k, stride, scale, shift, res, 1, "f16")
+        L.check(lib.mrcnn_debug_set(b"conv_pp", 1))
+        L.check(lib.mrcnn_debug_set(b"conv_pp_min_tiles", 1))       # force the ping-pong kernel onto small grids
+        L.check(lib.mrcnn_debug_set(b"conv_pp_min_kt", 2))
+        y1 = conv(x, w, k, stride, scale, shift, res, 1, "f16")
+    finally:
+        L.check(lib.mrcnn_debug_set(b"conv_pp", 1))
+        L.check(lib.mrcnn_debug_set(b"conv_pp_min_tiles", 256))
+        L.check(lib.mrcnn_debug_set(b"conv_pp_min_kt", 4))
+    np.testing.assert_array_equal(y1, y0)
+    ref = torch_ref(x, w, k, stride, scale, shift, res, 1)
+    assert np.abs(y1 - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max()), np.abs(y1 - ref).max()
+
+
+def test_pingpong_kernel_repeatable_under_load():
+    """Race screen of the hand-placed DMA / barrier schedule: the same launch repeated must give the same bits, on a
+    grid larger than the chip (several rounds of blocks, blocks at different phases sharing L2)."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((4, 128, 128, 256), np.float32)
+    w = rng.standard_normal((512, 3, 3, 256), np.float32) * np.float32(0.02)
+    y0 = conv(x, w, 3, 1, None, None, None, 1, "f16")
+    for _ in range(4):
+        np.testing.assert_array_equal(conv(x, w, 3, 1, None, None, None, 1, "f16"), y0)
+    L.check(L.lib().mrcnn_debug_set(b"conv_pp", 0))
+    try:
+        np.testing.assert_array_equal(conv(x, w, 3, 1, None, None, None, 1, "f16"), y0)
+    finally:
+        L.check(L.lib().mrcnn_debug_set(b"conv_pp", 1))

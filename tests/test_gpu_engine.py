@@ -27,7 +27,7 @@ def _nhwc_to_chw(x, h, w, c):
     return np.ascontiguousarray(x.reshape(h, w, c).transpose(2, 0, 1))
 
 
-def _check_stages(pkg, orc, om, m, cfg, images, b, check_trunk=True, trunk=None, f16=False):
+def _check_stages(pkg, orc, om, m, cfg, images, b, check_trunk=True, trunk=None, f16=False, tb=None):
     """f16: the engine runs fp16 activations/filters with fp32 accumulation (BASELINE configs[3]).  The
     convolutional stages are then compared with the fp32 CPU network at fp16-level tolerances, while
     every index/box stage stays bit-exact on the GPU's own taps (ROIAlign: same fp32 arithmetic on the
@@ -44,10 +44,11 @@ def _check_stages(pkg, orc, om, m, cfg, images, b, check_trunk=True, trunk=None,
     deltas = m.read_tensor("rpn_deltas", b).reshape(A, 4)
     if check_trunk:
         pyr, oprobs, odeltas = trunk
+        tb = b if tb is None else tb            # row of `trunk` that holds image b (the oracle may have run on a subset)
         for l in range(4):
-            assert _rel(P[l], pyr[l][b]) < conv_tol, f"P{l + 2}"
-        assert _rel(deltas, odeltas[b]) < conv_tol
-        assert np.abs(probs - oprobs[b]).max() < prob_tol
+            assert _rel(P[l], pyr[l][tb]) < conv_tol, f"P{l + 2}"
+        assert _rel(deltas, odeltas[tb]) < conv_tol
+        assert np.abs(probs - oprobs[tb]).max() < prob_tol
     # ---- ProposalLayer on the GPU's RPN outputs: bit-exact ---------------------------------------
     K = min(A, cfg.pre_nms_max_proposals)
     want_rois, dbg = om.proposals(probs, deltas, debug=True)
@@ -74,10 +75,16 @@ def _check_stages(pkg, orc, om, m, cfg, images, b, check_trunk=True, trunk=None,
     # ---- PyramidROIAlign (14×14) on the detections: bit-exact -------------------------------------
     pm = cfg.mask_pool_size
     pooled_m = m.read_tensor("pooled_mask", b).reshape(cfg.max_detections, pm, pm, 256).transpose(0, 3, 1, 2)
-    np.testing.assert_array_equal(pooled_m, rnd(om.roi_align(det, P, pm)))
+    samples = om.roi_align(det, P, pm)            # fp32 samples; the fp16 engine stores them rounded once
+    np.testing.assert_array_equal(pooled_m, rnd(samples))
+    # removeZeros predicate: decided on the fp32 samples in every mode (TimeDistributedClassifierLayer.swift:116-127)
+    flags = m.read_tensor("mask_row_flags", b).astype(np.int64)
+    want_flags = np.zeros(cfg.max_detections, np.int64)
+    want_flags[orc.mask_valid_rows(samples)] = 1
+    np.testing.assert_array_equal(flags, want_flags)
     # ---- mask head: same write set, values within 3e-4 --------------------------------------------
     mask = m.read_tensor("mask", b).reshape(cfg.max_detections, 4 * pm * pm)
-    want = om.masks(np.ascontiguousarray(pooled_m), det)
+    want = om.masks(np.ascontiguousarray(pooled_m), det, valid_from=samples)
     np.testing.assert_array_equal(mask == 0, want == 0)
     assert np.abs(mask - want).max() < (3e-2 if f16 else 3e-4)
     return det, mask

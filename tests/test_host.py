@@ -263,3 +263,54 @@ def test_sharded_predict_gloo(world, global_batch):
         wd, wm = _fake_predict(imgs[:world * 2])
         np.testing.assert_array_equal(gd, wd.numpy())
         np.testing.assert_array_equal(gm, wm.numpy())
+
+
+def test_unletterbox_boxes_follow_the_norm_boxes_convention(pkg):
+    """normalized coordinates are Matterport's norm_boxes (pixel = n*(size-1), far edge +1) — the convention
+    of anchors.py and the mask paste — so a box covering exactly the letterboxed content maps back to the full
+    source frame, and the content's centre pixel maps to the source's centre."""
+    ev = __import__("importlib").import_module("mask-rcnn-coreml_amd.evaluate")
+    h, w, H, W = 480, 640, 1024, 1024
+    nh, nw, py, px = ev.letterbox_geometry(h, w, H, W)
+    assert (nh, nw, py, px) == (768, 1024, 128, 0)
+    content = np.array([[py / (H - 1), px / (W - 1), (py + nh - 1) / (H - 1), (px + nw - 1) / (W - 1), 1, 0.9]])
+    back = ev.unletterbox_boxes(content, h, w, H, W)
+    np.testing.assert_allclose(back[0, :4], [0.0, 0.0, 1.0, 1.0], atol=1e-12)
+    # a 2:1 down-scaled interior box: pixel rows [228, 428) of the canvas = source rows [62.5, 187.5)
+    box = np.array([[228 / (H - 1), 100 / (W - 1), (428 - 1) / (H - 1), (300 - 1) / (W - 1), 1, 0.9]])
+    back = ev.unletterbox_boxes(box, h, w, H, W)
+    sy, sx = h / nh, w / nw
+    np.testing.assert_allclose(back[0, 0] * (h - 1), (228 - py) * sy, atol=1e-9)
+    np.testing.assert_allclose(back[0, 2] * (h - 1) + 1, (428 - py) * sy, atol=1e-9)
+    np.testing.assert_allclose(back[0, 1] * (w - 1), 100 * sx, atol=1e-9)
+    np.testing.assert_allclose(back[0, 3] * (w - 1) + 1, 300 * sx, atol=1e-9)
+    # boxes in the black borders clip to the frame
+    border = np.array([[0.0, 0.0, 50 / (H - 1), 1.0, 1, 0.9]])
+    assert ev.unletterbox_boxes(border, h, w, H, W)[0, 2] == 0.0
+
+
+def test_detection_agreement_counts(pkg):
+    ev = __import__("importlib").import_module("mask-rcnn-coreml_amd.evaluate")
+    a = np.zeros((6, 6), np.float32)
+    a[0] = [0.1, 0.1, 0.5, 0.5, 3, 0.99]
+    a[1] = [0.2, 0.2, 0.6, 0.6, 7, 0.95]
+    a[2] = [0.3, 0.3, 0.7, 0.7, 7, 0.90]
+    b = a.copy()
+    r = ev.detection_agreement(a, b)
+    assert r["matched"] == 3 and r["fraction"] == 1.0 and r["same_row"] == 3
+    b[[1, 2]] = b[[2, 1]]                         # neighbours swapped: still the same set
+    r = ev.detection_agreement(a, b)
+    assert r["matched"] == 3 and r["same_row"] == 1
+    b[0, 4] = 4                                   # class differs
+    b[2, 0] += 5e-4                               # box moved beyond the tolerance
+    r = ev.detection_agreement(a, b)
+    assert r["matched"] == 1 and abs(r["fraction"] - 1 / 3) < 1e-12
+    b[3] = [0.4, 0.4, 0.8, 0.8, 1, 0.8]           # an extra detection on one side lowers the fraction
+    assert ev.detection_agreement(a, b)["fraction"] == 0.25
+    assert ev.detection_agreement(np.zeros((4, 6)), np.zeros((4, 6)))["fraction"] == 1.0
+
+
+def test_bench_host_core_count():
+    import bench
+    physical, logical = bench.host_cores()
+    assert 1 <= physical <= logical == os.cpu_count()

@@ -1,23 +1,29 @@
 #!/bin/bash
-# PMC digest of the dominant conv kernel on one shape: pmc_conv_probe.sh <dtype> "<counter set 1>" "<counter set 2>" ...
-# (each set is its own rocprofv3 --pmc pass; RPN 3x3 256->512 @256², batch 8)
+# PMC digest of the conv kernels on one shape, 128-row vs ping-pong:
+#   pmc_conv_probe.sh <dtype> "<b h w cin cout k stride>" "<counter set 1>" "<counter set 2>" ...
+# (each set is its own rocprofv3 --pmc pass, kernel-trace only; both kernels: MRCNN_PP=0 / 1 with the size gate off)
 export TMPDIR=/tmp; R=$(pwd); cd /tmp
 dt=$1; shift
+shape=$1; shift
+for pp in 0 1; do
 for set in "$@"; do
-  rm -rf /tmp/p1; timeout 90 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/p1 -o p -- python $R/tools/conv_one.py 8 256 256 256 512 3 1 3 $dt > /tmp/p1.log 2>&1
-  python - <<'PY'
-import csv,glob,collections
+  rm -rf /tmp/p1; MRCNN_PP=$pp MRCNN_PP_MIN_TILES=1 timeout 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/p1 -o p -- python $R/tools/conv_one.py $shape 3 $dt > /tmp/p1.log 2>&1
+  PP=$pp python - <<'PY'
+import csv,glob,collections,os
 f=glob.glob('/tmp/p1/**/*counter_collection.csv',recursive=True)
-if not f: print("no output (timeout or unsupported counter set)")
+if not f: print("no output (timeout or unsupported counter set)"); print(open('/tmp/p1.log').read()[-600:])
 else:
     acc=collections.defaultdict(list)
-    dur=[]
+    name=None
     for r in csv.DictReader(open(f[0])):
-        if 'k_conv_mfma_glds' in r['Kernel_Name']:
-            acc[r['Counter_Name']].append(float(r['Counter_Value']))
-            if 'End_Timestamp' in r: dur.append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3)
+        if 'k_conv' in r['Kernel_Name']:
+            acc[r['Counter_Name']].append(float(r['Counter_Value'])); name=r['Kernel_Name'][:60]
     out={k: round(sum(v)/len(v)) for k,v in acc.items()}
-    if dur: out['avg_us']=round(sum(dur)/len(dur),1)
-    print(out)
+    kt=glob.glob('/tmp/p1/**/*kernel_trace.csv',recursive=True)
+    if kt:
+        d=[(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3 for r in csv.DictReader(open(kt[0])) if 'k_conv' in r['Kernel_Name']]
+        if d: out['avg_us']=round(sum(d)/len(d),1)
+    print('pp=%s'%os.environ['PP'], name, out, flush=True)
 PY
+done
 done
