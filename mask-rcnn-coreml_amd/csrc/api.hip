@@ -873,7 +873,7 @@ extern "C" int mrcnn_conv2d_nhwc(const float* in, int batch, int h, int w, int c
         if (residual) to_dev(residual, n_out, n_out, adt == MRCNN_F16, dres);
         dout.alloc(n_out * 4);
         ConvDesc d;
-        d.dtype = adt; d.wdtype = wdt; d.out_f32 = 1;
+        d.dtype = adt; d.wdtype = wdt; d.out_f32 = 0;      // fp16 mode stores fp16 (the path the engine's layers take), widened below
         d.in = din.p; d.B = batch; d.H = h; d.W = w; d.Cin = cin;
         d.in_sW = cin; d.in_sH = (long)w * cin; d.in_sB = (long)h * w * cin;
         d.wgt = dw.p; d.KH = d.KW = ksize; d.stride = stride; d.padH = d.padW = pad;
@@ -884,7 +884,13 @@ extern "C" int mrcnn_conv2d_nhwc(const float* in, int batch, int h, int w, int c
         Stream st;
         conv_forward(st.s, d);
         HIP_CHECK(hipStreamSynchronize(st.s));
-        HIP_CHECK(hipMemcpy(out, dout.p, n_out * 4, hipMemcpyDeviceToHost));
+        if (adt == MRCNN_F16) {
+            std::vector<_Float16> t(n_out);
+            HIP_CHECK(hipMemcpy(t.data(), dout.p, n_out * 2, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < n_out; ++i) out[i] = (float)t[i];
+        } else {
+            HIP_CHECK(hipMemcpy(out, dout.p, n_out * 4, hipMemcpyDeviceToHost));
+        }
     });
 }
 

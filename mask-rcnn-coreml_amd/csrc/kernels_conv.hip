@@ -497,7 +497,8 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     // fp16 layers with a large GEMM: the 256-row ping-pong kernel (kernels_conv_pp.hip), one block per CU
     int pp_bn = 0;
     if (half && pp_policy().on && d.Cin % 64 == 0 && a.Ktot / 64 >= pp_policy().min_kt && d.Npad % 256 == 0 &&
-        (long)((a.M + 255) / 256) * (d.Npad / 256) >= pp_policy().min_tiles)
+        (long)((a.M + 255) / 256) * (d.Npad / 256) >= pp_policy().min_tiles &&
+        a.vec_ok && !a.out_f32 && !d.deconv2 && !d.out2 && d.act != ACT_SIGMOID && d.H < 32760 && d.W < 32760)   // what pp_store_tile / PP_SRC_A cover
         pp_bn = 256;
     if (pp_bn) { a.tiles_m = (a.M + 255) / 256; a.tiles_n = d.Npad / pp_bn; }
     ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;

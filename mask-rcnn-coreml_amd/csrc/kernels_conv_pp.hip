@@ -17,8 +17,10 @@
 //     share of the global→LDS DMA for a later K tile, then they swap — the matrix pipe of every SIMD always has one
 //     wave feeding it;
 //   * operands arrive by global_load_lds_dwordx4 (16 B per lane, XOR-swizzled source chunks, zero page for padding
-//     taps — as in kernels_conv.hip) 1½–2 K tiles ahead; vmcnt is COUNTED (one `s_waitcnt vmcnt(6)` per K tile, never
-//     0 in steady state): the DMAs stay in flight across the barriers.
+//     taps — as in kernels_conv.hip) 1½–2 K tiles ahead, two per phase; vmcnt is COUNTED (one `s_waitcnt vmcnt(4)` per K
+//     tile, never 0 in steady state): the DMAs stay in flight across the barriers;
+//   * the epilogue goes straight from the accumulators to HBM (pp_store_tile: transposed result tiles + one
+//     v_permlane32_swap per 16 B) — no LDS staging, no barrier, so it needs nothing the next tile's prologue needs.
 //
 // LDS hazards are excluded by construction, not by observation.  With "slot" = the interval between two consecutive
 // barrier rendezvous, group 0 runs L(ph) in slot 2·ph and M(ph) in slot 2·ph+1 of a K tile, group 1 one slot later:
@@ -28,7 +30,8 @@
 //   WAR  the last reader of slab ph of K tile kt is group 1, whose reads are issued in slot 2ph+1 and retired by its
 //        lgkmcnt(0) at the top of slot 2ph+2: the slab's LDS rows may be overwritten by DMAs issued from slot 2ph+3
 //        on.  BN = 256 (two K-tile buffers, 128 KB): slab ph of tile kt+2 is issued in L(ph+2) of tile kt (slabs 2, 3
-//        in L(0), L(1) of tile kt+1) — slot 2ph+4 at the earliest; the B tile (read only in phase 0) in L(2), L(3).
+//        in L(0), L(1) of tile kt+1) — slot 2ph+4 at the earliest; the filter tile is read only in phase 0 (retired in
+//        slot 2), its 64-row piece p travels with slab p.
 //        BN = 128 (three buffers, 144 KB): tile kt+2 goes to the buffer of tile kt-1, whose last read retired two
 //        slots before the first issue.
 #include "conv_device.h"
@@ -54,6 +57,84 @@ namespace mrcnn {
         const bool ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;                          \
         ok ? reinterpret_cast<const T*>(reinterpret_cast<const char*>(pbase[P]) + (KOFF_)) : zero;             \
     })
+
+// ----------------------------------------------------------------------------------------------------------------
+// Epilogue straight from the accumulators (no LDS round trip, no barrier).  The MFMAs of these kernels take the FILTER
+// fragment as their first operand: the 32×32 result tile is then held transposed — lane (l31, kk) owns output pixel
+// l31 of the slab and channels 8q + 4kk + r (q, r = 0..3) of the column tile — so every lane has runs of four
+// consecutive channels of one pixel.  Per pair of runs (q = 2p, 2p+1): fused scale/shift (+ residual) + ReLU in fp32
+// exactly as conv_epilogue does, one rounding to fp16, then a v_permlane32_swap between the half-waves glues the
+// pieces into 16 contiguous bytes per lane (cdna guide T21): lane (l31, 0) stores channels 16p..16p+7 of its pixel,
+// lane (l31, 1) channels 16p+8..16p+15 — each wave writes whole 128-B lines (its 64 channels of a pixel) in four
+// back-to-back stores.
+// ----------------------------------------------------------------------------------------------------------------
+template <int TM_, int TN_, int ROWS_PER_WAVE_ROW, int COLS_PER_WAVE_COL>
+__device__ __forceinline__ void pp_store_tile(const ConvArgs& a, f32x16 (&acc)[TM_][TN_], int m0, int n0, int wrow, int wcol, int lane)
+{
+    using T = _Float16;
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int ohw = a.OH * a.OW;
+    const T* const res = static_cast<const T*>(a.res);
+    T* const out = static_cast<T*>(a.out);
+    const bool dense_out = a.out_sB == (long)ohw * a.out_sP;
+    const bool dense_res = a.res_sB == (long)ohw * a.res_sW && a.res_shift == 0;
+    bool out_of_range = false;
+#pragma unroll
+    for (int i = 0; i < TM_; ++i) {
+        const int m = m0 + wrow * ROWS_PER_WAVE_ROW + i * 32 + l31;
+        const bool ok_m = m < a.M;
+        long o_row = (long)m * a.out_sP, r_row = (long)m * a.res_sW;
+        if (!dense_out || (res && !dense_res)) {
+            const int mm = ok_m ? m : 0;
+            const int b = mm / ohw, pix = mm - b * ohw;
+            o_row = (long)b * a.out_sB + (long)pix * a.out_sP;
+            if (res) {
+                if (a.res_shift) {
+                    const int oh = pix / a.OW, ow = pix - oh * a.OW;
+                    r_row = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
+                } else r_row = (long)b * a.res_sB + (long)pix * a.res_sW;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN_; ++j) {
+            const int nb = n0 + wcol * COLS_PER_WAVE_COL + j * 32;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int ca = nb + 16 * p + 4 * kk, cb = ca + 8;
+                float4 va = make_float4(acc[i][j][8 * p + 0], acc[i][j][8 * p + 1], acc[i][j][8 * p + 2], acc[i][j][8 * p + 3]);
+                float4 vb = make_float4(acc[i][j][8 * p + 4], acc[i][j][8 * p + 5], acc[i][j][8 * p + 6], acc[i][j][8 * p + 7]);
+                float4 sa = make_float4(1.f, 1.f, 1.f, 1.f), sb_ = sa, ha = make_float4(0.f, 0.f, 0.f, 0.f), hb = ha;
+                if (a.scale) { sa = *reinterpret_cast<const float4*>(a.scale + ca); sb_ = *reinterpret_cast<const float4*>(a.scale + cb); }
+                if (a.shift) { ha = *reinterpret_cast<const float4*>(a.shift + ca); hb = *reinterpret_cast<const float4*>(a.shift + cb); }
+                va.x = va.x * sa.x + ha.x; va.y = va.y * sa.y + ha.y; va.z = va.z * sa.z + ha.z; va.w = va.w * sa.w + ha.w;
+                vb.x = vb.x * sb_.x + hb.x; vb.y = vb.y * sb_.y + hb.y; vb.z = vb.z * sb_.z + hb.z; vb.w = vb.w * sb_.w + hb.w;
+                if (res) {
+                    if (ok_m && ca < a.ncols) { const float4 r = load4<T>(res + r_row + ca); va.x += r.x; va.y += r.y; va.z += r.z; va.w += r.w; }
+                    if (ok_m && cb < a.ncols) { const float4 r = load4<T>(res + r_row + cb); vb.x += r.x; vb.y += r.y; vb.z += r.z; vb.w += r.w; }
+                }
+                if (a.act == ACT_RELU) {
+                    va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f); va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
+                    vb.x = fmaxf(vb.x, 0.f); vb.y = fmaxf(vb.y, 0.f); vb.z = fmaxf(vb.z, 0.f); vb.w = fmaxf(vb.w, 0.f);
+                }
+                if (ok_m && ca < a.ncols)
+                    out_of_range = out_of_range || !(fabsf(va.x) < 65504.0f) || !(fabsf(va.y) < 65504.0f) || !(fabsf(va.z) < 65504.0f) || !(fabsf(va.w) < 65504.0f);
+                if (ok_m && cb < a.ncols)
+                    out_of_range = out_of_range || !(fabsf(vb.x) < 65504.0f) || !(fabsf(vb.y) < 65504.0f) || !(fabsf(vb.z) < 65504.0f) || !(fabsf(vb.w) < 65504.0f);
+                f16x4 ha4, hb4;
+                ha4[0] = (_Float16)va.x; ha4[1] = (_Float16)va.y; ha4[2] = (_Float16)va.z; ha4[3] = (_Float16)va.w;
+                hb4[0] = (_Float16)vb.x; hb4[1] = (_Float16)vb.y; hb4[2] = (_Float16)vb.z; hb4[3] = (_Float16)vb.w;
+                uint2 pa = __builtin_bit_cast(uint2, ha4), pb = __builtin_bit_cast(uint2, hb4);
+                // upper half of the q = 2p runs <-> lower half of the q = 2p+1 runs
+                auto sx = __builtin_amdgcn_permlane32_swap(pa.x, pb.x, false, false);
+                auto sy = __builtin_amdgcn_permlane32_swap(pa.y, pb.y, false, false);
+                const int n_store = nb + 16 * p + 8 * kk;
+                if (ok_m && n_store < a.ncols)
+                    *reinterpret_cast<uint4*>(out + o_row + n_store) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            }
+        }
+    }
+    if (a.range_flag && out_of_range) atomicOr(a.range_flag, 1);
+}
 
 // ================================================================================================================
 // BN = 256: 2 (M) × 4 (N) waves, wave tile 128 × 64 = acc[4][2], four phases per K tile, two K-tile buffers.
@@ -122,13 +203,15 @@ __global__ __launch_bounds__(512) void k_conv_f16_pp256(const ConvArgs a)
 #define PP_ADV23 PP_ADV(ct23, kh23, kw23, ko23)
     // filter tile: 256 rows = four DMAs per thread (rows p·64 + wave·8 + lane>>3): one scalar base + lane offset + p·bstr
     const unsigned vb = (unsigned)(((size_t)(wave * 8 + (lane >> 3)) * a.Ktot + kq * 8) * sizeof(T));
-    const T* sb = wgt + (size_t)n0 * a.Ktot;                             // wave-uniform, advances one K tile per issue round
+    const T* sb01 = wgt + (size_t)n0 * a.Ktot;                           // wave-uniform filter bases of the two issue streams,
+    const T* sb23 = sb01;                                                //   one K tile further per round
     const unsigned bstr = (unsigned)((size_t)64 * a.Ktot * sizeof(T));    // byte distance of the four 64-row groups
     const unsigned dA = lds0 + (wr * 128 + (wave & 3) * 8) * ROWB;      // + buf·A_STAGE + p·4096
     const unsigned dB = lds0 + B_BASE + wave * 8 * ROWB;                // + buf·B_STAGE + p·8192
 #define PP_ISSUE_A01(P, BUF) { const T* src_ = PP_SRC_A(P, kh01, kw01, ko01); PP_GLDS_V(src_, dA + (BUF) * A_STAGE + (P) * 4096); }
 #define PP_ISSUE_A23(P, BUF) { const T* src_ = PP_SRC_A(P, kh23, kw23, ko23); PP_GLDS_V(src_, dA + (BUF) * A_STAGE + (P) * 4096); }
-#define PP_ISSUE_B(P, BUF) PP_GLDS_S(vb + (P) * bstr, sb, dB + (BUF) * B_STAGE + (P) * 8192);
+#define PP_ISSUE_B01(P, BUF) PP_GLDS_S(vb + (P) * bstr, sb01, dB + (BUF) * B_STAGE + (P) * 8192);
+#define PP_ISSUE_B23(P, BUF) PP_GLDS_S(vb + (P) * bstr, sb23, dB + (BUF) * B_STAGE + (P) * 8192);
 
     // ---- fragment reads: lane (l31, kk) of K group g reads chunk 2g+kk of row l31 of its slab
     const int l31 = lane & 31, kk = lane >> 5, swz = (l31 >> 1) & 7;
@@ -149,16 +232,15 @@ __global__ __launch_bounds__(512) void k_conv_f16_pp256(const ConvArgs a)
     f16x8 fb00, fb01, fb10, fb11, fb20, fb21, fb30, fb31;          // B fragments of the current K tile (K group, column tile)
 
     // ---- prologue: K tile 0 completely, of K tile 1 the part the steady state has in flight at a tile boundary
-    PP_ISSUE_A01(0, 0) PP_ISSUE_A01(1, 0) PP_ISSUE_A23(2, 0) PP_ISSUE_A23(3, 0)
-    PP_ISSUE_B(0, 0) PP_ISSUE_B(1, 0) PP_ISSUE_B(2, 0) PP_ISSUE_B(3, 0)
-    sb += BK;
+    PP_ISSUE_A01(0, 0) PP_ISSUE_B01(0, 0) PP_ISSUE_A01(1, 0) PP_ISSUE_B01(1, 0)
+    PP_ISSUE_A23(2, 0) PP_ISSUE_B23(2, 0) PP_ISSUE_A23(3, 0) PP_ISSUE_B23(3, 0)
+    sb01 += BK; sb23 += BK;
     PP_ADV01 PP_ADV23
     if (KT > 1) {
-        PP_ISSUE_A01(0, 1) PP_ISSUE_B(0, 1) PP_ISSUE_B(1, 1)
-        PP_ISSUE_A01(1, 1) PP_ISSUE_B(2, 1) PP_ISSUE_B(3, 1)
-        sb += BK;
+        PP_ISSUE_A01(0, 1) PP_ISSUE_B01(0, 1) PP_ISSUE_A01(1, 1) PP_ISSUE_B01(1, 1)
+        sb01 += BK;
         PP_ADV01
-        PP_VMCNT(6)
+        PP_VMCNT(4)
     } else {
         PP_VMCNT(0)
     }
@@ -183,8 +265,8 @@ __global__ __launch_bounds__(512) void k_conv_f16_pp256(const ConvArgs a)
     __builtin_amdgcn_sched_barrier(0);                                                                         \
     if (!dbg_noprio) __builtin_amdgcn_s_setprio(1);                                                            \
     if (!dbg_nomma) {                                                                                          \
-    PP_MFMA(fa0, fb00, acc[PH][0]) PP_MFMA(fa0, fb01, acc[PH][1]) PP_MFMA(fa1, fb10, acc[PH][0]) PP_MFMA(fa1, fb11, acc[PH][1]) \
-    PP_MFMA(fa2, fb20, acc[PH][0]) PP_MFMA(fa2, fb21, acc[PH][1]) PP_MFMA(fa3, fb30, acc[PH][0]) PP_MFMA(fa3, fb31, acc[PH][1]) \
+    PP_MFMA(fb00, fa0, acc[PH][0]) PP_MFMA(fb01, fa0, acc[PH][1]) PP_MFMA(fb10, fa1, acc[PH][0]) PP_MFMA(fb11, fa1, acc[PH][1]) \
+    PP_MFMA(fb20, fa2, acc[PH][0]) PP_MFMA(fb21, fa2, acc[PH][1]) PP_MFMA(fb30, fa3, acc[PH][0]) PP_MFMA(fb31, fa3, acc[PH][1]) \
     }                                                                                                          \
     __builtin_amdgcn_s_setprio(0);                                                                             \
     __builtin_amdgcn_sched_barrier(0);
@@ -193,25 +275,25 @@ __global__ __launch_bounds__(512) void k_conv_f16_pp256(const ConvArgs a)
 #define PP_KTILE(KTV, BUF)                                                                                     \
     {                                                                                                          \
         const bool has1 = (KTV) + 1 < KT && !dbg_nodma, has2 = (KTV) + 2 < KT && !dbg_nodma;                   \
-        /* phase 0: slab 0 + the whole B tile; DMA: slab 2 of tile kt+1 */                                     \
+        /* phase 0: slab 0 + the whole B tile; DMA: slab 2 / filter rows 128-191 of tile kt+1 */                                     \
         if (!dbg_nords) { PP_RD_A(0, BUF) PP_RD_B(BUF) }                                                       \
-        if (has1) PP_ISSUE_A23(2, (BUF) ^ 1)                                                                     \
+        if (has1) { PP_ISSUE_A23(2, (BUF) ^ 1) PP_ISSUE_B23(2, (BUF) ^ 1) }                                    \
         PP_BARRIER PP_WAIT_AB PP_MATH(0) PP_BARRIER                                                            \
-        /* phase 1: DMA: slab 3 of tile kt+1 */                                                                \
+        /* phase 1: DMA: slab 3 / filter rows 192-255 of tile kt+1 */                                                                \
         if (!dbg_nords) { PP_RD_A(1, BUF) }                                                                    \
-        if (has1) { PP_ISSUE_A23(3, (BUF) ^ 1) PP_ADV23 }                                                        \
+        if (has1) { PP_ISSUE_A23(3, (BUF) ^ 1) PP_ISSUE_B23(3, (BUF) ^ 1) sb23 += BK; PP_ADV23 }               \
         PP_BARRIER PP_WAIT_A PP_MATH(1) PP_BARRIER                                                             \
-        /* phase 2: DMA: slab 0 and filter rows 0-127 of tile kt+2 (over this tile's own buffer) */            \
+        /* phase 2: DMA: slab 0 / filter rows 0-63 of tile kt+2 (over this tile's own buffer) */            \
         if (!dbg_nords) { PP_RD_A(2, BUF) }                                                                    \
-        if (has2) { PP_ISSUE_A01(0, BUF) PP_ISSUE_B(0, BUF) PP_ISSUE_B(1, BUF) }                       \
+        if (has2) { PP_ISSUE_A01(0, BUF) PP_ISSUE_B01(0, BUF) }                                                \
         PP_BARRIER PP_WAIT_A PP_MATH(2) PP_BARRIER                                                             \
-        /* phase 3: DMA: slab 1 and filter rows 128-255 of tile kt+2; then tile kt+1 must have landed */       \
+        /* phase 3: DMA: slab 1 / filter rows 64-127 of tile kt+2; then tile kt+1 must have landed (4 younger DMAs stay in flight) */       \
         if (!dbg_nords) { PP_RD_A(3, BUF) }                                                                    \
         if (has2) {                                                                                            \
-            PP_ISSUE_A01(1, BUF) PP_ISSUE_B(2, BUF) PP_ISSUE_B(3, BUF)                                 \
-            sb += BK;                                                        \
+            PP_ISSUE_A01(1, BUF) PP_ISSUE_B01(1, BUF)                                                          \
+            sb01 += BK;                                                                                        \
             PP_ADV01                                                                                           \
-            PP_VMCNT(6)                                                                                        \
+            PP_VMCNT(4)                                                                                        \
         } else {                                                                                               \
             PP_VMCNT(0)                                                                                        \
         }                                                                                                      \
@@ -228,12 +310,13 @@ __global__ __launch_bounds__(512) void k_conv_f16_pp256(const ConvArgs a)
 #undef PP_WAIT_A
 #undef PP_RD_B
 #undef PP_RD_A
-#undef PP_ISSUE_B
+#undef PP_ISSUE_B23
+#undef PP_ISSUE_B01
 #undef PP_ISSUE_A23
 #undef PP_ISSUE_A01
 #undef PP_ADV23
 #undef PP_ADV01
-    conv_epilogue<T, BN, 4, 2, 2, 4, 4>(a, acc, smem, m0, n0);
+    pp_store_tile<4, 2, 128, 64>(a, acc, m0, n0, wr, wc, lane);
 }
 
 void conv_pp_launch(hipStream_t s, const ConvArgs& a, int bn)
