@@ -184,6 +184,32 @@ MRCNN_API int mrcnn_maskrcnn_predict(mrcnn_model* model, const uint8_t* rgb, int
 MRCNN_API int mrcnn_maskrcnn_predict_async(mrcnn_model* model, const uint8_t* rgb, int batch, int height,
                                            int width, float* detections, float* masks);
 
+/* ---------------------------------------------------------------------------------------------
+ * Multi-GPU (one process per GPU of a node; new functionality of the MI355X build — the reference runs one image on one
+ * device, the host loop that would drive this is Sources/maskrcnn/EvaluateCommand.swift:146-179).  A batch is split into
+ * contiguous blocks of images (blocks differ by at most one image), every rank loads the same artefacts and predicts
+ * its block, and ONE ncclAllGather over RCCL/xGMI — issued on the model's stream — hands every rank the fixed-size,
+ * zero-padded records of the whole batch in image order:
+ *     record = detections (maxDetections × 6 f32) ‖ mask (maxDetections × 28 × 28 f32)     316 000 B at the defaults.
+ * Per-image results do not depend on the world size (tests).  RCCL is bound at run time (librccl.so.1).
+ *   mrcnn_dist_unique_id   rank 0 creates the 128-byte rendezvous id; the HOST ships it to the other ranks (file, env, pipe)
+ *   mrcnn_dist_init        joins the communicator on the calling thread's current HIP device
+ *   mrcnn_dist_shard       [begin, end) of `rank` in a batch of `global_batch` images (host arithmetic, no GPU needed)
+ *   mrcnn_dist_record_floats  floats per image record
+ *   mrcnn_dist_all_gather_records  local results (end-begin images, `memspace`) → all `global_batch` results (`memspace`)
+ *   mrcnn_maskrcnn_predict_sharded  the whole step: every rank passes the SAME global batch (global_batch, H, W, 3) and
+ *                          receives detections (global_batch, maxDet, 6) / masks (global_batch, maxDet, 28, 28) */
+typedef struct mrcnn_dist mrcnn_dist;
+MRCNN_API int mrcnn_dist_unique_id(uint8_t* id128);
+MRCNN_API int mrcnn_dist_init(int rank, int world, const uint8_t* id128, mrcnn_dist** out);
+MRCNN_API void mrcnn_dist_destroy(mrcnn_dist* dist);
+MRCNN_API int mrcnn_dist_shard(int global_batch, int world, int rank, int* begin, int* end);
+MRCNN_API int64_t mrcnn_dist_record_floats(int max_detections, int mask_size);
+MRCNN_API int mrcnn_dist_all_gather_records(mrcnn_dist* dist, mrcnn_model* model, const float* detections, const float* masks,
+                                            int global_batch, int memspace, float* out_detections, float* out_masks);
+MRCNN_API int mrcnn_maskrcnn_predict_sharded(mrcnn_dist* dist, mrcnn_model* model, const uint8_t* rgb, int global_batch,
+                                             int height, int width, int memspace, float* detections, float* masks);
+
 /* Classifier.prediction(feature_map:) (task.py:106-113): feature_map (n,256,7,7) CHW →
  * probabilities (n, numClasses), bounding_boxes (n, numClasses*4) class-major. */
 MRCNN_API int mrcnn_classifier_predict(mrcnn_model* model, const float* feature_map, int n, int memspace,

@@ -30,6 +30,8 @@ EXPORTED_SYMBOLS = [
     "mrcnn_model_conv_profile_enable", "mrcnn_model_conv_profile_get", "mrcnn_model_conv_profile_shapes", "mrcnn_model_enable_graph", "mrcnn_bench_conv_dtype",
     "mrcnn_detections_decode", "mrcnn_mask_to_u8", "mrcnn_paste_masks", "mrcnn_generate_anchors", "mrcnn_letterbox_geometry", "mrcnn_letterbox_rgb",
     "mrcnn_model_check_range", "mrcnn_roi_align_nhwc", "mrcnn_conv2d_nhwc", "mrcnn_debug_set",
+    "mrcnn_dist_unique_id", "mrcnn_dist_init", "mrcnn_dist_destroy", "mrcnn_dist_shard", "mrcnn_dist_record_floats",
+    "mrcnn_dist_all_gather_records", "mrcnn_maskrcnn_predict_sharded",
 ]
 
 
@@ -126,6 +128,15 @@ def lib():
     L.mrcnn_conv2d_nhwc.argtypes = [vp] + [C.c_int] * 4 + [vp] + [C.c_int] * 3 + [vp, vp, vp, C.c_int, C.c_int, vp]
     L.mrcnn_debug_set.argtypes = [cp, C.c_int]
     L.mrcnn_model_check_range.argtypes = [vp, ip]
+    L.mrcnn_dist_unique_id.argtypes = [vp]
+    L.mrcnn_dist_init.argtypes = [C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.mrcnn_dist_destroy.argtypes = [vp]
+    L.mrcnn_dist_destroy.restype = None
+    L.mrcnn_dist_shard.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip]
+    L.mrcnn_dist_record_floats.argtypes = [C.c_int, C.c_int]
+    L.mrcnn_dist_record_floats.restype = C.c_int64
+    L.mrcnn_dist_all_gather_records.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]
+    L.mrcnn_maskrcnn_predict_sharded.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     L.mrcnn_roi_align_nhwc.argtypes = [C.POINTER(vp), ip, ip, C.c_int, C.c_int, vp, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double,
                                        C.c_int, vp, vp]
     _lib = L

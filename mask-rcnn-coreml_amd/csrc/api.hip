@@ -494,10 +494,6 @@ extern "C" float mrcnn_iou(const float a[4], const float b[4])
 // ================================================================================================
 // models
 // ================================================================================================
-struct mrcnn_model {
-    Model m;
-};
-
 extern "C" int mrcnn_model_load(int kind, const char* path, int max_batch, int compute_dtype, mrcnn_model** out_model)
 {
     return guarded([&] {

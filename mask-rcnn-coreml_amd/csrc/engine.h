@@ -183,3 +183,8 @@ void run_conv_dense(hipStream_t s, const PackedConv& pc, const void* in, int B, 
                     int pad, int act, const void* res = nullptr, int out_f32 = 0);
 
 }  // namespace mrcnn
+
+// the opaque handle of the C ABI (include/maskrcnn_hip.h)
+struct mrcnn_model {
+    mrcnn::Model m;
+};

@@ -146,7 +146,8 @@ void conv_set_range_flag(int* device_flag);
 // Picks the tile shape from Cout; returns the N tile it will use so that callers can pad weights.
 int conv_n_tile(int Cout);
 void conv_forward(hipStream_t s, const ConvDesc& d);
-// Test / measurement switches of the kernel choice ("conv_pp" 0|1, "conv_pp_min_tiles", "conv_pp_min_kt"); false = unknown key.
+// Test / measurement switches of the kernel choice ("conv_pp" 0|1, "conv_pp_split" 0|1, "conv_pp_min_tiles", "conv_pp_min_kt",
+// "conv_pp_min_fill" percent, "conv_pp_dbg" ablation bits); false = unknown key.
 bool conv_debug_set(const char* key, int value);
 
 // uint8 RGB (B,H,W,3) → fp32 (B, H+2*pad, W+2*pad, 4) minus mean, zero border, channel 3 = 0.

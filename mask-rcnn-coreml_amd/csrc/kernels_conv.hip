@@ -27,55 +27,6 @@
 
 namespace mrcnn {
 
-// fp32 → (hi, lo) fp16 pair with hi + lo = a to ~2^-22 relative: hi = a rounded toward zero to fp16,
-// lo = (a - hi) rounded toward zero to fp16 (a - hi is exact in fp32; for |a| below ~1e-2 lo lands in the
-// fp16 subnormals, whose 2^-24 absolute step is far under the fp32 rounding noise of the sums it feeds).
-// fp16 × fp16 products are exact in the MFMA's fp32 accumulate, so hi·w + lo·w reproduces the fp32 product
-// a·w for fp16-exact filters w.  |a| must stay below 65504 (as in any fp16 GPU path of the reference).
-__device__ __forceinline__ void split_hi_lo(const uint4 u0, const uint4 u1, f16x8& hi, f16x8& lo)
-{
-    const float a[8] = {__uint_as_float(u0.x), __uint_as_float(u0.y), __uint_as_float(u0.z), __uint_as_float(u0.w),
-                        __uint_as_float(u1.x), __uint_as_float(u1.y), __uint_as_float(u1.z), __uint_as_float(u1.w)};
-    uint32_t hw[4], lw[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const uint32_t h2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a[2 * p], a[2 * p + 1]));
-        // r = a - hi in ONE mixed-precision FMA (fp16 half of h2 × -1.0 + a): saves the widening conversion
-        float r0, r1;
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h2), "v"(a[2 * p]));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h2), "v"(a[2 * p + 1]));
-        hw[p] = h2;
-        lw[p] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r0, r1));
-    }
-    hi = __builtin_bit_cast(f16x8, uint4{hw[0], hw[1], hw[2], hw[3]});
-    lo = __builtin_bit_cast(f16x8, uint4{lw[0], lw[1], lw[2], lw[3]});
-}
-
-// Three-part variant (MRCNN_F32X3): hi + mid + lo carries all 24 significand bits — exact for 0.5 <= |a| < 65504, and to
-// 2^-24 absolute below (where the last part reaches the fp16 subnormal step): the fp32 product a·w is reproduced exactly.
-__device__ __forceinline__ void split_hi_mid_lo(const uint4 u0, const uint4 u1, f16x8& hi, f16x8& mid, f16x8& lo)
-{
-    const float a[8] = {__uint_as_float(u0.x), __uint_as_float(u0.y), __uint_as_float(u0.z), __uint_as_float(u0.w),
-                        __uint_as_float(u1.x), __uint_as_float(u1.y), __uint_as_float(u1.z), __uint_as_float(u1.w)};
-    uint32_t hw[4], mw[4], lw[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const uint32_t h2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a[2 * p], a[2 * p + 1]));
-        float r0, r1, q0, q1;
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h2), "v"(a[2 * p]));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h2), "v"(a[2 * p + 1]));
-        const uint32_t m2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r0, r1));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(q0) : "v"(m2), "v"(r0));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(q1) : "v"(m2), "v"(r1));
-        hw[p] = h2;
-        mw[p] = m2;
-        lw[p] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(q0, q1));
-    }
-    hi = __builtin_bit_cast(f16x8, uint4{hw[0], hw[1], hw[2], hw[3]});
-    mid = __builtin_bit_cast(f16x8, uint4{mw[0], mw[1], mw[2], mw[3]});
-    lo = __builtin_bit_cast(f16x8, uint4{lw[0], lw[1], lw[2], lw[3]});
-}
-
 // ------------------------------------------------------------------------------------------------
 // The implicit-GEMM kernel.  T = float   : v_mfma_f32_32x32x2_f32  (exact fp32, 157.3 TFLOP/s peak), K tile = 32
 //                            T = _Float16: v_mfma_f32_32x32x16_f16 (fp32 accumulate, ~2.5 PFLOP/s peak), K tile = 64
@@ -425,7 +376,7 @@ static void conv_launch(hipStream_t s, const ConvArgs& a, int bn)
     else hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 32, 1, 1, 4, 1, MRCNN_RING32, PARTS>), grid, dim3(256), 0, s, a);
 }
 
-void conv_pp_launch(hipStream_t s, const ConvArgs& a, int bn);   // kernels_conv_pp.hip
+void conv_pp_launch(hipStream_t s, const ConvArgs& a, int mode);   // kernels_conv_pp.hip: 0 fp16, 2 / 3 split parts
 
 // Run-time switches of the tile choice (A/B measurements through the micro-benchmark hook; defaults = the shipped policy)
 static int env_int(const char* name, int dflt)
@@ -433,10 +384,14 @@ static int env_int(const char* name, int dflt)
     const char* e = getenv(name);
     return e && *e ? atoi(e) : dflt;
 }
-struct PpPolicy { int on, min_tiles, min_kt, dbg; };
+struct PpPolicy { int on, min_tiles, min_kt, dbg, min_fill_pct, split; };
 static PpPolicy& pp_policy()
 {
-    static PpPolicy p = {env_int("MRCNN_PP", 1), env_int("MRCNN_PP_MIN_TILES", 256), env_int("MRCNN_PP_MIN_KT", 4), env_int("MRCNN_PP_DBG", 0)};
+    // Shipped policy = where the A/B of tools/conv_ab.py shows a gain (profiles/r02_conv_ab_*.txt): fp16 tensors, at least two
+    // full rounds of 256 tiles, K >= 512.  The split modes run the same kernel bit-identically but no faster (both kernels
+    // sit at the same power-limited MFMA rate): off unless asked for.
+    static PpPolicy p = {env_int("MRCNN_PP", 1), env_int("MRCNN_PP_MIN_TILES", 512), env_int("MRCNN_PP_MIN_KT", 8), env_int("MRCNN_PP_DBG", 0),
+                         env_int("MRCNN_PP_MIN_FILL", 85), env_int("MRCNN_PP_SPLIT", 0)};
     return p;
 }
 bool conv_debug_set(const char* key, int value)
@@ -446,6 +401,8 @@ bool conv_debug_set(const char* key, int value)
     else if (k == "conv_pp_min_tiles") pp_policy().min_tiles = value;
     else if (k == "conv_pp_min_kt") pp_policy().min_kt = value;
     else if (k == "conv_pp_dbg") pp_policy().dbg = value;
+    else if (k == "conv_pp_min_fill") pp_policy().min_fill_pct = value;
+    else if (k == "conv_pp_split") pp_policy().split = value;
     else return false;
     return true;
 }
@@ -494,16 +451,23 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
                (!d.res || (d.res_sW % cpt == 0 && d.res_sH % cpt == 0 && d.res_sB % cpt == 0 && al(d.res, 16))) &&
                (!d.deconv2 || (d.Cout % cpt == 0 && d.out_sH % cpt == 0 && d.out_sW % cpt == 0));
     a.tiles_n = d.Npad / bn;
-    // fp16 layers with a large GEMM: the 256-row ping-pong kernel (kernels_conv_pp.hip), one block per CU
+    // Layers with a large GEMM: the 256×256 persistent ping-pong kernel (kernels_conv_pp.hip), one block per CU — when the
+    // tiles fill whole rounds of the chip well enough (a static walk: the last round costs as much as a full one).
     int pp_bn = 0;
-    if (half && pp_policy().on && d.Cin % 64 == 0 && a.Ktot / 64 >= pp_policy().min_kt && d.Npad % 256 == 0 &&
-        (long)((a.M + 255) / 256) * (d.Npad / 256) >= pp_policy().min_tiles &&
-        a.vec_ok && !a.out_f32 && !d.deconv2 && !d.out2 && d.act != ACT_SIGMOID && d.H < 32760 && d.W < 32760)   // what pp_store_tile / PP_SRC_A cover
-        pp_bn = 256;
+    {
+        const PpPolicy& pol = pp_policy();
+        const long tiles = (long)((a.M + 255) / 256) * (d.Npad / 256);
+        const long rounds = (tiles + 255) / 256;
+        const bool fills = tiles >= pol.min_tiles && tiles * 100 >= rounds * 256 * pol.min_fill_pct;
+        const int bk_pp = half ? 64 : 32;
+        if (pol.on && (half || (split && pol.split)) && d.Cin % bk_pp == 0 && a.Ktot / bk_pp >= pol.min_kt && d.Npad % 256 == 0 && fills &&
+            a.vec_ok && (!half || !a.out_f32) && !d.deconv2 && !d.out2 && d.act != ACT_SIGMOID && d.H < 32760 && d.W < 32760)
+            pp_bn = 256;                    // ... and the epilogue / address forms pp_store_tile and PP_SRC_A cover
+    }
     if (pp_bn) { a.tiles_m = (a.M + 255) / 256; a.tiles_n = d.Npad / pp_bn; }
     ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
     const int e0 = prof ? prof_event(prof, s) : 0;
-    if (pp_bn) conv_pp_launch(s, a, pp_bn);
+    if (pp_bn) conv_pp_launch(s, a, half ? 0 : (wdtype == MRCNN_F32X3 ? 3 : 2));
     else if (half) conv_launch<_Float16, _Float16>(s, a, bn);
     else if (split && wdtype == MRCNN_F32X3) conv_launch<float, _Float16, 3>(s, a, bn);
     else if (split) conv_launch<float, _Float16, 2>(s, a, bn);

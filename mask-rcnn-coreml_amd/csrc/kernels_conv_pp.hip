@@ -1,39 +1,45 @@
-// kernels_conv_pp.hip — the deep-pipelined fp16 implicit-GEMM convolution of the trunk's large layers on gfx950:
-// 256-row block tiles, 8 waves in two groups that PING-PONG between "issue loads" and "issue MFMAs".
+// kernels_conv_pp.hip — the deep-pipelined implicit-GEMM convolution of the trunk's large layers on gfx950: 256×256 block
+// tiles, 8 waves in two groups that PING-PONG between "issue loads" and "issue MFMAs", persistent blocks (one per CU).
 //
 // Same contract as k_conv_mfma_glds (kernels_conv.hip; reference layers: the 3×3 / 1×1 convolutions of
-// MaskRCNN.mlmodel / Mask.mlmodel, Sources/maskrcnn/Python/Conversion/task.py:69-104): NHWC fp16 activations, filters
-// packed [cout][tap][cin] fp16, out[m][n] = Σ_k A[m][k]·Wt[n][k] in fp32 (v_mfma_f32_32x32x16_f16), the fused epilogue of
-// conv_device.h.  What changes is the main loop, built for the regime the round-1 profile showed the 128×128 kernel
-// to be in (MFMA issue 55 %, clock 1.49 GHz — LDS→VGPR and L2→LDS bytes per flop, one vmcnt(0)+barrier per K step):
+// MaskRCNN.mlmodel / Mask.mlmodel, Sources/maskrcnn/Python/Conversion/task.py:69-104): NHWC activations, filters packed
+// [cout][tap][cin] fp16, out[m][n] = Σ_k A[m][k]·Wt[n][k] accumulated in fp32 by v_mfma_f32_32x32x16_f16, fused
+// scale/shift/residual/ReLU epilogue.  MODE 0: fp16 activations (MRCNN_F16).  MODE 2 / 3: fp32 activations split in
+// registers into 2 / 3 fp16 parts, one MFMA pass per part (MRCNN_F32S / MRCNN_F32X3, see split_hi_lo in conv_device.h).
+// Results are BIT-IDENTICAL to the 128-row kernels (same products, same order of accumulation, same epilogue
+// arithmetic): which kernel a layer runs on depends on the batch size, per-image results must not
+// (tests/test_gpu_conv_kernels.py).
 //
-//   * block tile 256 × BN (BN = 256 or 128), K tile 64 (one 128-B run per operand row), 8 waves: wave tile 128×64
-//     (BN = 256: 2×4 waves) or 64×64 (BN = 128: 4×2 waves) → 0.75 / 1.0 ds_read_b128 per MFMA (was 1.5) and half /
-//     two thirds of the global→LDS bytes per flop of the 128×128 tile;
-//   * a K tile is consumed in PHASES of 8 MFMAs (one 32-row slab of the wave tile × all its columns × K = 64); the B
-//     fragments of the whole K tile are read once (phase 0) and stay in registers;
-//   * the two wave groups (waves 0-3 / 4-7 = one wave of each per SIMD) run ONE BARRIER APART: while group 0 issues
-//     the 8 MFMAs of a phase (256 matrix-pipe cycles, s_setprio 1), group 1 issues its LDS fragment reads and its
-//     share of the global→LDS DMA for a later K tile, then they swap — the matrix pipe of every SIMD always has one
-//     wave feeding it;
-//   * operands arrive by global_load_lds_dwordx4 (16 B per lane, XOR-swizzled source chunks, zero page for padding
-//     taps — as in kernels_conv.hip) 1½–2 K tiles ahead, two per phase; vmcnt is COUNTED (one `s_waitcnt vmcnt(4)` per K
-//     tile, never 0 in steady state): the DMAs stay in flight across the barriers;
-//   * the epilogue goes straight from the accumulators to HBM (pp_store_tile: transposed result tiles + one
-//     v_permlane32_swap per 16 B) — no LDS staging, no barrier, so it needs nothing the next tile's prologue needs.
+// Why this structure (measured): a CU moves at most ≈27 B/clk from L2 (tools/probes/dma_probe.hip), the
+// 128×128 fp16 tile needs 64 B/clk at full MFMA rate, LDS→VGPR reads and DMA writes share the LDS, and the matrix cores
+// pull the clock down to ≈1.45 GHz; the block-level fixed cost (prologue latency, LDS-staged epilogue) is exposed once a
+// block owns its CU.  Hence:
+//   * block tile 256×256, one 128-B run of K per operand row and step (64 fp16 / 32 fp32 channels), wave tile 128×64
+//     (2×4 waves): half the L2→LDS bytes and half the LDS→VGPR reads per MFMA of the 128×128 kernel;
+//   * a K step is consumed in four PHASES (one 32-row slab of the wave tile × its 64 columns): 8 MFMAs (fp16) or
+//     8 / 12 MFMAs + the hi/(mid/)lo split of the slab's activations (split modes); the filter fragments of the whole
+//     K step are read once (phase 0) and stay in registers;
+//   * the two wave groups (waves 0-3 / 4-7 = one wave of each per SIMD) run ONE BARRIER APART: while one group issues
+//     the MFMAs of a phase (s_setprio 1), the other issues its LDS fragment reads and its share of the global→LDS DMA
+//     (global_load_lds_dwordx4, XOR-swizzled source chunks, zero page for padding taps) for a K step 1½–2 steps ahead;
+//     vmcnt is COUNTED (one `s_waitcnt vmcnt(4 | 3)` per K step, never 0 in steady state);
+//   * the epilogue goes straight from the accumulators to HBM (transposed result tiles: a lane owns runs of four
+//     consecutive channels of one pixel; fp16: one v_permlane32_swap per 16 B) — no LDS staging, no barrier;
+//   * PERSISTENT blocks: a block walks its tiles; the DMA prologue of tile i+1 is issued BEFORE the epilogue of tile i
+//     (the epilogue needs no LDS), so neither the prologue's memory latency nor the store drain is exposed.
 //
-// LDS hazards are excluded by construction, not by observation.  With "slot" = the interval between two consecutive
-// barrier rendezvous, group 0 runs L(ph) in slot 2·ph and M(ph) in slot 2·ph+1 of a K tile, group 1 one slot later:
+// LDS hazards are excluded by construction.  With "slot" = the interval between two consecutive barrier rendezvous,
+// group 0 runs L(ph) in slot 2·ph and M(ph) in slot 2·ph+1 of a K step, group 1 one slot later:
 //   RAW  a DMA is visible to a ds_read only after the issuing wave's covering vmcnt AND a barrier the reader passed
-//        afterwards: every wave waits for K tile kt+1 at the end of its LAST L phase of K tile kt (group 1: the slot
-//        right before group 0's first read of kt+1);
-//   WAR  the last reader of slab ph of K tile kt is group 1, whose reads are issued in slot 2ph+1 and retired by its
-//        lgkmcnt(0) at the top of slot 2ph+2: the slab's LDS rows may be overwritten by DMAs issued from slot 2ph+3
-//        on.  BN = 256 (two K-tile buffers, 128 KB): slab ph of tile kt+2 is issued in L(ph+2) of tile kt (slabs 2, 3
-//        in L(0), L(1) of tile kt+1) — slot 2ph+4 at the earliest; the filter tile is read only in phase 0 (retired in
-//        slot 2), its 64-row piece p travels with slab p.
-//        BN = 128 (three buffers, 144 KB): tile kt+2 goes to the buffer of tile kt-1, whose last read retired two
-//        slots before the first issue.
+//        afterwards: every wave waits for K step kt+1 at the end of its LAST L phase of step kt (group 1: the slot right
+//        before group 0's first read of kt+1);
+//   WAR  the last reader of slab ph of step kt is group 1, whose reads are issued in slot 2ph+1 and retired by its
+//        lgkmcnt(0) at the top of slot 2ph+2: the slab's LDS rows may be overwritten by DMAs issued from slot 2ph+3 on.
+//        With two K-step buffers slab ph of step kt+2 is issued in L(ph+2) of step kt (slabs 2, 3 in L(0), L(1) of step
+//        kt+1) — slot 2ph+4 at the earliest; the filter tile is read only in phase 0 (retired in slot 2): its pieces
+//        travel with slabs 2/3 (→ the other buffer) and 0/1 (→ this buffer, from L(2) on).
+#include <type_traits>
+
 #include "conv_device.h"
 
 namespace mrcnn {
@@ -46,8 +52,9 @@ namespace mrcnn {
 #define PP_BARRIER asm volatile("s_barrier" ::: "memory");
 #define PP_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 #define PP_MFMA(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, C_, 0, 0, 0);
+#define PP_U4(X_) __builtin_bit_cast(uint4, X_)
 
-// Source of one staged activation row P for the tap (KH_, KW_) and byte offset KOFF_ (tap + channel tile, wave-uniform):
+// Source of one staged activation row P for the tap (KH_, KW_) and byte offset KOFF_ (tap + channel step, wave-uniform):
 // the row's pixel run, or the zero page when the tap falls outside the image (zero padding) / the row is beyond M.
 // Rebuilt at every issue from 3 registers per row (64-bit pixel base, packed 16-bit (ih0, iw0)): ~10 VALU in a load
 // phase instead of 7 live registers per row — the kernel's budget is 256 registers with a 128-register accumulator.
@@ -55,23 +62,22 @@ namespace mrcnn {
     ({                                                                                                         \
         const int ih = (int)(short)(ihw[P] & 0xffff) + (KH_), iw = (ihw[P] >> 16) + (KW_);                     \
         const bool ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;                          \
-        ok ? reinterpret_cast<const T*>(reinterpret_cast<const char*>(pbase[P]) + (KOFF_)) : zero;             \
+        ok ? pbase[P] + (KOFF_) : zero;                                                                        \
     })
 
 // ----------------------------------------------------------------------------------------------------------------
-// Epilogue straight from the accumulators (no LDS round trip, no barrier).  The MFMAs of these kernels take the FILTER
+// Epilogue straight from the accumulators (no LDS round trip, no barrier).  The MFMAs of this kernel take the FILTER
 // fragment as their first operand: the 32×32 result tile is then held transposed — lane (l31, kk) owns output pixel
 // l31 of the slab and channels 8q + 4kk + r (q, r = 0..3) of the column tile — so every lane has runs of four
-// consecutive channels of one pixel.  Per pair of runs (q = 2p, 2p+1): fused scale/shift (+ residual) + ReLU in fp32
-// exactly as conv_epilogue does, one rounding to fp16, then a v_permlane32_swap between the half-waves glues the
-// pieces into 16 contiguous bytes per lane (cdna guide T21): lane (l31, 0) stores channels 16p..16p+7 of its pixel,
-// lane (l31, 1) channels 16p+8..16p+15 — each wave writes whole 128-B lines (its 64 channels of a pixel) in four
-// back-to-back stores.
+// consecutive channels of one pixel.  Per run: fused scale/shift (+ residual) + ReLU in fp32 exactly as conv_epilogue
+// does.  fp32 tensors: one 16-B store per run.  fp16 tensors: one rounding, then per pair of runs (q = 2p, 2p+1) a
+// v_permlane32_swap between the half-waves glues the pieces into 16 contiguous bytes per lane (cdna guide T21): lane
+// (l31, 0) stores channels 16p..16p+7 of its pixel, lane (l31, 1) channels 16p+8..16p+15 — a wave writes whole
+// 128-B lines (its 64 channels of a pixel) in four back-to-back stores.
 // ----------------------------------------------------------------------------------------------------------------
-template <int TM_, int TN_, int ROWS_PER_WAVE_ROW, int COLS_PER_WAVE_COL>
-__device__ __forceinline__ void pp_store_tile(const ConvArgs& a, f32x16 (&acc)[TM_][TN_], int m0, int n0, int wrow, int wcol, int lane)
+template <typename T>
+__device__ __forceinline__ void pp_store_tile(const ConvArgs& a, f32x16 (&acc)[4][2], int m0, int n0, int wrow, int wcol, int lane)
 {
-    using T = _Float16;
     const int l31 = lane & 31, kk = lane >> 5;
     const int ohw = a.OH * a.OW;
     const T* const res = static_cast<const T*>(a.res);
@@ -80,8 +86,8 @@ __device__ __forceinline__ void pp_store_tile(const ConvArgs& a, f32x16 (&acc)[T
     const bool dense_res = a.res_sB == (long)ohw * a.res_sW && a.res_shift == 0;
     bool out_of_range = false;
 #pragma unroll
-    for (int i = 0; i < TM_; ++i) {
-        const int m = m0 + wrow * ROWS_PER_WAVE_ROW + i * 32 + l31;
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wrow * 128 + i * 32 + l31;
         const bool ok_m = m < a.M;
         long o_row = (long)m * a.out_sP, r_row = (long)m * a.res_sW;
         if (!dense_out || (res && !dense_res)) {
@@ -96,8 +102,8 @@ __device__ __forceinline__ void pp_store_tile(const ConvArgs& a, f32x16 (&acc)[T
             }
         }
 #pragma unroll
-        for (int j = 0; j < TN_; ++j) {
-            const int nb = n0 + wcol * COLS_PER_WAVE_COL + j * 32;
+        for (int j = 0; j < 2; ++j) {
+            const int nb = n0 + wcol * 64 + j * 32;
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int ca = nb + 16 * p + 4 * kk, cb = ca + 8;
@@ -108,28 +114,32 @@ __device__ __forceinline__ void pp_store_tile(const ConvArgs& a, f32x16 (&acc)[T
                 if (a.shift) { ha = *reinterpret_cast<const float4*>(a.shift + ca); hb = *reinterpret_cast<const float4*>(a.shift + cb); }
                 va.x = va.x * sa.x + ha.x; va.y = va.y * sa.y + ha.y; va.z = va.z * sa.z + ha.z; va.w = va.w * sa.w + ha.w;
                 vb.x = vb.x * sb_.x + hb.x; vb.y = vb.y * sb_.y + hb.y; vb.z = vb.z * sb_.z + hb.z; vb.w = vb.w * sb_.w + hb.w;
+                const bool ok_a = ok_m && ca < a.ncols, ok_b = ok_m && cb < a.ncols;
                 if (res) {
-                    if (ok_m && ca < a.ncols) { const float4 r = load4<T>(res + r_row + ca); va.x += r.x; va.y += r.y; va.z += r.z; va.w += r.w; }
-                    if (ok_m && cb < a.ncols) { const float4 r = load4<T>(res + r_row + cb); vb.x += r.x; vb.y += r.y; vb.z += r.z; vb.w += r.w; }
+                    if (ok_a) { const float4 r = load4<T>(res + r_row + ca); va.x += r.x; va.y += r.y; va.z += r.z; va.w += r.w; }
+                    if (ok_b) { const float4 r = load4<T>(res + r_row + cb); vb.x += r.x; vb.y += r.y; vb.z += r.z; vb.w += r.w; }
                 }
                 if (a.act == ACT_RELU) {
                     va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f); va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
                     vb.x = fmaxf(vb.x, 0.f); vb.y = fmaxf(vb.y, 0.f); vb.z = fmaxf(vb.z, 0.f); vb.w = fmaxf(vb.w, 0.f);
                 }
-                if (ok_m && ca < a.ncols)
-                    out_of_range = out_of_range || !(fabsf(va.x) < 65504.0f) || !(fabsf(va.y) < 65504.0f) || !(fabsf(va.z) < 65504.0f) || !(fabsf(va.w) < 65504.0f);
-                if (ok_m && cb < a.ncols)
-                    out_of_range = out_of_range || !(fabsf(vb.x) < 65504.0f) || !(fabsf(vb.y) < 65504.0f) || !(fabsf(vb.z) < 65504.0f) || !(fabsf(vb.w) < 65504.0f);
-                f16x4 ha4, hb4;
-                ha4[0] = (_Float16)va.x; ha4[1] = (_Float16)va.y; ha4[2] = (_Float16)va.z; ha4[3] = (_Float16)va.w;
-                hb4[0] = (_Float16)vb.x; hb4[1] = (_Float16)vb.y; hb4[2] = (_Float16)vb.z; hb4[3] = (_Float16)vb.w;
-                uint2 pa = __builtin_bit_cast(uint2, ha4), pb = __builtin_bit_cast(uint2, hb4);
-                // upper half of the q = 2p runs <-> lower half of the q = 2p+1 runs
-                auto sx = __builtin_amdgcn_permlane32_swap(pa.x, pb.x, false, false);
-                auto sy = __builtin_amdgcn_permlane32_swap(pa.y, pb.y, false, false);
-                const int n_store = nb + 16 * p + 8 * kk;
-                if (ok_m && n_store < a.ncols)
-                    *reinterpret_cast<uint4*>(out + o_row + n_store) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                if (ok_a) out_of_range = out_of_range || !(fabsf(va.x) < 65504.0f) || !(fabsf(va.y) < 65504.0f) || !(fabsf(va.z) < 65504.0f) || !(fabsf(va.w) < 65504.0f);
+                if (ok_b) out_of_range = out_of_range || !(fabsf(vb.x) < 65504.0f) || !(fabsf(vb.y) < 65504.0f) || !(fabsf(vb.z) < 65504.0f) || !(fabsf(vb.w) < 65504.0f);
+                if constexpr (sizeof(T) == 4) {
+                    if (ok_a) *reinterpret_cast<float4*>(out + o_row + ca) = va;
+                    if (ok_b) *reinterpret_cast<float4*>(out + o_row + cb) = vb;
+                } else {
+                    f16x4 ha4, hb4;
+                    ha4[0] = (_Float16)va.x; ha4[1] = (_Float16)va.y; ha4[2] = (_Float16)va.z; ha4[3] = (_Float16)va.w;
+                    hb4[0] = (_Float16)vb.x; hb4[1] = (_Float16)vb.y; hb4[2] = (_Float16)vb.z; hb4[3] = (_Float16)vb.w;
+                    const uint2 pa = __builtin_bit_cast(uint2, ha4), pb = __builtin_bit_cast(uint2, hb4);
+                    // upper half-wave's q = 2p runs <-> lower half-wave's q = 2p+1 runs
+                    const auto sx = __builtin_amdgcn_permlane32_swap(pa.x, pb.x, false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(pa.y, pb.y, false, false);
+                    const int n_store = nb + 16 * p + 8 * kk;
+                    if (ok_m && n_store < a.ncols)
+                        *reinterpret_cast<uint4*>(out + o_row + n_store) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                }
             }
         }
     }
@@ -137,89 +147,57 @@ __device__ __forceinline__ void pp_store_tile(const ConvArgs& a, f32x16 (&acc)[T
 }
 
 // ================================================================================================================
-// BN = 256: 2 (M) × 4 (N) waves, wave tile 128 × 64 = acc[4][2], four phases per K tile, two K-tile buffers.
-// ================================================================================================================
-__global__ __launch_bounds__(512) void k_conv_f16_pp256(const ConvArgs a)
+template <int MODE>
+__global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
 {
-    using T = _Float16;
-    constexpr int BM = 256, BN = 256, BK = 64, ROWB = 128;
-    constexpr int A_STAGE = BM * ROWB, B_STAGE = BN * ROWB, B_BASE = 2 * A_STAGE;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_STAGE + B_STAGE)];     // 128 KB; the epilogue reuses it
-    const T* const in = static_cast<const T*>(a.in);
-    const T* const wgt = static_cast<const T*>(a.wgt);
-    const T* const zero = static_cast<const T*>(a.zero_page);
-
-    // XCD-aware bijective block → tile map (the N tiles of one M tile adjacent, contiguous runs per XCD)
-    const int nblocks = a.tiles_m * a.tiles_n;
-    const int bid = blockIdx.x;
-    const int q8 = nblocks >> 3, r8 = nblocks & 7;
-    const int xcd = bid & 7, local = bid >> 3;
-    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
-    const int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
-    const int m0 = mt * BM, n0 = nt * BN;
+    constexpr bool SPLIT = MODE != 0;
+    using T = std::conditional_t<SPLIT, float, _Float16>;         // activation element
+    using TW = _Float16;                                          // filter element
+    constexpr int BM = 256, BN = 256;
+    constexpr int BK = SPLIT ? 32 : 64;                           // channels per K step = one 128-B run of an activation row
+    constexpr int ROWB = 128, BROWB = SPLIT ? 64 : 128;           // LDS row bytes of the activation / filter tile
+    constexpr int A_STAGE = BM * ROWB, B_STAGE = BN * BROWB, B_BASE = 2 * A_STAGE;
+    constexpr int BJ = 32 * BROWB;                                // LDS bytes between the two column tiles of a wave
+    constexpr int STEADY = SPLIT ? 3 : 4;                         // DMAs younger than K step kt+1 at the end of step kt
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_STAGE + B_STAGE)];     // 128 KB (fp16) / 96 KB (split)
+    const char* const in = static_cast<const char*>(a.in);
+    const TW* const wgt = static_cast<const TW*>(a.wgt);
+    const char* const zero = static_cast<const char*>(a.zero_page);
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wave >> 2, wc = wave & 3;                  // wave row (= ping-pong group) / wave column
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
 
-    // ---- staging: slab p (p = 0..3) of the A tile = rows {wr·128 + p·32 + 0..31 : wr = 0, 1}; one DMA per thread and slab:
-    //      wave w stages rows (w>>2)·128 + p·32 + (w&3)·8 + 0..7 (1 KB, lane-linear); chunk c of row r sits at c ^ ((r>>1)&7).
+    // ---- loop-invariant lane geometry -------------------------------------------------------------------------------
+    // staging: slab p (0..3) of the A tile = rows {wr·128 + p·32 + 0..31 : wr = 0, 1}; one DMA per thread and slab: wave w
+    // stages rows (w>>2)·128 + p·32 + (w&3)·8 + 0..7 (1 KB, lane-linear); 16-B chunk c of row r sits at c ^ ((r>>1)&7)
     const int srow = (wave & 3) * 8 + (lane >> 3);
     const int kq = (lane & 7) ^ ((srow >> 1) & 7);
+    const unsigned dA = lds0 + (wr * 128 + (wave & 3) * 8) * ROWB;      // + buf·A_STAGE + p·4096
+    // filter tile, fp16 tensors: four 64-row pieces of 128-B rows (row = p·64 + wave·8 + lane>>3, chunk as above);
+    //              split modes: two 128-row pieces of 64-B rows (row = q·128 + wave·16 + lane>>2, chunk c at c ^ ((r>>2)&3))
+    const unsigned vb = SPLIT ? (unsigned)(((size_t)(wave * 16 + (lane >> 2)) * a.Ktot + (((lane & 3) ^ ((lane >> 4) & 3)) << 3)) * sizeof(TW))
+                              : (unsigned)(((size_t)(wave * 8 + (lane >> 3)) * a.Ktot + kq * 8) * sizeof(TW));
+    const unsigned bstr = (unsigned)((size_t)(SPLIT ? 128 : 64) * a.Ktot * sizeof(TW));     // byte distance of the pieces
+    const unsigned dB = lds0 + B_BASE + wave * 1024;                    // + buf·B_STAGE + piece·8192
+    // fragment reads: lane (l31, kk) of K group g reads 16 B (fp16: chunk 2g+kk) or 32 B (fp32: chunks 4g+2kk, +1) of row l31
+    const int l31 = lane & 31, kk = lane >> 5, swz = (l31 >> 1) & 7;
+    const unsigned ra_base = lds0 + (wr * 128 + l31) * ROWB;
+    const unsigned ra0 = ra_base + (((SPLIT ? 0 + 2 * kk : 0 + kk) ^ swz) << 4), ra1 = ra_base + (((SPLIT ? 1 + 2 * kk : 2 + kk) ^ swz) << 4);
+    const unsigned ra2 = ra_base + (((SPLIT ? 4 + 2 * kk : 4 + kk) ^ swz) << 4), ra3 = ra_base + (((SPLIT ? 5 + 2 * kk : 6 + kk) ^ swz) << 4);
+    const unsigned rb_base = lds0 + B_BASE + (wc * 64 + l31) * BROWB;
+    const int swzb = SPLIT ? (l31 >> 2) & 3 : swz;
+    const unsigned rb0 = rb_base + (((0 + kk) ^ swzb) << 4), rb1 = rb_base + (((2 + kk) ^ swzb) << 4);
+    const unsigned rb2 = rb_base + (((4 + kk) ^ swz) << 4), rb3 = rb_base + (((6 + kk) ^ swz) << 4);      // fp16 tensors only
+
     const int ohw = a.OH * a.OW;
-    const T* pbase[4];       // pixel of tap (0, 0), channel chunk kq, of the row this thread stages in slab p
-    int ihw[4];              // (ih0 & 0xffff) | (iw0 << 16): input coordinates of tap (0, 0)
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int m = m0 + wr * 128 + p * 32 + srow;
-        const bool ok = m < a.M;
-        const int mm = ok ? m : 0;
-        const int b = mm / ohw, rem = mm - b * ohw;
-        const int oh = rem / a.OW, ow = rem - oh * a.OW;
-        const int ih0 = oh * a.stride - a.padH, iw0 = ow * a.stride - a.padW;
-        ihw[p] = ((ok ? ih0 : -32768) & 0xffff) | (iw0 << 16);      // a row beyond M never passes the bounds test
-        pbase[p] = in + ((long)b * a.in_sB + (long)ih0 * a.in_sH + (long)iw0 * a.in_sW + kq * 8);
-    }
     const int cin_tiles = a.Cin / BK;
     const int KT = a.KH * a.KW * cin_tiles;
+    const long tapW = a.in_sW * (long)sizeof(T), tapH = a.in_sH * (long)sizeof(T);
     // measurement-only ablations (a.dbg = 0 in production): 1 no s_setprio, 2 no group stagger, 4 no DMA in the main
     // loop, 8 no fragment reads, 16 no MFMAs
     const bool dbg_noprio = a.dbg & 1, dbg_nostagger = a.dbg & 2, dbg_nodma = a.dbg & 4, dbg_nords = a.dbg & 8, dbg_nomma = a.dbg & 16;
-    // two issue streams (wave-uniform scalar state): slabs 0, 1 (+ the filter tile) run one K tile ahead of slabs 2, 3
-    int ct01 = 0, kh01 = 0, kw01 = 0, ct23 = 0, kh23 = 0, kw23 = 0;
-    long ko01 = 0, ko23 = 0;                   // byte offset of the stream's current K tile from the tap-(0,0) pixel
-    const long tapW = a.in_sW * (long)sizeof(T), tapH = a.in_sH * (long)sizeof(T);
-#define PP_ADV(CT_, KH_, KW_, KO_)                                                                             \
-    {                                                                                                          \
-        KO_ += BK * (long)sizeof(T);                                                                           \
-        if (++CT_ == cin_tiles) {                                                                              \
-            CT_ = 0;                                                                                           \
-            if (++KW_ == a.KW) { KW_ = 0; ++KH_; }                                                             \
-            KO_ = KH_ * tapH + KW_ * tapW;                                                                     \
-        }                                                                                                      \
-    }
-#define PP_ADV01 PP_ADV(ct01, kh01, kw01, ko01)
-#define PP_ADV23 PP_ADV(ct23, kh23, kw23, ko23)
-    // filter tile: 256 rows = four DMAs per thread (rows p·64 + wave·8 + lane>>3): one scalar base + lane offset + p·bstr
-    const unsigned vb = (unsigned)(((size_t)(wave * 8 + (lane >> 3)) * a.Ktot + kq * 8) * sizeof(T));
-    const T* sb01 = wgt + (size_t)n0 * a.Ktot;                           // wave-uniform filter bases of the two issue streams,
-    const T* sb23 = sb01;                                                //   one K tile further per round
-    const unsigned bstr = (unsigned)((size_t)64 * a.Ktot * sizeof(T));    // byte distance of the four 64-row groups
-    const unsigned dA = lds0 + (wr * 128 + (wave & 3) * 8) * ROWB;      // + buf·A_STAGE + p·4096
-    const unsigned dB = lds0 + B_BASE + wave * 8 * ROWB;                // + buf·B_STAGE + p·8192
-#define PP_ISSUE_A01(P, BUF) { const T* src_ = PP_SRC_A(P, kh01, kw01, ko01); PP_GLDS_V(src_, dA + (BUF) * A_STAGE + (P) * 4096); }
-#define PP_ISSUE_A23(P, BUF) { const T* src_ = PP_SRC_A(P, kh23, kw23, ko23); PP_GLDS_V(src_, dA + (BUF) * A_STAGE + (P) * 4096); }
-#define PP_ISSUE_B01(P, BUF) PP_GLDS_S(vb + (P) * bstr, sb01, dB + (BUF) * B_STAGE + (P) * 8192);
-#define PP_ISSUE_B23(P, BUF) PP_GLDS_S(vb + (P) * bstr, sb23, dB + (BUF) * B_STAGE + (P) * 8192);
-
-    // ---- fragment reads: lane (l31, kk) of K group g reads chunk 2g+kk of row l31 of its slab
-    const int l31 = lane & 31, kk = lane >> 5, swz = (l31 >> 1) & 7;
-    const unsigned ra_base = lds0 + (wr * 128 + l31) * ROWB;
-    const unsigned rb_base = lds0 + B_BASE + (wc * 64 + l31) * ROWB;
-    const unsigned c0 = ((0 + kk) ^ swz) << 4, c1 = ((2 + kk) ^ swz) << 4, c2 = ((4 + kk) ^ swz) << 4, c3 = ((6 + kk) ^ swz) << 4;
-    const unsigned ra0 = ra_base + c0, ra1 = ra_base + c1, ra2 = ra_base + c2, ra3 = ra_base + c3;
-    const unsigned rb0 = rb_base + c0, rb1 = rb_base + c1, rb2 = rb_base + c2, rb3 = rb_base + c3;
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -228,102 +206,206 @@ __global__ __launch_bounds__(512) void k_conv_f16_pp256(const ConvArgs a)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-    f16x8 fa0, fa1, fa2, fa3;                                      // A fragments of the current phase (4 K groups)
-    f16x8 fb00, fb01, fb10, fb11, fb20, fb21, fb30, fb31;          // B fragments of the current K tile (K group, column tile)
+    f16x8 fa0, fa1, fa2, fa3;                                      // activation fragments of the current phase (16 B each)
+    f16x8 fb00, fb01, fb10, fb11, fb20, fb21, fb30, fb31;          // filter fragments of the current K step (K group, column tile)
 
-    // ---- prologue: K tile 0 completely, of K tile 1 the part the steady state has in flight at a tile boundary
-    PP_ISSUE_A01(0, 0) PP_ISSUE_B01(0, 0) PP_ISSUE_A01(1, 0) PP_ISSUE_B01(1, 0)
-    PP_ISSUE_A23(2, 0) PP_ISSUE_B23(2, 0) PP_ISSUE_A23(3, 0) PP_ISSUE_B23(3, 0)
-    sb01 += BK; sb23 += BK;
-    PP_ADV01 PP_ADV23
-    if (KT > 1) {
-        PP_ISSUE_A01(0, 1) PP_ISSUE_B01(0, 1) PP_ISSUE_A01(1, 1) PP_ISSUE_B01(1, 1)
-        sb01 += BK;
-        PP_ADV01
-        PP_VMCNT(4)
-    } else {
-        PP_VMCNT(0)
+    // ---- persistent walk over the tiles: virtual block v = blockIdx.x + step·gridDim.x through the XCD-aware bijective
+    //      map (the N tiles of one M tile adjacent, contiguous runs per XCD; gridDim.x is a multiple of 8 or = #tiles)
+    const int nblocks = a.tiles_m * a.tiles_n;
+    const int q8 = nblocks >> 3, r8 = nblocks & 7;
+    int pm0 = 0, pn0 = 0;
+    bool have_prev = false;
+    for (int v = blockIdx.x; v < nblocks; v += gridDim.x) {
+        const int xcd = v & 7, local = v >> 3;
+        const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+        const int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
+        const int m0 = mt * BM, n0 = nt * BN;
+
+        const char* pbase[4];    // pixel of tap (0, 0), channel chunk kq, of the row this thread stages in slab p
+        int ihw[4];              // (ih0 & 0xffff) | (iw0 << 16): input coordinates of tap (0, 0)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int m = m0 + wr * 128 + p * 32 + srow;
+            const bool ok = m < a.M;
+            const int mm = ok ? m : 0;
+            const int b = mm / ohw, rem = mm - b * ohw;
+            const int oh = rem / a.OW, ow = rem - oh * a.OW;
+            const int ih0 = oh * a.stride - a.padH, iw0 = ow * a.stride - a.padW;
+            ihw[p] = ((ok ? ih0 : -32768) & 0xffff) | (iw0 << 16);      // a row beyond M never passes the bounds test
+            pbase[p] = in + ((long)b * a.in_sB + (long)ih0 * a.in_sH + (long)iw0 * a.in_sW) * (long)sizeof(T) + kq * 16;
+        }
+        // two issue streams (wave-uniform scalar state): slabs 0, 1 (+ their filter pieces) run one K step ahead of slabs 2, 3
+        int ct01 = 0, kh01 = 0, kw01 = 0, ct23 = 0, kh23 = 0, kw23 = 0;
+        long ko01 = 0, ko23 = 0;                   // byte offset of the stream's current K step from the tap-(0,0) pixel
+        const TW* sb01 = wgt + (size_t)n0 * a.Ktot;
+        const TW* sb23 = sb01;
+#define PP_ADV(CT_, KH_, KW_, KO_)                                                                             \
+    {                                                                                                          \
+        KO_ += ROWB;                                                                                           \
+        if (++CT_ == cin_tiles) {                                                                              \
+            CT_ = 0;                                                                                           \
+            if (++KW_ == a.KW) { KW_ = 0; ++KH_; }                                                             \
+            KO_ = KH_ * tapH + KW_ * tapW;                                                                     \
+        }                                                                                                      \
     }
-    PP_BARRIER
-    if (wr == 1 && !dbg_nostagger) PP_BARRIER          // group 1 runs one barrier behind group 0 from here on
+#define PP_ISSUE_A01(P, BUF) { const char* src_ = PP_SRC_A(P, kh01, kw01, ko01); PP_GLDS_V(src_, dA + (BUF) * A_STAGE + (P) * 4096); }
+#define PP_ISSUE_A23(P, BUF) { const char* src_ = PP_SRC_A(P, kh23, kw23, ko23); PP_GLDS_V(src_, dA + (BUF) * A_STAGE + (P) * 4096); }
+#define PP_ISSUE_B01(P, BUF) PP_GLDS_S(vb + (P) * bstr, sb01, dB + (BUF) * B_STAGE + (P) * 8192);
+#define PP_ISSUE_B23(P, BUF) PP_GLDS_S(vb + (P) * bstr, sb23, dB + (BUF) * B_STAGE + (P) * 8192);
+        // the DMA of the four load phases: stream 23 → K step kt+1 (other buffer), stream 01 → K step kt+2 (this buffer)
+#define PP_L0_ISSUE(BUFN) { PP_ISSUE_A23(2, BUFN) if constexpr (!SPLIT) PP_ISSUE_B23(2, BUFN) }
+#define PP_L1_ISSUE(BUFN)                                                                                      \
+    {                                                                                                          \
+        PP_ISSUE_A23(3, BUFN)                                                                                  \
+        if constexpr (!SPLIT) { PP_ISSUE_B23(3, BUFN) } else { PP_ISSUE_B23(1, BUFN) }                         \
+        sb23 += BK;                                                                                            \
+        PP_ADV(ct23, kh23, kw23, ko23)                                                                         \
+    }
+#define PP_L2_ISSUE(BUF_) { PP_ISSUE_A01(0, BUF_) if constexpr (!SPLIT) PP_ISSUE_B01(0, BUF_) }
+#define PP_L3_ISSUE(BUF_)                                                                                      \
+    {                                                                                                          \
+        PP_ISSUE_A01(1, BUF_)                                                                                  \
+        if constexpr (!SPLIT) { PP_ISSUE_B01(1, BUF_) } else { PP_ISSUE_B01(0, BUF_) }                         \
+        sb01 += BK;                                                                                            \
+        PP_ADV(ct01, kh01, kw01, ko01)                                                                         \
+    }
+
+        // ---- prologue: K step 0 completely, of K step 1 the part the steady state has in flight at a step boundary.
+        //      LDS is free: every wave is past the re-join barrier of the previous tile.
+        PP_L2_ISSUE(0) PP_L3_ISSUE(0) PP_L0_ISSUE(0) PP_L1_ISSUE(0)
+        if (KT > 1) { PP_L2_ISSUE(1) PP_L3_ISSUE(1) }
+        // ---- epilogue of the PREVIOUS tile under the flight of those DMAs (registers → HBM, no LDS)
+        if (have_prev) {
+            pp_store_tile<T>(a, acc, pm0, pn0, wr, wc, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+            PP_VMCNT(0)              // stores and loads share the counter: drain both once per tile
+        } else if (KT > 1) {
+            PP_VMCNT(STEADY)
+        } else {
+            PP_VMCNT(0)
+        }
+        PP_BARRIER
+        if (wr == 1 && !dbg_nostagger) PP_BARRIER          // group 1 runs one barrier behind group 0 from here on
 
 #define PP_RD_A(PH, BUF)                                                                                       \
     PP_DSR(fa0, ra0, (BUF) * A_STAGE + (PH) * 4096) PP_DSR(fa1, ra1, (BUF) * A_STAGE + (PH) * 4096)            \
     PP_DSR(fa2, ra2, (BUF) * A_STAGE + (PH) * 4096) PP_DSR(fa3, ra3, (BUF) * A_STAGE + (PH) * 4096)
 #define PP_RD_B(BUF)                                                                                           \
-    PP_DSR(fb00, rb0, (BUF) * B_STAGE) PP_DSR(fb01, rb0, (BUF) * B_STAGE + 4096)                               \
-    PP_DSR(fb10, rb1, (BUF) * B_STAGE) PP_DSR(fb11, rb1, (BUF) * B_STAGE + 4096)                               \
-    PP_DSR(fb20, rb2, (BUF) * B_STAGE) PP_DSR(fb21, rb2, (BUF) * B_STAGE + 4096)                               \
-    PP_DSR(fb30, rb3, (BUF) * B_STAGE) PP_DSR(fb31, rb3, (BUF) * B_STAGE + 4096)
+    PP_DSR(fb00, rb0, (BUF) * B_STAGE) PP_DSR(fb01, rb0, (BUF) * B_STAGE + BJ)                                 \
+    PP_DSR(fb10, rb1, (BUF) * B_STAGE) PP_DSR(fb11, rb1, (BUF) * B_STAGE + BJ)                                 \
+    if constexpr (!SPLIT) {                                                                                    \
+        PP_DSR(fb20, rb2, (BUF) * B_STAGE) PP_DSR(fb21, rb2, (BUF) * B_STAGE + BJ)                             \
+        PP_DSR(fb30, rb3, (BUF) * B_STAGE) PP_DSR(fb31, rb3, (BUF) * B_STAGE + BJ)                             \
+    }
 // the wait names every fragment as read-write: nothing that consumes one can be scheduled above it
 #define PP_WAIT_A asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa0), "+v"(fa1), "+v"(fa2), "+v"(fa3)::"memory");
 #define PP_WAIT_AB                                                                                             \
-    asm volatile("s_waitcnt lgkmcnt(0)"                                                                        \
-                 : "+v"(fa0), "+v"(fa1), "+v"(fa2), "+v"(fa3), "+v"(fb00), "+v"(fb01), "+v"(fb10), "+v"(fb11), "+v"(fb20), "+v"(fb21), \
-                   "+v"(fb30), "+v"(fb31)::"memory");
+    if constexpr (!SPLIT) {                                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)"                                                                    \
+                     : "+v"(fa0), "+v"(fa1), "+v"(fa2), "+v"(fa3), "+v"(fb00), "+v"(fb01), "+v"(fb10), "+v"(fb11), "+v"(fb20),     \
+                       "+v"(fb21), "+v"(fb30), "+v"(fb31)::"memory");                                          \
+    } else {                                                                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)"                                                                    \
+                     : "+v"(fa0), "+v"(fa1), "+v"(fa2), "+v"(fa3), "+v"(fb00), "+v"(fb01), "+v"(fb10), "+v"(fb11)::"memory");     \
+    }
+// fp16: 4 K groups × 2 column tiles.  split: 2 K groups × (hi, [mid,] lo) × 2 column tiles, parts in the order of the
+// 128-row kernel (every product tile is added to the same accumulator in the same sequence → identical bits).
 #define PP_MATH(PH)                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
     if (!dbg_noprio) __builtin_amdgcn_s_setprio(1);                                                            \
     if (!dbg_nomma) {                                                                                          \
-    PP_MFMA(fb00, fa0, acc[PH][0]) PP_MFMA(fb01, fa0, acc[PH][1]) PP_MFMA(fb10, fa1, acc[PH][0]) PP_MFMA(fb11, fa1, acc[PH][1]) \
-    PP_MFMA(fb20, fa2, acc[PH][0]) PP_MFMA(fb21, fa2, acc[PH][1]) PP_MFMA(fb30, fa3, acc[PH][0]) PP_MFMA(fb31, fa3, acc[PH][1]) \
+        if constexpr (!SPLIT) {                                                                                \
+            PP_MFMA(fb00, fa0, acc[PH][0]) PP_MFMA(fb01, fa0, acc[PH][1]) PP_MFMA(fb10, fa1, acc[PH][0]) PP_MFMA(fb11, fa1, acc[PH][1]) \
+            PP_MFMA(fb20, fa2, acc[PH][0]) PP_MFMA(fb21, fa2, acc[PH][1]) PP_MFMA(fb30, fa3, acc[PH][0]) PP_MFMA(fb31, fa3, acc[PH][1]) \
+        } else {                                                                                               \
+            f16x8 hi, mid, lo;                                                                                 \
+            if constexpr (MODE == 3) split_hi_mid_lo(PP_U4(fa0), PP_U4(fa1), hi, mid, lo); else split_hi_lo(PP_U4(fa0), PP_U4(fa1), hi, lo); \
+            PP_MFMA(fb00, hi, acc[PH][0]) PP_MFMA(fb01, hi, acc[PH][1])                                        \
+            if constexpr (MODE == 3) { PP_MFMA(fb00, mid, acc[PH][0]) PP_MFMA(fb01, mid, acc[PH][1]) }         \
+            PP_MFMA(fb00, lo, acc[PH][0]) PP_MFMA(fb01, lo, acc[PH][1])                                        \
+            if constexpr (MODE == 3) split_hi_mid_lo(PP_U4(fa2), PP_U4(fa3), hi, mid, lo); else split_hi_lo(PP_U4(fa2), PP_U4(fa3), hi, lo); \
+            PP_MFMA(fb10, hi, acc[PH][0]) PP_MFMA(fb11, hi, acc[PH][1])                                        \
+            if constexpr (MODE == 3) { PP_MFMA(fb10, mid, acc[PH][0]) PP_MFMA(fb11, mid, acc[PH][1]) }         \
+            PP_MFMA(fb10, lo, acc[PH][0]) PP_MFMA(fb11, lo, acc[PH][1])                                        \
+        }                                                                                                      \
     }                                                                                                          \
     __builtin_amdgcn_s_setprio(0);                                                                             \
     __builtin_amdgcn_sched_barrier(0);
 
-    // One K tile on buffer BUF (compile-time): four L/M phase pairs.  has1 / has2: K tiles kt+1 / kt+2 exist.
-#define PP_KTILE(KTV, BUF)                                                                                     \
+        // One K step on buffer BUF (compile-time): four L/M phase pairs.  has1 / has2: K steps kt+1 / kt+2 exist.
+#define PP_KSTEP(KTV, BUF)                                                                                     \
     {                                                                                                          \
         const bool has1 = (KTV) + 1 < KT && !dbg_nodma, has2 = (KTV) + 2 < KT && !dbg_nodma;                   \
-        /* phase 0: slab 0 + the whole B tile; DMA: slab 2 / filter rows 128-191 of tile kt+1 */                                     \
+        /* phase 0: slab 0 + the whole filter tile; DMA: slab 2 (+ filter piece) of step kt+1 */               \
         if (!dbg_nords) { PP_RD_A(0, BUF) PP_RD_B(BUF) }                                                       \
-        if (has1) { PP_ISSUE_A23(2, (BUF) ^ 1) PP_ISSUE_B23(2, (BUF) ^ 1) }                                    \
+        if (has1) PP_L0_ISSUE((BUF) ^ 1)                                                                       \
         PP_BARRIER PP_WAIT_AB PP_MATH(0) PP_BARRIER                                                            \
-        /* phase 1: DMA: slab 3 / filter rows 192-255 of tile kt+1 */                                                                \
+        /* phase 1: DMA: slab 3 (+ filter piece) of step kt+1 */                                               \
         if (!dbg_nords) { PP_RD_A(1, BUF) }                                                                    \
-        if (has1) { PP_ISSUE_A23(3, (BUF) ^ 1) PP_ISSUE_B23(3, (BUF) ^ 1) sb23 += BK; PP_ADV23 }               \
+        if (has1) PP_L1_ISSUE((BUF) ^ 1)                                                                       \
         PP_BARRIER PP_WAIT_A PP_MATH(1) PP_BARRIER                                                             \
-        /* phase 2: DMA: slab 0 / filter rows 0-63 of tile kt+2 (over this tile's own buffer) */            \
+        /* phase 2: DMA: slab 0 (+ filter piece) of step kt+2, over this step's own buffer */                  \
         if (!dbg_nords) { PP_RD_A(2, BUF) }                                                                    \
-        if (has2) { PP_ISSUE_A01(0, BUF) PP_ISSUE_B01(0, BUF) }                                                \
+        if (has2) PP_L2_ISSUE(BUF)                                                                             \
         PP_BARRIER PP_WAIT_A PP_MATH(2) PP_BARRIER                                                             \
-        /* phase 3: DMA: slab 1 / filter rows 64-127 of tile kt+2; then tile kt+1 must have landed (4 younger DMAs stay in flight) */       \
+        /* phase 3: DMA: slab 1 (+ filter piece) of step kt+2; then step kt+1 must have landed (STEADY younger DMAs stay in flight) */ \
         if (!dbg_nords) { PP_RD_A(3, BUF) }                                                                    \
         if (has2) {                                                                                            \
-            PP_ISSUE_A01(1, BUF) PP_ISSUE_B01(1, BUF)                                                          \
-            sb01 += BK;                                                                                        \
-            PP_ADV01                                                                                           \
-            PP_VMCNT(4)                                                                                        \
+            PP_L3_ISSUE(BUF)                                                                                   \
+            PP_VMCNT(STEADY)                                                                                   \
         } else {                                                                                               \
             PP_VMCNT(0)                                                                                        \
         }                                                                                                      \
         PP_BARRIER PP_WAIT_A PP_MATH(3) PP_BARRIER                                                             \
     }
-    for (int kt = 0; kt < KT; kt += 2) {
-        PP_KTILE(kt, 0)
-        if (kt + 1 < KT) PP_KTILE(kt + 1, 1)
+        for (int kt = 0; kt < KT; kt += 2) {
+            PP_KSTEP(kt, 0)
+            if (kt + 1 < KT) PP_KSTEP(kt + 1, 1)
+        }
+        if (wr == 0 && !dbg_nostagger) PP_BARRIER          // re-join: every wave's last fragment read has retired behind this rendezvous
+        pm0 = m0; pn0 = n0; have_prev = true;
     }
-    if (wr == 0 && !dbg_nostagger) PP_BARRIER          // re-join: every wave's last fragment read has retired behind this rendezvous
-#undef PP_KTILE
+    if (have_prev) pp_store_tile<T>(a, acc, pm0, pn0, wr, wc, lane);
+#undef PP_KSTEP
 #undef PP_MATH
 #undef PP_WAIT_AB
 #undef PP_WAIT_A
 #undef PP_RD_B
 #undef PP_RD_A
+#undef PP_L3_ISSUE
+#undef PP_L2_ISSUE
+#undef PP_L1_ISSUE
+#undef PP_L0_ISSUE
 #undef PP_ISSUE_B23
 #undef PP_ISSUE_B01
 #undef PP_ISSUE_A23
 #undef PP_ISSUE_A01
-#undef PP_ADV23
-#undef PP_ADV01
-    pp_store_tile<4, 2, 128, 64>(a, acc, m0, n0, wr, wc, lane);
+#undef PP_ADV
 }
 
-void conv_pp_launch(hipStream_t s, const ConvArgs& a, int bn)
+// mode: 0 fp16 tensors, 2 / 3 fp32 tensors split in 2 / 3 fp16 parts.  One persistent block per CU.
+void conv_pp_launch(hipStream_t s, const ConvArgs& a, int mode)
 {
-    const dim3 grid(a.tiles_m * a.tiles_n);
-    MRCNN_REQUIRE(bn == 256, MRCNN_ERR_UNSUPPORTED, "conv_pp: N tile %d", bn);
-    hipLaunchKernelGGL(k_conv_f16_pp256, grid, dim3(512), 0, s, a);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        hipDeviceProp_t p;
+        HIP_CHECK(hipGetDeviceProperties(&p, dev));
+        n_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount / 8 * 8 : 256;
+        if (n_cu <= 0) n_cu = 8;
+    }
+    const int ntiles = a.tiles_m * a.tiles_n;
+    const dim3 grid(ntiles < n_cu ? ntiles : n_cu);
+    if (mode == 0) hipLaunchKernelGGL(k_conv_pp<0>, grid, dim3(512), 0, s, a);
+    else if (mode == 2) hipLaunchKernelGGL(k_conv_pp<2>, grid, dim3(512), 0, s, a);
+    else if (mode == 3) hipLaunchKernelGGL(k_conv_pp<3>, grid, dim3(512), 0, s, a);
+    else fail(MRCNN_ERR_UNSUPPORTED, "conv_pp: mode %d", mode);
 }
 
 }  // namespace mrcnn

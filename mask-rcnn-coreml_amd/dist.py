@@ -86,3 +86,77 @@ def predict_sharded(predict_fn, images, max_det: int, mask_size: int):
     if world > 1:
         rec = gather_uneven(rec, images.shape[0])
     return unpack_records(rec, max_det, mask_size)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The same exchange behind the C ABI (mask-rcnn-coreml_amd/csrc/dist.hip): ncclAllGather called from librccl directly on the
+# model's stream — what a Swift / C host links against.  torch is not involved; the 128-byte rendezvous id travels by
+# whatever channel the host has (bench.py: a torch.distributed broadcast; examples/maskrcnn_predict_mgpu.c: a file).
+# ---------------------------------------------------------------------------------------------------------------------
+class NativeDist:
+    """mrcnn_dist handle: one per process / GPU."""
+
+    def __init__(self, rank: int, world: int, unique_id: bytes):
+        import ctypes as C
+        from . import _lib
+        assert len(unique_id) == 128
+        self._lib, self._C = _lib, C
+        self.rank, self.world = rank, world
+        self._h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _lib.check(_lib.lib().mrcnn_dist_init(rank, world, buf, C.byref(self._h)))
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import _lib
+        buf = (C.c_uint8 * 128)()
+        _lib.check(_lib.lib().mrcnn_dist_unique_id(buf))
+        return bytes(buf)
+
+    @staticmethod
+    def shard(global_batch: int, world: int, rank: int) -> Tuple[int, int]:
+        import ctypes as C
+        from . import _lib
+        lo, hi = C.c_int(0), C.c_int(0)
+        _lib.check(_lib.lib().mrcnn_dist_shard(global_batch, world, rank, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def close(self):
+        if self._h:
+            self._lib.lib().mrcnn_dist_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def all_gather_records(self, model, det, mask, global_batch: int, out_det, out_mask):
+        """det/mask: this rank's results; out_*: (global_batch, ...) — all numpy (host) or all torch CUDA tensors (device)."""
+        import numpy as np
+        host = isinstance(out_det, np.ndarray)
+        ptr = (lambda a: a.ctypes.data) if host else (lambda t: t.data_ptr())
+        self._lib.check(self._lib.lib().mrcnn_dist_all_gather_records(
+            self._h, model._h, None if det is None else ptr(det), None if mask is None else ptr(mask), global_batch,
+            self._lib.HOST if host else self._lib.DEVICE, ptr(out_det), ptr(out_mask)))
+        return out_det, out_mask
+
+    def predict_sharded(self, model, images):
+        """images: the GLOBAL batch (B,H,W,3) uint8, identical on every rank — numpy or torch CUDA tensor."""
+        import numpy as np
+        B, H, W, _ = images.shape
+        D, S = model.max_detections, model.mask_size
+        if isinstance(images, np.ndarray):
+            imgs = np.ascontiguousarray(images, dtype=np.uint8)
+            det = np.empty((B, D, 6), np.float32)
+            mask = np.empty((B, D, S, S), np.float32)
+            self._lib.check(self._lib.lib().mrcnn_maskrcnn_predict_sharded(self._h, model._h, imgs.ctypes.data, B, H, W, self._lib.HOST,
+                                                                           det.ctypes.data, mask.ctypes.data))
+            return det, mask
+        det = torch.empty((B, D, 6), dtype=torch.float32, device=images.device)
+        mask = torch.empty((B, D, S, S), dtype=torch.float32, device=images.device)
+        self._lib.check(self._lib.lib().mrcnn_maskrcnn_predict_sharded(self._h, model._h, images.data_ptr(), B, H, W, self._lib.DEVICE,
+                                                                       det.data_ptr(), mask.data_ptr()))
+        return det, mask

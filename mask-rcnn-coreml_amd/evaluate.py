@@ -60,13 +60,15 @@ def detection_agreement(det_a: np.ndarray, det_b: np.ndarray, box_tol: float = 1
     zero-padded.  A row of A is matched to at most one row of B with the SAME class id and every box coordinate
     within `box_tol` (order-insensitive: scores that differ in the last bits may swap neighbours).  Returns counts,
     the matched fraction over max(nA, nB), the largest score difference over matched pairs and — when the 28×28
-    masks are given — the largest mask difference over matched pairs."""
+    masks are given — the largest mask difference over matched pairs whose mask is present on both sides, plus the
+    number of pairs where the mask layer's removeZeros rule (a pooled row with an exactly-zero sample is skipped,
+    TimeDistributedMaskLayer.swift:52) emptied the mask on one side only."""
     a = np.asarray(det_a, dtype=np.float32)
     b = np.asarray(det_b, dtype=np.float32)
     ia = np.flatnonzero(a[:, 5] > 0)
     ib = np.flatnonzero(b[:, 5] > 0)
     used = np.zeros(len(ib), dtype=bool)
-    matched, same_row, dscore, dmask = 0, 0, 0.0, 0.0
+    matched, same_row, dscore, dmask, presence = 0, 0, 0.0, 0.0, 0
     for i in ia:
         ok = (~used) & (b[ib, 4] == a[i, 4]) & (np.abs(b[ib, :4] - a[i, :4]).max(axis=1) <= box_tol)
         js = np.flatnonzero(ok)
@@ -78,10 +80,15 @@ def detection_agreement(det_a: np.ndarray, det_b: np.ndarray, box_tol: float = 1
         same_row += int(ib[j] == i)
         dscore = max(dscore, float(abs(b[ib[j], 5] - a[i, 5])))
         if masks_a is not None and masks_b is not None:
-            dmask = max(dmask, float(np.abs(np.asarray(masks_a[i], np.float32) - np.asarray(masks_b[ib[j]], np.float32)).max()))
+            ma, mb = np.asarray(masks_a[i], np.float32), np.asarray(masks_b[ib[j]], np.float32)
+            if (ma == 0).all() != (mb == 0).all():
+                presence += 1            # the reference's removeZeros rule dropped the mask on one side only (an exact-zero sample)
+            else:
+                dmask = max(dmask, float(np.abs(ma - mb).max()))
     denom = max(len(ia), len(ib))
     return {"n_a": int(len(ia)), "n_b": int(len(ib)), "matched": int(matched), "same_row": int(same_row),
-            "fraction": (matched / denom) if denom else 1.0, "max_score_diff": dscore, "max_mask_diff": dmask}
+            "fraction": (matched / denom) if denom else 1.0, "max_score_diff": dscore, "max_mask_diff": dmask,
+            "mask_presence_mismatch": int(presence)}
 
 
 def evaluate(model: MaskRCNN, images: Iterable[Tuple[int, np.ndarray]], dataset_id: str = "coco",

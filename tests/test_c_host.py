@@ -17,12 +17,12 @@ LIBDIR = os.path.join(ROOT, "mask-rcnn-coreml_amd")
 SO = os.path.join(LIBDIR, "libmaskrcnn_hip.so")
 
 
-def _build_example(tmp_path):
+def _build_example(tmp_path, name="maskrcnn_predict"):
     if not os.path.exists(SO):
         pytest.skip("libmaskrcnn_hip.so not built (run python __graft_entry__.py)")
-    exe = str(tmp_path / "maskrcnn_predict")
+    exe = str(tmp_path / name)
     cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", INC,
-           os.path.join(ROOT, "examples", "maskrcnn_predict.c"), "-L", LIBDIR, "-lmaskrcnn_hip",
+           os.path.join(ROOT, "examples", name + ".c"), "-L", LIBDIR, "-lmaskrcnn_hip",
            f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
@@ -83,3 +83,45 @@ def test_c_host_matches_python_mirror(pkg, small_model, tmp_path, dtype):
         bx, by, bw, bh = dd.boundingBox
         assert (x, y, w, h) == (float(bx), float(by), float(bw), float(bh))
         assert msum == float(np.asarray(out["mask"][idx], dtype=np.float64).sum())
+
+
+
+def test_mgpu_c_host_builds_and_fails_loudly_without_gpu(tmp_path):
+    exe = _build_example(tmp_path, "maskrcnn_predict_mgpu")
+    if HAS_GPU:
+        pytest.skip("GPU present: covered by test_mgpu_c_host_world_one")
+    (tmp_path / "x.rgb").write_bytes(bytes(4 * 4 * 3))
+    r = subprocess.run([exe, str(tmp_path), str(tmp_path / "x.rgb"), "1"], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, RANK="0", WORLD_SIZE="1"))
+    assert r.returncode == 3 and "no CPU fallback" in r.stderr and r.stdout == ""        # MRCNN_ERR_HIP from mrcnn_dist_unique_id
+
+
+@pytest.mark.gpu
+def test_mgpu_c_host_world_one(pkg, small_model, tmp_path):
+    """The plain-C multi-GPU host at world size 1 (one GPU here): rendezvous id, ncclCommInitRank, shard, predict, ncclAllGather —
+    its printed records must be those of the Python mirror's batched predict."""
+    models = importlib.import_module("mask-rcnn-coreml_amd.models")
+    exe = _build_example(tmp_path, "maskrcnn_predict_mgpu")
+    d, cfg = small_model
+    B = 3
+    imgs = np.random.default_rng(22).integers(0, 256, (B, cfg.image_height, cfg.image_width, 3), dtype=np.uint8)
+    (tmp_path / "imgs.rgb").write_bytes(imgs.tobytes())
+    r = subprocess.run([exe, d, str(tmp_path / "imgs.rgb"), str(B), "f32x3"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, RANK="0", WORLD_SIZE="1"))
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[0].startswith("world 1 batch 3 seconds ")
+    m = models.load_maskrcnn(d, max_batch=B, compute_dtype="f32x3")
+    det, mask = m.predict(imgs)
+    pos = 1
+    total = 0
+    for b in range(B):
+        dets = pkg.Detection.detectionsFromFeatureValue(det[b], mask[b])
+        assert lines[pos] == f"image {b} detections {len(dets)}"
+        for row, dd in zip((l.split() for l in lines[pos + 1:pos + 1 + len(dets)]), dets):
+            assert (int(row[0]), int(row[1])) == (dd.index, dd.classId) and float(row[2]) == float(dd.score)
+            assert float(row[7]) == float(np.asarray(mask[b][dd.index], dtype=np.float64).sum())
+        pos += 1 + len(dets)
+        total += len(dets)
+    assert pos == len(lines) and total > 0
+    pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None

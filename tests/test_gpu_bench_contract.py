@@ -10,7 +10,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--arch", "resnet50", "--size", "256", "--batch", "2", "--steps", "3", "--warmup", "1", "--cpu-images", "1"]
+SMALL = ["--arch", "resnet50", "--size", "256", "--batch", "2", "--steps", "3", "--warmup", "1", "--cpu-images", "1", "--e2e-images", "2"]
 
 
 def _check(line, n_gpus=1, steps=3, warmup=1):
@@ -24,7 +24,7 @@ def _check(line, n_gpus=1, steps=3, warmup=1):
     assert abs(j["value"] - n_gpus * 2 * 1e3 / j["ms_per_step"]) / j["value"] < 1e-2            # whole-job images per second
     r = j["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and 0 < r["frac"] < 1
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r and r["kernel"].startswith("k_conv_mfma_glds<")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r and r["kernel"].startswith("k_conv_")
     return j
 
 
@@ -37,7 +37,15 @@ def test_bench_json_contract():
     c = j["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["unit"] == "images/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert c["value"] < j["value"]
-    assert set(j["other_modes"]) == {"f32x3", "f32s", "f16"} and all(v["value"] > 0 for v in j["other_modes"].values())
+    assert j["dtype"] == "f32x3" and r_peak(j) == pytest.approx(2500.0 / 3, rel=1e-3)
+    assert set(j["other_modes"]) == {"f32", "f32s", "f16"} and all(v["value"] > 0 for v in j["other_modes"].values())
+    p = j["parity_e2e"]
+    assert p["images"] == 2 and set(p["modes"]) == {"f32", "f32x3", "f32s", "f16"}
+    assert p["modes"]["f32x3"]["fraction"] >= 0.9 and p["modes"]["f32"]["fraction"] >= 0.9
+
+
+def r_peak(j):
+    return j["roofline"]["peak"]
 
 
 def test_bench_under_torchrun_with_rccl_leg():

@@ -29,14 +29,17 @@ def conv(x, w, k, stride, scale=None, shift=None, res=None, act=1, dtype="f16"):
     return out
 
 
-def torch_ref(x, w, k, stride, scale, shift, res, act):
+def torch_ref(x, w, k, stride, scale, shift, res, act, dtype="f16"):
+    """fp64 reference on the operands the engine sees: fp16 mode rounds activations, filters and residual to fp16; the
+    split modes keep fp32 activations and use fp16 filters."""
     import torch
     import torch.nn.functional as F
-    h = lambda a: torch.from_numpy(np.asarray(a, np.float32).astype(np.float16).astype(np.float32))
-    y = F.conv2d(h(x).permute(0, 3, 1, 2), h(w).permute(0, 3, 1, 2), stride=stride, padding=k // 2)
-    y = y * torch.from_numpy(scale)[None, :, None, None] + torch.from_numpy(shift)[None, :, None, None]
+    h = lambda a: torch.from_numpy(np.asarray(a, np.float32).astype(np.float16).astype(np.float64))
+    f = (lambda a: torch.from_numpy(np.asarray(a, np.float64))) if dtype != "f16" else h
+    y = F.conv2d(f(x).permute(0, 3, 1, 2), h(w).permute(0, 3, 1, 2), stride=stride, padding=k // 2)
+    y = y * torch.from_numpy(scale.astype(np.float64))[None, :, None, None] + torch.from_numpy(shift.astype(np.float64))[None, :, None, None]
     if res is not None:
-        y = y + h(res).permute(0, 3, 1, 2)
+        y = y + f(res).permute(0, 3, 1, 2)
     if act == 1:
         y = F.relu(y)
     return y.permute(0, 2, 3, 1).contiguous().numpy()
@@ -49,12 +52,16 @@ SHAPES = [  # B, H, W, Cin, Cout, k, stride, residual
     (1, 96, 96, 64, 256, 3, 2, False),       # stride 2, Cin = 64 (one channel tile per tap: a tap change every K tile)
     (3, 40, 40, 320, 256, 1, 1, False),      # odd K-tile count (5)
     (1, 33, 47, 192, 300, 3, 1, True),       # Cout not a multiple of the tile (Npad 384 → the 128-row kernel on both sides)
+    (5, 40, 40, 96, 256, 3, 1, False),       # M = 8000 (ragged), 96 channels: fp16 K step does not divide (128-row kernel), split does
 ]
 
 
+@pytest.mark.parametrize("dtype", ["f16", "f32s", "f32x3"])
 @pytest.mark.parametrize("shape", SHAPES)
-def test_pingpong_kernel_equals_128row_kernel_bitwise(shape):
+def test_pingpong_kernel_equals_128row_kernel_bitwise(shape, dtype):
     B, H, W, Ci, Co, k, stride, with_res = shape
+    if dtype == "f16" and Ci % 64:
+        pytest.skip("the fp16 kernels step K by 64 channels")
     rng = np.random.default_rng(sum(shape))
     x = rng.standard_normal((B, H, W, Ci), np.float32)
     w = (rng.standard_normal((Co, k, k, Ci), np.float32) * np.float32(1.0 / np.sqrt(k * k * Ci)))
@@ -65,31 +72,41 @@ def test_pingpong_kernel_equals_128row_kernel_bitwise(shape):
     lib = L.lib()
     try:
         L.check(lib.mrcnn_debug_set(b"conv_pp", 0))
-        y0 = conv(x, w, k, stride, scale, shift, res, 1, "f16")
+        y0 = conv(x, w, k, stride, scale, shift, res, 1, dtype)
         L.check(lib.mrcnn_debug_set(b"conv_pp", 1))
         L.check(lib.mrcnn_debug_set(b"conv_pp_min_tiles", 1))       # force the ping-pong kernel onto small grids
         L.check(lib.mrcnn_debug_set(b"conv_pp_min_kt", 2))
-        y1 = conv(x, w, k, stride, scale, shift, res, 1, "f16")
+        L.check(lib.mrcnn_debug_set(b"conv_pp_min_fill", 0))
+        L.check(lib.mrcnn_debug_set(b"conv_pp_split", 1))
+        y1 = conv(x, w, k, stride, scale, shift, res, 1, dtype)
     finally:
         L.check(lib.mrcnn_debug_set(b"conv_pp", 1))
-        L.check(lib.mrcnn_debug_set(b"conv_pp_min_tiles", 256))
-        L.check(lib.mrcnn_debug_set(b"conv_pp_min_kt", 4))
+        L.check(lib.mrcnn_debug_set(b"conv_pp_min_tiles", 512))
+        L.check(lib.mrcnn_debug_set(b"conv_pp_min_kt", 8))
+        L.check(lib.mrcnn_debug_set(b"conv_pp_min_fill", 85))
+        L.check(lib.mrcnn_debug_set(b"conv_pp_split", 0))
     np.testing.assert_array_equal(y1, y0)
-    ref = torch_ref(x, w, k, stride, scale, shift, res, 1)
-    assert np.abs(y1 - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max()), np.abs(y1 - ref).max()
+    ref = torch_ref(x, w, k, stride, scale, shift, res, 1, dtype)
+    tol = {"f16": 2e-3, "f32s": 2e-5, "f32x3": 1e-5}[dtype]      # fp16 output rounding / 22-bit split / fp32 summation order
+    assert np.abs(y1 - ref).max() <= tol * max(1.0, np.abs(ref).max()), (np.abs(y1 - ref).max(), np.abs(ref).max())
 
 
-def test_pingpong_kernel_repeatable_under_load():
+@pytest.mark.parametrize("dtype", ["f16", "f32x3"])
+def test_pingpong_kernel_repeatable_under_load(dtype):
     """Race screen of the hand-placed DMA / barrier schedule: the same launch repeated must give the same bits, on a
     grid larger than the chip (several rounds of blocks, blocks at different phases sharing L2)."""
     rng = np.random.default_rng(3)
     x = rng.standard_normal((4, 128, 128, 256), np.float32)
     w = rng.standard_normal((512, 3, 3, 256), np.float32) * np.float32(0.02)
-    y0 = conv(x, w, 3, 1, None, None, None, 1, "f16")
+    L.check(L.lib().mrcnn_debug_set(b"conv_pp_split", 1))
+    L.check(L.lib().mrcnn_debug_set(b"conv_pp_min_tiles", 1))
+    y0 = conv(x, w, 3, 1, None, None, None, 1, dtype)
     for _ in range(4):
-        np.testing.assert_array_equal(conv(x, w, 3, 1, None, None, None, 1, "f16"), y0)
+        np.testing.assert_array_equal(conv(x, w, 3, 1, None, None, None, 1, dtype), y0)
     L.check(L.lib().mrcnn_debug_set(b"conv_pp", 0))
     try:
-        np.testing.assert_array_equal(conv(x, w, 3, 1, None, None, None, 1, "f16"), y0)
+        np.testing.assert_array_equal(conv(x, w, 3, 1, None, None, None, 1, dtype), y0)
     finally:
         L.check(L.lib().mrcnn_debug_set(b"conv_pp", 1))
+        L.check(L.lib().mrcnn_debug_set(b"conv_pp_split", 0))
+        L.check(L.lib().mrcnn_debug_set(b"conv_pp_min_tiles", 512))

@@ -394,3 +394,31 @@ def test_layers_with_strided_and_device_arrays(pkg, orc):
     assert 0 < nd < 12
     assert (got[:nd, 6:] == -1).all()             # kept rows: only 6 floats written (DetectionLayer.swift:217-224)
     assert (got[nd:] == 0).all()                  # padding rows: zeroed over the whole row stride (padTailWithZeros, :229-231)
+
+
+def test_native_dist_world_one_through_rccl(pkg, small_model):
+    """The multi-GPU leg behind the C ABI at world size 1 on the one GPU of this box: ncclGetUniqueId → ncclCommInitRank →
+    predict_sharded (shard + predict + ncclAllGather on the model's stream) must return exactly what predict returns, from
+    host and from device buffers; all_gather_records alone likewise."""
+    import torch
+    il = __import__("importlib")
+    models, dmod = il.import_module("mask-rcnn-coreml_amd.models"), il.import_module("mask-rcnn-coreml_amd.dist")
+    d, cfg = small_model
+    m = models.load_maskrcnn(d, max_batch=3)
+    images = rand_images(3, cfg.image_height, cfg.image_width, seed=17)
+    det, mask = m.predict(images)
+    uid = dmod.NativeDist.unique_id()
+    assert len(uid) == 128 and any(uid)
+    nd = dmod.NativeDist(0, 1, uid)
+    d1, m1 = nd.predict_sharded(m, images)
+    np.testing.assert_array_equal(d1, det)
+    np.testing.assert_array_equal(m1, mask)
+    d2, m2 = nd.predict_sharded(m, torch.from_numpy(images).cuda())
+    np.testing.assert_array_equal(d2.cpu().numpy(), det)
+    np.testing.assert_array_equal(m2.cpu().numpy(), mask)
+    out_d, out_m = np.full_like(det, np.nan), np.full_like(mask, np.nan)
+    nd.all_gather_records(m, det, mask, 3, out_d, out_m)
+    np.testing.assert_array_equal(out_d, det)
+    np.testing.assert_array_equal(out_m, mask)
+    nd.close()
+    pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None

@@ -314,3 +314,23 @@ def test_bench_host_core_count():
     import bench
     physical, logical = bench.host_cores()
     assert 1 <= physical <= logical == os.cpu_count()
+
+
+def test_native_dist_shard_matches_the_torch_twin(pkg):
+    """mrcnn_dist_shard (C ABI, host arithmetic) = dist.shard_bounds for every (batch, world, rank): contiguous blocks that
+    differ by at most one image and cover the batch exactly; record geometry = 316 000 B at the defaults."""
+    import ctypes as C
+    dmod = importlib.import_module("mask-rcnn-coreml_amd.dist")
+    L = importlib.import_module("mask-rcnn-coreml_amd._lib")
+    for world in (1, 2, 3, 4, 7, 8):
+        for batch in (0, 1, 5, 8, 31, 32, 64, 65):
+            covered = []
+            for rank in range(world):
+                lo, hi = dmod.NativeDist.shard(batch, world, rank)
+                assert (lo, hi) == dmod.shard_bounds(batch, world, rank)
+                covered += list(range(lo, hi))
+            assert covered == list(range(batch))
+    assert L.lib().mrcnn_dist_record_floats(100, 28) * 4 == 316000
+    lo, hi = C.c_int(), C.c_int()
+    assert L.lib().mrcnn_dist_shard(8, 4, 4, C.byref(lo), C.byref(hi)) != 0          # rank out of range: status, no abort
+    assert b"dist_shard" in L.lib().mrcnn_last_error()

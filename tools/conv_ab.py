@@ -25,13 +25,17 @@ SHAPES = [  # (name, batch, h, w, cin, cout, k, stride)
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 min_tiles = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+DT = {"f16": L.F16, "f32s": L.F32S, "f32x3": L.F32X3}[sys.argv[4] if len(sys.argv) > 4 else "f16"]
 
 
 def run(shape, pp):
     L.check(lib.mrcnn_debug_set(b"conv_pp", pp))
     L.check(lib.mrcnn_debug_set(b"conv_pp_min_tiles", min_tiles))
+    L.check(lib.mrcnn_debug_set(b"conv_pp_min_fill", 0))
+    L.check(lib.mrcnn_debug_set(b"conv_pp_min_kt", 1))
+    L.check(lib.mrcnn_debug_set(b"conv_pp_split", 1))
     ms, fl = C.c_float(0), C.c_double(0)
-    L.check(lib.mrcnn_bench_conv_dtype(*shape[1:], iters, L.F16, C.byref(ms), C.byref(fl)))
+    L.check(lib.mrcnn_bench_conv_dtype(*shape[1:], iters, DT, C.byref(ms), C.byref(fl)))
     return ms.value * 1e3, fl.value / ms.value / 1e9
 
 

@@ -7,7 +7,7 @@ dt=$1; shift
 shape=$1; shift
 for pp in 0 1; do
 for set in "$@"; do
-  rm -rf /tmp/p1; MRCNN_PP=$pp MRCNN_PP_MIN_TILES=1 timeout 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/p1 -o p -- python $R/tools/conv_one.py $shape 3 $dt > /tmp/p1.log 2>&1
+  rm -rf /tmp/p1; MRCNN_PP=$pp MRCNN_PP_MIN_TILES=1 MRCNN_PP_MIN_FILL=0 timeout 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/p1 -o p -- python $R/tools/conv_one.py $shape 3 $dt > /tmp/p1.log 2>&1
   PP=$pp python - <<'PY'
 import csv,glob,collections,os
 f=glob.glob('/tmp/p1/**/*counter_collection.csv',recursive=True)

@@ -8,7 +8,7 @@ L = importlib.import_module("mask-rcnn-coreml_amd._lib")
 lib = L.lib()
 SH = [(8, 256, 256, 256, 512, 3, 1), (8, 128, 128, 256, 256, 3, 1), (8, 64, 64, 256, 256, 3, 1)]
 sh = SH[int(sys.argv[1]) if len(sys.argv) > 1 else 0]
-L.check(lib.mrcnn_debug_set(b"conv_pp_min_tiles", 1))
+L.check(lib.mrcnn_debug_set(b"conv_pp_min_tiles", 1)); L.check(lib.mrcnn_debug_set(b"conv_pp_min_fill", 0)); L.check(lib.mrcnn_debug_set(b"conv_pp_min_kt", 1))
 
 def run(pp, dbg, iters=10):
     L.check(lib.mrcnn_debug_set(b"conv_pp", pp)); L.check(lib.mrcnn_debug_set(b"conv_pp_dbg", dbg))

@@ -4,7 +4,7 @@ import ctypes as C, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 L = importlib.import_module("mask-rcnn-coreml_amd._lib")
 lib = L.lib()
-L.check(lib.mrcnn_debug_set(b"conv_pp_min_tiles", 1))
+L.check(lib.mrcnn_debug_set(b"conv_pp_min_tiles", 1)); L.check(lib.mrcnn_debug_set(b"conv_pp_min_fill", 0)); L.check(lib.mrcnn_debug_set(b"conv_pp_min_kt", 1))
 L.check(lib.mrcnn_debug_set(b"conv_pp_min_kt", 1))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 def run(cin, pp, dbg, iters=10):
