@@ -110,7 +110,9 @@ def test_mgpu_c_host_world_one(pkg, small_model, tmp_path):
                        env=dict(os.environ, RANK="0", WORLD_SIZE="1"))
     assert r.returncode == 0, r.stderr
     lines = r.stdout.strip().splitlines()
-    assert lines[0].startswith("world 1 batch 3 seconds ")
+    while lines and not lines[0].startswith("world "):        # RCCL prints its version banner on stdout at communicator creation
+        lines.pop(0)
+    assert lines and lines[0].startswith("world 1 batch 3 seconds ")
     m = models.load_maskrcnn(d, max_batch=B, compute_dtype="f32x3")
     det, mask = m.predict(imgs)
     pos = 1

@@ -22,6 +22,9 @@ def _anchors_for(pkg, anchors_mod, size, tmp_path):
 def _run_proposal(pkg, probs, deltas, params, out_stride=4, prefill=np.nan):
     layer = pkg.ProposalLayer(params)
     maxp = params.get("maxProposals", 1000)
+    # ProposalLayer.outputShapes (ProposalLayer.swift:97-101): the deltas' shape with dim 0 = maxProposals
+    A = probs.shape[0]
+    assert layer.outputShapes([[A, 1, 2, 1, 1], [A, 1, 4, 1, 1]]) == [[maxp, 1, 4, 1, 1]]
     out = np.full((maxp, out_stride), np.float32(prefill), dtype=np.float32)
     ML = pkg.MLMultiArray
     layer.evaluate([ML(probs), ML(deltas)], [ML(out, shape=(maxp, 1, out_stride, 1, 1))])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-GEMM-shape table of the conv family inside a real predict (live HIP events through the C ABI):
-   conv_layer_table.py [f32|f16] [steps] [batch]   — BASELINE configs[1] (R101 1024², batch 8), synthetic weights."""
+   conv_layer_table.py [f32|f16|f32s|f32x3] [steps] [batch]   — BASELINE configs[1] (R101 1024², batch 8), synthetic weights."""
 import importlib
 import os
 import sys
@@ -28,7 +28,7 @@ rows = m.conv_profile_shapes()
 tot = sum(r[5] for r in rows)
 print(f"{'M':>8} {'N':>5} {'K':>6} tile  n/step   us/launch  TFLOP/s  share")
 for M, N, K, tile, n, ms, fl in sorted(rows, key=lambda r: -r[5]):
-    print(f"{M:8d} {N:5d} {K:6d} {('128', '64', '32', '256')[tile]:>4} {n / steps:7.1f} {ms / n * 1e3:11.1f} {fl / ms / 1e9:8.1f} {ms / tot * 100:6.1f}%")
+    print(f"{M:8d} {N:5d} {K:6d} {('128', '64', '32', '256', 'pp256', 'pp128')[tile]:>4} {n / steps:7.1f} {ms / n * 1e3:11.1f} {fl / ms / 1e9:8.1f} {ms / tot * 100:6.1f}%")
 m.conv_profile_enable(False)
 import time
 m.predict(img)

@@ -1,28 +1,51 @@
 #!/bin/bash
-# Regenerates everything under profiles/ for round $1 (default r01) on a GPU box:
-#   gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh r01'
+# Regenerates everything under profiles/ for round $1 (default r02) on a GPU box:
+#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r02'
 # Outputs land in gpurun_out/profiles_<round>/ (merged back by gpurun); copy them into profiles/ and commit.
+# Counter passes follow MI355X_MICROARCH.md: --pmc in its own run with --kernel-trace only, FETCH_SIZE and WRITE_SIZE separately.
 set -u
-RND=${1:-r01}
+RND=${1:-r02}
+MODES=${2:-"f32x3 f16 f32s f32"}
 R=$(pwd)
 OUT=$R/gpurun_out/profiles_$RND
 mkdir -p $OUT
 export TMPDIR=/tmp
-python bench.py --steps 10 --warmup 3 > $OUT/${RND}_bench_n1.json 2> $OUT/bench_f32.err
-python bench.py --steps 10 --warmup 3 --dtype f16 --no-cpu-baseline --no-other-modes > $OUT/${RND}_bench_n1_f16.json 2> $OUT/bench_f16.err
-python bench.py --steps 10 --warmup 3 --dtype f32s --no-cpu-baseline --no-other-modes > $OUT/${RND}_bench_n1_f32s.json 2> $OUT/bench_f32s.err
+python bench.py --steps 10 --warmup 3 > $OUT/${RND}_bench_n1.json 2> $OUT/bench_default.err
+for dt in $MODES; do
+  [ $dt = f32x3 ] || python bench.py --steps 10 --warmup 3 --dtype $dt --no-cpu-baseline --no-other-modes > $OUT/${RND}_bench_n1_$dt.json 2> $OUT/bench_$dt.err
+  python tools/conv_layer_table.py $dt 3 8 > $OUT/${RND}_conv_shapes_$dt.txt 2>/dev/null
+done
+python tools/conv_layer_table.py f32x3 5 1 > $OUT/${RND}_conv_shapes_f32x3_batch1.txt 2>/dev/null
 cd /tmp
-for dt in f32 f16 f32s; do
+BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-modes --no-kernel-events"
+for dt in $MODES; do
   rm -rf /tmp/prof_$dt
   timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$dt -o p -- python $R/bench.py --steps 5 --warmup 2 --dtype $dt --no-cpu-baseline --no-other-modes > $OUT/stats_$dt.json 2> $OUT/stats_$dt.err
   db=$(find /tmp/prof_$dt -name "*.db" | head -1)
-  sfx=""; [ $dt != f32 ] && sfx="_$dt"
-  python $R/tools/rocpd_summary.py $db $OUT/${RND}_kernel_stats$sfx.csv
+  python $R/tools/rocpd_summary.py $db $OUT/${RND}_kernel_stats_$dt.csv
+  i=0
+  for set in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAIT_INST_LDS" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
+    i=$((i+1)); rm -rf /tmp/pmc_${dt}_$i
+    timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_${dt}_$i -o p -- $BENCH --dtype $dt > /dev/null 2> $OUT/pmc_${dt}_$i.err
+  done
+  python $R/tools/pmc_digest.py $OUT/${RND}_pmc_kernels_$dt.json $OUT/${RND}_kernel_stats_$dt.csv /tmp/pmc_${dt}_1 /tmp/pmc_${dt}_2 /tmp/pmc_${dt}_3 /tmp/pmc_${dt}_4 /tmp/pmc_${dt}_5 > $OUT/${RND}_pmc_kernels_$dt.txt
+  python - <<PY
+import json
+d = json.load(open("$OUT/${RND}_pmc_kernels_$dt.json"))["kernels"]
+conv = {k: v for k, v in d.items() if k.startswith("k_conv") and "hbm_bytes_per_launch" in v}
+k = max(conv, key=lambda k: conv[k].get("percent_of_gpu_time", 0))
+json.dump({"kernel": k, "launches_sampled": conv[k]["launches_sampled"], "hbm_bytes_per_launch_corrected": conv[k]["hbm_bytes_per_launch"],
+           "FETCH_SIZE_avg_KB_raw": conv[k]["counters_avg_per_launch"]["FETCH_SIZE"], "WRITE_SIZE_avg_KB": conv[k]["counters_avg_per_launch"]["WRITE_SIZE"],
+           "note": "dominant conv kernel of bench.py --dtype $dt; 2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes (tools/refresh_profiles.sh)"},
+          open("$OUT/${RND}_pmc_traffic_$dt.json", "w"), indent=1)
+PY
 done
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmc_$c
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-modes --no-kernel-events > /dev/null 2> $OUT/pmc_$c.err
-done
-python $R/tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $OUT/${RND}_pmc_traffic.json
-head -4 $OUT/${RND}_kernel_stats.csv | cut -c1-160
-cut -c1-400 $OUT/${RND}_bench_n1.json
+cd $R
+for dt in f16 f32x3; do timeout 300 python tools/conv_ab.py 3 10 1 $dt > $OUT/${RND}_conv_ab_$dt.txt 2>/dev/null; done
+timeout 200 python tools/pp_ablate.py 0 > $OUT/${RND}_pp_ablate_f16.txt 2>/dev/null
+timeout 200 python tools/pp_ktfit.py 512 > $OUT/${RND}_pp_ktfit_f16.txt 2>/dev/null
+[ -x tools/probes/dma_probe ] && timeout 120 ./tools/probes/dma_probe 4096 > $OUT/${RND}_dma_probe.txt 2>&1
+timeout 400 python tools/fp64_trunk_parity.py --out $OUT/${RND}_fp64_trunk_parity.json > $OUT/fp64.log 2>&1
+head -5 $OUT/${RND}_kernel_stats_f32x3.csv | cut -c1-160
+cut -c1-300 $OUT/${RND}_bench_n1.json
+cat $OUT/${RND}_pmc_kernels_f32x3.txt
