@@ -26,8 +26,15 @@ if _ROOT not in sys.path:
 from oracle import oracle as orc  # noqa: E402
 
 _pkg = importlib.import_module("mask-rcnn-coreml_amd")
-weights_mod = importlib.import_module("mask-rcnn-coreml_amd.weights")
-BN_EPS = weights_mod.BN_EPS
+weights_mod = importlib.import_module("mask-rcnn-coreml_amd.weights")     # the .mrcw container reader only
+BN_EPS = 1e-3       # Keras BatchNormalization epsilon of the published Matterport graph (stated here, not imported)
+
+
+def _stage_blocks(architecture: str):
+    """Residual block letters per stage of the published ResNet-50 / ResNet-101 (stage 4: 6 / 23 blocks) — the oracle's own
+    table, so that a wrong layer list in the product cannot be shared by the checker."""
+    n4 = {"resnet50": 6, "resnet101": 23}[architecture]
+    return {2: ["a", "b", "c"], 3: ["a", "b", "c", "d"], 4: [chr(ord("a") + i) for i in range(n4)], 5: ["a", "b", "c"]}
 
 
 class _W:
@@ -74,7 +81,7 @@ class OracleMaskRCNN:
         x = F.relu(w.bn(w.conv(x, "conv1", stride=2), "bn_conv1"))
         x = F.pad(x, (0, 1, 0, 1), value=float("-inf"))          # Keras 'same' pool: pad bottom/right
         x = F.max_pool2d(x, 3, 2)
-        blocks = weights_mod.resnet_stage_blocks(self.cfg.architecture)
+        blocks = _stage_blocks(self.cfg.architecture)
         feats = []
         for stage in (2, 3, 4, 5):
             for b in blocks[stage]:
