@@ -76,7 +76,7 @@ namespace mrcnn {
 // 128-B lines (its 64 channels of a pixel) in four back-to-back stores.
 // ----------------------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void pp_store_tile(const ConvArgs& a, f32x16 (&acc)[4][2], int m0, int n0, int wrow, int wcol, int lane)
+__device__ __forceinline__ bool pp_store_tile(const ConvArgs& a, f32x16 (&acc)[4][2], int m0, int n0, int wrow, int wcol, int lane)
 {
     const int l31 = lane & 31, kk = lane >> 5;
     const int ohw = a.OH * a.OW;
@@ -84,21 +84,25 @@ __device__ __forceinline__ void pp_store_tile(const ConvArgs& a, f32x16 (&acc)[4
     T* const out = static_cast<T*>(a.out);
     const bool dense_out = a.out_sB == (long)ohw * a.out_sP;
     const bool dense_res = a.res_sB == (long)ohw * a.res_sW && a.res_shift == 0;
+    const bool relu = a.act == ACT_RELU;
     bool out_of_range = false;
+    // slab outermost, channel runs innermost: the four 32-B pieces of a pixel's 128-B line leave in back-to-back stores
+    // (measured: with the channel runs outermost — scale / shift fetched once per run — the stores of a line are spread
+    // over the epilogue and the tile's fixed cost grows by 25 %: the L2 no longer merges them before they reach HBM)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wrow * 128 + i * 32 + l31;
-        const bool ok_m = m < a.M;
-        long o_row = (long)m * a.out_sP, r_row = (long)m * a.res_sW;
+        const bool ok_mi = m < a.M;
+        long o_rowi = (long)m * a.out_sP, r_rowi = (long)m * a.res_sW;
         if (!dense_out || (res && !dense_res)) {
-            const int mm = ok_m ? m : 0;
+            const int mm = ok_mi ? m : 0;
             const int b = mm / ohw, pix = mm - b * ohw;
-            o_row = (long)b * a.out_sB + (long)pix * a.out_sP;
+            o_rowi = (long)b * a.out_sB + (long)pix * a.out_sP;
             if (res) {
                 if (a.res_shift) {
                     const int oh = pix / a.OW, ow = pix - oh * a.OW;
-                    r_row = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
-                } else r_row = (long)b * a.res_sB + (long)pix * a.res_sW;
+                    r_rowi = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
+                } else r_rowi = (long)b * a.res_sB + (long)pix * a.res_sW;
             }
         }
 #pragma unroll
@@ -107,27 +111,30 @@ __device__ __forceinline__ void pp_store_tile(const ConvArgs& a, f32x16 (&acc)[4
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int ca = nb + 16 * p + 4 * kk, cb = ca + 8;
-                float4 va = make_float4(acc[i][j][8 * p + 0], acc[i][j][8 * p + 1], acc[i][j][8 * p + 2], acc[i][j][8 * p + 3]);
-                float4 vb = make_float4(acc[i][j][8 * p + 4], acc[i][j][8 * p + 5], acc[i][j][8 * p + 6], acc[i][j][8 * p + 7]);
                 float4 sa = make_float4(1.f, 1.f, 1.f, 1.f), sb_ = sa, ha = make_float4(0.f, 0.f, 0.f, 0.f), hb = ha;
                 if (a.scale) { sa = *reinterpret_cast<const float4*>(a.scale + ca); sb_ = *reinterpret_cast<const float4*>(a.scale + cb); }
                 if (a.shift) { ha = *reinterpret_cast<const float4*>(a.shift + ca); hb = *reinterpret_cast<const float4*>(a.shift + cb); }
+                float4 va = make_float4(acc[i][j][8 * p + 0], acc[i][j][8 * p + 1], acc[i][j][8 * p + 2], acc[i][j][8 * p + 3]);
+                float4 vb = make_float4(acc[i][j][8 * p + 4], acc[i][j][8 * p + 5], acc[i][j][8 * p + 6], acc[i][j][8 * p + 7]);
                 va.x = va.x * sa.x + ha.x; va.y = va.y * sa.y + ha.y; va.z = va.z * sa.z + ha.z; va.w = va.w * sa.w + ha.w;
                 vb.x = vb.x * sb_.x + hb.x; vb.y = vb.y * sb_.y + hb.y; vb.z = vb.z * sb_.z + hb.z; vb.w = vb.w * sb_.w + hb.w;
-                const bool ok_a = ok_m && ca < a.ncols, ok_b = ok_m && cb < a.ncols;
+                const bool ok_a = ok_mi && ca < a.ncols, ok_b = ok_mi && cb < a.ncols;
                 if (res) {
-                    if (ok_a) { const float4 r = load4<T>(res + r_row + ca); va.x += r.x; va.y += r.y; va.z += r.z; va.w += r.w; }
-                    if (ok_b) { const float4 r = load4<T>(res + r_row + cb); vb.x += r.x; vb.y += r.y; vb.z += r.z; vb.w += r.w; }
+                    if (ok_a) { const float4 r = load4<T>(res + r_rowi + ca); va.x += r.x; va.y += r.y; va.z += r.z; va.w += r.w; }
+                    if (ok_b) { const float4 r = load4<T>(res + r_rowi + cb); vb.x += r.x; vb.y += r.y; vb.z += r.z; vb.w += r.w; }
                 }
-                if (a.act == ACT_RELU) {
+                if (relu) {
                     va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f); va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
                     vb.x = fmaxf(vb.x, 0.f); vb.y = fmaxf(vb.y, 0.f); vb.z = fmaxf(vb.z, 0.f); vb.w = fmaxf(vb.w, 0.f);
                 }
+                // fp16-range watchdog (|v| >= 65504, inf or NaN)
                 if (ok_a) out_of_range = out_of_range || !(fabsf(va.x) < 65504.0f) || !(fabsf(va.y) < 65504.0f) || !(fabsf(va.z) < 65504.0f) || !(fabsf(va.w) < 65504.0f);
                 if (ok_b) out_of_range = out_of_range || !(fabsf(vb.x) < 65504.0f) || !(fabsf(vb.y) < 65504.0f) || !(fabsf(vb.z) < 65504.0f) || !(fabsf(vb.w) < 65504.0f);
-                if constexpr (sizeof(T) == 4) {
-                    if (ok_a) *reinterpret_cast<float4*>(out + o_row + ca) = va;
-                    if (ok_b) *reinterpret_cast<float4*>(out + o_row + cb) = vb;
+                if (a.dbg & 32) {                      // measurement only: the epilogue's arithmetic without its stores
+                    asm volatile("" ::"v"(va.x), "v"(va.y), "v"(va.z), "v"(va.w), "v"(vb.x), "v"(vb.y), "v"(vb.z), "v"(vb.w));
+                } else if constexpr (sizeof(T) == 4) {
+                    if (ok_a) *reinterpret_cast<float4*>(out + o_rowi + ca) = va;
+                    if (ok_b) *reinterpret_cast<float4*>(out + o_rowi + cb) = vb;
                 } else {
                     f16x4 ha4, hb4;
                     ha4[0] = (_Float16)va.x; ha4[1] = (_Float16)va.y; ha4[2] = (_Float16)va.z; ha4[3] = (_Float16)va.w;
@@ -137,13 +144,13 @@ __device__ __forceinline__ void pp_store_tile(const ConvArgs& a, f32x16 (&acc)[4
                     const auto sx = __builtin_amdgcn_permlane32_swap(pa.x, pb.x, false, false);
                     const auto sy = __builtin_amdgcn_permlane32_swap(pa.y, pb.y, false, false);
                     const int n_store = nb + 16 * p + 8 * kk;
-                    if (ok_m && n_store < a.ncols)
-                        *reinterpret_cast<uint4*>(out + o_row + n_store) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                    if (ok_mi && n_store < a.ncols)
+                        *reinterpret_cast<uint4*>(out + o_rowi + n_store) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
                 }
             }
         }
     }
-    if (a.range_flag && out_of_range) atomicOr(a.range_flag, 1);
+    return out_of_range;      // the caller raises the watchdog flag once, at the end of the kernel (keeps the VMEM count of a tile exact)
 }
 
 // ================================================================================================================
@@ -159,6 +166,7 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
     constexpr int A_STAGE = BM * ROWB, B_STAGE = BN * BROWB, B_BASE = 2 * A_STAGE;
     constexpr int BJ = 32 * BROWB;                                // LDS bytes between the two column tiles of a wave
     constexpr int STEADY = SPLIT ? 3 : 4;                         // DMAs younger than K step kt+1 at the end of step kt
+    constexpr int TILE_STORES = SPLIT ? 32 : 16;                  // 16-B store instructions of pp_store_tile per wave on an interior tile
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_STAGE + B_STAGE)];     // 128 KB (fp16) / 96 KB (split)
     const char* const in = static_cast<const char*>(a.in);
     const TW* const wgt = static_cast<const TW*>(a.wgt);
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
     const int KT = a.KH * a.KW * cin_tiles;
     const long tapW = a.in_sW * (long)sizeof(T), tapH = a.in_sH * (long)sizeof(T);
     // measurement-only ablations (a.dbg = 0 in production): 1 no s_setprio, 2 no group stagger, 4 no DMA in the main
-    // loop, 8 no fragment reads, 16 no MFMAs
+    // loop, 8 no fragment reads, 16 no MFMAs, 32 epilogue without its stores, 64 no epilogue
     const bool dbg_noprio = a.dbg & 1, dbg_nostagger = a.dbg & 2, dbg_nodma = a.dbg & 4, dbg_nords = a.dbg & 8, dbg_nomma = a.dbg & 16;
 
     f32x16 acc[4][2];
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
     const int nblocks = a.tiles_m * a.tiles_n;
     const int q8 = nblocks >> 3, r8 = nblocks & 7;
     int pm0 = 0, pn0 = 0;
-    bool have_prev = false;
+    bool have_prev = false, range_trip = false;
     for (int v = blockIdx.x; v < nblocks; v += gridDim.x) {
         const int xcd = v & 7, local = v >> 3;
         const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
@@ -276,14 +284,21 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
         if (KT > 1) { PP_L2_ISSUE(1) PP_L3_ISSUE(1) }
         // ---- epilogue of the PREVIOUS tile under the flight of those DMAs (registers → HBM, no LDS)
         if (have_prev) {
-            pp_store_tile<T>(a, acc, pm0, pn0, wr, wc, lane);
+            if (!(a.dbg & 64)) range_trip |= pp_store_tile<T>(a, acc, pm0, pn0, wr, wc, lane);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-            PP_VMCNT(0)              // stores and loads share the counter: drain both once per tile
+            // K step 0 must have landed; the epilogue's stores are YOUNGER than it and share the counter (gfx9: loads and
+            // stores retire in issue order).  On an interior tile every wave issued exactly TILE_STORES stores, so a counted
+            // wait leaves them (and the K-step-1 DMAs) in flight — the store drain of 256 CUs bursting together is not
+            // waited for.  Edge tiles (some stores skipped: the count is not exact) drain everything.
+            const bool interior = pm0 + BM <= a.M && pn0 + BN <= a.ncols;
+            if (interior && KT > 1) { PP_VMCNT(TILE_STORES + STEADY) }
+            else if (interior) { PP_VMCNT(TILE_STORES) }
+            else { PP_VMCNT(0) }
         } else if (KT > 1) {
             PP_VMCNT(STEADY)
         } else {
@@ -370,7 +385,8 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
         if (wr == 0 && !dbg_nostagger) PP_BARRIER          // re-join: every wave's last fragment read has retired behind this rendezvous
         pm0 = m0; pn0 = n0; have_prev = true;
     }
-    if (have_prev) pp_store_tile<T>(a, acc, pm0, pn0, wr, wc, lane);
+    if (have_prev && !(a.dbg & 64)) range_trip |= pp_store_tile<T>(a, acc, pm0, pn0, wr, wc, lane);
+    if (a.range_flag && range_trip) atomicOr(a.range_flag, 1);
 #undef PP_KSTEP
 #undef PP_MATH
 #undef PP_WAIT_AB

@@ -21,9 +21,33 @@ import os
 import sys
 
 
+_demangled = {}
+
+
 def short(name):
-    n = name.split("(")[0]
-    return n.replace("void ", "").replace("mrcnn::", "")
+    """rocprofv3 hands out some kernel names mangled: demangle (llvm-cxxfilt / c++filt), drop the argument list and namespace."""
+    if name.startswith("_Z"):
+        if name not in _demangled:
+            out = name
+            for tool in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "c++filt"):
+                try:
+                    import subprocess
+                    out = subprocess.run([tool, name], capture_output=True, text=True, timeout=20).stdout.strip() or name
+                    break
+                except Exception:
+                    continue
+            _demangled[name] = out
+        name = _demangled[name]
+    depth, cut = 0, len(name)
+    for i, ch in enumerate(name):            # the argument list starts at the first '(' outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            cut = i
+            break
+    return name[:cut].replace("void ", "").replace("mrcnn::", "").strip()
 
 
 def main():
