@@ -388,9 +388,9 @@ struct PpPolicy { int on, min_tiles, min_kt, dbg, min_fill_pct, split; };
 static PpPolicy& pp_policy()
 {
     // Shipped policy = where the A/B of tools/conv_ab.py shows a gain (profiles/r02_conv_ab_*.txt): fp16 tensors, at least two
-    // full rounds of 256 tiles, K >= 512.  The split modes run the same kernel bit-identically but no faster (both kernels
+    // full rounds of 256 tiles, K >= 1024 (at K = 512 the in-engine shape table shows a loss: 564 vs 618 TFLOP/s).  The split modes run the same kernel bit-identically but no faster (both kernels
     // sit at the same power-limited MFMA rate): off unless asked for.
-    static PpPolicy p = {env_int("MRCNN_PP", 1), env_int("MRCNN_PP_MIN_TILES", 512), env_int("MRCNN_PP_MIN_KT", 8), env_int("MRCNN_PP_DBG", 0),
+    static PpPolicy p = {env_int("MRCNN_PP", 1), env_int("MRCNN_PP_MIN_TILES", 512), env_int("MRCNN_PP_MIN_KT", 16), env_int("MRCNN_PP_DBG", 0),
                          env_int("MRCNN_PP_MIN_FILL", 85), env_int("MRCNN_PP_SPLIT", 0)};
     return p;
 }

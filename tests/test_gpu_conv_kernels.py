@@ -82,7 +82,7 @@ def test_pingpong_kernel_equals_128row_kernel_bitwise(shape, dtype):
     finally:
         L.check(lib.mrcnn_debug_set(b"conv_pp", 1))
         L.check(lib.mrcnn_debug_set(b"conv_pp_min_tiles", 512))
-        L.check(lib.mrcnn_debug_set(b"conv_pp_min_kt", 8))
+        L.check(lib.mrcnn_debug_set(b"conv_pp_min_kt", 16))
         L.check(lib.mrcnn_debug_set(b"conv_pp_min_fill", 85))
         L.check(lib.mrcnn_debug_set(b"conv_pp_split", 0))
     np.testing.assert_array_equal(y1, y0)

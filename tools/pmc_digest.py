@@ -21,23 +21,38 @@ import os
 import sys
 
 
-_demangled = {}
+import re
+
+
+def _demangle_mrcnn(name):
+    """Minimal Itanium demangling of this library's kernels (GNU c++filt does not know DF16_ = _Float16; no llvm-cxxfilt here):
+    _ZN5mrcnn<len><ident>I<template args>E... with args f / DF16_ / Li<n>E / Lb<0|1>E."""
+    m = re.match(r"_ZN5mrcnn(\d+)", name)
+    if not m:
+        return name
+    n = int(m.group(1))
+    ident = name[m.end():m.end() + n]
+    rest = name[m.end() + n:]
+    args = []
+    if rest.startswith("I"):
+        i = 1
+        while i < len(rest) and rest[i] != "E":
+            if rest.startswith("DF16_", i):
+                args.append("_Float16"); i += 5
+            elif rest[i] == "f":
+                args.append("float"); i += 1
+            elif rest[i] == "L":
+                j = rest.index("E", i)
+                args.append(rest[i + 2:j].replace("n", "-")); i = j + 1
+            else:
+                break
+    return ident + ("<" + ", ".join(args) + ">" if args else "")
 
 
 def short(name):
-    """rocprofv3 hands out some kernel names mangled: demangle (llvm-cxxfilt / c++filt), drop the argument list and namespace."""
+    """rocprofv3 hands out some kernel names mangled; drop the argument list and the namespace."""
     if name.startswith("_Z"):
-        if name not in _demangled:
-            out = name
-            for tool in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "c++filt"):
-                try:
-                    import subprocess
-                    out = subprocess.run([tool, name], capture_output=True, text=True, timeout=20).stdout.strip() or name
-                    break
-                except Exception:
-                    continue
-            _demangled[name] = out
-        name = _demangled[name]
+        return _demangle_mrcnn(name)
     depth, cut = 0, len(name)
     for i, ch in enumerate(name):            # the argument list starts at the first '(' outside template brackets
         if ch == "<":
