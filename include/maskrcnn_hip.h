@@ -337,6 +337,9 @@ MRCNN_API int mrcnn_paste_masks(const float* detections, int64_t det_stride, con
                                 int image_h, int image_w, float threshold, int memspace, uint8_t* out);
 /* 28×28 mask → 8-bit: UInt8(255 - v/2*255) (Detection.swift:83-85). */
 MRCNN_API int mrcnn_mask_to_u8(const float* mask, int64_t n, uint8_t* out);
+/* The same on Double input — the type Core ML hands maskFromFeatureValue (Detection.swift:77); for hosts that widen the fp32
+ * mask of mrcnn_maskrcnn_predict first the result is identical (float → double is exact). */
+MRCNN_API int mrcnn_mask_to_u8_f64(const double* mask, int64_t n, uint8_t* out);
 
 #ifdef __cplusplus
 }

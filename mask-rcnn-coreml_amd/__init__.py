@@ -22,7 +22,7 @@ def __getattr__(name):
         "ProposalLayer": ".layers", "PyramidROIAlignLayer": ".layers",
         "TimeDistributedClassifierLayer": ".layers", "DetectionLayer": ".layers",
         "TimeDistributedMaskLayer": ".layers", "MLMultiArray": ".layers",
-        "Detection": ".detection", "IOU": ".detection",
+        "Detection": ".detection", "IOU": ".detection", "COCO": ".coco",
     }
     if name in lazy:
         return getattr(importlib.import_module(lazy[name], __name__), name)

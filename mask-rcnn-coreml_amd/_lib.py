@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "mrcnn_detections_decode", "mrcnn_mask_to_u8", "mrcnn_paste_masks", "mrcnn_generate_anchors", "mrcnn_letterbox_geometry", "mrcnn_letterbox_rgb",
     "mrcnn_model_check_range", "mrcnn_roi_align_nhwc", "mrcnn_conv2d_nhwc", "mrcnn_debug_set",
     "mrcnn_dist_unique_id", "mrcnn_dist_init", "mrcnn_dist_destroy", "mrcnn_dist_shard", "mrcnn_dist_record_floats",
-    "mrcnn_dist_all_gather_records", "mrcnn_maskrcnn_predict_sharded",
+    "mrcnn_dist_all_gather_records", "mrcnn_maskrcnn_predict_sharded", "mrcnn_mask_to_u8_f64",
 ]
 
 
@@ -120,6 +120,7 @@ def lib():
     L.mrcnn_bench_conv_dtype.argtypes = [C.c_int] * 9 + [f32p, C.POINTER(C.c_double)]
     L.mrcnn_detections_decode.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(DetectionRecord), C.c_int64, i64p]
     L.mrcnn_mask_to_u8.argtypes = [vp, C.c_int64, vp]
+    L.mrcnn_mask_to_u8_f64.argtypes = [vp, C.c_int64, vp]
     ip = C.POINTER(C.c_int)
     L.mrcnn_letterbox_geometry.argtypes = [C.c_int] * 4 + [ip] * 4
     L.mrcnn_letterbox_rgb.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int]

@@ -1026,3 +1026,16 @@ extern "C" int mrcnn_mask_to_u8(const float* mask, int64_t n, uint8_t* out)
         }
     });
 }
+
+// the same for a host that holds the mask as Double, as Core ML hands it to Detection.maskFromFeatureValue (Detection.swift:77)
+extern "C" int mrcnn_mask_to_u8_f64(const double* mask, int64_t n, uint8_t* out)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(mask && out && n >= 0, MRCNN_ERR_INVALID, "bad argument");
+        for (int64_t i = 0; i < n; ++i) {
+            double v = 255.0 - (mask[i] / 2.0 * 255.0);                         // Detection.swift:83-85
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            out[i] = (uint8_t)v;
+        }
+    });
+}

@@ -114,3 +114,13 @@ def evaluate(model: MaskRCNN, images: Iterable[Tuple[int, np.ndarray]], dataset_
 
 def evaluate_from_dir(model_dir: str, images, **kw):
     return evaluate(load_maskrcnn(model_dir, max_batch=1), images, **kw)
+
+
+def evaluate_coco(model: MaskRCNN, annotations_json: str, load_image, dataset_id: str = "coco", limit: Optional[int] = 5, verbose: bool = True):
+    """`maskrcnn evaluate` over a COCO annotation file (EvaluateCommand.swift:159-200): the first `limit` images sorted by id
+    (`coco.makeImageIterator(limit: 5, sortById: true)`, :165), each loaded by `load_image(COCOImage) -> (h,w,3) uint8` (the
+    reference reads `<dataset dir>/<file_name>`; decoding image files is left to the host — no codec ships here)."""
+    from .coco import COCO
+    coco = COCO(annotations_json)
+    items = [(im.id, load_image(im)) for im, _ in coco.makeImageIterator(limit=limit, sortById=True)]
+    return evaluate(model, items, dataset_id=dataset_id, limit=None, verbose=verbose)

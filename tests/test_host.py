@@ -334,3 +334,45 @@ def test_native_dist_shard_matches_the_torch_twin(pkg):
     lo, hi = C.c_int(), C.c_int()
     assert L.lib().mrcnn_dist_shard(8, 4, 4, C.byref(lo), C.byref(hi)) != 0          # rank out of range: status, no abort
     assert b"dist_shard" in L.lib().mrcnn_last_error()
+
+
+def test_coco_instances_reader(pkg, tmp_path):
+    """COCO.swift counterpart: decode instances_*.json, index annotations by image id in file order, iterate sorted by id with a
+    limit (EvaluateCommand.swift:165 uses limit 5, sortById true); a limit beyond the image count is an error, like the Swift slice."""
+    import json
+    coco_mod = importlib.import_module("mask-rcnn-coreml_amd.coco")
+    doc = {"info": {"description": "t", "url": "http://x", "version": "1", "year": 2017, "contributor": "c"},
+           "images": [{"id": 42, "file_name": "b.jpg", "width": 640, "height": 480, "coco_url": "ignored"},
+                      {"id": 7, "file_name": "a.jpg", "width": 500, "height": 375},
+                      {"id": 19, "file_name": "c.jpg", "width": 64, "height": 64}],
+           "annotations": [{"id": 1, "image_id": 42, "category_id": 18, "bbox": [1.5, 2, 30, 40], "iscrowd": 0},
+                           {"id": 2, "image_id": 7, "category_id": 1, "bbox": [0, 0, 10, 10]},
+                           {"id": 3, "image_id": 42, "category_id": 3, "bbox": [5, 5, 6, 7]}]}
+    p = tmp_path / "instances_val.json"
+    p.write_text(json.dumps(doc))
+    coco = pkg.COCO(str(p))
+    assert [i.id for i in coco.images] == [42, 7, 19]
+    assert [a.id for a in coco.index[42]] == [1, 3] and coco.index[42][0].bbox == (1.5, 2.0, 30.0, 40.0)
+    got = list(coco.makeImageIterator(limit=2, sortById=True))
+    assert [(im.id, im.fileName, im.width, im.height, [a.id for a in anns]) for im, anns in got] == [
+        (7, "a.jpg", 500, 375, [2]), (19, "c.jpg", 64, 64, [])]
+    assert [im.id for im, _ in coco.makeImageIterator()] == [42, 7, 19]                  # file order without sortById
+    with pytest.raises(ValueError):
+        list(coco.makeImageIterator(limit=4))
+    bad = tmp_path / "bad.json"
+    bad.write_text(json.dumps({"images": [], "annotations": []}))
+    with pytest.raises(ValueError, match="info"):
+        coco_mod.COCO(str(bad))
+
+
+def test_mask_to_u8_double_path_equals_float_path():
+    """Detection.swift:77-98 quantises a Double mask; the fp32 mask widened to double must give the same bytes as the float entry."""
+    L = importlib.import_module("mask-rcnn-coreml_amd._lib")
+    m = np.random.default_rng(4).random(784 * 3).astype(np.float32)
+    m[:4] = [0.0, 1.0, 0.5, 2.0]
+    a, b = np.empty(m.size, np.uint8), np.empty(m.size, np.uint8)
+    L.check(L.lib().mrcnn_mask_to_u8(m.ctypes.data, m.size, a.ctypes.data))
+    md = m.astype(np.float64)
+    L.check(L.lib().mrcnn_mask_to_u8_f64(md.ctypes.data, m.size, b.ctypes.data))
+    np.testing.assert_array_equal(a, b)
+    assert a[0] == 255 and a[1] == 127 and a[3] == 0
