@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
     ap.add_argument("--arch", default="resnet101")
     ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--num-classes", type=int, default=81, help="BASELINE configs[4] uses 2")
+    ap.add_argument("--pre-nms", type=int, default=6000, help="preNMSMaxProposals (BASELINE configs[4]: 12000)")
     ap.add_argument("--dtype", default="f32x3", choices=["f32", "f16", "f32s", "f32x3"],
                     help="compute mode of the convolutions.  f32x3 (default): fp32 tensors, every product a*w formed EXACTLY on the "
                          "fp16 matrix cores from a three-part split of the fp32 activation against the fp16-stored filter "
@@ -111,7 +113,8 @@ def main():
     weights = importlib.import_module("mask-rcnn-coreml_amd.weights")
     dmod = importlib.import_module("mask-rcnn-coreml_amd.dist")
 
-    cfg = pkg.ModelConfig(architecture=args.arch, input_image_shape=(args.size, args.size, 3))
+    cfg = pkg.ModelConfig(architecture=args.arch, input_image_shape=(args.size, args.size, 3), num_classes=args.num_classes,
+                          pre_nms_max_proposals=args.pre_nms)
     model_dir = tempfile.mkdtemp(prefix=f"mrcnn_bench_r{rank}_")
     weights.save_synthetic_models(model_dir, cfg, seed=0, forced_load=True)
     m = models.load_maskrcnn(model_dir, max_batch=args.batch, compute_dtype=args.dtype)
@@ -182,8 +185,9 @@ def main():
                                     "3-part split of the activation (the filters are fp16 in the artefact, task.py:90)",
                            "f32": "fp32 tensors, v_mfma_f32_32x32x2_f32", "f32s": "fp32 tensors, 2-part split of the activations (22 of 24 bits)",
                            "f16": "fp16 tensors, fp16 MFMA, fp32 accumulate; box path and outputs fp32"}[args.dtype],
-            "config": {"workload": f"BASELINE configs[1]: {args.arch}+FPN {args.size}x{args.size}, batch {B} per GPU, "
-                                   f"81 classes, pre_nms 6000, max_proposals 1000, max_detections 100; "
+            "config": {"workload": (f"BASELINE configs[1]: " if (args.arch, args.size, args.num_classes, args.pre_nms, B) == ("resnet101", 1024, 81, 6000, 8) else "")
+                                   + f"{args.arch}+FPN {args.size}x{args.size}, batch {B} per GPU, "
+                                   f"{args.num_classes} classes, pre_nms {args.pre_nms}, max_proposals 1000, max_detections 100; "
                                    f"synthetic seeded weights (forced full load)",
                        "global_batch": n_gpus * B, "parallelism": f"dp{n_gpus}" if n_gpus > 1 else "single",
                        "proposals_kept_image0": n_prop, "detections_image0": n_det},

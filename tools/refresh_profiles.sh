@@ -46,6 +46,12 @@ timeout 200 python tools/pp_ablate.py 0 > $OUT/${RND}_pp_ablate_f16.txt 2>/dev/n
 timeout 200 python tools/pp_ktfit.py 512 > $OUT/${RND}_pp_ktfit_f16.txt 2>/dev/null
 [ -x tools/probes/dma_probe ] && timeout 120 ./tools/probes/dma_probe 4096 > $OUT/${RND}_dma_probe.txt 2>&1
 timeout 400 python tools/fp64_trunk_parity.py --out $OUT/${RND}_fp64_trunk_parity.json > $OUT/fp64.log 2>&1
+# per-GPU slices of the other BASELINE configs (configs[2]: ResNet50; configs[3]: fp16; configs[4]: 1536², 2 classes, pre_nms 12000) and the batch sweep
+python bench.py --steps 10 --warmup 3 --arch resnet50 --no-cpu-baseline --no-other-modes > $OUT/${RND}_bench_n1_resnet50.json 2>/dev/null
+python bench.py --steps 10 --warmup 3 --arch resnet50 --dtype f16 --no-cpu-baseline --no-other-modes > $OUT/${RND}_bench_n1_resnet50_f16.json 2>/dev/null
+python bench.py --steps 5 --warmup 2 --size 1536 --num-classes 2 --pre-nms 12000 --no-cpu-baseline --no-other-modes > $OUT/${RND}_bench_n1_config5_1536.json 2>/dev/null
+for b in 1 2 4 16 32; do python bench.py --steps 10 --warmup 3 --batch $b --no-cpu-baseline --no-other-modes --no-kernel-events > $OUT/${RND}_bench_n1_batch$b.json 2>/dev/null; done
+timeout 900 python tools/soak_determinism.py 100 > $OUT/${RND}_soak_determinism.txt 2>&1
 head -5 $OUT/${RND}_kernel_stats_f32x3.csv | cut -c1-160
 cut -c1-300 $OUT/${RND}_bench_n1.json
 cat $OUT/${RND}_pmc_kernels_f32x3.txt
