@@ -205,6 +205,7 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
     const long tapW = a.in_sW * (long)sizeof(T), tapH = a.in_sH * (long)sizeof(T);
     // measurement-only ablations (a.dbg = 0 in production): 1 no s_setprio, 2 no group stagger, 4 no DMA in the main
     // loop, 8 no fragment reads, 16 no MFMAs, 32 epilogue without its stores, 64 no epilogue
+    const bool dbg_cheapsplit = a.dbg & 128;     // split modes: every part = the hi part (same MFMAs, a third of the VALU work)
     const bool dbg_noprio = a.dbg & 1, dbg_nostagger = a.dbg & 2, dbg_nodma = a.dbg & 4, dbg_nords = a.dbg & 8, dbg_nomma = a.dbg & 16;
 
     f32x16 acc[4][2];
@@ -339,11 +340,13 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
             PP_MFMA(fb20, fa2, acc[PH][0]) PP_MFMA(fb21, fa2, acc[PH][1]) PP_MFMA(fb30, fa3, acc[PH][0]) PP_MFMA(fb31, fa3, acc[PH][1]) \
         } else {                                                                                               \
             f16x8 hi, mid, lo;                                                                                 \
-            if constexpr (MODE == 3) split_hi_mid_lo(PP_U4(fa0), PP_U4(fa1), hi, mid, lo); else split_hi_lo(PP_U4(fa0), PP_U4(fa1), hi, lo); \
+            if (dbg_cheapsplit) { split_hi_lo(PP_U4(fa0), PP_U4(fa1), hi, lo); mid = lo = hi; }                \
+            else if constexpr (MODE == 3) split_hi_mid_lo(PP_U4(fa0), PP_U4(fa1), hi, mid, lo); else split_hi_lo(PP_U4(fa0), PP_U4(fa1), hi, lo); \
             PP_MFMA(fb00, hi, acc[PH][0]) PP_MFMA(fb01, hi, acc[PH][1])                                        \
             if constexpr (MODE == 3) { PP_MFMA(fb00, mid, acc[PH][0]) PP_MFMA(fb01, mid, acc[PH][1]) }         \
             PP_MFMA(fb00, lo, acc[PH][0]) PP_MFMA(fb01, lo, acc[PH][1])                                        \
-            if constexpr (MODE == 3) split_hi_mid_lo(PP_U4(fa2), PP_U4(fa3), hi, mid, lo); else split_hi_lo(PP_U4(fa2), PP_U4(fa3), hi, lo); \
+            if (dbg_cheapsplit) { split_hi_lo(PP_U4(fa2), PP_U4(fa3), hi, lo); mid = lo = hi; }                \
+            else if constexpr (MODE == 3) split_hi_mid_lo(PP_U4(fa2), PP_U4(fa3), hi, mid, lo); else split_hi_lo(PP_U4(fa2), PP_U4(fa3), hi, lo); \
             PP_MFMA(fb10, hi, acc[PH][0]) PP_MFMA(fb11, hi, acc[PH][1])                                        \
             if constexpr (MODE == 3) { PP_MFMA(fb10, mid, acc[PH][0]) PP_MFMA(fb11, mid, acc[PH][1]) }         \
             PP_MFMA(fb10, lo, acc[PH][0]) PP_MFMA(fb11, lo, acc[PH][1])                                        \
