@@ -62,7 +62,7 @@ namespace mrcnn {
     ({                                                                                                         \
         const int ih = (int)(short)(ihw[P] & 0xffff) + (KH_), iw = (ihw[P] >> 16) + (KW_);                     \
         const bool ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;                          \
-        ok ? pbase[P] + (KOFF_) : zero;                                                                        \
+        (ok && !dbg_hotsrc) ? pbase[P] + (KOFF_) : zero;                                                       \
     })
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
     const long tapW = a.in_sW * (long)sizeof(T), tapH = a.in_sH * (long)sizeof(T);
     // measurement-only ablations (a.dbg = 0 in production): 1 no s_setprio, 2 no group stagger, 4 no DMA in the main
     // loop, 8 no fragment reads, 16 no MFMAs, 32 epilogue without its stores, 64 no epilogue
-    const bool dbg_cheapsplit = a.dbg & 128;     // split modes: every part = the hi part (same MFMAs, a third of the VALU work)
+    const bool dbg_hotsrc = a.dbg & 256;         // 256: every activation DMA reads the zero page (DMA issue + LDS writes, no L2 traffic)
     const bool dbg_noprio = a.dbg & 1, dbg_nostagger = a.dbg & 2, dbg_nodma = a.dbg & 4, dbg_nords = a.dbg & 8, dbg_nomma = a.dbg & 16;
 
     f32x16 acc[4][2];
@@ -331,6 +331,8 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
     }
 // fp16: 4 K groups × 2 column tiles.  split: 2 K groups × (hi, [mid,] lo) × 2 column tiles, parts in the order of the
 // 128-row kernel (every product tile is added to the same accumulator in the same sequence → identical bits).
+// (Tried and measured worse: converting the slab in the LOAD phase, under the partner's MFMAs — the load phase, already
+// holding the blocking DMA issue, becomes the longer one: 0.87× instead of 0.98× of the 128-row kernel in f32x3.)
 #define PP_MATH(PH)                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
     if (!dbg_noprio) __builtin_amdgcn_s_setprio(1);                                                            \
@@ -340,13 +342,11 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
             PP_MFMA(fb20, fa2, acc[PH][0]) PP_MFMA(fb21, fa2, acc[PH][1]) PP_MFMA(fb30, fa3, acc[PH][0]) PP_MFMA(fb31, fa3, acc[PH][1]) \
         } else {                                                                                               \
             f16x8 hi, mid, lo;                                                                                 \
-            if (dbg_cheapsplit) { split_hi_lo(PP_U4(fa0), PP_U4(fa1), hi, lo); mid = lo = hi; }                \
-            else if constexpr (MODE == 3) split_hi_mid_lo(PP_U4(fa0), PP_U4(fa1), hi, mid, lo); else split_hi_lo(PP_U4(fa0), PP_U4(fa1), hi, lo); \
+            if constexpr (MODE == 3) split_hi_mid_lo(PP_U4(fa0), PP_U4(fa1), hi, mid, lo); else split_hi_lo(PP_U4(fa0), PP_U4(fa1), hi, lo); \
             PP_MFMA(fb00, hi, acc[PH][0]) PP_MFMA(fb01, hi, acc[PH][1])                                        \
             if constexpr (MODE == 3) { PP_MFMA(fb00, mid, acc[PH][0]) PP_MFMA(fb01, mid, acc[PH][1]) }         \
             PP_MFMA(fb00, lo, acc[PH][0]) PP_MFMA(fb01, lo, acc[PH][1])                                        \
-            if (dbg_cheapsplit) { split_hi_lo(PP_U4(fa2), PP_U4(fa3), hi, lo); mid = lo = hi; }                \
-            else if constexpr (MODE == 3) split_hi_mid_lo(PP_U4(fa2), PP_U4(fa3), hi, mid, lo); else split_hi_lo(PP_U4(fa2), PP_U4(fa3), hi, lo); \
+            if constexpr (MODE == 3) split_hi_mid_lo(PP_U4(fa2), PP_U4(fa3), hi, mid, lo); else split_hi_lo(PP_U4(fa2), PP_U4(fa3), hi, lo); \
             PP_MFMA(fb10, hi, acc[PH][0]) PP_MFMA(fb11, hi, acc[PH][1])                                        \
             if constexpr (MODE == 3) { PP_MFMA(fb10, mid, acc[PH][0]) PP_MFMA(fb11, mid, acc[PH][1]) }         \
             PP_MFMA(fb10, lo, acc[PH][0]) PP_MFMA(fb11, lo, acc[PH][1])                                        \

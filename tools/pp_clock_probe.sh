@@ -1,0 +1,17 @@
+#!/bin/bash
+# clock of the ping-pong kernel variants: GRBM_GUI_ACTIVE / 8 / duration
+export TMPDIR=/tmp; R=$(pwd); cd /tmp
+for dbg in ${2:-0 4 8 12 256}; do
+  rm -rf /tmp/p1; MRCNN_PP=1 MRCNN_PP_SPLIT=1 MRCNN_PP_MIN_TILES=1 MRCNN_PP_MIN_FILL=0 MRCNN_PP_DBG=$dbg timeout 120 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/p1 -o p -- python $R/tools/conv_one.py 8 256 256 256 512 3 1 3 $1 > /tmp/p1.log 2>&1
+  DBG=$dbg python - <<'PY'
+import csv,glob,collections,os
+f=glob.glob('/tmp/p1/**/*counter_collection.csv',recursive=True)
+acc=collections.defaultdict(list)
+for r in csv.DictReader(open(f[0])):
+    if 'k_conv' in r['Kernel_Name']: acc[r['Counter_Name']].append(float(r['Counter_Value']))
+kt=glob.glob('/tmp/p1/**/*kernel_trace.csv',recursive=True)
+d=[(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3 for r in csv.DictReader(open(kt[0])) if 'k_conv' in r['Kernel_Name']]
+g=sum(acc['GRBM_GUI_ACTIVE'])/len(acc['GRBM_GUI_ACTIVE']); m=sum(acc['SQ_VALU_MFMA_BUSY_CYCLES'])/len(acc['SQ_VALU_MFMA_BUSY_CYCLES']); us=sum(d)/len(d)
+print(f"dbg={os.environ['DBG']}: {us:8.1f} us  clock {g/8/us/1e3:5.2f} GHz  mfma util {m/(1024*g/8):5.3f}", flush=True)
+PY
+done

@@ -27,10 +27,25 @@ __global__ __launch_bounds__(512) void k_probe(const char* src, size_t window, i
     size_t pos = (size_t)wave * 8 * row_stride;
     const size_t step = pattern == 2 ? 1024 : (size_t)8 * row_stride * 8;   // next 8 rows of this wave (8 waves interleaved)
     uint4 acc = make_uint4(0, 0, 0, 0);
+    typedef unsigned srd_t __attribute__((ext_vector_type(4)));
+    const unsigned long long b64 = (unsigned long long)base;
+    srd_t srd;
+    srd[0] = __builtin_amdgcn_readfirstlane((unsigned)b64);
+    srd[1] = __builtin_amdgcn_readfirstlane((unsigned)(b64 >> 32) & 0xffffu);      // stride 0
+    srd[2] = 0xffffffffu;                                                           // num_records (bytes)
+    srd[3] = 0x00020000u;                                                           // raw buffer, dword data format (gfx9 SRD word 3)
     for (int i = 0; i < iters; ++i) {
         const char* p = base + (pos % window) + off;
         if (MODE == 0) {
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\ts_waitcnt vmcnt(%2)" ::"v"(p), "s"(dst + (i & 15) * 1024), "n"(DEPTH) : "memory", "m0");
+        } else if (MODE == 2) {          // scalar base + 32-bit lane offset
+            const unsigned voff = (unsigned)((pos % window) + off);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_waitcnt vmcnt(%3)" ::"v"(voff), "s"(base), "s"(dst + (i & 15) * 1024), "n"(DEPTH) : "memory", "m0");
+        } else if (MODE == 3) {          // buffer resource + 32-bit lane offset
+            const unsigned voff = (unsigned)((pos % window) + off);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds\n\ts_waitcnt vmcnt(%3)" ::"v"(voff), "s"(srd), "s"(dst + (i & 15) * 1024), "n"(DEPTH) : "memory", "m0");
+        } else if (MODE == 4) {          // dword per lane (256 B per instruction), vaddr form: is the cost per instruction or per byte?
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off\n\ts_waitcnt vmcnt(%2)" ::"v"(p), "s"(dst + (i & 15) * 1024), "n"(DEPTH) : "memory", "m0");
         } else {
             // bursts of 4 loads, waited inside the statement (a destination must not be reused while its load is in flight)
             uint4 v0, v1, v2, v3;
@@ -79,6 +94,9 @@ int main(int argc, char** argv)
             snprintf(nm, sizeof nm, "LDS-DMA depth 16, %s", pn[pattern]); run(nm, k_probe<0, 16>, window, 4608, pattern, 256);
             snprintf(nm, sizeof nm, "to-VGPR depth 8, %s", pn[pattern]); run(nm, k_probe<1, 8>, window, 4608, pattern, 256);
         }
+    run("LDS-DMA saddr+voffset depth 8, swizzled", k_probe<2, 8>, (size_t)64 << 10, 4608, 0, 256);
+    run("LDS-DMA buffer_load offen depth 8, swizzled", k_probe<3, 8>, (size_t)64 << 10, 4608, 0, 256);
+    run("LDS-DMA dword (256 B/instr) vaddr depth 8 [bytes x4 in the rate!]", k_probe<4, 8>, (size_t)64 << 10, 4608, 0, 256);
     run("LDS-DMA depth 8, swizzled, stride 128 (NHWC 64ch)", k_probe<0, 8>, (size_t)2 << 20, 128, 0, 256);
     run("LDS-DMA depth 8, swizzled, stride 512 (NHWC 256ch)", k_probe<0, 8>, (size_t)2 << 20, 512, 0, 256);
     run("LDS-DMA depth 8, swizzled, 1 CU only", k_probe<0, 8>, (size_t)64 << 10, 4608, 0, 1);
