@@ -1,5 +1,7 @@
 #!/bin/bash
-# clock of the ping-pong kernel variants: GRBM_GUI_ACTIVE / 8 / duration
+# Sustained clock and MFMA-busy of the ping-pong kernel and its ablations on the largest layer (RPN 3x3 256->512 at 256², batch 8):
+#   pp_clock_probe.sh <f16|f32s|f32x3> ["<dbg bits> ..."]   dbg: 0 shipped, 4 no DMA in the main loop, 8 no fragment reads, 256 DMA from the zero page
+# clock = GRBM_GUI_ACTIVE / 8 XCDs / duration; util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles)
 export TMPDIR=/tmp; R=$(pwd); cd /tmp
 for dbg in ${2:-0 4 8 12 256}; do
   rm -rf /tmp/p1; MRCNN_PP=1 MRCNN_PP_SPLIT=1 MRCNN_PP_MIN_TILES=1 MRCNN_PP_MIN_FILL=0 MRCNN_PP_DBG=$dbg timeout 120 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/p1 -o p -- python $R/tools/conv_one.py 8 256 256 256 512 3 1 3 $1 > /tmp/p1.log 2>&1

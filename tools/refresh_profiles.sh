@@ -44,7 +44,10 @@ cd $R
 for dt in f16 f32x3; do timeout 300 python tools/conv_ab.py 3 10 1 $dt > $OUT/${RND}_conv_ab_$dt.txt 2>/dev/null; done
 timeout 200 python tools/pp_ablate.py 0 > $OUT/${RND}_pp_ablate_f16.txt 2>/dev/null
 timeout 200 python tools/pp_ktfit.py 512 > $OUT/${RND}_pp_ktfit_f16.txt 2>/dev/null
+[ -x tools/probes/dma_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-inline-asm -o tools/probes/dma_probe tools/probes/dma_probe.hip 2>/dev/null
 [ -x tools/probes/dma_probe ] && timeout 120 ./tools/probes/dma_probe 4096 > $OUT/${RND}_dma_probe.txt 2>&1
+bash tools/pp_clock_probe.sh f16 "0 4 8 12 256" > $OUT/${RND}_pp_clock_f16.txt 2>&1
+bash tools/pp_clock_probe.sh f32x3 "0 4 8 12 256" > $OUT/${RND}_pp_clock_f32x3.txt 2>&1
 timeout 400 python tools/fp64_trunk_parity.py --out $OUT/${RND}_fp64_trunk_parity.json > $OUT/fp64.log 2>&1
 # per-GPU slices of the other BASELINE configs (configs[2]: ResNet50; configs[3]: fp16; configs[4]: 1536², 2 classes, pre_nms 12000) and the batch sweep
 python bench.py --steps 10 --warmup 3 --arch resnet50 --no-cpu-baseline --no-other-modes > $OUT/${RND}_bench_n1_resnet50.json 2>/dev/null
