@@ -363,16 +363,19 @@ def parity_e2e(hip_pred, oracle_pred, n):
     for mode, (hd, hk) in hip_pred.items():
         tot_m = tot_d = same = 0
         identical = presence = 0
-        ds = dm = 0.0
+        ds = dm = dm_behind = 0.0
+        n_behind = 0
         for i in range(n):
             a = ev.detection_agreement(hd[i], od[i], 1e-4, hk[i], ok[i])
             tot_m += a["matched"]; tot_d += max(a["n_a"], a["n_b"]); same += a["same_row"]
             identical += int(a["matched"] == max(a["n_a"], a["n_b"]))
             ds = max(ds, a["max_score_diff"]); dm = max(dm, a["max_mask_diff"]); presence += a["mask_presence_mismatch"]
+            dm_behind = max(dm_behind, a["max_mask_diff_behind_presence_mismatch"]); n_behind += a["masks_behind_presence_mismatch"]
         out["modes"][mode] = {"detections": int(tot_d), "matched": int(tot_m), "fraction": round(tot_m / max(tot_d, 1), 4),
                               "same_rank": int(same), "images_fully_matched": int(identical),
                               "max_score_diff": float(np.float32(ds)), "max_mask_diff": float(np.float32(dm)),
-                              "mask_presence_mismatch": int(presence)}
+                              "mask_presence_mismatch": int(presence), "masks_behind_presence_mismatch": int(n_behind),
+                              "max_mask_diff_behind_presence_mismatch": float(np.float32(dm_behind))}
     return out
 
 

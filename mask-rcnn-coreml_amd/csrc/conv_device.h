@@ -23,7 +23,6 @@ struct ConvArgs {
     int tiles_m, tiles_n;
     int vec_ok;          // epilogue may use vector stores / residual loads
     int out_f32;         // store fp32 even when the activations are fp16 (RPN outputs, class logits, masks)
-    const void* zero_page;   // >= 16 B of zeros in HBM: source of out-of-image taps for the DMA variant
     int* range_flag;         // optional: set to 1 when an output leaves the fp16 range (|v| >= 65504 or NaN)
     int dbg;                 // ablation switches of the ping-pong kernels (measurement only; 0 in production)
 };

@@ -560,7 +560,6 @@ void Model::load(int kind_, const std::string& path, int max_batch_, int dtype_)
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     own_stream = true;
     if (const char* e = getenv("MRCNN_GRAPH")) use_graph = atoi(e) != 0;
-    conv_one_time_init();
     boxes_one_time_init();
     range_flag.alloc(sizeof(int));
     HIP_CHECK(hipMemset(range_flag.p, 0, sizeof(int)));

@@ -137,8 +137,7 @@ struct ConvProfile {
     ~ConvProfile();
 };
 void conv_set_profiler(ConvProfile* p);   // thread-local; nullptr disables
-// One-time per-process set-up (zero page, dynamic-LDS opt-ins); idempotent, called at model / layer creation.
-void conv_one_time_init();
+// One-time per-process set-up; idempotent, called at model / layer creation.
 void boxes_one_time_init();
 // While set (thread-local), every conv launch ORs 1 into *device_flag when one of its outputs leaves the fp16
 // range (|v| >= 65504, inf or NaN): the watchdog of the fp16-MFMA modes, whose next layer reads it through fp16.

@@ -21,7 +21,7 @@
 //     K step are read once (phase 0) and stay in registers;
 //   * the two wave groups (waves 0-3 / 4-7 = one wave of each per SIMD) run ONE BARRIER APART: while one group issues
 //     the MFMAs of a phase (s_setprio 1), the other issues its LDS fragment reads and its share of the global→LDS DMA
-//     (global_load_lds_dwordx4, XOR-swizzled source chunks, zero page for padding taps) for a K step 1½–2 steps ahead;
+//     (buffer_load_dwordx4 … lds, XOR-swizzled source chunks, out-of-range offsets = zeros for padding taps) for a K step 1½–2 steps ahead;
 //     vmcnt is COUNTED (one `s_waitcnt vmcnt(4 | 3)` per K step, never 0 in steady state);
 //   * the epilogue goes straight from the accumulators to HBM (transposed result tiles: a lane owns runs of four
 //     consecutive channels of one pixel; fp16: one v_permlane32_swap per 16 B) — no LDS staging, no barrier;
@@ -46,8 +46,12 @@ namespace mrcnn {
 
 #define PP_GLDS_V(SRC, DST)                                                                                    \
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(SRC), "s"(DST) : "memory", "m0");
-#define PP_GLDS_S(VOFF, SBASE, DST)                                                                            \
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(VOFF), "s"(SBASE), "s"(DST) : "memory", "m0");
+// buffer form: 128-bit resource (scalar) + 32-bit lane offset + scalar offset; lanes whose offset lies beyond the resource's
+// num_records deposit ZEROS in LDS (hardware range check) — padding taps and rows beyond M need no zero page
+#define PP_BLDS(VOFF, SRD, SOFF, DST)                                                                          \
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(VOFF), "s"(SRD), "s"(SOFF), "s"(DST) : "memory", "m0");
+#define PP_BLDS0(VOFF, SRD, DST)                                                                               \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(VOFF), "s"(SRD), "s"(DST) : "memory", "m0");
 #define PP_DSR(DSTV, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DSTV) : "v"(ADDR), "n"(OFF));
 #define PP_BARRIER asm volatile("s_barrier" ::: "memory");
 #define PP_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -55,14 +59,15 @@ namespace mrcnn {
 #define PP_U4(X_) __builtin_bit_cast(uint4, X_)
 
 // Source of one staged activation row P for the tap (KH_, KW_) and byte offset KOFF_ (tap + channel step, wave-uniform):
-// the row's pixel run, or the zero page when the tap falls outside the image (zero padding) / the row is beyond M.
-// Rebuilt at every issue from 3 registers per row (64-bit pixel base, packed 16-bit (ih0, iw0)): ~10 VALU in a load
-// phase instead of 7 live registers per row — the kernel's budget is 256 registers with a 128-register accumulator.
-#define PP_SRC_A(P, KH_, KW_, KOFF_)                                                                           \
+// the 32-bit byte offset of the row's pixel run in the activation resource, or an offset beyond it (→ zeros) when the tap
+// falls outside the image (zero padding) / the row is beyond M.  Rebuilt at every issue from 2 registers per row (offset
+// of tap (0, 0), packed 16-bit (ih0, iw0)): a handful of VALU in a load phase instead of live registers per row — the
+// kernel's budget is 256 registers with a 128-register accumulator.
+#define PP_OFF_A(P, KH_, KW_, KOFF_)                                                                           \
     ({                                                                                                         \
         const int ih = (int)(short)(ihw[P] & 0xffff) + (KH_), iw = (ihw[P] >> 16) + (KW_);                     \
         const bool ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;                          \
-        (ok && !dbg_hotsrc) ? pbase[P] + (KOFF_) : zero;                                                       \
+        ok ? (dbg_hotsrc ? (unsigned)(kq * 16) : obase[P] + (unsigned)(KOFF_)) : OOB;                          \
     })
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -76,7 +81,7 @@ namespace mrcnn {
 // 128-B lines (its 64 channels of a pixel) in four back-to-back stores.
 // ----------------------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ bool pp_store_tile(const ConvArgs& a, f32x16 (&acc)[4][2], int m0, int n0, int wrow, int wcol, int lane)
+__device__ __forceinline__ bool pp_store_tile(const ConvArgs& a, f32x16 (&acc)[4][2], const float* tab, int m0, int n0, int wrow, int wcol, int lane)
 {
     const int l31 = lane & 31, kk = lane >> 5;
     const int ohw = a.OH * a.OW;
@@ -111,9 +116,14 @@ __device__ __forceinline__ bool pp_store_tile(const ConvArgs& a, f32x16 (&acc)[4
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int ca = nb + 16 * p + 4 * kk, cb = ca + 8;
+                // scale / shift come from the tile's LDS table (DMA'd at the start of the tile): fetched from global memory
+                // here, every fetch would queue behind the previous iteration's stores (`out` may alias them as far as the
+                // compiler knows; loads and stores share vmcnt) — 16 serialized store-acknowledge + load round trips per
+                // tile, measured as 110 of the 300 us fixed cost of the RPN 3x3 layer
+                const int cl = wcol * 64 + j * 32 + 16 * p + 4 * kk;
                 float4 sa = make_float4(1.f, 1.f, 1.f, 1.f), sb_ = sa, ha = make_float4(0.f, 0.f, 0.f, 0.f), hb = ha;
-                if (a.scale) { sa = *reinterpret_cast<const float4*>(a.scale + ca); sb_ = *reinterpret_cast<const float4*>(a.scale + cb); }
-                if (a.shift) { ha = *reinterpret_cast<const float4*>(a.shift + ca); hb = *reinterpret_cast<const float4*>(a.shift + cb); }
+                if (a.scale) { sa = *reinterpret_cast<const float4*>(tab + cl); sb_ = *reinterpret_cast<const float4*>(tab + cl + 8); }
+                if (a.shift) { ha = *reinterpret_cast<const float4*>(tab + 256 + cl); hb = *reinterpret_cast<const float4*>(tab + 256 + cl + 8); }
                 float4 va = make_float4(acc[i][j][8 * p + 0], acc[i][j][8 * p + 1], acc[i][j][8 * p + 2], acc[i][j][8 * p + 3]);
                 float4 vb = make_float4(acc[i][j][8 * p + 4], acc[i][j][8 * p + 5], acc[i][j][8 * p + 6], acc[i][j][8 * p + 7]);
                 va.x = va.x * sa.x + ha.x; va.y = va.y * sa.y + ha.y; va.z = va.z * sa.z + ha.z; va.w = va.w * sa.w + ha.w;
@@ -168,14 +178,30 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
     constexpr int STEADY = SPLIT ? 3 : 4;                         // DMAs younger than K step kt+1 at the end of step kt
     constexpr int TILE_STORES = SPLIT ? 32 : 16;                  // 16-B store instructions of pp_store_tile per wave on an interior tile
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_STAGE + B_STAGE)];     // 128 KB (fp16) / 96 KB (split)
+    __shared__ __attribute__((aligned(16))) float s_tab[2][2][BN];      // scale | shift of this tile's and the previous tile's columns
     const char* const in = static_cast<const char*>(a.in);
     const TW* const wgt = static_cast<const TW*>(a.wgt);
-    const char* const zero = static_cast<const char*>(a.zero_page);
+    // The DMAs address both operands through buffer resources (raw, stride 0): 32-bit lane offsets, and a lane whose offset
+    // lies beyond the resource deposits zeros in LDS (no zero page, no memory access for padding taps).  Measured against
+    // 64-bit lane addresses (global_load_lds) in this kernel: +5…8 % on the large fp16 layers (profiles/r02_conv_ab_dmaform.txt).
+    // The activation resource is re-based at every tile on the first image the tile touches: offsets stay small whatever the batch.
+    constexpr unsigned OOB = 0xffffff00u;
+    typedef unsigned srd_t __attribute__((ext_vector_type(4)));
+    srd_t srdA, srdB;
+    {
+        const unsigned long long wa = (unsigned long long)(uintptr_t)wgt;
+        srdB[0] = __builtin_amdgcn_readfirstlane((unsigned)wa);
+        srdB[1] = __builtin_amdgcn_readfirstlane((unsigned)(wa >> 32) & 0xffffu);
+        srdB[2] = 0xffffffffu;
+        srdB[3] = 0x00020000u;
+        srdA[3] = 0x00020000u;
+    }
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wave >> 2, wc = wave & 3;                  // wave row (= ping-pong group) / wave column
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
+    const unsigned tab0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&s_tab[0][0][0]);
 
     // ---- loop-invariant lane geometry -------------------------------------------------------------------------------
     // staging: slab p (0..3) of the A tile = rows {wr·128 + p·32 + 0..31 : wr = 0, 1}; one DMA per thread and slab: wave w
@@ -202,10 +228,10 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
     const int ohw = a.OH * a.OW;
     const int cin_tiles = a.Cin / BK;
     const int KT = a.KH * a.KW * cin_tiles;
-    const long tapW = a.in_sW * (long)sizeof(T), tapH = a.in_sH * (long)sizeof(T);
+    const unsigned tapW = (unsigned)(a.in_sW * (long)sizeof(T)), tapH = (unsigned)(a.in_sH * (long)sizeof(T));
     // measurement-only ablations (a.dbg = 0 in production): 1 no s_setprio, 2 no group stagger, 4 no DMA in the main
     // loop, 8 no fragment reads, 16 no MFMAs, 32 epilogue without its stores, 64 no epilogue
-    const bool dbg_hotsrc = a.dbg & 256;         // 256: every activation DMA reads the zero page (DMA issue + LDS writes, no L2 traffic)
+    const bool dbg_hotsrc = a.dbg & 256;         // 256: every activation DMA reads the first bytes of the tensor (DMA issue + LDS writes, L1-hot source)
     const bool dbg_noprio = a.dbg & 1, dbg_nostagger = a.dbg & 2, dbg_nodma = a.dbg & 4, dbg_nords = a.dbg & 8, dbg_nomma = a.dbg & 16;
 
     f32x16 acc[4][2];
@@ -224,13 +250,27 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
     const int q8 = nblocks >> 3, r8 = nblocks & 7;
     int pm0 = 0, pn0 = 0;
     bool have_prev = false, range_trip = false;
+    int tb = 0;                  // table buffer of the tile being computed (the previous tile's epilogue reads tb ^ 1)
     for (int v = blockIdx.x; v < nblocks; v += gridDim.x) {
         const int xcd = v & 7, local = v >> 3;
         const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
         const int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
         const int m0 = mt * BM, n0 = nt * BN;
 
-        const char* pbase[4];    // pixel of tap (0, 0), channel chunk kq, of the row this thread stages in slab p
+        // scale / shift of the tile's 256 columns → LDS (one 1-KB DMA each, waves 0 and 1): the oldest vector-memory
+        // operations of the tile, so every counted wait below covers them; read by the epilogue one tile later, behind
+        // this tile's barriers.  Two buffers: a slower wave may still be in the previous tile's epilogue.
+        if (wave == 0 && a.scale) { const char* src_ = reinterpret_cast<const char*>(a.scale + n0) + lane * 16; PP_GLDS_V(src_, tab0 + tb * 2048); }
+        if (wave == 1 && a.shift) { const char* src_ = reinterpret_cast<const char*>(a.shift + n0) + lane * 16; PP_GLDS_V(src_, tab0 + tb * 2048 + 1024); }
+        const int b0 = m0 / ohw;
+        {
+            const unsigned long long ia = (unsigned long long)(uintptr_t)(in + (long)b0 * a.in_sB * (long)sizeof(T));
+            const unsigned long long rest = (unsigned long long)(a.M / ohw - b0) * (unsigned long long)a.in_sB * sizeof(T);
+            srdA[0] = __builtin_amdgcn_readfirstlane((unsigned)ia);
+            srdA[1] = __builtin_amdgcn_readfirstlane((unsigned)(ia >> 32) & 0xffffu);
+            srdA[2] = __builtin_amdgcn_readfirstlane((unsigned)(rest < OOB ? rest : OOB));
+        }
+        unsigned obase[4];       // byte offset (from the resource base, mod 2^32: it may lie before it) of tap (0, 0), channel chunk kq, of the row this thread stages in slab p
         int ihw[4];              // (ih0 & 0xffff) | (iw0 << 16): input coordinates of tap (0, 0)
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -241,13 +281,12 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
             const int oh = rem / a.OW, ow = rem - oh * a.OW;
             const int ih0 = oh * a.stride - a.padH, iw0 = ow * a.stride - a.padW;
             ihw[p] = ((ok ? ih0 : -32768) & 0xffff) | (iw0 << 16);      // a row beyond M never passes the bounds test
-            pbase[p] = in + ((long)b * a.in_sB + (long)ih0 * a.in_sH + (long)iw0 * a.in_sW) * (long)sizeof(T) + kq * 16;
+            obase[p] = (unsigned)(((long)(b - b0) * a.in_sB + (long)ih0 * a.in_sH + (long)iw0 * a.in_sW) * (long)sizeof(T) + kq * 16);
         }
         // two issue streams (wave-uniform scalar state): slabs 0, 1 (+ their filter pieces) run one K step ahead of slabs 2, 3
         int ct01 = 0, kh01 = 0, kw01 = 0, ct23 = 0, kh23 = 0, kw23 = 0;
-        long ko01 = 0, ko23 = 0;                   // byte offset of the stream's current K step from the tap-(0,0) pixel
-        const TW* sb01 = wgt + (size_t)n0 * a.Ktot;
-        const TW* sb23 = sb01;
+        unsigned ko01 = 0, ko23 = 0;               // byte offset of the stream's current K step from the tap-(0,0) pixel
+        unsigned so01 = (unsigned)((size_t)n0 * a.Ktot * sizeof(TW)), so23 = so01;      // byte offset of the stream's K step in the filter
 #define PP_ADV(CT_, KH_, KW_, KO_)                                                                             \
     {                                                                                                          \
         KO_ += ROWB;                                                                                           \
@@ -257,17 +296,17 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
             KO_ = KH_ * tapH + KW_ * tapW;                                                                     \
         }                                                                                                      \
     }
-#define PP_ISSUE_A01(P, BUF) { const char* src_ = PP_SRC_A(P, kh01, kw01, ko01); PP_GLDS_V(src_, dA + (BUF) * A_STAGE + (P) * 4096); }
-#define PP_ISSUE_A23(P, BUF) { const char* src_ = PP_SRC_A(P, kh23, kw23, ko23); PP_GLDS_V(src_, dA + (BUF) * A_STAGE + (P) * 4096); }
-#define PP_ISSUE_B01(P, BUF) PP_GLDS_S(vb + (P) * bstr, sb01, dB + (BUF) * B_STAGE + (P) * 8192);
-#define PP_ISSUE_B23(P, BUF) PP_GLDS_S(vb + (P) * bstr, sb23, dB + (BUF) * B_STAGE + (P) * 8192);
+#define PP_ISSUE_A01(P, BUF_) { const unsigned off_ = PP_OFF_A(P, kh01, kw01, ko01); PP_BLDS0(off_, srdA, dA + (BUF_) * A_STAGE + (P) * 4096) }
+#define PP_ISSUE_A23(P, BUF_) { const unsigned off_ = PP_OFF_A(P, kh23, kw23, ko23); PP_BLDS0(off_, srdA, dA + (BUF_) * A_STAGE + (P) * 4096) }
+#define PP_ISSUE_B01(P, BUF_) PP_BLDS(vb + (P) * bstr, srdB, so01, dB + (BUF_) * B_STAGE + (P) * 8192)
+#define PP_ISSUE_B23(P, BUF_) PP_BLDS(vb + (P) * bstr, srdB, so23, dB + (BUF_) * B_STAGE + (P) * 8192)
         // the DMA of the four load phases: stream 23 → K step kt+1 (other buffer), stream 01 → K step kt+2 (this buffer)
 #define PP_L0_ISSUE(BUFN) { PP_ISSUE_A23(2, BUFN) if constexpr (!SPLIT) PP_ISSUE_B23(2, BUFN) }
 #define PP_L1_ISSUE(BUFN)                                                                                      \
     {                                                                                                          \
         PP_ISSUE_A23(3, BUFN)                                                                                  \
         if constexpr (!SPLIT) { PP_ISSUE_B23(3, BUFN) } else { PP_ISSUE_B23(1, BUFN) }                         \
-        sb23 += BK;                                                                                            \
+        so23 += BK * sizeof(TW);                                                                               \
         PP_ADV(ct23, kh23, kw23, ko23)                                                                         \
     }
 #define PP_L2_ISSUE(BUF_) { PP_ISSUE_A01(0, BUF_) if constexpr (!SPLIT) PP_ISSUE_B01(0, BUF_) }
@@ -275,7 +314,7 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
     {                                                                                                          \
         PP_ISSUE_A01(1, BUF_)                                                                                  \
         if constexpr (!SPLIT) { PP_ISSUE_B01(1, BUF_) } else { PP_ISSUE_B01(0, BUF_) }                         \
-        sb01 += BK;                                                                                            \
+        so01 += BK * sizeof(TW);                                                                               \
         PP_ADV(ct01, kh01, kw01, ko01)                                                                         \
     }
 
@@ -285,7 +324,7 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
         if (KT > 1) { PP_L2_ISSUE(1) PP_L3_ISSUE(1) }
         // ---- epilogue of the PREVIOUS tile under the flight of those DMAs (registers → HBM, no LDS)
         if (have_prev) {
-            if (!(a.dbg & 64)) range_trip |= pp_store_tile<T>(a, acc, pm0, pn0, wr, wc, lane);
+            if (!(a.dbg & 64)) range_trip |= pp_store_tile<T>(a, acc, &s_tab[tb ^ 1][0][0], pm0, pn0, wr, wc, lane);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -386,9 +425,9 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
             if (kt + 1 < KT) PP_KSTEP(kt + 1, 1)
         }
         if (wr == 0 && !dbg_nostagger) PP_BARRIER          // re-join: every wave's last fragment read has retired behind this rendezvous
-        pm0 = m0; pn0 = n0; have_prev = true;
+        pm0 = m0; pn0 = n0; have_prev = true; tb ^= 1;
     }
-    if (have_prev && !(a.dbg & 64)) range_trip |= pp_store_tile<T>(a, acc, pm0, pn0, wr, wc, lane);
+    if (have_prev && !(a.dbg & 64)) range_trip |= pp_store_tile<T>(a, acc, &s_tab[tb ^ 1][0][0], pm0, pn0, wr, wc, lane);
     if (a.range_flag && range_trip) atomicOr(a.range_flag, 1);
 #undef PP_KSTEP
 #undef PP_MATH

@@ -62,13 +62,15 @@ def detection_agreement(det_a: np.ndarray, det_b: np.ndarray, box_tol: float = 1
     the matched fraction over max(nA, nB), the largest score difference over matched pairs and — when the 28×28
     masks are given — the largest mask difference over matched pairs whose mask is present on both sides, plus the
     number of pairs where the mask layer's removeZeros rule (a pooled row with an exactly-zero sample is skipped,
-    TimeDistributedMaskLayer.swift:52) emptied the mask on one side only."""
+    TimeDistributedMaskLayer.swift:52) emptied the mask on one side only; pairs behind the first such row are reported
+    separately (`*_behind_presence_mismatch`)."""
     a = np.asarray(det_a, dtype=np.float32)
     b = np.asarray(det_b, dtype=np.float32)
     ia = np.flatnonzero(a[:, 5] > 0)
     ib = np.flatnonzero(b[:, 5] > 0)
     used = np.zeros(len(ib), dtype=bool)
-    matched, same_row, dscore, dmask, presence = 0, 0, 0.0, 0.0, 0
+    matched, same_row, dscore, presence = 0, 0, 0.0, 0
+    pairs = []                       # (row in A, row in B, mask difference or None when the mask is present on one side only)
     for i in ia:
         ok = (~used) & (b[ib, 4] == a[i, 4]) & (np.abs(b[ib, :4] - a[i, :4]).max(axis=1) <= box_tol)
         js = np.flatnonzero(ok)
@@ -83,12 +85,20 @@ def detection_agreement(det_a: np.ndarray, det_b: np.ndarray, box_tol: float = 1
             ma, mb = np.asarray(masks_a[i], np.float32), np.asarray(masks_b[ib[j]], np.float32)
             if (ma == 0).all() != (mb == 0).all():
                 presence += 1            # the reference's removeZeros rule dropped the mask on one side only (an exact-zero sample)
+                pairs.append((int(i), int(ib[j]), None))
             else:
-                dmask = max(dmask, float(np.abs(ma - mb).max()))
+                pairs.append((int(i), int(ib[j]), float(np.abs(ma - mb).max())))
+    # A row dropped by removeZeros on ONE side shifts the class lookup of every later row of that side (the mask layer
+    # indexes `detections` with the compact index, TimeDistributedMaskLayer.swift:71): rows behind the first such row are
+    # compared separately — their masks belong to different classes by the reference's own rule.
+    cliff = min([min(i, j) for i, j, d in pairs if d is None], default=None)
+    before = [d for i, j, d in pairs if d is not None and (cliff is None or max(i, j) < cliff)]
+    after = [d for i, j, d in pairs if d is not None and not (cliff is None or max(i, j) < cliff)]
     denom = max(len(ia), len(ib))
     return {"n_a": int(len(ia)), "n_b": int(len(ib)), "matched": int(matched), "same_row": int(same_row),
-            "fraction": (matched / denom) if denom else 1.0, "max_score_diff": dscore, "max_mask_diff": dmask,
-            "mask_presence_mismatch": int(presence)}
+            "fraction": (matched / denom) if denom else 1.0, "max_score_diff": dscore,
+            "max_mask_diff": max(before, default=0.0), "mask_presence_mismatch": int(presence),
+            "max_mask_diff_behind_presence_mismatch": max(after, default=0.0), "masks_behind_presence_mismatch": len(after)}
 
 
 def evaluate(model: MaskRCNN, images: Iterable[Tuple[int, np.ndarray]], dataset_id: str = "coco",

@@ -310,6 +310,27 @@ def test_detection_agreement_counts(pkg):
     assert ev.detection_agreement(np.zeros((4, 6)), np.zeros((4, 6)))["fraction"] == 1.0
 
 
+def test_detection_agreement_separates_masks_behind_a_dropped_row(pkg):
+    """A mask emptied by removeZeros on one side only is counted, and the pairs behind it (whose class lookup the reference's
+    compact index shifts, TimeDistributedMaskLayer.swift:71) do not enter `max_mask_diff`."""
+    ev = __import__("importlib").import_module("mask-rcnn-coreml_amd.evaluate")
+    a = np.zeros((5, 6), np.float32)
+    for i in range(4):
+        a[i] = [0.1 * i, 0.1 * i, 0.1 * i + 0.3, 0.1 * i + 0.3, 1 + i, 0.99 - 0.01 * i]
+    ma = np.full((5, 4, 4), 0.5, np.float32)
+    ma[4] = 0
+    mb = ma.copy()
+    mb[0] += 1e-5
+    r = ev.detection_agreement(a, a.copy(), 1e-4, ma, mb)
+    assert r["mask_presence_mismatch"] == 0 and abs(r["max_mask_diff"] - 1e-5) < 1e-7 and r["masks_behind_presence_mismatch"] == 0
+    mb[1] = 0                                      # dropped on side B only
+    mb[2] = 0.9                                    # ... so the rows behind it carry another class's mask
+    r = ev.detection_agreement(a, a.copy(), 1e-4, ma, mb)
+    assert r["mask_presence_mismatch"] == 1 and r["matched"] == 4
+    assert abs(r["max_mask_diff"] - 1e-5) < 1e-7
+    assert r["masks_behind_presence_mismatch"] == 2 and abs(r["max_mask_diff_behind_presence_mismatch"] - 0.4) < 1e-6
+
+
 def test_bench_host_core_count():
     import bench
     physical, logical = bench.host_cores()

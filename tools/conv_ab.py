@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """A/B of the fp16 conv kernels on the trunk's big layer shapes: the 128-row kernel vs the 256-row ping-pong kernel,
-interleaved rounds in one process (cdna guide §5.4 rule 24).  usage: conv_ab.py [rounds] [iters]"""
+interleaved rounds in one process (cdna guide §5.4 rule 24).  usage: conv_ab.py [rounds] [iters] [min_tiles] [dtype] [pp_dbg]
+(pp_dbg: a third column with the ping-pong kernel under that conv_pp_dbg value, e.g. 512 = the other DMA addressing form)"""
 import ctypes as C
 import importlib
 import os
@@ -26,10 +27,12 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 min_tiles = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 DT = {"f16": L.F16, "f32s": L.F32S, "f32x3": L.F32X3}[sys.argv[4] if len(sys.argv) > 4 else "f16"]
+alt_dbg = int(sys.argv[5]) if len(sys.argv) > 5 else None
 
 
-def run(shape, pp):
+def run(shape, pp, dbg=0):
     L.check(lib.mrcnn_debug_set(b"conv_pp", pp))
+    L.check(lib.mrcnn_debug_set(b"conv_pp_dbg", dbg))
     L.check(lib.mrcnn_debug_set(b"conv_pp_min_tiles", min_tiles))
     L.check(lib.mrcnn_debug_set(b"conv_pp_min_fill", 0))
     L.check(lib.mrcnn_debug_set(b"conv_pp_min_kt", 1))
@@ -40,9 +43,15 @@ def run(shape, pp):
 
 
 for sh in SHAPES:
-    res = {0: [], 1: []}
+    res = {0: [], 1: [], 2: []}
     for r in range(rounds):
         for pp in (0, 1):
             res[pp].append(run(sh, pp))
+        if alt_dbg is not None:
+            res[2].append(run(sh, 1, alt_dbg))
     b0 = min(res[0]); b1 = min(res[1])
-    print(f"{sh[0]:30s} 128-row {b0[0]:8.1f} us {b0[1]:7.1f} TF | ping-pong {b1[0]:8.1f} us {b1[1]:7.1f} TF | x{b0[0] / b1[0]:.2f}", flush=True)
+    alt = ""
+    if alt_dbg is not None:
+        b2 = min(res[2])
+        alt = f" | dbg {alt_dbg} {b2[0]:8.1f} us {b2[1]:7.1f} TF x{b0[0] / b2[0]:.2f}"
+    print(f"{sh[0]:30s} 128-row {b0[0]:8.1f} us {b0[1]:7.1f} TF | ping-pong {b1[0]:8.1f} us {b1[1]:7.1f} TF | x{b0[0] / b1[0]:.2f}{alt}", flush=True)
