@@ -48,12 +48,16 @@ timeout 200 python tools/pp_ktfit.py 512 > $OUT/${RND}_pp_ktfit_f16.txt 2>/dev/n
 [ -x tools/probes/dma_probe ] && timeout 120 ./tools/probes/dma_probe 4096 > $OUT/${RND}_dma_probe.txt 2>&1
 bash tools/pp_clock_probe.sh f16 "0 4 8 12 256" > $OUT/${RND}_pp_clock_f16.txt 2>&1
 bash tools/pp_clock_probe.sh f32x3 "0 4 8 12 256" > $OUT/${RND}_pp_clock_f32x3.txt 2>&1
+timeout 200 bash tools/power_probe.sh > $OUT/${RND}_power_probe.txt 2>&1
+timeout 200 bash tools/mfma_power.sh > $OUT/${RND}_mfma_power.txt 2>&1
 timeout 400 python tools/fp64_trunk_parity.py --out $OUT/${RND}_fp64_trunk_parity.json > $OUT/fp64.log 2>&1
 # per-GPU slices of the other BASELINE configs (configs[2]: ResNet50; configs[3]: fp16; configs[4]: 1536², 2 classes, pre_nms 12000) and the batch sweep
 python bench.py --steps 10 --warmup 3 --arch resnet50 --no-cpu-baseline --no-other-modes > $OUT/${RND}_bench_n1_resnet50.json 2>/dev/null
 python bench.py --steps 10 --warmup 3 --arch resnet50 --dtype f16 --no-cpu-baseline --no-other-modes > $OUT/${RND}_bench_n1_resnet50_f16.json 2>/dev/null
 python bench.py --steps 5 --warmup 2 --size 1536 --num-classes 2 --pre-nms 12000 --no-cpu-baseline --no-other-modes > $OUT/${RND}_bench_n1_config5_1536.json 2>/dev/null
 for b in 1 2 4 16 32; do python bench.py --steps 10 --warmup 3 --batch $b --no-cpu-baseline --no-other-modes --no-kernel-events > $OUT/${RND}_bench_n1_batch$b.json 2>/dev/null; done
+# 64-image end-to-end agreement with the CPU oracle (about 6 minutes of host time)
+python bench.py --steps 5 --warmup 2 --e2e-images 64 --no-kernel-events 2>/dev/null | python -c "import json,sys; print(json.dumps(json.loads(sys.stdin.read())['parity_e2e'], indent=1))" > $OUT/${RND}_parity_e2e_64.json
 timeout 900 python tools/soak_determinism.py 100 > $OUT/${RND}_soak_determinism.txt 2>&1
 head -5 $OUT/${RND}_kernel_stats_f32x3.csv | cut -c1-160
 cut -c1-300 $OUT/${RND}_bench_n1.json
