@@ -164,7 +164,7 @@ __device__ __forceinline__ bool pp_store_tile(const ConvArgs& a, f32x16 (&acc)[4
 }
 
 // ================================================================================================================
-template <int MODE, bool PRE = false>
+template <int MODE>
 __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
 {
     constexpr bool SPLIT = MODE != 0;
@@ -243,7 +243,6 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
     f16x8 fa0, fa1, fa2, fa3;                                      // activation fragments of the current phase (16 B each)
     f16x8 fb00, fb01, fb10, fb11, fb20, fb21, fb30, fb31;          // filter fragments of the current K step (K group, column tile)
-    f16x8 ph_hi, ph_mid, ph_lo;                                    // PRE: the parts of the phase's first K group, split in the load segment
 
     // ---- persistent walk over the tiles: virtual block v = blockIdx.x + step·gridDim.x through the XCD-aware bijective
     //      map (the N tiles of one M tile adjacent, contiguous runs per XCD; gridDim.x is a multiple of 8 or = #tiles)
@@ -372,7 +371,9 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
 // fp16: 4 K groups × 2 column tiles.  split: 2 K groups × (hi, [mid,] lo) × 2 column tiles, parts in the order of the
 // 128-row kernel (every product tile is added to the same accumulator in the same sequence → identical bits).
 // (Tried and measured worse: converting the slab in the LOAD phase, under the partner's MFMAs — the load phase, already
-// holding the blocking DMA issue, becomes the longer one: 0.87× instead of 0.98× of the 128-row kernel in f32x3.)
+// holding the blocking DMA issue, becomes the longer one: 0.87× instead of 0.98× of the 128-row kernel in f32x3.
+// Tried and measured neutral: only the FIRST K group's split moved into the load segment, so that the math segment
+// opens with MFMAs — 3 262 vs 3 278 µs: the split kernels run at the board's power cap)
 #define PP_MATH(PH)                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
     if (!dbg_noprio) __builtin_amdgcn_s_setprio(1);                                                            \
@@ -382,8 +383,7 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
             PP_MFMA(fb20, fa2, acc[PH][0]) PP_MFMA(fb21, fa2, acc[PH][1]) PP_MFMA(fb30, fa3, acc[PH][0]) PP_MFMA(fb31, fa3, acc[PH][1]) \
         } else {                                                                                               \
             f16x8 hi, mid, lo;                                                                                 \
-            if constexpr (PRE) { hi = ph_hi; mid = ph_mid; lo = ph_lo; }                                       \
-            else if constexpr (MODE == 3) split_hi_mid_lo(PP_U4(fa0), PP_U4(fa1), hi, mid, lo); else split_hi_lo(PP_U4(fa0), PP_U4(fa1), hi, lo); \
+            if constexpr (MODE == 3) split_hi_mid_lo(PP_U4(fa0), PP_U4(fa1), hi, mid, lo); else split_hi_lo(PP_U4(fa0), PP_U4(fa1), hi, lo); \
             PP_MFMA(fb00, hi, acc[PH][0]) PP_MFMA(fb01, hi, acc[PH][1])                                        \
             if constexpr (MODE == 3) { PP_MFMA(fb00, mid, acc[PH][0]) PP_MFMA(fb01, mid, acc[PH][1]) }         \
             PP_MFMA(fb00, lo, acc[PH][0]) PP_MFMA(fb01, lo, acc[PH][1])                                        \
@@ -396,15 +396,6 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
     __builtin_amdgcn_s_setprio(0);                                                                             \
     __builtin_amdgcn_sched_barrier(0);
 
-        // PRE (split modes): the fragment wait and the split of the phase's FIRST K group move into the load segment, behind the
-        // DMA issue — the math segment then opens with MFMAs instead of 28 VALU (a segment's head is where VALU is most
-        // expensive, MI355X_MICROARCH "start-of-segment VALU penalty"); the second K group is split under the first one's MFMAs.
-#define PP_PRESPLIT(WAIT_)                                                                                     \
-    if constexpr (SPLIT && PRE) {                                                                              \
-        WAIT_                                                                                                  \
-        if constexpr (MODE == 3) split_hi_mid_lo(PP_U4(fa0), PP_U4(fa1), ph_hi, ph_mid, ph_lo); else split_hi_lo(PP_U4(fa0), PP_U4(fa1), ph_hi, ph_lo); \
-        __builtin_amdgcn_sched_barrier(0);          /* the split stays on this side of the rendezvous */           \
-    }
         // One K step on buffer BUF (compile-time): four L/M phase pairs.  has1 / has2: K steps kt+1 / kt+2 exist.
 #define PP_KSTEP(KTV, BUF)                                                                                     \
     {                                                                                                          \
@@ -412,17 +403,14 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
         /* phase 0: slab 0 + the whole filter tile; DMA: slab 2 (+ filter piece) of step kt+1 */               \
         if (!dbg_nords) { PP_RD_A(0, BUF) PP_RD_B(BUF) }                                                       \
         if (has1) PP_L0_ISSUE((BUF) ^ 1)                                                                       \
-        PP_PRESPLIT(PP_WAIT_AB)                                                                                \
         PP_BARRIER PP_WAIT_AB PP_MATH(0) PP_BARRIER                                                            \
         /* phase 1: DMA: slab 3 (+ filter piece) of step kt+1 */                                               \
         if (!dbg_nords) { PP_RD_A(1, BUF) }                                                                    \
         if (has1) PP_L1_ISSUE((BUF) ^ 1)                                                                       \
-        PP_PRESPLIT(PP_WAIT_A)                                                                                 \
         PP_BARRIER PP_WAIT_A PP_MATH(1) PP_BARRIER                                                             \
         /* phase 2: DMA: slab 0 (+ filter piece) of step kt+2, over this step's own buffer */                  \
         if (!dbg_nords) { PP_RD_A(2, BUF) }                                                                    \
         if (has2) PP_L2_ISSUE(BUF)                                                                             \
-        PP_PRESPLIT(PP_WAIT_A)                                                                                 \
         PP_BARRIER PP_WAIT_A PP_MATH(2) PP_BARRIER                                                             \
         /* phase 3: DMA: slab 1 (+ filter piece) of step kt+2; then step kt+1 must have landed (STEADY younger DMAs stay in flight) */ \
         if (!dbg_nords) { PP_RD_A(3, BUF) }                                                                    \
@@ -432,7 +420,6 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
         } else {                                                                                               \
             PP_VMCNT(0)                                                                                        \
         }                                                                                                      \
-        PP_PRESPLIT(PP_WAIT_A)                                                                                 \
         PP_BARRIER PP_WAIT_A PP_MATH(3) PP_BARRIER                                                             \
     }
         for (int kt = 0; kt < KT; kt += 2) {
@@ -445,7 +432,6 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a)
     if (have_prev && !(a.dbg & 64)) range_trip |= pp_store_tile<T>(a, acc, &s_tab[tb ^ 1][0][0], pm0, pn0, wr, wc, lane);
     if (a.range_flag && range_trip) atomicOr(a.range_flag, 1);
 #undef PP_KSTEP
-#undef PP_PRESPLIT
 #undef PP_MATH
 #undef PP_WAIT_AB
 #undef PP_WAIT_A
@@ -477,10 +463,8 @@ void conv_pp_launch(hipStream_t s, const ConvArgs& a, int mode)
     const int ntiles = a.tiles_m * a.tiles_n;
     const dim3 grid(ntiles < n_cu ? ntiles : n_cu);
     if (mode == 0) hipLaunchKernelGGL(k_conv_pp<0>, grid, dim3(512), 0, s, a);
-    else if (mode == 2 && (a.dbg & 128)) hipLaunchKernelGGL((k_conv_pp<2, true>), grid, dim3(512), 0, s, a);
-    else if (mode == 3 && (a.dbg & 128)) hipLaunchKernelGGL((k_conv_pp<3, true>), grid, dim3(512), 0, s, a);
-    else if (mode == 2) hipLaunchKernelGGL((k_conv_pp<2>), grid, dim3(512), 0, s, a);
-    else if (mode == 3) hipLaunchKernelGGL((k_conv_pp<3>), grid, dim3(512), 0, s, a);
+    else if (mode == 2) hipLaunchKernelGGL(k_conv_pp<2>, grid, dim3(512), 0, s, a);
+    else if (mode == 3) hipLaunchKernelGGL(k_conv_pp<3>, grid, dim3(512), 0, s, a);
     else fail(MRCNN_ERR_UNSUPPORTED, "conv_pp: mode %d", mode);
 }
 
