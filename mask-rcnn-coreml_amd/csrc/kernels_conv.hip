@@ -349,8 +349,9 @@ int conv_n_tile(int Cout)
     return 32;
 }
 
+static int g_tn4 = -1;       // split modes, 128x128 tile as 4 waves of 32x128: -1 by policy (conv_forward), 0 never, 1 always (tests)
 template <typename T, typename TW, int PARTS = 2>
-static void conv_launch(hipStream_t s, const ConvArgs& a, int bn)
+static void conv_launch(hipStream_t s, const ConvArgs& a, int bn, bool wide_waves = false)
 {
     // 8 waves as 4 (M) × 2 (N): 128×128 block tile, 32×64 per wave; narrower N tiles keep 128 rows.
     const dim3 grid(a.tiles_m * a.tiles_n);
@@ -364,17 +365,12 @@ static void conv_launch(hipStream_t s, const ConvArgs& a, int bn)
 #define MRCNN_RING128S 3    /* split mode: a step is 8 MFMAs per wave, two tiles in flight (+2 %) */
 #endif
     constexpr int R128 = (sizeof(T) == 4 && sizeof(TW) == 2) ? MRCNN_RING128S : 2;
-#ifndef MRCNN_SPLIT_WIDE
-#define MRCNN_SPLIT_WIDE 0
-#endif
-#if MRCNN_SPLIT_WIDE
     if constexpr (sizeof(T) == 4 && sizeof(TW) == 2) {
-        // Experiment kept behind a switch (measured neutral): 128×256 block, 32×128 per wave — the
-        // hi/lo conversion of an activation fragment feeds eight MFMAs instead of four, 0.75 LDS reads per MFMA
-        // instead of 1, a third less L2→LDS traffic per flop, but 168 VGPRs = one block per CU.
-        if (bn == 256) { hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 256, 1, 4, 4, 2, 2>), grid, dim3(512), 0, s, a); return; }
+        // Split modes, long K: the same 128x128 tile as 4 waves of 32x128 — one register split of an activation fragment feeds
+        // four column tiles instead of two (half the split VALU and half the activation-fragment LDS reads per MFMA): +2-4 % on
+        // the 3x3 layers, bit-identical (same products, same order per accumulator); short-K layers lose to its 4-wave epilogue.
+        if (bn == 128 && wide_waves) { hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 128, 1, 4, 4, 1, R128, PARTS>), grid, dim3(256), 0, s, a); return; }
     }
-#endif
     if (bn == 128) hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 128, 1, 2, 4, 2, R128, PARTS>), grid, dim3(512), 0, s, a);
     else if (bn == 64) hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 64, 1, 1, 4, 2, MRCNN_RING64, PARTS>), grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 32, 1, 1, 4, 1, MRCNN_RING32, PARTS>), grid, dim3(256), 0, s, a);
@@ -407,6 +403,7 @@ bool conv_debug_set(const char* key, int value)
     else if (k == "conv_pp_dbg") pp_policy().dbg = value;
     else if (k == "conv_pp_min_fill") pp_policy().min_fill_pct = value;
     else if (k == "conv_pp_split") pp_policy().split = value;
+    else if (k == "conv_tn4") g_tn4 = value;
     else return false;
     return true;
 }
@@ -444,7 +441,6 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     MRCNN_REQUIRE(d.Npad % bn_max == 0 && d.Npad >= a.ncols, MRCNN_ERR_SHAPE, "conv: Npad %d incompatible with tile %d", d.Npad, bn_max);
     a.tiles_m = (a.M + BM_DEFAULT - 1) / BM_DEFAULT;
     int bn = bn_max;
-    if (MRCNN_SPLIT_WIDE && split && bn_max == 128 && d.Npad % 256 == 0 && (long)a.tiles_m * (d.Npad / 256) >= 512) bn = 256;
     while (bn > 32 && (long)a.tiles_m * (d.Npad / bn) < 512) bn >>= 1;
     const size_t out_es = a.out_f32 ? 4 : 2;
     auto al = [](const void* p, size_t n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
@@ -468,12 +464,13 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
             pp_bn = 256;                    // ... and the epilogue / address forms pp_store_tile and PP_SRC_A cover
     }
     if (pp_bn) { a.tiles_m = (a.M + 255) / 256; a.tiles_n = d.Npad / pp_bn; }
+    const bool wide_waves = split && bn == 128 && (g_tn4 < 0 ? a.Ktot / bk >= 64 : g_tn4 != 0);      // K >= 2048: the 3x3 layers
     ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
     const int e0 = prof ? prof_event(prof, s) : 0;
     if (pp_bn) conv_pp_launch(s, a, half ? 0 : (wdtype == MRCNN_F32X3 ? 3 : 2));
     else if (half) conv_launch<_Float16, _Float16>(s, a, bn);
-    else if (split && wdtype == MRCNN_F32X3) conv_launch<float, _Float16, 3>(s, a, bn);
-    else if (split) conv_launch<float, _Float16, 2>(s, a, bn);
+    else if (split && wdtype == MRCNN_F32X3) conv_launch<float, _Float16, 3>(s, a, bn, wide_waves);
+    else if (split) conv_launch<float, _Float16, 2>(s, a, bn, wide_waves);
     else conv_launch<float, float>(s, a, bn);
     if (prof) {
         const int e1 = prof_event(prof, s);

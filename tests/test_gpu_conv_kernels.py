@@ -91,6 +91,31 @@ def test_pingpong_kernel_equals_128row_kernel_bitwise(shape, dtype):
     assert np.abs(y1 - ref).max() <= tol * max(1.0, np.abs(ref).max()), (np.abs(y1 - ref).max(), np.abs(ref).max())
 
 
+@pytest.mark.parametrize("dtype", ["f32s", "f32x3"])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 256, 256, 3, 1, True), (1, 72, 56, 128, 300, 3, 1, False), (3, 40, 40, 320, 256, 1, 1, False)])
+def test_wide_wave_variant_equals_the_eight_wave_tile_bitwise(shape, dtype):
+    """Split modes: the 128x128 tile run by 4 waves of 32x128 (policy: K >= 2048, i.e. per-image results of a layer must not
+    depend on which of the two the policy picked) against the same tile run by 8 waves of 32x64 — ragged M, ragged N, residual."""
+    B, H, W, Ci, Co, k, stride, with_res = shape
+    rng = np.random.default_rng(sum(shape) + 1)
+    x = rng.standard_normal((B, H, W, Ci), np.float32)
+    w = (rng.standard_normal((Co, k, k, Ci), np.float32) * np.float32(1.0 / np.sqrt(k * k * Ci)))
+    scale = (0.5 + rng.random(Co)).astype(np.float32)
+    shift = rng.standard_normal(Co).astype(np.float32) * np.float32(0.1)
+    res = rng.standard_normal((B, H, W, Co), np.float32) if with_res else None
+    lib = L.lib()
+    try:
+        L.check(lib.mrcnn_debug_set(b"conv_pp", 0))
+        L.check(lib.mrcnn_debug_set(b"conv_tn4", 0))
+        y0 = conv(x, w, k, stride, scale, shift, res, 1, dtype)
+        L.check(lib.mrcnn_debug_set(b"conv_tn4", 1))
+        y1 = conv(x, w, k, stride, scale, shift, res, 1, dtype)
+    finally:
+        L.check(lib.mrcnn_debug_set(b"conv_tn4", -1))
+        L.check(lib.mrcnn_debug_set(b"conv_pp", 1))
+    np.testing.assert_array_equal(y1, y0)
+
+
 @pytest.mark.parametrize("dtype", ["f16", "f32x3"])
 def test_pingpong_kernel_repeatable_under_load(dtype):
     """Race screen of the hand-placed DMA / barrier schedule: the same launch repeated must give the same bits, on a
