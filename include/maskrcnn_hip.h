@@ -261,7 +261,7 @@ MRCNN_API int mrcnn_model_stage_ms(mrcnn_model* model, const char* stage, float*
 
 /* Live per-kernel profile of the convolution family during predict (bench.py roofline leg): when
  * enabled every conv launch is bracketed by HIP events on the model's stream.  tile: 0 = the
- * 128x128 kernel, 1 = 128x64, 2 = 128x32, 3 = 128x256 (MRCNN_F32S only).  enable(1) opens a measurement window (totals reset);
+ * 128x128 kernel, 1 = 128x64, 2 = 128x32, 3 = 128x128 run by four waves of 32x128 (split modes, K >= 2048), 4 = 256x256 ping-pong.  enable(1) opens a measurement window (totals reset);
  * enable(0) closes it and the totals stay readable — the events cost ~2 % (fp32) / ~13 % (fp16) of a step,
  * so bench.py opens the window for the first steps of its timed region only.
  * total_flops is ALGORITHMIC work (2*M*N*K of the convolution, padding excluded). */

@@ -124,7 +124,7 @@ struct ConvDesc {
 // has been synchronised) folds the elapsed times into per-tile-shape totals.
 struct ConvProfile {
     struct Slot { long launches = 0; double ms = 0, flops = 0; };
-    Slot by_tile[6];                 // 0: 128x128, 1: 128x64, 2: 128x32, 3: 128x256 (split mode), 4 / 5: 256x256 / 256x128 ping-pong (fp16)
+    Slot by_tile[6];                 // 0: 128x128, 1: 128x64, 2: 128x32, 3: 128x128 run by 4 waves of 32x128 (split modes, long K), 4: 256x256 ping-pong
     std::vector<hipEvent_t> pool;
     struct Shape { int M, N, K, tile; bool operator<(const Shape& o) const { return std::tie(M, N, K, tile) < std::tie(o.M, o.N, o.K, o.tile); } };
     std::map<Shape, Slot> by_shape;  // per GEMM shape (M = images·OH·OW, N = output columns, K = taps·Cin)

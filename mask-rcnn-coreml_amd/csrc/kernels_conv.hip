@@ -475,7 +475,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     if (prof) {
         const int e1 = prof_event(prof, s);
         const double k = d.algo_k > 0 ? d.algo_k : a.Ktot;
-        const int tile = pp_bn == 256 ? 4 : (pp_bn == 128 ? 5 : (bn == 128 ? 0 : (bn == 64 ? 1 : (bn == 32 ? 2 : 3))));
+        const int tile = pp_bn == 256 ? 4 : (wide_waves ? 3 : (bn == 128 ? 0 : (bn == 64 ? 1 : 2)));
         prof->pending.push_back({tile, 2.0 * (double)a.M * (double)a.ncols * k, e0, e1, {a.M, a.ncols, a.Ktot, tile}});
     }
     HIP_CHECK(hipGetLastError());
