@@ -316,7 +316,8 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes
 // candidates in chunks of 64.  For chunk c the "already suppressed" word is the OR of word c of the
 // rows kept so far — up to max_keep independent 8-B loads spread over the block, ONE memory latency
 // per chunk (an incremental removed[] array needed up to 64 dependent row sweeps per chunk and made
-// the scan 8x slower).  Wave 0 then resolves the chunk from the diagonal word with ballot/readlane.
+// the scan 8x slower), requested one chunk AHEAD (see the loop).  Wave 0 then resolves the chunk from
+// the diagonal word with ballot/readlane.
 // per_class_max > 0: candidates carry classes; a class stops selecting after per_class_max keeps
 // (each class is its own nonMaxSupression call in DetectionLayer.swift:170-183).
 // ------------------------------------------------------------------------------------------------
@@ -345,12 +346,27 @@ __global__ __launch_bounds__(256) void k_nms_scan(const float* __restrict__ boxe
     const float* bx = boxes + (size_t)b * boxes_sB;
     const uint64_t* mk = mask + (size_t)b * mask_sB;
     int32_t* kidx = keep_idx + (size_t)b * keep_sB;
+    // Software pipeline: everything chunk c+1 needs from memory is requested BEFORE chunk c is resolved — word c+1 of the rows
+    // kept up to chunk c-1 (spread over the block), and, in wave 0, word c+1 and the diagonal word of the 64 rows of chunks c
+    // and c+1 themselves (which of chunk c's rows get kept is only known after the resolve: their words are fetched for all
+    // 64 and OR-ed in under the kept mask).  The memory latency of a chunk hides behind the previous chunk's resolve.
+    uint64_t part = 0;          // this thread's share of OR_{rows kept before chunk c-1 was resolved} word c
+    uint64_t prev_w = 0;        // wave 0: word c of row (c-1)*64 + lane
+    uint64_t prev_kept = 0;     // wave 0 (uniform): which rows of chunk c-1 were kept
+    uint64_t diag = (wv == 0 && lane < n) ? mk[(size_t)lane * W] : 0ull;       // wave 0: word c of row c*64 + lane
     for (int c = 0; c < nW; ++c) {
         const int kc0 = s_kc;
-        // word c of every row kept so far (rows live in earlier chunks, so the word is in the computed triangle)
-        uint64_t acc = 0;
-        for (int k = t; k < kc0; k += 256) acc |= mk[(size_t)kept[k] * W + c];
-        uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
+        uint64_t part_n = 0, prev_w_n = 0, diag_n = 0;
+        if (c + 1 < nW) {
+            for (int k = t; k < kc0; k += 256) part_n |= mk[(size_t)kept[k] * W + c + 1];
+            if (wv == 0) {
+                const int row = c * 64 + lane, rown = row + 64;
+                if (row < n) prev_w_n = mk[(size_t)row * W + c + 1];
+                if (rown < n) diag_n = mk[(size_t)rown * W + c + 1];
+            }
+        }
+        uint32_t lo = (uint32_t)part, hi = (uint32_t)(part >> 32);
+        if (wv == 0 && ((prev_kept >> lane) & 1ull)) { lo |= (uint32_t)prev_w; hi |= (uint32_t)(prev_w >> 32); }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { lo |= __shfl_xor(lo, o); hi |= __shfl_xor(hi, o); }
         if (lane == 0) s_part[wv] = ((uint64_t)hi << 32) | lo;
@@ -359,10 +375,10 @@ __global__ __launch_bounds__(256) void k_nms_scan(const float* __restrict__ boxe
             const uint64_t removed = s_part[0] | s_part[1] | s_part[2] | s_part[3];
             const int row = c * 64 + lane;
             const bool inr = row < n;
-            const uint64_t diag = inr ? mk[(size_t)row * W + c] : 0ull;
             const bool ok = inr && rect_selectable(*reinterpret_cast<const float4*>(bx + (size_t)(inr ? row : 0) * 4));
             const int mycls = (cls && inr) ? cls[(size_t)b * cls_sB + row] : 0;
             uint64_t m = __ballot(ok) & ~removed;
+            uint64_t km = 0;
             int kc = kc0;
             while (m != 0ull && kc < max_keep) {
                 const int i = __ffsll((unsigned long long)m) - 1;
@@ -390,15 +406,18 @@ __global__ __launch_bounds__(256) void k_nms_scan(const float* __restrict__ boxe
                         if (per_class_max > 0) kept_cls[kc] = ci;
                     }
                     ++kc;
+                    km |= 1ull << i;
                     const uint32_t dlo = __shfl((uint32_t)(diag & 0xFFFFFFFFull), i);
                     const uint32_t dhi = __shfl((uint32_t)(diag >> 32), i);
                     m &= ~(((uint64_t)dhi << 32) | dlo);
                 }
             }
+            prev_kept = km;
             if (lane == 0) s_kc = kc;
         }
         __syncthreads();
         if (s_kc >= max_keep) break;
+        part = part_n; prev_w = prev_w_n; diag = diag_n;
     }
     if (t == 0) keep_count[b] = s_kc;
 }
