@@ -1,8 +1,8 @@
 #!/bin/bash
 # The board's sustained matrix rate with no data movement (tools/probes/mfma_probe.hip) with rocm-smi power / clock samples beside it.
 R=$(cd "$(dirname "$0")/.." && pwd)
-[ -x $R/tools/probes/mfma_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $R/tools/probes/mfma_probe $R/tools/probes/mfma_probe.hip
-for cfg in "8 0" "4 0" "8 1"; do
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $R/tools/probes/mfma_probe $R/tools/probes/mfma_probe.hip
+for cfg in "8 0" "8 2" "4 0" "8 1"; do
   set -- $cfg
   $R/tools/probes/mfma_probe 6 $1 $2 > /tmp/mf.log 2>&1 &
   pid=$!
