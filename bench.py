@@ -217,6 +217,7 @@ def main():
                         f"; the kernel EXECUTES {parts} fp16 MFMA flops per algorithmic flop ({round(achieved * parts, 1)} of "
                         f"{PEAK_FP16_MFMA_TFLOPS} TFLOP/s), so the peak for algorithmic flops is 1/{parts} of the fp16 MFMA peak" if parts > 1 else ""),
                     "traffic": pmc_traffic(args.dtype),
+                    "sustained_peak": sustained_peak(args.dtype, parts, achieved),
                     "launches_per_step": launches // ev_steps, "event_steps": ev_steps,
                     "avg_launch_ms": round(ms / launches, 4),
                     "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
@@ -276,6 +277,23 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sustained_peak(dtype, parts, achieved):
+    """What the matrix cores of this board sustain for seconds with NO data movement (tools/probes/mfma_probe.hip under
+    tools/mfma_power.sh, committed under profiles/): the fp16 MFMA on operands that change every instruction, the fp32 MFMA
+    on constants.  Informational — `peak` / `frac` above stay the nominal figures of MI355X_MICROARCH.md."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_mfma_power.txt")
+    try:
+        want = "v_mfma_f32_32x32x2_f32" if dtype == "f32" else "random data"
+        for line in open(path):
+            if line.startswith(want) or want in line.split(":")[0]:
+                tf = float(line.split(" s, ")[1].split(" TFLOP/s")[0])
+                return {"value": round(tf / parts, 1), "unit": "TFLOP/s", "frac": round(achieved * parts / tf, 4),
+                        "source": "profiles/r02_mfma_power.txt (whole chip, 6 s, no operand traffic; the board clocks down under matrix load)"}
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
 
 
 def pmc_traffic(dtype):
