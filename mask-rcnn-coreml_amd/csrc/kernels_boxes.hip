@@ -346,6 +346,9 @@ __global__ __launch_bounds__(256) void k_nms_scan(const float* __restrict__ boxe
     const float* bx = boxes + (size_t)b * boxes_sB;
     const uint64_t* mk = mask + (size_t)b * mask_sB;
     int32_t* kidx = keep_idx + (size_t)b * keep_sB;
+    // The two rendezvous of a chunk exchange LDS data only (s_part, s_kc, kept[]): a plain barrier behind an LDS wait —
+    // __syncthreads() would also drain vmcnt, i.e. wait for the requests issued ahead for the next chunk.
+#define NMS_LDS_BARRIER asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // Software pipeline: everything chunk c+1 needs from memory is requested BEFORE chunk c is resolved — word c+1 of the rows
     // kept up to chunk c-1 (spread over the block), and, in wave 0, word c+1 and the diagonal word of the 64 rows of chunks c
     // and c+1 themselves (which of chunk c's rows get kept is only known after the resolve: their words are fetched for all
@@ -370,55 +373,66 @@ __global__ __launch_bounds__(256) void k_nms_scan(const float* __restrict__ boxe
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { lo |= __shfl_xor(lo, o); hi |= __shfl_xor(hi, o); }
         if (lane == 0) s_part[wv] = ((uint64_t)hi << 32) | lo;
-        __syncthreads();
+        NMS_LDS_BARRIER
         if (wv == 0) {
             const uint64_t removed = s_part[0] | s_part[1] | s_part[2] | s_part[3];
             const int row = c * 64 + lane;
             const bool inr = row < n;
             const bool ok = inr && rect_selectable(*reinterpret_cast<const float4*>(bx + (size_t)(inr ? row : 0) * 4));
             const int mycls = (cls && inr) ? cls[(size_t)b * cls_sB + row] : 0;
+            // The resolve is a serial chain over the chunk's surviving candidates: kept on the SCALAR unit (wave-uniform mask,
+            // s_ff1, v_readlane for the picked lane's diagonal word / class / class count) — a cross-lane __shfl per step
+            // (ds_bpermute: an LDS round trip) and an LDS read-modify-write of the class counter made a detection chunk cost 9 us.
+            // Class counts of the chunk's own classes live in registers (every lane carries the count of ITS class, all lanes of a
+            // class updated together) and go back to LDS once per chunk.
             uint64_t m = __ballot(ok) & ~removed;
-            uint64_t km = 0;
+            m = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(m >> 32)) << 32) |
+                (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)m);          // (the builtin returns a SIGNED int)
+            const uint32_t dlo_v = (uint32_t)(diag & 0xFFFFFFFFull), dhi_v = (uint32_t)(diag >> 32);
+            const bool small_cls = (unsigned)mycls < (unsigned)NCLS;
+            int mycnt = (per_class_max > 0 && inr && small_cls) ? cls_cnt[mycls] : 0;
+            uint64_t km = 0;            // the chunk's kept lanes; their indices are written once, in parallel, after the loop
             int kc = kc0;
             while (m != 0ull && kc < max_keep) {
-                const int i = __ffsll((unsigned long long)m) - 1;
-                m &= ~(1ull << i);
+                const int i = __builtin_ctzll(m);
+                m &= m - 1;
                 bool take = true;
-                int ci = 0;
                 if (per_class_max > 0) {
-                    ci = __shfl(mycls, i);
+                    const int ci = __builtin_amdgcn_readlane(mycls, i);
                     int cnt;
-                    if ((unsigned)ci < (unsigned)NCLS) cnt = cls_cnt[ci];
+                    if ((unsigned)ci < (unsigned)NCLS) cnt = __builtin_amdgcn_readlane(mycnt, i);
                     else {
-                        cnt = 0;
-                        for (int base = 0; base < kc; base += 64) {
-                            const bool eq = (base + lane < kc) && kept_cls[base + lane] == ci;
+                        cnt = __popcll(__ballot(mycls == ci) & km);              // kept in this chunk
+                        for (int base = 0; base < kc0; base += 64) {            // ... and in the earlier ones
+                            const bool eq = (base + lane < kc0) && kept_cls[base + lane] == ci;
                             cnt += __popcll(__ballot(eq));
                         }
                     }
                     take = cnt < per_class_max;
-                    if (take && (unsigned)ci < (unsigned)NCLS) cls_cnt[ci] = cnt + 1;   // every lane, same value
+                    if (take && mycls == ci) ++mycnt;
                 }
                 if (take) {
-                    if (lane == 0) {
-                        kidx[kc] = c * 64 + i;
-                        kept[kc] = c * 64 + i;
-                        if (per_class_max > 0) kept_cls[kc] = ci;
-                    }
                     ++kc;
                     km |= 1ull << i;
-                    const uint32_t dlo = __shfl((uint32_t)(diag & 0xFFFFFFFFull), i);
-                    const uint32_t dhi = __shfl((uint32_t)(diag >> 32), i);
+                    const uint32_t dlo = __builtin_amdgcn_readlane(dlo_v, i), dhi = __builtin_amdgcn_readlane(dhi_v, i);
                     m &= ~(((uint64_t)dhi << 32) | dlo);
                 }
             }
+            if ((km >> lane) & 1ull) {
+                const int slot = kc0 + __popcll(km & ((1ull << lane) - 1ull));
+                kidx[slot] = row;
+                kept[slot] = row;
+                if (per_class_max > 0) kept_cls[slot] = mycls;
+            }
+            if (per_class_max > 0 && inr && small_cls) cls_cnt[mycls] = mycnt;      // lanes of one class write the same value
             prev_kept = km;
             if (lane == 0) s_kc = kc;
         }
-        __syncthreads();
+        NMS_LDS_BARRIER
         if (s_kc >= max_keep) break;
         part = part_n; prev_w = prev_w_n; diag = diag_n;
     }
+#undef NMS_LDS_BARRIER
     if (t == 0) keep_count[b] = s_kc;
 }
 

@@ -135,3 +135,31 @@ def test_pingpong_kernel_repeatable_under_load(dtype):
         L.check(L.lib().mrcnn_debug_set(b"conv_pp", 1))
         L.check(L.lib().mrcnn_debug_set(b"conv_pp_split", 0))
         L.check(L.lib().mrcnn_debug_set(b"conv_pp_min_tiles", 512))
+
+
+@pytest.mark.parametrize("dtype,batch", [("f32x3", 66), ("f16", 132)])
+def test_activation_tensor_beyond_4_gib(dtype, batch):
+    """The DMAs address activations with 32-bit offsets from a buffer resource that every block re-bases on the first image
+    it touches: a tensor of more than 4 GiB (here 4.3 GiB: batch x 256 x 256 x 256) must give, for any image, exactly what
+    that image gives alone (fp16: the ping-pong kernel; f32x3: the 128-row kernels).  Stride 2 keeps the output small."""
+    import psutil
+    if psutil.virtual_memory().available < 40 * 2**30:
+        pytest.skip("needs ~25 GB of host memory for the staging copies")
+    rng = np.random.default_rng(11)
+    H = W = 256
+    Ci, Co = 256, 256
+    probe = [0, batch // 2, batch - 1]
+    x = np.zeros((batch, H, W, Ci), np.float32)
+    for b in probe:
+        x[b] = rng.standard_normal((H, W, Ci), np.float32)
+    assert x.nbytes // (2 if dtype == "f16" else 1) > 2**32
+    w = rng.standard_normal((Co, 3, 3, Ci), np.float32) * np.float32(0.02)
+    shift = rng.standard_normal(Co).astype(np.float32)
+    y = conv(x, w, 3, 2, None, shift, None, 1, dtype)
+    for b in probe:
+        np.testing.assert_array_equal(y[b], conv(x[b:b + 1], w, 3, 2, None, shift, None, 1, dtype)[0])
+    # an all-zero image gives relu(shift) everywhere (its padding taps and its neighbours' data never leak in)
+    want = np.maximum(shift, 0)
+    if dtype == "f16":
+        want = want.astype(np.float16).astype(np.float32)
+    np.testing.assert_array_equal(y[1], np.broadcast_to(want, y[1].shape))
