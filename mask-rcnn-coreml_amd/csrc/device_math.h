@@ -102,6 +102,40 @@ __device__ __forceinline__ float iou_yxyx(float4 fa, float4 fb)
     return (float)(inter / (areaA + areaB - inter));
 }
 
+// iou_yxyx(fa, fb) > thr without the fp64 division in all but the borderline cases (the NMS bit-matrix evaluates it for
+// every overlapping pair).  The reference's decision is  Float(inter / union) > thr  (Utils.swift:236-246): the quotient is
+// rounded to double, then to float, both monotone — so the decision is "quotient above T", T = the midpoint of thr and the
+// next float above it, except within a few ulps of T.  inter is compared with T·union under a relative margin of 2^-48
+// (the three products round with 2^-53 each); inside the margin the original expression decides.  thr_mid < 0 (a negative
+// or non-finite threshold): always the original expression.
+__device__ __forceinline__ double iou_threshold_midpoint(float thr)
+{
+    if (!(thr >= 0.0f) || !(thr < 3.0e38f)) return -1.0;
+    return 0.5 * ((double)thr + (double)__uint_as_float(__float_as_uint(thr) + 1u));
+}
+__device__ __forceinline__ bool iou_exceeds(float4 fa, float4 fb, float thr, double thr_mid)
+{
+    const RectD a = rect_from(fa), b = rect_from(fb);
+    const double areaA = fabs(a.w) * fabs(a.h);
+    if (areaA <= 0) return 0.0f > thr;
+    const double areaB = fabs(b.w) * fabs(b.h);
+    if (areaB <= 0) return 0.0f > thr;
+    const double aminx = a.w < 0 ? a.x + a.w : a.x, amaxx = a.w < 0 ? a.x : a.x + a.w;
+    const double aminy = a.h < 0 ? a.y + a.h : a.y, amaxy = a.h < 0 ? a.y : a.y + a.h;
+    const double bminx = b.w < 0 ? b.x + b.w : b.x, bmaxx = b.w < 0 ? b.x : b.x + b.w;
+    const double bminy = b.h < 0 ? b.y + b.h : b.y, bmaxy = b.h < 0 ? b.y : b.y + b.h;
+    const double ix0 = fmax(aminx, bminx), iy0 = fmax(aminy, bminy);
+    const double ix1 = fmin(amaxx, bmaxx), iy1 = fmin(amaxy, bmaxy);
+    const double inter = fmax(iy1 - iy0, 0.0) * fmax(ix1 - ix0, 0.0);
+    const double uni = areaA + areaB - inter;
+    if (thr_mid >= 0.0) {
+        const double p = thr_mid * uni;
+        if (inter > p * (1.0 + 0x1p-48)) return true;
+        if (inter < p * (1.0 - 0x1p-48)) return false;
+    }
+    return (float)(inter / uni) > thr;
+}
+
 // Monotone float → uint32 key (ascending key == ascending float); -0 is folded onto +0 so that it
 // ties with +0 as in a float comparison.
 __device__ __forceinline__ uint32_t order_key(float f)

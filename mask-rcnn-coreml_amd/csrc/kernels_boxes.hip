@@ -271,44 +271,64 @@ __global__ __launch_bounds__(1024) void k_sort_decode(const uint64_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// NMS part 1: suppression bit-matrix.  Block = one wave = rows rb*64.., columns cb*64..; only
-// cb >= rb is computed.  Bit j of mask[i][cb] ⇔ column box (cb*64+j) > i, same class, IoU > thr.
+// NMS part 1: suppression bit-matrix.  Bit j of mask[i][cb] ⇔ column box (cb*64+j) > i, same class, IoU > thr; only the
+// words cb >= (i / 64) are computed.  Block (rb, split) = 4 waves holding the 64 rows rb*64.. in registers (one row per
+// lane); wave w of split s walks the column chunks cb = rb + 4 s + w, + 4·gridDim.y, ... (a wave-private LDS slot holds
+// the chunk's 64 boxes: no block barrier).  Per chunk two phases:
+//   1. every (row, column) pair through the exact FLOAT disjointness test (6 VALU per pair on pre-sorted corners,
+//      column box broadcast from LDS) → a 64-bit candidate word per row;
+//   2. each lane walks ITS candidates only (ctz loop) through the fp64 IoU decision (iou_exceeds: the reference's
+//      Double arithmetic, the division only in borderline cases).
+// Round 1 ran one 64-thread block per (rb, cb) pair and sent EVERY column through the fp64 IoU with its division whenever
+// one of the 64 rows overlapped it (almost always, with a handful of lanes active): 256 us per batch of 8 x 6000 boxes.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes, long boxes_sB,
-                                                 const int32_t* __restrict__ cls, long cls_sB,
-                                                 const int32_t* __restrict__ n_dev, int n_const, float thr,
-                                                 uint64_t* __restrict__ mask, long mask_sB, int W)
+__global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxes, long boxes_sB,
+                                                  const int32_t* __restrict__ cls, long cls_sB,
+                                                  const int32_t* __restrict__ n_dev, int n_const, float thr,
+                                                  uint64_t* __restrict__ mask, long mask_sB, int W)
 {
-    const int cb = blockIdx.x, rb = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
-    if (cb < rb) return;
+    __shared__ float4 s_raw[4][64];      // (y1, x1, y2, x2) of the wave's column chunk
+    __shared__ float4 s_srt[4][64];      // (min y, min x, max y, max x)
+    __shared__ int32_t s_cls[4][64];
+    const int rb = blockIdx.x, b = blockIdx.z, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n = n_dev ? n_dev[b] : n_const;
     if (rb * 64 >= n) return;
-    __shared__ float4 cbox[64];
-    __shared__ int32_t ccls[64];
+    const int nW = (n + 63) / 64;
     const float* bx = boxes + (size_t)b * boxes_sB;
-    const int cj = cb * 64 + lane;
-    cbox[lane] = cj < n ? *reinterpret_cast<const float4*>(bx + (size_t)cj * 4) : make_float4(0, 0, 0, 0);
-    ccls[lane] = (cls && cj < n) ? cls[(size_t)b * cls_sB + cj] : 0;
-    __syncthreads();
     const int i = rb * 64 + lane;
-    if (i >= n) return;
-    const float4 me = *reinterpret_cast<const float4*>(bx + (size_t)i * 4);
-    const int mycls = cls ? cls[(size_t)b * cls_sB + i] : 0;
-    uint64_t bits = 0;
-    for (int j = 0; j < 64; ++j) {
-        const int gj = cb * 64 + j;
-        if (gj <= i || gj >= n) continue;
-        if (cls && ccls[j] != mycls) continue;
-        // exact float pre-test: disjoint (or merely touching) boxes have intersection 0, hence IoU 0 — which is
-        // "not suppressed" only for a non-negative threshold (IOU() == 0 > thr holds for a caller-supplied thr < 0)
-        const float4 o = cbox[j];
-        if (thr >= 0.0f &&
-            (fminf(fmaxf(o.x, o.z), fmaxf(me.x, me.z)) <= fmaxf(fminf(o.x, o.z), fminf(me.x, me.z)) ||
-             fminf(fmaxf(o.y, o.w), fmaxf(me.y, me.w)) <= fmaxf(fminf(o.y, o.w), fminf(me.y, me.w))))
-            continue;
-        if (iou_yxyx(o, me) > thr) bits |= 1ull << j;           // IOU(anchorA = candidate, anchorB = selected)
+    const bool in_i = i < n;
+    const float4 me = in_i ? *reinterpret_cast<const float4*>(bx + (size_t)i * 4) : make_float4(0, 0, 0, 0);
+    const float4 ms = make_float4(fminf(me.x, me.z), fminf(me.y, me.w), fmaxf(me.x, me.z), fmaxf(me.y, me.w));
+    const int mycls = (cls && in_i) ? cls[(size_t)b * cls_sB + i] : 0;
+    const bool pretest = thr >= 0.0f;     // IOU() == 0 > thr holds for a caller-supplied thr < 0: then every pair is a candidate
+    const double thr_mid = iou_threshold_midpoint(thr);
+    const int stride = 4 * (int)gridDim.y;
+    for (int cb = rb + 4 * (int)blockIdx.y + wv; cb < nW; cb += stride) {
+        const int cj = cb * 64 + lane;
+        const float4 cv = cj < n ? *reinterpret_cast<const float4*>(bx + (size_t)cj * 4) : make_float4(0, 0, 0, 0);
+        s_raw[wv][lane] = cv;
+        s_srt[wv][lane] = make_float4(fminf(cv.x, cv.z), fminf(cv.y, cv.w), fmaxf(cv.x, cv.z), fmaxf(cv.y, cv.w));
+        if (cls) s_cls[wv][lane] = cj < n ? cls[(size_t)b * cls_sB + cj] : 0;
+        const int jn = min(64, n - cb * 64);
+        // phase 1 — exact float pre-test: disjoint (or merely touching) boxes have intersection 0, hence IoU 0
+        uint64_t cand = 0;
+        for (int j = 0; j < jn; ++j) {
+            const float4 c = s_srt[wv][j];
+            bool hit = !pretest || !(fminf(c.z, ms.z) <= fmaxf(c.x, ms.x) || fminf(c.w, ms.w) <= fmaxf(c.y, ms.y));
+            if (cls) hit = hit && s_cls[wv][j] == mycls;
+            cand |= hit ? 1ull << j : 0ull;
+        }
+        if (cb == rb) cand &= ~((2ull << lane) - 1ull);        // only columns behind the row itself (gj > i)
+        // phase 2 — the reference's fp64 IoU on the candidates
+        uint64_t bits = 0;
+        while (cand != 0ull) {
+            const int j = __builtin_ctzll(cand);
+            cand &= cand - 1;
+            if (iou_exceeds(s_raw[wv][j], me, thr, thr_mid)) bits |= 1ull << j;      // IOU(anchorA = candidate, anchorB = selected)
+        }
+        if (in_i) mask[(size_t)b * mask_sB + (size_t)i * W + cb] = bits;
     }
-    mask[(size_t)b * mask_sB + (size_t)i * W + cb] = bits;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -483,7 +503,7 @@ void proposal_forward(hipStream_t s, const ProposalWorkspace& ws, const float* p
     hipLaunchKernelGGL(k_sort_decode, dim3(B), dim3(1024), sort_lds, s, ws.cand, K, ws.Kpad, deltas, deltas_sB, anchors,
                        stdv, ws.topk_idx, ws.boxes);
     const long boxes_sB = (long)K * 4, mask_sB = (long)K * ws.W;
-    hipLaunchKernelGGL(k_nms_mask, dim3(ws.W, ws.W, B), dim3(64), 0, s, ws.boxes, boxes_sB, (const int32_t*)nullptr, 0L,
+    hipLaunchKernelGGL(k_nms_mask, dim3(ws.W, ws.W >= 16 ? 4 : 1, B), dim3(256), 0, s, ws.boxes, boxes_sB, (const int32_t*)nullptr, 0L,
                        (const int32_t*)nullptr, K, nms_thr, ws.nms_mask, mask_sB, ws.W);
     hipLaunchKernelGGL(k_nms_scan, dim3(B), dim3(256), (size_t)ws.max_keep * 4, s, ws.boxes, boxes_sB, (const int32_t*)nullptr, 0L,
                        (const int32_t*)nullptr, K, ws.nms_mask, mask_sB, ws.W, ws.max_keep, 0, ws.keep_idx,
@@ -636,7 +656,7 @@ void detection_forward(hipStream_t s, const DetectionWorkspace& ws, const float*
     hipLaunchKernelGGL(k_det_filter_decode, dim3(B), dim3(1024), 0, s, rois, rois_sB, roi_stride, cls6, cls_sB, N, stdv,
                        score_thr, ws.count, ws.src, ws.boxes, ws.score, ws.cls);
     const long boxes_sB = (long)N * 4, mask_sB = (long)N * ws.W;
-    hipLaunchKernelGGL(k_nms_mask, dim3(ws.W, ws.W, B), dim3(64), 0, s, ws.boxes, boxes_sB, ws.cls, (long)N, ws.count, 0,
+    hipLaunchKernelGGL(k_nms_mask, dim3(ws.W, ws.W >= 16 ? 4 : 1, B), dim3(256), 0, s, ws.boxes, boxes_sB, ws.cls, (long)N, ws.count, 0,
                        nms_thr, ws.nms_mask, mask_sB, ws.W);
     boxes_one_time_init();
     const size_t scan_lds = (size_t)N * 8;
