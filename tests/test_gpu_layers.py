@@ -45,6 +45,48 @@ def test_proposal_layer_random(pkg, anchors_mod, orc, tmp_path, size, pre, maxp)
     np.testing.assert_array_equal(got, want)
 
 
+def test_proposal_nms_threshold_on_the_iou_boundary(pkg, orc, tmp_path):
+    """The bit-matrix kernel decides  Float(inter / union) > thr  without the division except within 2^-48 of the boundary
+    (iou_exceeds): thresholds placed EXACTLY on the float IoU of a pair, one float below and one above it, must flip the
+    decision where the reference's expression does.  Custom anchors (the layer reads anchors.bin), zero deltas: 36 isolated
+    pairs of overlapping boxes, one pair per cell of a 6x6 grid — a pair's decision alone decides whether its second box survives."""
+    rng = np.random.default_rng(17)
+    P = 36
+    cell = 1.0 / 6
+    boxes = []
+    for k in range(P):
+        oy, ox = (k // 6) * cell, (k % 6) * cell
+        y1, x1 = oy + 0.01 + rng.random() * 0.02, ox + 0.01 + rng.random() * 0.02
+        h, w = 0.06 + rng.random() * 0.03, 0.06 + rng.random() * 0.03
+        dy, dx = rng.random() * 0.03, rng.random() * 0.03
+        boxes.append([y1, x1, y1 + h, x1 + w])
+        boxes.append([y1 + dy, x1 + dx, y1 + dy + h * (0.8 + 0.3 * rng.random()), x1 + dx + w * (0.8 + 0.3 * rng.random())])
+    anchors = np.asarray(boxes, np.float32)
+    A = anchors.shape[0]
+    p = str(tmp_path / "anchors_custom.bin")
+    anchors.tofile(p)
+    pkg.MaskRCNNConfig.defaultConfig().anchorsURL = p
+    fg = np.linspace(0.99, 0.5, A).astype(np.float32)          # first box of a pair outranks its partner
+    probs = np.stack([1 - fg, fg], axis=1).astype(np.float32)
+    deltas = np.zeros((A, 4), np.float32)
+    params = dict(pkg.ModelConfig().proposal_layer_params(), preNMSMaxProposals=A, maxProposals=A)
+    _, dbg = orc.proposal_layer(probs, deltas, anchors, A, A, 0.7, debug=True)
+    dec = dbg["boxes"]                                          # decoded + clipped, in score order = anchor order here
+    flips = 0
+    for k in range(P):
+        f = np.float32(orc.iou(dec[2 * k + 1], dec[2 * k]))     # IOU(candidate, selected)
+        assert 0.2 < f < 1.0
+        outs = []
+        for thr in (np.nextafter(f, np.float32(0)), f, np.nextafter(f, np.float32(1))):
+            params["nmsIOUThreshold"] = float(thr)
+            got = _run_proposal(pkg, probs, deltas, params)
+            want = orc.proposal_layer(probs, deltas, anchors, A, A, float(thr))
+            np.testing.assert_array_equal(got, want)
+            outs.append(got)
+        flips += int(not np.array_equal(outs[0], outs[1]))      # IoU == thr: "not above"; one float lower: above
+    assert flips == P                                           # every boundary was really exercised
+
+
 def test_proposal_layer_ties_and_padding(pkg, anchors_mod, orc, tmp_path):
     """Saturated scores (many exact ties → lowest anchor index wins), far fewer survivors than
     maxProposals (zero padding), wider output rows (only 4 floats of kept rows are written)."""
