@@ -233,12 +233,94 @@ __global__ __launch_bounds__(256) void k_compact(const uint32_t* __restrict__ ke
 }
 
 // ------------------------------------------------------------------------------------------------
-// in-LDS bitonic sort of the K candidates, then gather + decode + clip
+// bitonic sort of the K candidates (64-bit keys: score key << 32 | anchor index, all distinct), then gather + decode + clip.
+// One 1024-thread block per image.  k_sort_decode<E>: Kpad = 1024·E, thread t owns the E consecutive elements t·E ..:
+// a compare-exchange distance below E stays in the thread's registers, below 64·E inside the wave (lane shuffle), and only
+// the distances from 64·E up (10 of the 91 stages at Kpad = 8192) go through LDS and a block barrier — the all-LDS form
+// (kept for Kpad < 1024) spent 138 us of its stages' 91 barriers on 8 of the chip's 256 CUs.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void decode_sorted(const uint64_t key, int i, int b, int K, const float* dl, const float* anchors, float4 stdv,
+                                              int32_t* topk_idx, float* boxes)
+{
+    const uint32_t idx = (uint32_t)(key & 0xFFFFFFFFull);
+    topk_idx[(size_t)b * K + i] = (int32_t)idx;
+    float4 d = *reinterpret_cast<const float4*>(dl + (size_t)idx * 4);
+    const float4 an = *reinterpret_cast<const float4*>(anchors + (size_t)idx * 4);
+    d.x = d.x * stdv.x; d.y = d.y * stdv.y; d.z = d.z * stdv.z; d.w = d.w * stdv.w;   // Utils.swift:173-180
+    *reinterpret_cast<float4*>(boxes + ((size_t)b * K + i) * 4) = decode_clip_box(an, d);
+}
+
+template <int E>
 __global__ __launch_bounds__(1024) void k_sort_decode(const uint64_t* __restrict__ cand, int K, int Kpad,
                                                       const float* __restrict__ deltas, long deltas_sB,
                                                       const float* __restrict__ anchors, float4 stdv,
                                                       int32_t* __restrict__ topk_idx, float* __restrict__ boxes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* a = reinterpret_cast<uint64_t*>(smem);          // [E][1024]: element (t, r) at r·1024 + t (conflict-free columns)
+    const int b = blockIdx.x, t = threadIdx.x;
+    const uint64_t* c = cand + (size_t)b * Kpad;
+    uint64_t v[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) { const int i = t * E + r; v[r] = i < K ? c[i] : ~0ull; }
+    for (int k = 2; k <= Kpad; k <<= 1) {
+        int j = k >> 1;
+        for (; j >= 64 * E; j >>= 1) {                         // partner in another wave: through LDS
+#pragma unroll
+            for (int r = 0; r < E; ++r) a[r * 1024 + t] = v[r];
+            __syncthreads();
+            const int tp = t ^ (j / E);
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                const uint64_t y = a[r * 1024 + tp];
+                const int i = t * E + r;
+                const bool take_min = ((i & j) == 0) == ((i & k) == 0);
+                v[r] = take_min ? (v[r] < y ? v[r] : y) : (v[r] > y ? v[r] : y);
+            }
+            __syncthreads();
+        }
+        for (; j >= E; j >>= 1) {                              // partner in another lane of this wave
+            const int d = j / E;
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                const uint32_t ylo = __shfl_xor((uint32_t)v[r], d), yhi = __shfl_xor((uint32_t)(v[r] >> 32), d);
+                const uint64_t y = ((uint64_t)yhi << 32) | ylo;
+                const int i = t * E + r;
+                const bool take_min = ((i & j) == 0) == ((i & k) == 0);
+                v[r] = take_min ? (v[r] < y ? v[r] : y) : (v[r] > y ? v[r] : y);
+            }
+        }
+        // partner in this thread's registers: the distance is a compile-time constant once unrolled (a run-time register
+        // index would send v[] to scratch memory)
+#pragma unroll
+        for (int jj = E >> 1; jj > 0; jj >>= 1) {
+            if (jj <= (k >> 1)) {
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    if ((r & jj) == 0) {
+                        const int i = t * E + r;
+                        const bool up = (i & k) == 0;
+                        const uint64_t x = v[r], y = v[r | jj];
+                        const bool sw = (x > y) == up;
+                        v[r] = sw ? y : x;
+                        v[r | jj] = sw ? x : y;
+                    }
+                }
+            }
+        }
+    }
+    const float* dl = deltas + (size_t)b * deltas_sB;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int i = t * E + r;
+        if (i < K) decode_sorted(v[r], i, b, K, dl, anchors, stdv, topk_idx, boxes);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_sort_decode_lds(const uint64_t* __restrict__ cand, int K, int Kpad,
+                                                          const float* __restrict__ deltas, long deltas_sB,
+                                                          const float* __restrict__ anchors, float4 stdv,
+                                                          int32_t* __restrict__ topk_idx, float* __restrict__ boxes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* a = reinterpret_cast<uint64_t*>(smem);
@@ -260,14 +342,7 @@ __global__ __launch_bounds__(1024) void k_sort_decode(const uint64_t* __restrict
         }
     }
     const float* dl = deltas + (size_t)b * deltas_sB;
-    for (int i = t; i < K; i += 1024) {
-        const uint32_t idx = (uint32_t)(a[i] & 0xFFFFFFFFull);
-        topk_idx[(size_t)b * K + i] = (int32_t)idx;
-        float4 d = *reinterpret_cast<const float4*>(dl + (size_t)idx * 4);
-        const float4 an = *reinterpret_cast<const float4*>(anchors + (size_t)idx * 4);
-        d.x = d.x * stdv.x; d.y = d.y * stdv.y; d.z = d.z * stdv.z; d.w = d.w * stdv.w;   // Utils.swift:173-180
-        *reinterpret_cast<float4*>(boxes + ((size_t)b * K + i) * 4) = decode_clip_box(an, d);
-    }
+    for (int i = t; i < K; i += 1024) decode_sorted(a[i], i, b, K, dl, anchors, stdv, topk_idx, boxes);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -500,8 +575,16 @@ void proposal_forward(hipStream_t s, const ProposalWorkspace& ws, const float* p
                   "preNMSMaxProposals %d exceeds the in-LDS sort capacity (max 16384)", K);
     boxes_one_time_init();
     const float4 stdv = make_float4(std4[0], std4[1], std4[2], std4[3]);
-    hipLaunchKernelGGL(k_sort_decode, dim3(B), dim3(1024), sort_lds, s, ws.cand, K, ws.Kpad, deltas, deltas_sB, anchors,
-                       stdv, ws.topk_idx, ws.boxes);
+#define MRCNN_SORT(KERNEL) hipLaunchKernelGGL(KERNEL, dim3(B), dim3(1024), sort_lds, s, ws.cand, K, ws.Kpad, deltas, deltas_sB, anchors, stdv, ws.topk_idx, ws.boxes)
+    switch (ws.Kpad / 1024) {
+    case 1: MRCNN_SORT(k_sort_decode<1>); break;
+    case 2: MRCNN_SORT(k_sort_decode<2>); break;
+    case 4: MRCNN_SORT(k_sort_decode<4>); break;
+    case 8: MRCNN_SORT(k_sort_decode<8>); break;
+    case 16: MRCNN_SORT(k_sort_decode<16>); break;
+    default: MRCNN_SORT(k_sort_decode_lds); break;          // Kpad < 1024
+    }
+#undef MRCNN_SORT
     const long boxes_sB = (long)K * 4, mask_sB = (long)K * ws.W;
     hipLaunchKernelGGL(k_nms_mask, dim3(ws.W, ws.W >= 16 ? 4 : 1, B), dim3(256), 0, s, ws.boxes, boxes_sB, (const int32_t*)nullptr, 0L,
                        (const int32_t*)nullptr, K, nms_thr, ws.nms_mask, mask_sB, ws.W);
@@ -679,7 +762,8 @@ void boxes_one_time_init()
     HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
     if (dev >= 0 && dev < 64 && done[dev]) return;
-    HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_decode, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_decode<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_decode<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_nms_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_det_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     if (dev >= 0 && dev < 64) done[dev] = true;
