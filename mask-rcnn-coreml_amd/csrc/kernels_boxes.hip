@@ -109,23 +109,35 @@ __global__ __launch_bounds__(256) void k_keys_hist0(const float* __restrict__ pr
 __global__ __launch_bounds__(256) void k_select_scan(uint32_t* __restrict__ hist, uint32_t* __restrict__ state,
                                                      int pass, int K)
 {
-    __shared__ uint32_t part[256];
     const int b = blockIdx.x, t = threadIdx.x;
     const int nbins = pass == 2 ? 256 : 4096, per = nbins / 256, bits = pass == 2 ? 8 : 12;
     const uint32_t* h = hist + ((size_t)b * 3 + pass) * 4096;
     uint32_t* st = state + (size_t)b * 8;
     uint32_t s = 0;
     for (int i = 0; i < per; ++i) s += h[t * per + i];
-    part[t] = s;
+    // above[t] = keys in the groups above group t (suffix sum over the 256 groups: wave scan from the top + wave totals);
+    // the group holding the k-th largest key is the one with above < k <= above + own — found by its own thread
+    // (a single thread walking the groups from the top cost 12 us per pass)
+    __shared__ uint32_t wtot[4];
+    __shared__ int s_g;
+    const int lane = t & 63, wv = t >> 6;
+    uint32_t inc = s;                                  // inclusive suffix sum inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_down(inc, o);
+        if (lane + o < 64) inc += v;
+    }
+    if (lane == 0) wtot[wv] = inc;
+    if (t == 0) s_g = 0;                              // group 0 takes what no group above it holds
     __syncthreads();
-    if (t == 0) {
-        const uint32_t k = pass == 0 ? (uint32_t)K : st[ST_KREM];
-        uint32_t above = 0;
-        int g = 255;
-        for (; g > 0; --g) {
-            if (above + part[g] >= k) break;
-            above += part[g];
-        }
+    uint32_t above_t = inc - s;
+    for (int w = wv + 1; w < 4; ++w) above_t += wtot[w];
+    const uint32_t k = pass == 0 ? (uint32_t)K : st[ST_KREM];
+    if (t > 0 && above_t < k && above_t + s >= k) s_g = t;         // at most one group qualifies (k >= 1)
+    __syncthreads();
+    if (t == s_g) {
+        const int g = t;
+        uint32_t above = above_t;
         int bin = (g + 1) * per - 1;
         for (; bin > g * per; --bin) {
             if (above + h[bin] >= k) break;
@@ -184,7 +196,8 @@ __global__ __launch_bounds__(256) void k_compact(const uint32_t* __restrict__ ke
                                                  int nblk, uint64_t* __restrict__ cand, int Kpad)
 {
     __shared__ uint32_t red[256];
-    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t wsum[4], wsumg[4];
+    __shared__ uint32_t s_gbase;
     const int b = blockIdx.y, t = threadIdx.x, blk = blockIdx.x;
     uint32_t* st = state + (size_t)b * 8;
     const uint32_t T = st[ST_T], need = st[ST_NEED], ngt = st[ST_NGT], tiebin = st[ST_TIEBIN];
@@ -201,30 +214,40 @@ __global__ __launch_bounds__(256) void k_compact(const uint32_t* __restrict__ ke
     const int i0 = blk * CHUNK + t * 4;
     const uint4 kv = *reinterpret_cast<const uint4*>(keys + (size_t)b * keys_sB + i0);
     const uint32_t k[4] = {kv.x, kv.y, kv.z, kv.w};
-    uint32_t nt = 0;
+    uint32_t nt = 0, ng = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) nt += (i0 + j < A && k[j] == T) ? 1u : 0u;
-    // exclusive scan of nt over the 256 threads (wave scan + 4 wave totals)
+    for (int j = 0; j < 4; ++j) {
+        nt += (i0 + j < A && k[j] == T) ? 1u : 0u;
+        ng += (i0 + j < A && k[j] > T) ? 1u : 0u;
+    }
+    // exclusive scans of nt (ties, in index order) and ng (keys above T) over the 256 threads (wave scan + 4 wave totals)
     const int lane = t & 63, wv = t >> 6;
-    uint32_t inc = nt;
+    uint32_t inc = nt, incg = ng;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t v = __shfl_up(inc, o);
-        if (lane >= o) inc += v;
+        const uint32_t v = __shfl_up(inc, o), vg = __shfl_up(incg, o);
+        if (lane >= o) { inc += v; incg += vg; }
     }
-    if (lane == 63) wsum[wv] = inc;
+    if (lane == 63) { wsum[wv] = inc; wsumg[wv] = incg; }
     __syncthreads();
-    uint32_t wbase = 0;
-    for (int i = 0; i < wv; ++i) wbase += wsum[i];
+    uint32_t wbase = 0, wbaseg = 0;
+    for (int i = 0; i < wv; ++i) { wbase += wsum[i]; wbaseg += wsumg[i]; }
+    // ONE reservation per block for its keys above T (their order is free: they are sorted next) — one atomic per key
+    // serialised 6 000 updates of a single word per image (56 us)
+    if (t == 0) {
+        const uint32_t total = wsumg[0] + wsumg[1] + wsumg[2] + wsumg[3];
+        s_gbase = total ? atomicAdd(&st[ST_SLOT], total) : 0u;
+    }
+    __syncthreads();
     uint32_t rank = tie_base + wbase + inc - nt;
+    uint32_t slot = s_gbase + wbaseg + incg - ng;
     uint64_t* c = cand + (size_t)b * Kpad;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (i0 + j >= A) continue;
         const uint64_t v = ((uint64_t)(~k[j]) << 32) | (uint32_t)(i0 + j);
         if (k[j] > T) {
-            const uint32_t slot = atomicAdd(&st[ST_SLOT], 1u);
-            c[slot] = v;
+            c[slot++] = v;
         } else if (k[j] == T) {
             if (rank < need) c[ngt + rank] = v;
             ++rank;
