@@ -158,7 +158,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int r = rr + ps * RPP;
                 const int m = m0 + r;
-                if (m >= a.M) break;
+                if (m >= a.M) continue;          // (not `break`: an early exit keeps the loop rolled and sends rv[] to scratch memory)
                 int b = 0, pix = m, oh = 0, ow = 0;
                 if (need_bp) { b = m / ohw; pix = m - b * ohw; }
                 if (need_yx) { oh = pix / a.OW; ow = pix - oh * a.OW; }

@@ -349,6 +349,8 @@ int conv_n_tile(int Cout)
     return 32;
 }
 
+static int g_min_blocks = 448;   // narrow the N tile while the grid has fewer blocks than this: 7/8 of two blocks per CU (the
+                                 // box head's 504 tiles of 128 columns beat 1008 of 64: +1.1 % end to end, tools/e2e_ab.py)
 static int g_tn4 = -1;       // split modes, 128x128 tile as 4 waves of 32x128: -1 by policy (conv_forward), 0 never, 1 always (tests)
 template <typename T, typename TW, int PARTS = 2>
 static void conv_launch(hipStream_t s, const ConvArgs& a, int bn, bool wide_waves = false)
@@ -404,6 +406,7 @@ bool conv_debug_set(const char* key, int value)
     else if (k == "conv_pp_min_fill") pp_policy().min_fill_pct = value;
     else if (k == "conv_pp_split") pp_policy().split = value;
     else if (k == "conv_tn4") g_tn4 = value;
+    else if (k == "conv_min_blocks") g_min_blocks = value;
     else return false;
     return true;
 }
@@ -416,7 +419,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     const bool split = d.dtype == MRCNN_F32 && (wdtype == MRCNN_F16 || wdtype == MRCNN_F32X3);
     MRCNN_REQUIRE(d.dtype == MRCNN_F32 || half, MRCNN_ERR_UNSUPPORTED, "conv: dtype %d", d.dtype);
     MRCNN_REQUIRE(wdtype == d.dtype || split, MRCNN_ERR_UNSUPPORTED, "conv: activation dtype %d with filter dtype %d", d.dtype, wdtype);
-    const int bk = half ? 64 : 32, es = half ? 2 : 4;
+    const int bk = half ? 64 : 32;
     MRCNN_REQUIRE(d.Cin % bk == 0, MRCNN_ERR_SHAPE, "conv: Cin %d not a multiple of %d", d.Cin, bk);
     ConvArgs a;
     a.in = d.in; a.wgt = d.wgt; a.scale = d.scale; a.shift = d.shift; a.res = d.res; a.out = d.out; a.out2 = d.out2;
@@ -436,13 +439,12 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     a.range_flag = g_range_flag;
     a.dbg = pp_policy().dbg;
     // Tile choice: the widest N tile the packed weights allow, narrowed while the grid would leave
-    // the chip under-filled (< 2 blocks per CU) — C5, the top FPN levels and the small RPN levels.
+    // the chip under-filled (< 7/8 of 2 blocks per CU) — C5, the top FPN levels and the small RPN levels.
     const int bn_max = conv_n_tile(a.ncols);
     MRCNN_REQUIRE(d.Npad % bn_max == 0 && d.Npad >= a.ncols, MRCNN_ERR_SHAPE, "conv: Npad %d incompatible with tile %d", d.Npad, bn_max);
     a.tiles_m = (a.M + BM_DEFAULT - 1) / BM_DEFAULT;
     int bn = bn_max;
-    while (bn > 32 && (long)a.tiles_m * (d.Npad / bn) < 512) bn >>= 1;
-    const size_t out_es = a.out_f32 ? 4 : 2;
+    while (bn > 32 && (long)a.tiles_m * (d.Npad / bn) < g_min_blocks) bn >>= 1;
     auto al = [](const void* p, size_t n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
     const int cpt = half ? 8 : 4;        // columns per epilogue thread: 16 B of the activation type
     a.vec_ok = a.ncols % cpt == 0 && d.out2 == nullptr && d.out_sP % cpt == 0 && d.out_sB % cpt == 0 && al(d.out, 16) &&
