@@ -2,6 +2,7 @@
 // compute mode; kernels_conv_pp.hip: the 256-row ping-pong fp16 tiles): launch arguments, 16-B load/store helpers and the
 // fused epilogue.  Private to libmaskrcnn_hip.so.
 #pragma once
+#include <type_traits>
 #include "kernels.h"
 
 namespace mrcnn {
@@ -24,7 +25,8 @@ struct ConvArgs {
     int vec_ok;          // epilogue may use vector stores / residual loads
     int out_f32;         // store fp32 even when the activations are fp16 (RPN outputs, class logits, masks)
     int* range_flag;         // optional: set to 1 when an output leaves the fp16 range (|v| >= 65504 or NaN)
-    int dbg;                 // ablation switches of the ping-pong kernels (measurement only; 0 in production)
+    int dbg;
+    int direct;              // the layer's epilogue can go straight from the accumulators (conv_epilogue_direct)                 // ablation switches of the ping-pong kernels (measurement only; 0 in production)
 };
 
 static constexpr int BM_DEFAULT = 128;   // rows of the block tile = WM*TM*32
@@ -64,8 +66,13 @@ __device__ __forceinline__ void store8h(_Float16* p, const float4 lo, const floa
     *reinterpret_cast<f16x8*>(p) = h;
 }
 
-// Epilogue shared by the conv kernels: accumulators → LDS (fp32 C tile) → full-row vector stores with
-// fused scale/shift (BN + bias), residual, activation, column split / 2×2 scatter.
+// The kernels issue their MFMAs with the FILTER fragment as first operand: a 32×32 result tile is held transposed — lane
+// (l31, kk) owns output PIXEL l31 of the tile and channels 8q + 4kk + r (q, r = 0..3), i.e. element e = 4q + r of the
+// accumulator vector: runs of four consecutive channels of one pixel.
+//
+// conv_epilogue (general path): accumulators → LDS (fp32 C tile, rows padded by 16 B so that the 16-B run writes of a
+// half-wave — one pixel row per lane — fall in distinct banks) → full-row vector stores with fused scale/shift (BN + bias),
+// residual, activation, column split / 2×2 scatter.  conv_epilogue_direct (below): the common case without the LDS round trip.
 // CPASS = 1: the whole BM×BN tile is staged at once; CPASS = WN (tiles whose fp32 C tile would not fit
 // beside a second block: 128×256): one pass per wave column, BM × TN·32 columns each.
 template <typename T, int BN, int TM, int TN, int WM, int WN, int CPASS>
@@ -74,7 +81,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
     static_assert(CPASS == 1 || CPASS == WN, "column passes");
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32;
-    constexpr int CW = BN / CPASS;     // columns staged per pass = row length of the LDS C tile
+    constexpr int CW = BN / CPASS;     // columns staged per pass
+    constexpr int CWP = CW + 4;        // row length of the LDS C tile (floats)
     const int t = threadIdx.x;
     const int wave = t >> 6, lane = t & 63;
     const int wm = wave / WN, wn = wave - wm * WN;
@@ -143,9 +151,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
-                        Cs[row * CW + (CPASS == 1 ? wn * TN * 32 : 0) + j * 32 + l31] = acc[i][j][e];
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = wm * TM * 32 + i * 32 + l31;                                              // pixel
+                        const int col = (CPASS == 1 ? wn * TN * 32 : 0) + j * 32 + 8 * q + 4 * kk;                // channel run
+                        *reinterpret_cast<float4*>(&Cs[row * CWP + col]) =
+                            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
                     }
         }
         __syncthreads();
@@ -165,7 +175,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
                 float4 v[NV];
 #pragma unroll
                 for (int q = 0; q < NV; ++q) {
-                    float4 x = *reinterpret_cast<const float4*>(&Cs[r * CW + c4 * CPT + 4 * q]);
+                    float4 x = *reinterpret_cast<const float4*>(&Cs[r * CWP + c4 * CPT + 4 * q]);
                     x.x = x.x * sc[q].x + sh[q].x; x.y = x.y * sc[q].y + sh[q].y; x.z = x.z * sc[q].z + sh[q].z; x.w = x.w * sc[q].w + sh[q].w;
                     if (res) { x.x += rv[ps][q].x; x.y += rv[ps][q].y; x.z += rv[ps][q].z; x.w += rv[ps][q].w; }
                     if (a.act == ACT_RELU) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
@@ -195,7 +205,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
                 for (int c = 0; c < CPT; ++c) {
                     const int nn = n + c;
                     if (nn >= a.ncols) break;
-                    float v = Cs[r * CW + c4 * CPT + c];
+                    float v = Cs[r * CWP + c4 * CPT + c];
                     v = v * (a.scale ? a.scale[nn] : 1.0f) + (a.shift ? a.shift[nn] : 0.0f);
                     if (res) {
                         long ro;
@@ -219,6 +229,111 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
                     }
                     if (a.out_f32) static_cast<float*>(dst)[o] = v;
                     else static_cast<T*>(dst)[o] = (T)v;
+                }
+            }
+        }
+    }
+    if (a.range_flag && out_of_range) atomicOr(a.range_flag, 1);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// conv_epilogue_direct: the common epilogue (vectorisable output, no column split, no 2×2 scatter, no sigmoid) straight
+// from the transposed accumulators — no LDS staging, no barrier.  Per run of four channels: fused scale/shift (+ residual)
+// + ReLU in fp32 in exactly the order conv_epilogue applies them (bit-identical results).  fp32 tensors: one 16-B store per
+// run.  fp16 tensors: one rounding, then per pair of runs (q = 2p, 2p+1) a v_permlane32_swap between the half-waves glues
+// the pieces into 16 contiguous bytes per lane (cdna guide T21): a wave writes 64-B pieces of a pixel's channel line in
+// back-to-back stores.  Short-K layers (the bottleneck blocks' 1×1 convolutions) spend most of their time here: against the
+// LDS-staged form this is ≈ 2.5× fewer instructions per output (measured: DESIGN.md §3.1).
+//   tab: scale[BN] | shift[BN] of the block's columns in LDS (written by the kernel before its first barrier);
+//   row0 = first pixel row of the wave tile (absolute), colrel0 = its first column relative to the block tile.
+// The residual of the whole wave tile is requested before the first store (`res` and `out` may alias as far as the
+// compiler knows: a load behind a store waits for it).
+// ----------------------------------------------------------------------------------------------------------------
+template <typename T, int BN, int TMS, int TNS>
+__device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x16 (&acc)[TMS][TNS], const float* tab, int row0, int n0, int colrel0, int lane)
+{
+    using Raw = std::conditional_t<sizeof(T) == 4, float4, uint2>;          // four residual elements as loaded
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int ohw = a.OH * a.OW;
+    const T* const res = static_cast<const T*>(a.res);
+    T* const out = static_cast<T*>(a.out);
+    const bool dense_out = a.out_sB == (long)ohw * a.out_sP;
+    const bool dense_res = a.res_sB == (long)ohw * a.res_sW && a.res_shift == 0;
+    const bool relu = a.act == ACT_RELU;
+    bool out_of_range = false;
+#pragma unroll
+    for (int i = 0; i < TMS; ++i) {
+        const int m = row0 + i * 32 + l31;
+        const bool ok_mi = m < a.M;
+        long o_row = (long)m * a.out_sP, r_row = (long)m * a.res_sW;
+        if (!dense_out || (res && !dense_res)) {
+            const int mm = ok_mi ? m : 0;
+            const int b = mm / ohw, pix = mm - b * ohw;
+            o_row = (long)b * a.out_sB + (long)pix * a.out_sP;
+            if (res) {
+                if (a.res_shift) {
+                    const int oh = pix / a.OW, ow = pix - oh * a.OW;
+                    r_row = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
+                } else r_row = (long)b * a.res_sB + (long)pix * a.res_sW;
+            }
+        }
+        Raw rr[TNS][2][2];
+        if (res) {
+#pragma unroll
+            for (int j = 0; j < TNS; ++j)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int ca = n0 + colrel0 + j * 32 + 16 * p + 4 * kk, cb = ca + 8;
+                    rr[j][p][0] = Raw{}; rr[j][p][1] = Raw{};
+                    if (ok_mi && ca < a.ncols) rr[j][p][0] = *reinterpret_cast<const Raw*>(res + r_row + ca);
+                    if (ok_mi && cb < a.ncols) rr[j][p][1] = *reinterpret_cast<const Raw*>(res + r_row + cb);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < TNS; ++j) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int cl = colrel0 + j * 32 + 16 * p + 4 * kk;          // column inside the block tile
+                const int ca = n0 + cl, cb = ca + 8;
+                const float4 sa = *reinterpret_cast<const float4*>(tab + cl), sb_ = *reinterpret_cast<const float4*>(tab + cl + 8);
+                const float4 ha = *reinterpret_cast<const float4*>(tab + BN + cl), hb = *reinterpret_cast<const float4*>(tab + BN + cl + 8);
+                float4 va = make_float4(acc[i][j][8 * p + 0], acc[i][j][8 * p + 1], acc[i][j][8 * p + 2], acc[i][j][8 * p + 3]);
+                float4 vb = make_float4(acc[i][j][8 * p + 4], acc[i][j][8 * p + 5], acc[i][j][8 * p + 6], acc[i][j][8 * p + 7]);
+                va.x = va.x * sa.x + ha.x; va.y = va.y * sa.y + ha.y; va.z = va.z * sa.z + ha.z; va.w = va.w * sa.w + ha.w;
+                vb.x = vb.x * sb_.x + hb.x; vb.y = vb.y * sb_.y + hb.y; vb.z = vb.z * sb_.z + hb.z; vb.w = vb.w * sb_.w + hb.w;
+                const bool ok_a = ok_mi && ca < a.ncols, ok_b = ok_mi && cb < a.ncols;
+                if (res) {
+                    float4 ra, rb;
+                    if constexpr (sizeof(T) == 4) { ra = rr[j][p][0]; rb = rr[j][p][1]; }
+                    else {
+                        const f16x4 h0 = __builtin_bit_cast(f16x4, rr[j][p][0]), h1 = __builtin_bit_cast(f16x4, rr[j][p][1]);
+                        ra = make_float4((float)h0[0], (float)h0[1], (float)h0[2], (float)h0[3]);
+                        rb = make_float4((float)h1[0], (float)h1[1], (float)h1[2], (float)h1[3]);
+                    }
+                    va.x += ra.x; va.y += ra.y; va.z += ra.z; va.w += ra.w;
+                    vb.x += rb.x; vb.y += rb.y; vb.z += rb.z; vb.w += rb.w;
+                }
+                if (relu) {
+                    va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f); va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
+                    vb.x = fmaxf(vb.x, 0.f); vb.y = fmaxf(vb.y, 0.f); vb.z = fmaxf(vb.z, 0.f); vb.w = fmaxf(vb.w, 0.f);
+                }
+                // fp16-range watchdog (|v| >= 65504, inf or NaN)
+                if (ok_a) out_of_range = out_of_range || !(fabsf(va.x) < 65504.0f) || !(fabsf(va.y) < 65504.0f) || !(fabsf(va.z) < 65504.0f) || !(fabsf(va.w) < 65504.0f);
+                if (ok_b) out_of_range = out_of_range || !(fabsf(vb.x) < 65504.0f) || !(fabsf(vb.y) < 65504.0f) || !(fabsf(vb.z) < 65504.0f) || !(fabsf(vb.w) < 65504.0f);
+                if constexpr (sizeof(T) == 4) {
+                    if (ok_a) *reinterpret_cast<float4*>(out + o_row + ca) = va;
+                    if (ok_b) *reinterpret_cast<float4*>(out + o_row + cb) = vb;
+                } else {
+                    f16x4 ha4, hb4;
+                    ha4[0] = (_Float16)va.x; ha4[1] = (_Float16)va.y; ha4[2] = (_Float16)va.z; ha4[3] = (_Float16)va.w;
+                    hb4[0] = (_Float16)vb.x; hb4[1] = (_Float16)vb.y; hb4[2] = (_Float16)vb.z; hb4[3] = (_Float16)vb.w;
+                    const uint2 pa = __builtin_bit_cast(uint2, ha4), pb = __builtin_bit_cast(uint2, hb4);
+                    // upper half-wave's q = 2p runs <-> lower half-wave's q = 2p+1 runs
+                    const auto sx = __builtin_amdgcn_permlane32_swap(pa.x, pb.x, false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(pa.y, pb.y, false, false);
+                    const int n_store = n0 + colrel0 + j * 32 + 16 * p + 8 * kk;
+                    if (ok_mi && n_store < a.ncols)
+                        *reinterpret_cast<uint4*>(out + o_row + n_store) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
                 }
             }
         }

@@ -45,7 +45,7 @@ namespace mrcnn {
 //     (k+1)&1 and lands while tile k is being multiplied; one vmcnt(0) + barrier per K step.
 // ------------------------------------------------------------------------------------------------
 template <typename T, typename TW, int BN, int TM, int TN, int WM, int WN, int STAGES, int PARTS = 2>
-__global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs a)
+__global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfma_glds(const ConvArgs a)     // two blocks per CU
 {
     // SPLIT: fp32 activations × fp16 filters as PARTS (2 or 3) fp16 MFMA passes over a split of the activations
     constexpr bool SPLIT = sizeof(T) == 4 && sizeof(TW) == 2;
@@ -65,12 +65,14 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
     constexpr int BROWB = SPLIT ? 64 : 128;                     // bytes of one filter row per K step
     constexpr int A_STAGE = BM * ROWB, B_STAGE = BN * BROWB;
     constexpr int CPASS = BM * BN * 4 > 64 * 1024 ? WN : 1;    // column passes of the epilogue (fp32 C tile of at most 64 KB)
-    constexpr int C_BYTES = BM * (BN / CPASS) * 4;
+    constexpr int C_BYTES = BM * (BN / CPASS + 4) * 4;         // rows padded by 16 B (conv_epilogue)
     static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
     constexpr int NLOADS = SPLIT ? AP : AP + BP;                // DMA instructions per tile per thread (SPLIT: waves past BN/16 issue no filter DMA)
     constexpr int SMEM_OPS = STAGES * (A_STAGE + B_STAGE);      // ring of operand buffers
     constexpr int SMEM = SMEM_OPS > C_BYTES ? SMEM_OPS : C_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    constexpr bool DIRECT_OK = CPASS == 1 && BN >= 64;                 // (the 32-wide tiles fill the LDS of two blocks to the byte)
+    __shared__ __attribute__((aligned(16))) float s_tab[DIRECT_OK ? 2 * BN : 4];       // scale | shift of the block's columns (direct epilogue)
     const T* const in = static_cast<const T*>(a.in);
     const TW* const wgt = static_cast<const TW*>(a.wgt);
 
@@ -200,6 +202,15 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
     // NLOADS·(STAGES-2) most recent DMAs stay outstanding across the barrier.  STAGES = 2 for the
     // 128-wide tile (a step is 2048 MFMA cycles per wave, longer than the DMA latency); the narrow
     // tiles run on under-filled grids with short steps and use deeper rings.
+    // direct epilogue (conv_device.h): its scale / shift table goes to LDS before the first barrier
+    const bool direct = DIRECT_OK && a.direct;
+    if (direct && t < BN / 2) {
+        const int c = (t < BN / 4 ? t : t - BN / 4) * 4;
+        const float* src = t < BN / 4 ? a.scale : a.shift;
+        const float fill = t < BN / 4 ? 1.0f : 0.0f;
+        *reinterpret_cast<float4*>(&s_tab[(t < BN / 4 ? 0 : BN) + c]) =
+            src ? *reinterpret_cast<const float4*>(src + n0 + c) : make_float4(fill, fill, fill, fill);
+    }
     MRCNN_DMA_TILE(0, 0)
     if (STAGES > 2 && KT > 1) MRCNN_DMA_TILE(1, 1)
     if (STAGES > 3 && KT > 2) MRCNN_DMA_TILE(2, 2)
@@ -240,13 +251,13 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
                     _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                           \
                         const uint32_t au = c == 0 ? av[G][i].x : c == 1 ? av[G][i].y : c == 2 ? av[G][i].z : av[G][i].w;  \
                         const uint32_t bu = c == 0 ? bv[G][j].x : c == 1 ? bv[G][j].y : c == 2 ? bv[G][j].z : bv[G][j].w;  \
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(au), __uint_as_float(bu), acc[i][j], 0, 0, 0); \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(bu), __uint_as_float(au), acc[i][j], 0, 0, 0); \
                     }                                                                                          \
         } else {                                                                                               \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                     \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[G][i]),    \
-                                                                       __builtin_bit_cast(f16x8, bv[G][j]), acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bv[G][j]),    \
+                                                                       __builtin_bit_cast(f16x8, av[G][i]), acc[i][j], 0, 0, 0); \
         }                                                                                                      \
     }
 #define MRCNN_KMATH_SPLIT(G)                                                                                   \
@@ -255,12 +266,12 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
         if constexpr (PARTS == 3) split_hi_mid_lo(av[2 * G][i], av[2 * G + 1][i], hi, lo, lo2);                \
         else split_hi_lo(av[2 * G][i], av[2 * G + 1][i], hi, lo);                                              \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                         \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, __builtin_bit_cast(f16x8, bv[G][j]), acc[i][j], 0, 0, 0); \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bv[G][j]), hi, acc[i][j], 0, 0, 0); \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                         \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo, __builtin_bit_cast(f16x8, bv[G][j]), acc[i][j], 0, 0, 0); \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bv[G][j]), lo, acc[i][j], 0, 0, 0); \
         if constexpr (PARTS == 3) {                                                                            \
             _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                     \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo2, __builtin_bit_cast(f16x8, bv[G][j]), acc[i][j], 0, 0, 0); \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bv[G][j]), lo2, acc[i][j], 0, 0, 0); \
         }                                                                                                      \
     }
 #define MRCNN_STEP(BUF, NBUF, KTV)                                                                             \
@@ -298,6 +309,9 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_mfma_glds(const ConvArgs 
 #undef MRCNN_GLDS_V
 #undef MRCNN_GLDS_S
 #undef MRCNN_SET_TAP
+    if constexpr (DIRECT_OK) {
+        if (direct) { conv_epilogue_direct<T, BN, TM, TN>(a, acc, s_tab, m0 + wm * TM * 32, n0, wn * TN * 32, lane); return; }
+    }
     conv_epilogue<T, BN, TM, TN, WM, WN, CPASS>(a, acc, smem, m0, n0);
 }
 
@@ -351,6 +365,7 @@ int conv_n_tile(int Cout)
 
 static int g_min_blocks = 448;   // narrow the N tile while the grid has fewer blocks than this: 7/8 of two blocks per CU (the
                                  // box head's 504 tiles of 128 columns beat 1008 of 64: +1.1 % end to end, tools/e2e_ab.py)
+static int g_direct = 1;         // 0: every layer through the LDS-staged epilogue; 1: fp16 tensors direct; 2: all modes direct (A/B, tests)
 static int g_tn4 = -1;       // split modes, 128x128 tile as 4 waves of 32x128: -1 by policy (conv_forward), 0 never, 1 always (tests)
 template <typename T, typename TW, int PARTS = 2>
 static void conv_launch(hipStream_t s, const ConvArgs& a, int bn, bool wide_waves = false)
@@ -406,6 +421,7 @@ bool conv_debug_set(const char* key, int value)
     else if (k == "conv_pp_min_fill") pp_policy().min_fill_pct = value;
     else if (k == "conv_pp_split") pp_policy().split = value;
     else if (k == "conv_tn4") g_tn4 = value;
+    else if (k == "conv_direct") g_direct = value;
     else if (k == "conv_min_blocks") g_min_blocks = value;
     else return false;
     return true;
@@ -452,6 +468,10 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
                (!d.res || (d.res_sW % cpt == 0 && d.res_sH % cpt == 0 && d.res_sB % cpt == 0 && al(d.res, 16))) &&
                (!d.deconv2 || (d.Cout % cpt == 0 && d.out_sH % cpt == 0 && d.out_sW % cpt == 0));
     a.tiles_n = d.Npad / bn;
+    // Direct epilogue: fp16 tensors only by default (g_direct = 1).  With fp32 tensors a lane's 16-B store holds four channels of
+    // one pixel — 64 scattered pieces per store instruction — and the LDS-staged full-row stores win by 1.4 % end to end
+    // (tools/e2e_ab.py f32x3 conv_direct 0 1); with fp16 tensors (eight channels per store) the direct form wins by 0.9 %.
+    a.direct = (g_direct && (half || g_direct > 1) && a.vec_ok && !d.out2 && !d.deconv2 && d.act != ACT_SIGMOID && (!half || !a.out_f32)) ? 1 : 0;
     // Layers with a large GEMM: the 256×256 persistent ping-pong kernel (kernels_conv_pp.hip), one block per CU — when the
     // tiles fill whole rounds of the chip well enough (a static walk: the last round costs as much as a full one).
     int pp_bn = 0;

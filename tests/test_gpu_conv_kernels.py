@@ -116,6 +116,46 @@ def test_wide_wave_variant_equals_the_eight_wave_tile_bitwise(shape, dtype):
     np.testing.assert_array_equal(y1, y0)
 
 
+@pytest.mark.parametrize("dtype", ["f16", "f32", "f32s", "f32x3"])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 256, 256, 1, 1, True), (1, 72, 56, 128, 300, 3, 1, True), (3, 40, 40, 64, 128, 1, 2, False),
+                                   (1, 33, 47, 192, 64, 3, 1, True)])
+def test_direct_epilogue_equals_the_lds_staged_epilogue_bitwise(shape, dtype):
+    """The epilogue straight from the (transposed) accumulators — the default for fp16 tensors — against the LDS-staged
+    full-row form (the default for fp32 tensors), forced either way in every mode: ragged M, ragged N (vector stores still
+    possible), residual, stride 2, 64- and 128-wide tiles."""
+    B, H, W, Ci, Co, k, stride, with_res = shape
+    rng = np.random.default_rng(sum(shape) + 5)
+    x = rng.standard_normal((B, H, W, Ci), np.float32)
+    w = (rng.standard_normal((Co, k, k, Ci), np.float32) * np.float32(1.0 / np.sqrt(k * k * Ci)))
+    scale = (0.5 + rng.random(Co)).astype(np.float32)
+    shift = rng.standard_normal(Co).astype(np.float32) * np.float32(0.1)
+    oh, ow = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    res = rng.standard_normal((B, oh, ow, Co), np.float32) if with_res else None
+    lib = L.lib()
+    try:
+        L.check(lib.mrcnn_debug_set(b"conv_pp", 0))
+        L.check(lib.mrcnn_debug_set(b"conv_direct", 0))
+        y0 = conv(x, w, k, stride, scale, shift, res, 1, dtype)
+        L.check(lib.mrcnn_debug_set(b"conv_direct", 2))
+        y1 = conv(x, w, k, stride, scale, shift, res, 1, dtype)
+    finally:
+        L.check(lib.mrcnn_debug_set(b"conv_direct", 1))
+        L.check(lib.mrcnn_debug_set(b"conv_pp", 1))
+    np.testing.assert_array_equal(y1, y0)
+    ref = torch_ref(x, w, k, stride, scale, shift, res, 1, dtype if dtype != "f32" else "f32s")
+    if dtype == "f32":          # exact-fp32 MFMA on fp32 filters: the reference must not round the filters to fp16
+        import torch
+        import torch.nn.functional as F
+        t = lambda a: torch.from_numpy(np.asarray(a, np.float64))
+        r = F.conv2d(t(x).permute(0, 3, 1, 2), t(w).permute(0, 3, 1, 2), stride=stride, padding=k // 2)
+        r = r * t(scale)[None, :, None, None] + t(shift)[None, :, None, None]
+        if res is not None:
+            r = r + t(res).permute(0, 3, 1, 2)
+        ref = F.relu(r).permute(0, 2, 3, 1).contiguous().numpy()
+    tol = {"f16": 2e-3, "f32": 2e-5, "f32s": 2e-5, "f32x3": 1e-5}[dtype]
+    assert np.abs(y1 - ref).max() <= tol * max(1.0, np.abs(ref).max()), (np.abs(y1 - ref).max(), np.abs(ref).max())
+
+
 @pytest.mark.parametrize("dtype", ["f16", "f32x3"])
 def test_pingpong_kernel_repeatable_under_load(dtype):
     """Race screen of the hand-placed DMA / barrier schedule: the same launch repeated must give the same bits, on a
