@@ -113,19 +113,26 @@ __device__ __forceinline__ double iou_threshold_midpoint(float thr)
     if (!(thr >= 0.0f) || !(thr < 3.0e38f)) return -1.0;
     return 0.5 * ((double)thr + (double)__uint_as_float(__float_as_uint(thr) + 1u));
 }
-__device__ __forceinline__ bool iou_exceeds(float4 fa, float4 fb, float thr, double thr_mid)
+// The per-box half of the IoU (standardized CGRect extents and area, Utils.swift:220-235), computed once per box.
+struct RectExt {
+    double minx, maxx, miny, maxy, area;
+};
+__device__ __forceinline__ RectExt rect_ext(float4 f)
 {
-    const RectD a = rect_from(fa), b = rect_from(fb);
-    const double areaA = fabs(a.w) * fabs(a.h);
+    const RectD a = rect_from(f);
+    RectExt e;
+    e.area = fabs(a.w) * fabs(a.h);
+    e.minx = a.w < 0 ? a.x + a.w : a.x; e.maxx = a.w < 0 ? a.x : a.x + a.w;
+    e.miny = a.h < 0 ? a.y + a.h : a.y; e.maxy = a.h < 0 ? a.y : a.y + a.h;
+    return e;
+}
+__device__ __forceinline__ bool iou_exceeds(const RectExt& a, const RectExt& b, float thr, double thr_mid)
+{
+    const double areaA = a.area, areaB = b.area;
     if (areaA <= 0) return 0.0f > thr;
-    const double areaB = fabs(b.w) * fabs(b.h);
     if (areaB <= 0) return 0.0f > thr;
-    const double aminx = a.w < 0 ? a.x + a.w : a.x, amaxx = a.w < 0 ? a.x : a.x + a.w;
-    const double aminy = a.h < 0 ? a.y + a.h : a.y, amaxy = a.h < 0 ? a.y : a.y + a.h;
-    const double bminx = b.w < 0 ? b.x + b.w : b.x, bmaxx = b.w < 0 ? b.x : b.x + b.w;
-    const double bminy = b.h < 0 ? b.y + b.h : b.y, bmaxy = b.h < 0 ? b.y : b.y + b.h;
-    const double ix0 = fmax(aminx, bminx), iy0 = fmax(aminy, bminy);
-    const double ix1 = fmin(amaxx, bmaxx), iy1 = fmin(amaxy, bmaxy);
+    const double ix0 = fmax(a.minx, b.minx), iy0 = fmax(a.miny, b.miny);
+    const double ix1 = fmin(a.maxx, b.maxx), iy1 = fmin(a.maxy, b.maxy);
     const double inter = fmax(iy1 - iy0, 0.0) * fmax(ix1 - ix0, 0.0);
     const double uni = areaA + areaB - inter;
     if (thr_mid >= 0.0) {

@@ -376,7 +376,7 @@ __global__ __launch_bounds__(1024) void k_sort_decode_lds(const uint64_t* __rest
 //   1. every (row, column) pair through the exact FLOAT disjointness test (6 VALU per pair on pre-sorted corners,
 //      column box broadcast from LDS) → a 64-bit candidate word per row;
 //   2. each lane walks ITS candidates only (ctz loop) through the fp64 IoU decision (iou_exceeds: the reference's
-//      Double arithmetic, the division only in borderline cases).
+//      Double arithmetic on per-box extents computed once, the division only in borderline cases).
 // Round 1 ran one 64-thread block per (rb, cb) pair and sent EVERY column through the fp64 IoU with its division whenever
 // one of the 64 rows overlapped it (almost always, with a handful of lanes active): 256 us per batch of 8 x 6000 boxes.
 // ------------------------------------------------------------------------------------------------
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxe
                                                   const int32_t* __restrict__ n_dev, int n_const, float thr,
                                                   uint64_t* __restrict__ mask, long mask_sB, int W)
 {
-    __shared__ float4 s_raw[4][64];      // (y1, x1, y2, x2) of the wave's column chunk
+    __shared__ double s_ext[4][5][64];   // standardized extents + area of the wave's column chunk (RectExt, one array per field)
     __shared__ float4 s_srt[4][64];      // (min y, min x, max y, max x)
     __shared__ int32_t s_cls[4][64];
     const int rb = blockIdx.x, b = blockIdx.z, lane = threadIdx.x & 63;
@@ -398,6 +398,7 @@ __global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxe
     const bool in_i = i < n;
     const float4 me = in_i ? *reinterpret_cast<const float4*>(bx + (size_t)i * 4) : make_float4(0, 0, 0, 0);
     const float4 ms = make_float4(fminf(me.x, me.z), fminf(me.y, me.w), fmaxf(me.x, me.z), fmaxf(me.y, me.w));
+    const RectExt me_ext = rect_ext(me);
     const int mycls = (cls && in_i) ? cls[(size_t)b * cls_sB + i] : 0;
     const bool pretest = thr >= 0.0f;     // IOU() == 0 > thr holds for a caller-supplied thr < 0: then every pair is a candidate
     const double thr_mid = iou_threshold_midpoint(thr);
@@ -405,7 +406,11 @@ __global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxe
     for (int cb = rb + 4 * (int)blockIdx.y + wv; cb < nW; cb += stride) {
         const int cj = cb * 64 + lane;
         const float4 cv = cj < n ? *reinterpret_cast<const float4*>(bx + (size_t)cj * 4) : make_float4(0, 0, 0, 0);
-        s_raw[wv][lane] = cv;
+        {
+            const RectExt ce = rect_ext(cv);
+            s_ext[wv][0][lane] = ce.minx; s_ext[wv][1][lane] = ce.maxx; s_ext[wv][2][lane] = ce.miny; s_ext[wv][3][lane] = ce.maxy;
+            s_ext[wv][4][lane] = ce.area;
+        }
         s_srt[wv][lane] = make_float4(fminf(cv.x, cv.z), fminf(cv.y, cv.w), fmaxf(cv.x, cv.z), fmaxf(cv.y, cv.w));
         if (cls) s_cls[wv][lane] = cj < n ? cls[(size_t)b * cls_sB + cj] : 0;
         const int jn = min(64, n - cb * 64);
@@ -423,7 +428,8 @@ __global__ __launch_bounds__(256) void k_nms_mask(const float* __restrict__ boxe
         while (cand != 0ull) {
             const int j = __builtin_ctzll(cand);
             cand &= cand - 1;
-            if (iou_exceeds(s_raw[wv][j], me, thr, thr_mid)) bits |= 1ull << j;      // IOU(anchorA = candidate, anchorB = selected)
+            const RectExt ce = {s_ext[wv][0][j], s_ext[wv][1][j], s_ext[wv][2][j], s_ext[wv][3][j], s_ext[wv][4][j]};
+            if (iou_exceeds(ce, me_ext, thr, thr_mid)) bits |= 1ull << j;            // IOU(anchorA = candidate, anchorB = selected)
         }
         if (in_i) mask[(size_t)b * mask_sB + (size_t)i * W + cb] = bits;
     }
