@@ -331,6 +331,16 @@ def test_detection_agreement_separates_masks_behind_a_dropped_row(pkg):
     assert r["masks_behind_presence_mismatch"] == 2 and abs(r["max_mask_diff_behind_presence_mismatch"] - 0.4) < 1e-6
 
 
+def test_bench_sustained_peak_reads_the_committed_probe():
+    """bench.py's `roofline.sustained_peak` comes from the committed probe output (profiles/r02_mfma_power.txt): the fp16 MFMA
+    rate on changing operands divided by the passes a product takes; the fp32 MFMA rate for the fp32 mode."""
+    import bench
+    sp = bench.sustained_peak("f32x3", 3, 300.0)
+    assert sp is not None and 400 < sp["value"] < 700 and abs(sp["frac"] - 300.0 / sp["value"]) < 1e-3
+    assert abs(bench.sustained_peak("f16", 1, 500.0)["value"] - 3 * sp["value"]) < 1.0
+    assert 140 < bench.sustained_peak("f32", 1, 100.0)["value"] < 160
+
+
 def test_bench_host_core_count():
     import bench
     physical, logical = bench.host_cores()
