@@ -26,7 +26,8 @@ struct ConvArgs {
     int out_f32;         // store fp32 even when the activations are fp16 (RPN outputs, class logits, masks)
     int* range_flag;         // optional: set to 1 when an output leaves the fp16 range (|v| >= 65504 or NaN)
     int dbg;
-    int direct;              // the layer's epilogue can go straight from the accumulators (conv_epilogue_direct)                 // ablation switches of the ping-pong kernels (measurement only; 0 in production)
+    int direct;              // the layer's epilogue can go straight from the accumulators (conv_epilogue_direct)
+    const float* sel_w; const int32_t* sel_cid; float* sel_partial;      // deconv2: selected-class dot instead of the store (ConvDesc)                 // ablation switches of the ping-pong kernels (measurement only; 0 in production)
 };
 
 static constexpr int BM_DEFAULT = 128;   // rows of the block tile = WM*TM*32
@@ -185,6 +186,31 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
                     }
                     out_of_range = out_of_range || !(fabsf(x.x) < 65504.0f) || !(fabsf(x.y) < 65504.0f) || !(fabsf(x.z) < 65504.0f) || !(fabsf(x.w) < 65504.0f);
                     v[q] = x;
+                }
+                if (a.sel_partial) {
+                    // selected-class dot over this thread's channels, then over the TPR threads of the row (a 128-channel part of
+                    // one output pixel); fixed order: identical for every batch size
+                    const int cid = a.sel_cid[b];
+                    float dot = 0.f;
+                    if (cid >= 0) {
+                        const float* wr = a.sel_w + (size_t)cid * a.Cout + co;
+#pragma unroll
+                        for (int q = 0; q < NV; ++q) {
+                            float4 x = v[q];
+                            if constexpr (sizeof(T) == 2) {          // the value the fp16 tensor would have held
+                                x.x = (float)(_Float16)x.x; x.y = (float)(_Float16)x.y; x.z = (float)(_Float16)x.z; x.w = (float)(_Float16)x.w;
+                            }
+                            const float4 y = *reinterpret_cast<const float4*>(wr + 4 * q);
+                            dot += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+                        }
+                    }
+#pragma unroll
+                    for (int o = TPR / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, TPR);
+                    if (c4 == 0 && cid >= 0) {
+                        const long P = (long)(2 * oh + (qd >> 1)) * (2 * a.OW) + (2 * ow + (qd & 1));
+                        a.sel_partial[((long)b * 4 * ohw + P) * (a.Cout / 128) + co / 128] = dot;
+                    }
+                    continue;
                 }
                 long o;
                 if (a.deconv2) o = (long)b * a.out_sB + (long)(2 * oh + (qd >> 1)) * a.out_sH + (long)(2 * ow + (qd & 1)) * a.out_sW + co;

@@ -100,10 +100,13 @@ struct MaskHead {
     int mode = MRCNN_F32;          // compute mode the head was loaded with (MRCNN_F32 | MRCNN_F16 | MRCNN_F32S)
     void load(const MrcwFile& f, int capacity_rows, int mode);
     // pooled: n rows of 14*14*C NHWC → feat (n, 28*28, C) = ReLU(deconv)
-    void forward_features(hipStream_t s, const void* pooled_nhwc, int n);
+    // sel_partial != nullptr: the deconvolution leaves the selected-class partial dots instead of feat (ConvDesc::sel_partial)
+    void forward_features(hipStream_t s, const void* pooled_nhwc, int n, const int32_t* sel_cid = nullptr, float* sel_partial = nullptr);
     // feat → all-class sigmoid masks, NHWC (n, 784, nc) in `full`
     void forward_full(hipStream_t s, int n);
 };
+
+bool engine_debug_set(const char* key, int value);     // "mask_fused"
 
 struct StageTimer {
     bool enabled = false;
@@ -150,6 +153,8 @@ struct Model {
     ProposalWorkspace prop_ws;
     DetectionWorkspace det_ws;
     MaskSelectWorkspace msel_ws;
+    float* mask_partial = nullptr;     // [B][max_det][28*28][2] partial selected-class dots of the fused mask tail
+    bool fuse_mask_tail = true;        // MRCNN_FUSE_MASK_TAIL=0 / mrcnn_debug_set("mask_fused", 0): deconvolution output + k_mask_select
     StageTimer timer;
     ConvProfile conv_profile;
     // Optional: the ~200 launches of one predict captured once per batch size and replayed as a hipGraph

@@ -446,7 +446,15 @@ void MaskHead::load(const MrcwFile& f, int capacity_rows, int dtype_)
     }
 }
 
-void MaskHead::forward_features(hipStream_t s, const void* pooled_nhwc, int n)
+// process-wide A/B switch of the fused mask tail (tests, tools/e2e_ab.py): mrcnn_debug_set("mask_fused", 0 | 1)
+static int g_fuse_mask_tail = 1;
+bool engine_debug_set(const char* key, int value)
+{
+    if (std::string(key) == "mask_fused") { g_fuse_mask_tail = value; return true; }
+    return false;
+}
+
+void MaskHead::forward_features(hipStream_t s, const void* pooled_nhwc, int n, const int32_t* sel_cid, float* sel_partial)
 {
     MRCNN_REQUIRE(n <= cap, MRCNN_ERR_SHAPE, "mask head: %d rows exceed capacity %d", n, cap);
     if (n <= 0) return;
@@ -465,6 +473,7 @@ void MaskHead::forward_features(hipStream_t s, const void* pooled_nhwc, int n)
     d.deconv2 = 1; d.act = ACT_RELU;
     d.out = feat; d.out_sW = Co; d.out_sH = (long)2 * pool * Co; d.out_sB = (long)4 * pool * pool * Co;
     d.out_sP = Co;
+    if (sel_partial) { d.sel_w = final_w.as<float>(); d.sel_cid = sel_cid; d.sel_partial = sel_partial; }   // feat is not written
     conv_forward(s, d);
 }
 
@@ -560,6 +569,7 @@ void Model::load(int kind_, const std::string& path, int max_batch_, int dtype_)
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     own_stream = true;
     if (const char* e = getenv("MRCNN_GRAPH")) use_graph = atoi(e) != 0;
+    if (const char* e = getenv("MRCNN_FUSE_MASK_TAIL")) fuse_mask_tail = atoi(e) != 0;
     boxes_one_time_init();
     range_flag.alloc(sizeof(int));
     HIP_CHECK(hipMemset(range_flag.p, 0, sizeof(int)));
@@ -806,6 +816,8 @@ void Model::build_maskrcnn()
         msel_ws.flags = (int32_t*)ar.alloc_b((size_t)Bm * max_det * 4);
         msel_ws.mapping = (int32_t*)ar.alloc_b((size_t)Bm * max_det * 4);
         msel_ws.kept = (int32_t*)ar.alloc_b((size_t)Bm * 4);
+        msel_ws.sel_cid = (int32_t*)ar.alloc_b((size_t)Bm * max_det * 4);
+        mask_partial = ar.alloc_f((size_t)Bm * max_det * 4 * mask_pool * mask_pool * (256 / 128));
         if (real) {
             prop_ws.bind(pws, Bm, A, K, max_prop);
             det_ws.bind(dws, Bm, max_prop, max_det);
@@ -912,13 +924,23 @@ void Model::enqueue_pipeline(hipStream_t s, int batch)
     // TimeDistributedMask
     const int HW = 4 * mask_pool * mask_pool;
     mask_valid_rows_forward(s, nullptr, (long)max_det * mrow, mrow, mrow, max_det, batch, msel_ws, dtype);
-    mask_head.forward_features(s, pooled_mask, batch * max_det);
     // Rows the reference's mask layer never writes (an invalid row below the kept count,
     // TimeDistributedMaskLayer.swift:58-89) hold whatever Core ML's buffer held; here they are defined: zero.
     HIP_CHECK(hipMemsetAsync(mask_out, 0, (size_t)batch * max_det * HW * sizeof(float), s));
-    mask_select_forward(s, mask_head.feat, (long)max_det * HW * mask_head.deconv.Cout, HW, mask_head.deconv.Cout,
-                        mask_head.final_w.as<float>(), mask_head.final_b.as<float>(), nc, detections, (long)max_det * 6, 6, max_det,
-                        batch, msel_ws, mask_out, (long)max_det * HW, HW, dtype);
+    const bool fused_tail = fuse_mask_tail && g_fuse_mask_tail && mask_head.deconv.Cout % 128 == 0;
+    if (fused_tail) {
+        // the deconvolution's epilogue takes the dot with the selected class's 1x1 filter: its 256-channel output (642 MB of
+        // fp32 per batch of 8) is never written nor read back
+        mask_select_classes(s, detections, (long)max_det * 6, 6, max_det, batch, nc, msel_ws, msel_ws.sel_cid);
+        mask_head.forward_features(s, pooled_mask, batch * max_det, msel_ws.sel_cid, mask_partial);
+        mask_select_from_partials(s, mask_partial, mask_head.deconv.Cout / 128, HW, mask_head.final_b.as<float>(), nc, detections,
+                                  (long)max_det * 6, 6, max_det, batch, msel_ws, mask_out, (long)max_det * HW, HW);
+    } else {
+        mask_head.forward_features(s, pooled_mask, batch * max_det);
+        mask_select_forward(s, mask_head.feat, (long)max_det * HW * mask_head.deconv.Cout, HW, mask_head.deconv.Cout,
+                            mask_head.final_w.as<float>(), mask_head.final_b.as<float>(), nc, detections, (long)max_det * 6, 6, max_det,
+                            batch, msel_ws, mask_out, (long)max_det * HW, HW, dtype);
+    }
     timer.mark(s, "TimeDistributedMask-Eval");
     conv_set_profiler(nullptr);
     conv_set_range_flag(nullptr);

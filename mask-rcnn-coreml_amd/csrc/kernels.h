@@ -117,6 +117,13 @@ struct ConvDesc {
     long out_sH = 0, out_sW = 0;  // only used when deconv2
     // algorithmic reduction length per output (defaults to KH*KW*Cin; conv1 pads 147 → 224)
     int algo_k = 0;
+    // deconv2 only — selected-class dot instead of the store (the mask head's last two layers fused): for input image
+    // (= ROI row) b with class sel_cid[b] >= 0, every output pixel P contributes
+    //   sel_partial[(b * 4*OH*OW + P) * (Cout/128) + h] = Σ_{co in 128-channel part h} y[P][co] * sel_w[sel_cid[b]][co]
+    // (y = the activated output, rounded to fp16 first when dtype is MRCNN_F16); nothing is written to `out`.
+    const float* sel_w = nullptr;
+    const int32_t* sel_cid = nullptr;
+    float* sel_partial = nullptr;
 };
 
 // Live per-kernel profile of the conv family: when a profiler is active on the calling thread every
@@ -174,6 +181,7 @@ struct MaskSelectWorkspace {
     int32_t* flags = nullptr;      // [B][D] row is all-nonzero
     int32_t* mapping = nullptr;    // [B][D] compact index → row
     int32_t* kept = nullptr;       // [B]
+    int32_t* sel_cid = nullptr;    // [B][D] class per row for the fused tail (mask_select_classes), -1 = not written
 };
 // flags/mapping of MultiArrayBatchProvider(removeZeros:true): pooled (B, D, row_len) contiguous rows.
 // pooled == nullptr: ws.flags already holds the predicate (written by roi_align_forward's row_flags from the fp32
@@ -185,6 +193,14 @@ void mask_valid_rows_forward(hipStream_t s, const void* pooled, long pooled_sB, 
 void mask_select_forward(hipStream_t s, const void* feat, long feat_sB, int HW, int C, const float* w,
                          const float* bias, int nc, const float* det, long det_sB, long det_stride, int D, int B,
                          const MaskSelectWorkspace& ws, float* out, long out_sB, long out_stride, int dtype);
+// The same result from the partial dots a deconv2 convolution in selected-class mode left (ConvDesc::sel_partial):
+//   mask_select_classes: sel_cid[b*D + row] = the class the layer would use for that row, -1 for rows it does not write;
+//   mask_select_from_partials: sigmoid(Σ_h partial[...][h] + bias[class]) into the rows the layer writes, zero padding as above.
+void mask_select_classes(hipStream_t s, const float* det, long det_sB, long det_stride, int D, int B, int nc,
+                         const MaskSelectWorkspace& ws, int32_t* sel_cid);     // sel_cid = ws.sel_cid in the engine
+void mask_select_from_partials(hipStream_t s, const float* partial, int parts, int HW, const float* bias, int nc, const float* det,
+                               long det_sB, long det_stride, int D, int B, const MaskSelectWorkspace& ws, float* out, long out_sB,
+                               long out_stride);
 // Variant for precomputed per-class masks (n_kept-compacted or in-place), used by the stand-alone layer:
 // masks (B, D, nc, HW) in place (row r of the batch = detection r).
 void mask_select_from_full_forward(hipStream_t s, const float* masks, long masks_sB, int HW, int nc,

@@ -454,13 +454,16 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     a.out_f32 = (!half || d.out_f32) ? 1 : 0;
     a.range_flag = g_range_flag;
     a.dbg = pp_policy().dbg;
+    a.sel_w = d.sel_w; a.sel_cid = d.sel_cid; a.sel_partial = d.sel_partial;
+    MRCNN_REQUIRE(!d.sel_partial || (d.deconv2 && d.sel_w && d.sel_cid && d.Cout % 128 == 0 && d.Npad == 4 * d.Cout && !d.out2),
+                  MRCNN_ERR_INVALID, "conv: the selected-class mode needs a 2x2 transposed convolution with Cout a multiple of 128");
     // Tile choice: the widest N tile the packed weights allow, narrowed while the grid would leave
     // the chip under-filled (< 7/8 of 2 blocks per CU) — C5, the top FPN levels and the small RPN levels.
     const int bn_max = conv_n_tile(a.ncols);
     MRCNN_REQUIRE(d.Npad % bn_max == 0 && d.Npad >= a.ncols, MRCNN_ERR_SHAPE, "conv: Npad %d incompatible with tile %d", d.Npad, bn_max);
     a.tiles_m = (a.M + BM_DEFAULT - 1) / BM_DEFAULT;
     int bn = bn_max;
-    while (bn > 32 && (long)a.tiles_m * (d.Npad / bn) < g_min_blocks) bn >>= 1;
+    while (bn > 32 && !d.sel_partial && (long)a.tiles_m * (d.Npad / bn) < g_min_blocks) bn >>= 1;     // (selected-class mode: fixed 128-channel parts)
     auto al = [](const void* p, size_t n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
     const int cpt = half ? 8 : 4;        // columns per epilogue thread: 16 B of the activation type
     a.vec_ok = a.ncols % cpt == 0 && d.out2 == nullptr && d.out_sP % cpt == 0 && d.out_sB % cpt == 0 && al(d.out, 16) &&
@@ -468,6 +471,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
                (!d.res || (d.res_sW % cpt == 0 && d.res_sH % cpt == 0 && d.res_sB % cpt == 0 && al(d.res, 16))) &&
                (!d.deconv2 || (d.Cout % cpt == 0 && d.out_sH % cpt == 0 && d.out_sW % cpt == 0));
     a.tiles_n = d.Npad / bn;
+    MRCNN_REQUIRE(!d.sel_partial || (bn == 128 && a.vec_ok), MRCNN_ERR_INVALID, "conv: the selected-class mode needs the 128-wide vector epilogue");
     // Direct epilogue: fp16 tensors only by default (g_direct = 1).  With fp32 tensors a lane's 16-B store holds four channels of
     // one pixel — 64 scattered pieces per store instruction — and the LDS-staged full-row stores win by 1.4 % end to end
     // (tools/e2e_ab.py f32x3 conv_direct 0 1); with fp16 tensors (eight channels per store) the direct form wins by 0.9 %.
@@ -823,6 +827,70 @@ void mask_select_forward(hipStream_t s, const void* feat, long feat_sB, int HW, 
     else
         hipLaunchKernelGGL(k_mask_select<float>, dim3(49, D, B), dim3(256), 0, s, (const float*)feat, feat_sB, HW, C, w, bias, nc, det, det_sB,
                            det_stride, D, ws.mapping, ws.kept, out, out_sB, out_stride);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// The fused form of the mask head's tail: the deconvolution leaves, per output pixel, `parts` partial dots with the selected
+// class's 1x1 filter (conv_epilogue, ConvDesc::sel_partial) instead of its 256-channel fp32 output (642 MB per batch of 8
+// that this layer used to read back).  Same control flow as k_mask_select — what TimeDistributedMaskLayer.swift:58-89 writes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_mask_select_classes(const float* __restrict__ det, long det_sB, long det_stride, int D, int nc,
+                                                             const int32_t* __restrict__ mapping, const int32_t* __restrict__ kept,
+                                                             int32_t* __restrict__ sel_cid)
+{
+    const int b = blockIdx.x;
+    const int nk = kept[b];
+    for (int r = threadIdx.x; r < D; r += blockDim.x) sel_cid[(size_t)b * D + r] = -1;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nk; i += blockDim.x) {
+        const int actual = mapping[(size_t)b * D + i];
+        if (actual >= nk) continue;                     // would be overwritten by the zero padding
+        int cid = (int)det[(size_t)b * det_sB + (size_t)i * det_stride + 4];      // the COMPACT index's class (:71)
+        cid = cid < 0 ? 0 : (cid >= nc ? nc - 1 : cid);
+        sel_cid[(size_t)b * D + actual] = cid;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mask_select_partials(const float* __restrict__ partial, int parts, int HW,
+                                                              const float* __restrict__ bias, int D,
+                                                              const int32_t* __restrict__ sel_cid, const int32_t* __restrict__ kept,
+                                                              float* __restrict__ out, long out_sB, long out_stride)
+{
+    const int r = blockIdx.y, b = blockIdx.z;
+    const int nk = kept[b];
+    float* orow = out + (size_t)b * out_sB + (size_t)r * out_stride;
+    const int cid = sel_cid[(size_t)b * D + r];
+    if (r >= nk) {                                       // zero padding (:87-89)
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < out_stride; e += (long)gridDim.x * 256) orow[e] = 0.0f;
+        return;
+    }
+    if (cid < 0) return;                                 // a row the layer never writes
+    const float* pr = partial + ((size_t)b * D + r) * HW * parts;
+    const float bs = bias[cid];
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+        float sum = pr[(size_t)p * parts];
+        for (int h = 1; h < parts; ++h) sum += pr[(size_t)p * parts + h];
+        orow[p] = 1.0f / (1.0f + expf(-(sum + bs)));
+    }
+}
+
+void mask_select_classes(hipStream_t s, const float* det, long det_sB, long det_stride, int D, int B, int nc,
+                         const MaskSelectWorkspace& ws, int32_t* sel_cid)
+{
+    if (D <= 0 || B <= 0) return;
+    hipLaunchKernelGGL(k_mask_select_classes, dim3(B), dim3(128), 0, s, det, det_sB, det_stride, D, nc, ws.mapping, ws.kept, sel_cid);
+    HIP_CHECK(hipGetLastError());
+}
+
+void mask_select_from_partials(hipStream_t s, const float* partial, int parts, int HW, const float* bias, int nc, const float* det,
+                               long det_sB, long det_stride, int D, int B, const MaskSelectWorkspace& ws, float* out, long out_sB,
+                               long out_stride)
+{
+    (void)nc; (void)det; (void)det_sB; (void)det_stride;
+    if (D <= 0 || B <= 0) return;
+    hipLaunchKernelGGL(k_mask_select_partials, dim3((HW + 255) / 256, D, B), dim3(256), 0, s, partial, parts, HW, bias, D, ws.sel_cid, ws.kept,
+                       out, out_sB, out_stride);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -472,6 +472,30 @@ def test_engine_lifecycle_streams_and_handles(pkg, small_model):
     assert float(total) == float(det_ref[:, :, 5].astype(np.float32).sum(dtype=np.float32)) or abs(float(total) - det_ref[:, :, 5].sum()) < 1e-3
 
 
+@pytest.mark.parametrize("mode", ["f32", "f32x3", "f16"])
+def test_fused_mask_tail_equals_deconvolution_plus_select(pkg, weights_mod, tmp_path_factory, mode):
+    """The mask head's tail as shipped (the deconvolution's epilogue takes the dot with the selected class's 1x1 filter and a
+    small kernel adds the two 128-channel partials) against the unfused form (256-channel deconvolution output + k_mask_select):
+    same detections, same set of written / zero rows, masks within the fp32 summation-order noise of a 256-term dot."""
+    models = __import__("importlib").import_module("mask-rcnn-coreml_amd.models")
+    L = __import__("importlib").import_module("mask-rcnn-coreml_amd._lib")
+    cfg = pkg.ModelConfig(architecture="resnet50", input_image_shape=(256, 256, 3), num_classes=7, max_detections=20)
+    d = str(tmp_path_factory.mktemp("fuse_" + mode))
+    weights_mod.save_synthetic_models(d, cfg, seed=5, forced_load=True)
+    m = models.load_maskrcnn(d, max_batch=3, compute_dtype=mode)
+    imgs = np.random.default_rng(9).integers(0, 256, (3, 256, 256, 3), dtype=np.uint8)
+    try:
+        L.check(L.lib().mrcnn_debug_set(b"mask_fused", 0))
+        d0, k0 = m.predict(imgs)
+        L.check(L.lib().mrcnn_debug_set(b"mask_fused", 1))
+        d1, k1 = m.predict(imgs)
+    finally:
+        L.check(L.lib().mrcnn_debug_set(b"mask_fused", 1))
+    np.testing.assert_array_equal(d1, d0)
+    np.testing.assert_array_equal((k1 == 0).all(axis=(2, 3)), (k0 == 0).all(axis=(2, 3)))
+    assert (d0[..., 5] > 0).sum() > 0 and np.abs(k1 - k0).max() < 2e-6
+
+
 def test_engine_graph_replay_matches_stream_launches(pkg, small_model):
     """Opt-in hipGraph replay: captured on the second call per batch size, identical results, bypassed (not broken)
     while the profilers record events, and droppable."""
