@@ -515,32 +515,72 @@ __global__ __launch_bounds__(256) void k_nms_scan(const float* __restrict__ boxe
             const uint32_t dlo_v = (uint32_t)(diag & 0xFFFFFFFFull), dhi_v = (uint32_t)(diag >> 32);
             const bool small_cls = (unsigned)mycls < (unsigned)NCLS;
             int mycnt = (per_class_max > 0 && inr && small_cls) ? cls_cnt[mycls] : 0;
-            uint64_t km = 0;            // the chunk's kept lanes; their indices are written once, in parallel, after the loop
+            uint64_t km = 0;            // the chunk's kept lanes; their indices are written once, in parallel, after the resolve
             int kc = kc0;
-            while (m != 0ull && kc < max_keep) {
-                const int i = __builtin_ctzll(m);
-                m &= m - 1;
-                bool take = true;
-                if (per_class_max > 0) {
-                    const int ci = __builtin_amdgcn_readlane(mycls, i);
-                    int cnt;
-                    if ((unsigned)ci < (unsigned)NCLS) cnt = __builtin_amdgcn_readlane(mycnt, i);
-                    else {
-                        cnt = __popcll(__ballot(mycls == ci) & km);              // kept in this chunk
-                        for (int base = 0; base < kc0; base += 64) {            // ... and in the earlier ones
-                            const bool eq = (base + lane < kc0) && kept_cls[base + lane] == ci;
-                            cnt += __popcll(__ballot(eq));
+            // Wave-parallel resolve (the common case): the greedy rule "candidate i is kept iff no KEPT earlier candidate of the
+            // chunk suppresses it" is evaluated in rounds over the whole chunk at once.  P = the transposed 64x64 diagonal block
+            // (lane i: the alive earlier candidates that would suppress i — six shuffle-exchange stages); per round every
+            // undecided candidate whose potential suppressors are all decided settles (kept iff none of them is kept): the number
+            // of rounds is the depth of the longest suppression chain in the chunk (typically 2-4) instead of one serial step per
+            // kept candidate.  The per-class limit couples candidates through a running count: chunks in which a class could reach
+            // it (count + 64 > limit), or with class ids beyond the counter table, take the serial loop below.
+            const bool fast = per_class_max <= 0 || __ballot(inr && (!small_cls || mycnt + 64 > per_class_max)) == 0ull;
+            if (fast) {
+                const bool alive = (m >> lane) & 1ull;
+                uint64_t P = alive ? diag : 0ull;
+                // 64x64 bit-matrix transpose across the lanes: stage s swaps the off-diagonal s x s blocks of every 2s x 2s block
+                // (cm = the columns c with (c & s) != 0)
+#define NMS_TRANSPOSE_STAGE(S, CM)                                                                             \
+                {                                                                                              \
+                    const uint32_t ylo = __shfl_xor((uint32_t)P, S), yhi = __shfl_xor((uint32_t)(P >> 32), S); \
+                    const uint64_t y = ((uint64_t)yhi << 32) | ylo;                                            \
+                    P = (lane & S) ? ((P & CM) | ((y >> S) & ~CM)) : ((P & ~CM) | ((y << S) & CM));            \
+                }
+                NMS_TRANSPOSE_STAGE(32, 0xFFFFFFFF00000000ull) NMS_TRANSPOSE_STAGE(16, 0xFFFF0000FFFF0000ull)
+                NMS_TRANSPOSE_STAGE(8, 0xFF00FF00FF00FF00ull) NMS_TRANSPOSE_STAGE(4, 0xF0F0F0F0F0F0F0F0ull)
+                NMS_TRANSPOSE_STAGE(2, 0xCCCCCCCCCCCCCCCCull) NMS_TRANSPOSE_STAGE(1, 0xAAAAAAAAAAAAAAAAull)
+#undef NMS_TRANSPOSE_STAGE
+                uint64_t und = m, kept_m = 0;
+                while (und != 0ull) {
+                    const bool und_i = (und >> lane) & 1ull;
+                    const bool ready = und_i && (P & und) == 0ull;
+                    const bool keep_i = ready && (P & kept_m) == 0ull;
+                    const uint64_t nk = __ballot(keep_i), nd = __ballot(ready);
+                    kept_m |= nk;
+                    und &= ~nd;
+                }
+                const int room = max_keep - kc0;                      // > 0: the chunk loop ends once max_keep is reached
+                const bool mine = (kept_m >> lane) & 1ull;
+                km = __ballot(mine && __popcll(kept_m & ((1ull << lane) - 1ull)) < room);
+                kc = kc0 + __popcll(km);
+                if (per_class_max > 0 && ((km >> lane) & 1ull)) atomicAdd(&cls_cnt[mycls], 1);      // small_cls holds on this path
+            } else {
+                while (m != 0ull && kc < max_keep) {
+                    const int i = __builtin_ctzll(m);
+                    m &= m - 1;
+                    bool take = true;
+                    if (per_class_max > 0) {
+                        const int ci = __builtin_amdgcn_readlane(mycls, i);
+                        int cnt;
+                        if ((unsigned)ci < (unsigned)NCLS) cnt = __builtin_amdgcn_readlane(mycnt, i);
+                        else {
+                            cnt = __popcll(__ballot(mycls == ci) & km);              // kept in this chunk
+                            for (int base = 0; base < kc0; base += 64) {            // ... and in the earlier ones
+                                const bool eq = (base + lane < kc0) && kept_cls[base + lane] == ci;
+                                cnt += __popcll(__ballot(eq));
+                            }
                         }
+                        take = cnt < per_class_max;
+                        if (take && mycls == ci) ++mycnt;
                     }
-                    take = cnt < per_class_max;
-                    if (take && mycls == ci) ++mycnt;
+                    if (take) {
+                        ++kc;
+                        km |= 1ull << i;
+                        const uint32_t dlo = __builtin_amdgcn_readlane(dlo_v, i), dhi = __builtin_amdgcn_readlane(dhi_v, i);
+                        m &= ~(((uint64_t)dhi << 32) | dlo);
+                    }
                 }
-                if (take) {
-                    ++kc;
-                    km |= 1ull << i;
-                    const uint32_t dlo = __builtin_amdgcn_readlane(dlo_v, i), dhi = __builtin_amdgcn_readlane(dhi_v, i);
-                    m &= ~(((uint64_t)dhi << 32) | dlo);
-                }
+                if (per_class_max > 0 && inr && small_cls) cls_cnt[mycls] = mycnt;      // lanes of one class write the same value
             }
             if ((km >> lane) & 1ull) {
                 const int slot = kc0 + __popcll(km & ((1ull << lane) - 1ull));
@@ -548,7 +588,6 @@ __global__ __launch_bounds__(256) void k_nms_scan(const float* __restrict__ boxe
                 kept[slot] = row;
                 if (per_class_max > 0) kept_cls[slot] = mycls;
             }
-            if (per_class_max > 0 && inr && small_cls) cls_cnt[mycls] = mycnt;      // lanes of one class write the same value
             prev_kept = km;
             if (lane == 0) s_kc = kc;
         }
