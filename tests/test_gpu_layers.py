@@ -87,6 +87,36 @@ def test_proposal_nms_threshold_on_the_iou_boundary(pkg, orc, tmp_path):
     assert flips == P                                           # every boundary was really exercised
 
 
+def test_proposal_nms_long_suppression_chain(pkg, orc, tmp_path):
+    """The greedy scan resolves a 64-candidate chunk in wave-parallel rounds whose count is the depth of the longest suppression
+    chain: here a chain as long as the input — 200 boxes in a row, each overlapping only its neighbours above the threshold
+    (keep, drop, keep, ...), crossing chunk borders — next to a cluster in which one box suppresses 40 others at once."""
+    n_chain, n_cluster = 200, 41
+    boxes = []
+    for i in range(n_chain):                       # IoU(i, i+1) = 0.6, IoU(i, i+2) = 1/3
+        x1 = 0.05 + i * 0.004
+        boxes.append([0.10, x1, 0.30, x1 + 0.016])
+    boxes.append([0.50, 0.40, 0.80, 0.70])         # the cluster's head ...
+    rng = np.random.default_rng(4)
+    for _ in range(n_cluster - 1):                 # ... and 40 slightly jittered copies of it
+        j = rng.random(4) * 0.01
+        boxes.append([0.50 + j[0], 0.40 + j[1], 0.80 - j[2], 0.70 - j[3]])
+    anchors = np.asarray(boxes, np.float32)
+    A = anchors.shape[0]
+    p = str(tmp_path / "anchors_chain.bin")
+    anchors.tofile(p)
+    pkg.MaskRCNNConfig.defaultConfig().anchorsURL = p
+    fg = np.linspace(0.99, 0.5, A).astype(np.float32)
+    probs = np.stack([1 - fg, fg], axis=1).astype(np.float32)
+    deltas = np.zeros((A, 4), np.float32)
+    params = dict(pkg.ModelConfig().proposal_layer_params(), preNMSMaxProposals=A, maxProposals=A, nmsIOUThreshold=0.5)
+    got = _run_proposal(pkg, probs, deltas, params)
+    want, dbg = orc.proposal_layer(probs, deltas, anchors, A, A, 0.5, debug=True)
+    np.testing.assert_array_equal(got, want)
+    keep = dbg["keep"]
+    assert list(keep[:n_chain // 2]) == list(range(0, n_chain, 2)) and dbg["count"] == n_chain // 2 + 1      # every other box + the head
+
+
 def test_proposal_layer_ties_and_padding(pkg, anchors_mod, orc, tmp_path):
     """Saturated scores (many exact ties → lowest anchor index wins), far fewer survivors than
     maxProposals (zero padding), wider output rows (only 4 floats of kept rows are written)."""
