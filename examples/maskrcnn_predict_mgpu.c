@@ -59,15 +59,23 @@ int main(int argc, char** argv)
     const char* id_file = getenv("MRCNN_DIST_ID_FILE");
     if (world > 1 && !id_file) { fprintf(stderr, "MRCNN_DIST_ID_FILE must name a path all ranks can reach\n"); return 64; }
 
-    /* ---- rendezvous: 128 bytes from rank 0 to everyone ---- */
+    /* ---- rendezvous: 128 bytes from rank 0 to everyone, through a file --------------------------------------------
+     * A file left behind by an earlier run must never be taken for this run's id (ncclCommInitRank with mismatched ids
+     * hangs): rank 0 removes the path before it creates the id and again once every rank has joined, and the file carries
+     * a launch nonce (MRCNN_DIST_NONCE, set by the launcher to the same fresh value for all ranks) that readers verify. */
+    const char* nonce = getenv("MRCNN_DIST_NONCE");
+    char want[64];
+    memset(want, 0, sizeof want);
+    if (nonce) strncpy(want, nonce, sizeof want - 1);
     uint8_t id[128];
     if (rank == 0) {
+        if (world > 1) (void)remove(id_file);
         CHECK(mrcnn_dist_unique_id(id));
         if (world > 1) {
             char tmp[4096];
             snprintf(tmp, sizeof tmp, "%s.tmp", id_file);
             FILE* f = fopen(tmp, "wb");
-            if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) { fprintf(stderr, "cannot write %s\n", tmp); return 73; }
+            if (!f || fwrite(id, 1, sizeof id, f) != sizeof id || fwrite(want, 1, sizeof want, f) != sizeof want) { fprintf(stderr, "cannot write %s\n", tmp); return 73; }
             fclose(f);
             if (rename(tmp, id_file) != 0) { fprintf(stderr, "cannot publish %s\n", id_file); return 73; }
         }
@@ -76,17 +84,19 @@ int main(int argc, char** argv)
         for (;;) {
             FILE* f = fopen(id_file, "rb");
             if (f) {
-                const size_t n = fread(id, 1, sizeof id, f);
+                char got[64];
+                const size_t n = fread(id, 1, sizeof id, f), k = fread(got, 1, sizeof got, f);
                 fclose(f);
-                if (n == sizeof id) break;
+                if (n == sizeof id && k == sizeof got && memcmp(got, want, sizeof want) == 0) break;      /* else: stale or half-written */
             }
-            if (now_s() > t_end) { fprintf(stderr, "[rank %d] no rendezvous id in %s after 120 s\n", rank, id_file); return 75; }
+            if (now_s() > t_end) { fprintf(stderr, "[rank %d] no rendezvous id for this launch in %s after 120 s\n", rank, id_file); return 75; }
             struct timespec nap = {0, 20 * 1000 * 1000};
             nanosleep(&nap, NULL);
         }
     }
     mrcnn_dist* dist = NULL;
     CHECK(mrcnn_dist_init(rank, world, id, &dist));
+    if (rank == 0 && world > 1) (void)remove(id_file);        /* every rank has joined: the id is spent */
 
     /* ---- every rank loads the same artefacts (replicated weights, ~250 MB) ---- */
     char path[4][4096];

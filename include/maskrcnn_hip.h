@@ -53,7 +53,7 @@ MRCNN_API int mrcnn_device_count(void);
 typedef enum {
     MRCNN_F32 = 0, MRCNN_F64 = 1, MRCNN_F16 = 2, MRCNN_U8 = 3, MRCNN_I32 = 4,
     MRCNN_F32S = 5,  /* compute mode only (mrcnn_model_load): fp32 tensors, fp16 filters, split-fp16 MFMA — see there */
-    MRCNN_F32X3 = 6  /* compute mode only: as MRCNN_F32S with a three-part split (all 24 significand bits: exact products) */
+    MRCNN_F32X3 = 6  /* compute mode only: as MRCNN_F32S with a three-part split (all 24 significand bits for |a| >= 0.5) */
 } mrcnn_dtype;
 typedef enum { MRCNN_HOST = 0, MRCNN_DEVICE = 1 } mrcnn_memspace;
 
@@ -154,8 +154,14 @@ typedef struct mrcnn_model mrcnn_model;
  * (task.py:90), fp32 accumulate: products are exact, the split carries 22 of the 24 significand bits —
  * fp32-grade results at several times the fp32-MFMA rate.  Requires fp16-representable filters, which is
  * what the converter writes; an artefact with genuine fp32 filters is refused in this mode).  MRCNN_F32X3 is the same
- * with THREE parts: every activation in [0.5, 65504) is represented exactly (2^-24 absolute below), so each product
- * equals the fp32 product — three MFMA passes instead of two.
+ * with THREE parts — three MFMA passes instead of two.  The bound that holds: an activation with 0.5 <= |a| < 65504 is
+ * represented exactly (its product with an fp16 filter is then exact and only the fp32 summation order differs from an fp32
+ * engine); a smaller one is carried to 2^-24 ABSOLUTE, truncated toward zero (the third part reaches the fp16 subnormal
+ * step; this also relies on the MFMA not flushing fp16 subnormals, which gfx950 does not), i.e. about 14 significant bits
+ * at |a| = 1e-3.  An output is therefore off by at most 2^-24 * sum|w| beyond fp32 summation noise: invisible while a layer's
+ * activations are O(1) or larger (every tensor of a BatchNorm-folded trunk), but unlike fp32 the mode is NOT scale-invariant —
+ * a model whose activations are uniformly tiny should be loaded with MRCNN_F32 (tests/test_gpu_conv_kernels.py,
+ * profiles/r03_split_scale_curve.txt).
  * In MRCNN_F16 and MRCNN_F32S every convolution watches its outputs: if one leaves the fp16 range (|v| >= 65504,
  * which the next layer could not read), the synchronous predict fails with MRCNN_ERR_UNSUPPORTED instead of
  * returning saturated results (mrcnn_model_get_int key "range_overflows" counts such calls). */
@@ -198,7 +204,22 @@ MRCNN_API int mrcnn_maskrcnn_predict_async(mrcnn_model* model, const uint8_t* rg
  *   mrcnn_dist_record_floats  floats per image record
  *   mrcnn_dist_all_gather_records  local results (end-begin images, `memspace`) → all `global_batch` results (`memspace`)
  *   mrcnn_maskrcnn_predict_sharded  the whole step: every rank passes the SAME global batch (global_batch, H, W, 3) and
- *                          receives detections (global_batch, maxDet, 6) / masks (global_batch, maxDet, 28, 28) */
+ *                          receives detections (global_batch, maxDet, 6) / masks (global_batch, maxDet, 28, 28)
+ * A rank never skips the collective: what it contributes is a SLOT = its records zero-padded to the largest shard + a
+ * 4-word trailer [status, images, 0, 0].  A rank whose local predict failed (HIP error, the data-dependent fp16-range
+ * watchdog) sends zeroed records with its status, and EVERY rank returns that status after the gather (its own message on
+ * the failing rank, "rank r failed ..." on the others) — nobody is left blocked in ncclAllGather.
+ *   mrcnn_dist_all_gather_records_async / mrcnn_dist_wait  the same exchange (device buffers only) issued on the handle's
+ *                          own stream behind the model's stream: returns at once, the model's NEXT predict overlaps it (the
+ *                          model's stream only waits until the results are packed before it may overwrite them);
+ *                          mrcnn_dist_wait joins it and reports remote failures.  One exchange in flight per handle.
+ *   mrcnn_dist_plan        host arithmetic of one exchange, no GPU needed: table[4*r + {0,1,2,3}] = {first image, end image,
+ *                          float offset of rank r's slot in the gathered buffer, record floats rank r contributes};
+ *                          *slot_floats = floats per slot
+ *   mrcnn_dist_simulate_host  the pack -> concatenate (what ncclAllGather does) -> unpack code of the device path run on
+ *                          host buffers for all `world` ranks in one process (detections[r] / masks[r] = rank r's local
+ *                          results, status[r] optional): the seam through which the layout is tested at world sizes the
+ *                          build machine does not have */
 typedef struct mrcnn_dist mrcnn_dist;
 MRCNN_API int mrcnn_dist_unique_id(uint8_t* id128);
 MRCNN_API int mrcnn_dist_init(int rank, int world, const uint8_t* id128, mrcnn_dist** out);
@@ -209,6 +230,13 @@ MRCNN_API int mrcnn_dist_all_gather_records(mrcnn_dist* dist, mrcnn_model* model
                                             int global_batch, int memspace, float* out_detections, float* out_masks);
 MRCNN_API int mrcnn_maskrcnn_predict_sharded(mrcnn_dist* dist, mrcnn_model* model, const uint8_t* rgb, int global_batch,
                                              int height, int width, int memspace, float* detections, float* masks);
+MRCNN_API int mrcnn_dist_all_gather_records_async(mrcnn_dist* dist, mrcnn_model* model, const float* detections, const float* masks,
+                                                  int global_batch, float* out_detections, float* out_masks);
+MRCNN_API int mrcnn_dist_wait(mrcnn_dist* dist);
+MRCNN_API int mrcnn_dist_plan(int global_batch, int world, int max_detections, int mask_size, int64_t* table, int64_t* slot_floats);
+MRCNN_API int mrcnn_dist_simulate_host(int world, int global_batch, int max_detections, int mask_size, const float* const* detections,
+                                       const float* const* masks, const int32_t* status, float* out_detections, float* out_masks,
+                                       int32_t* status_out);
 
 /* Classifier.prediction(feature_map:) (task.py:106-113): feature_map (n,256,7,7) CHW →
  * probabilities (n, numClasses), bounding_boxes (n, numClasses*4) class-major. */
@@ -221,7 +249,9 @@ MRCNN_API int mrcnn_mask_predict(mrcnn_model* model, const float* feature_map, i
 /* Introspection: "num_classes", "image_height", "image_width", "max_proposals", "max_detections", "num_anchors",
  * "pre_nms_max_proposals", "pre_nms_count" (= min(num_anchors, pre_nms_max_proposals)), "mask_size" (side of the
  * square masks predict returns: 2 × the mask pool size = 28), "max_batch", "compute_dtype", "range_overflows",
- * "graph_enabled", "graph_launches"; any other key is looked up in the artefact's integer metadata. */
+ * "graph_enabled", "graph_launches", "gpu_busy_us" / "predict_calls" (GPU time between the first and the last command of
+ * the synchronous predicts of this handle, HIP events on the model's stream, and their count); any other key is looked up in
+ * the artefact's integer metadata. */
 MRCNN_API int mrcnn_model_get_int(mrcnn_model* model, const char* key, int64_t* value);
 
 /* Debug taps for parity tests: copies a named intermediate of the last predict (image b) to a host

@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = [
     "mrcnn_model_check_range", "mrcnn_roi_align_nhwc", "mrcnn_conv2d_nhwc", "mrcnn_debug_set",
     "mrcnn_dist_unique_id", "mrcnn_dist_init", "mrcnn_dist_destroy", "mrcnn_dist_shard", "mrcnn_dist_record_floats",
     "mrcnn_dist_all_gather_records", "mrcnn_maskrcnn_predict_sharded", "mrcnn_mask_to_u8_f64",
+    "mrcnn_dist_all_gather_records_async", "mrcnn_dist_wait", "mrcnn_dist_plan", "mrcnn_dist_simulate_host",
 ]
 
 
@@ -138,6 +139,10 @@ def lib():
     L.mrcnn_dist_record_floats.restype = C.c_int64
     L.mrcnn_dist_all_gather_records.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]
     L.mrcnn_maskrcnn_predict_sharded.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.mrcnn_dist_all_gather_records_async.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp]
+    L.mrcnn_dist_wait.argtypes = [vp]
+    L.mrcnn_dist_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, i64p, i64p]
+    L.mrcnn_dist_simulate_host.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp]
     L.mrcnn_roi_align_nhwc.argtypes = [C.POINTER(vp), ip, ip, C.c_int, C.c_int, vp, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double,
                                        C.c_int, vp, vp]
     _lib = L

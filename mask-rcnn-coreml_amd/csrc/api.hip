@@ -616,6 +616,8 @@ extern "C" int mrcnn_model_get_int(mrcnn_model* model, const char* key, int64_t*
         else if (k == "mask_size") *value = 2 * m.mask_pool;
         else if (k == "range_overflows") *value = m.range_overflows;
         else if (k == "graph_launches") *value = m.graph_launches;
+        else if (k == "gpu_busy_us") *value = (int64_t)(m.gpu_busy_ms * 1e3);
+        else if (k == "predict_calls") *value = m.predict_calls;
         else if (k == "graph_enabled") *value = m.use_graph ? 1 : 0;
         else *value = m.file.get_int(k);
     });

@@ -392,7 +392,9 @@ __device__ __forceinline__ void split_hi_lo(const uint4 u0, const uint4 u1, f16x
 }
 
 // Three-part variant (MRCNN_F32X3): hi + mid + lo carries all 24 significand bits — exact for 0.5 <= |a| < 65504, and to
-// 2^-24 absolute below (where the last part reaches the fp16 subnormal step): the fp32 product a·w is reproduced exactly.
+// 2^-24 absolute below (where the last part reaches the fp16 subnormal step and is truncated toward zero): for |a| >= 0.5
+// the fp32 product a·w is reproduced exactly; the bound for smaller activations is the one include/maskrcnn_hip.h states
+// and tests/test_gpu_conv_kernels.py::test_split_modes_scale_curve_stays_inside_the_documented_bound pins.
 __device__ __forceinline__ void split_hi_mid_lo(const uint4 u0, const uint4 u1, f16x8& hi, f16x8& mid, f16x8& lo)
 {
     const float a[8] = {__uint_as_float(u0.x), __uint_as_float(u0.y), __uint_as_float(u0.z), __uint_as_float(u0.w),

@@ -6,14 +6,29 @@
 // the batch is split into contiguous blocks (blocks differ by at most one image), weights and anchors are replicated,
 // there is NO collective on the data path, and the only exchange is ONE ncclAllGather of zero-padded records
 //     record = detections (maxDet × 6 f32) ‖ masks (maxDet × S × S f32)          316 000 B at the defaults
-// issued on the model's own stream.  RCCL is bound at run time (dlopen of librccl.so.1): a single-GPU host needs no RCCL,
-// and a process that already holds a copy (torch ships one) shares it.  The torch.distributed twin of this file is
-// mask-rcnn-coreml_amd/dist.py (used for the gloo/CPU tests of the same shard arithmetic and record layout).
+// RCCL is bound at run time (dlopen of librccl.so.1): a single-GPU host needs no RCCL, and a process that already holds
+// a copy (torch ships one) shares it.  The torch.distributed twin of this file is mask-rcnn-coreml_amd/dist.py.
+//
+// What a rank sends is a SLOT: its records, zero-padded to the largest shard, followed by a 4-word trailer
+//     [status, images in the shard, 0, 0]
+// so that a rank whose local predict failed (a HIP error, the fp16-range watchdog — data dependent) still takes part in
+// the collective — with zeroed records and its status code — and EVERY rank raises after the gather.  Skipping the
+// collective on a local failure would leave the other ranks blocked in ncclAllGather for ever.
+//
+// Layout arithmetic (slot size, where rank r's records start in the gathered buffer, which image rows they become) lives
+// in ONE function, plan_entries(), used by the device path and by the host seam mrcnn_dist_simulate_host (tests drive the
+// pack → concatenate → unpack code at world sizes 1–8 without a GPU and compare with dist.py).
+//
+// Overlap: mrcnn_dist_all_gather_records_async issues pack / all-gather / unpack on the handle's own stream behind an
+// event on the model's stream and returns; the model's next predict runs under it (the pack reads the caller's result
+// buffers: the model's stream waits for the pack, not for the exchange, before it may overwrite them).  mrcnn_dist_wait
+// joins and raises the remote statuses.
 #include <dlfcn.h>
 #include <string.h>
 
 #include <memory>
 #include <mutex>
+#include <vector>
 
 #include "engine.h"
 
@@ -38,27 +53,35 @@ Rccl& rccl()
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
     if (r.lib) return r;
+    // resolved into a local table first: a missing symbol must not leave a half-bound table behind
+    Rccl t;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
-        r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (r.lib) break;
+        t.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (t.lib) break;
     }
-    MRCNN_REQUIRE(r.lib, MRCNN_ERR_CONFIG, "cannot load RCCL (librccl.so.1): %s", dlerror());
+    MRCNN_REQUIRE(t.lib, MRCNN_ERR_CONFIG, "cannot load RCCL (librccl.so.1): %s", dlerror());
+    const char* missing = nullptr;
     auto sym = [&](const char* s) {
-        void* p = dlsym(r.lib, s);
-        MRCNN_REQUIRE(p, MRCNN_ERR_CONFIG, "RCCL lacks %s", s);
+        void* p = dlsym(t.lib, s);
+        if (!p && !missing) missing = s;
         return p;
     };
-    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
-    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
-    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
-    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
-    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    t.GetUniqueId = reinterpret_cast<decltype(t.GetUniqueId)>(sym("ncclGetUniqueId"));
+    t.CommInitRank = reinterpret_cast<decltype(t.CommInitRank)>(sym("ncclCommInitRank"));
+    t.CommDestroy = reinterpret_cast<decltype(t.CommDestroy)>(sym("ncclCommDestroy"));
+    t.AllGather = reinterpret_cast<decltype(t.AllGather)>(sym("ncclAllGather"));
+    t.GetErrorString = reinterpret_cast<decltype(t.GetErrorString)>(sym("ncclGetErrorString"));
+    if (missing) {
+        dlclose(t.lib);
+        fail(MRCNN_ERR_CONFIG, "RCCL lacks %s", missing);
+    }
+    r = t;
     return r;
 }
-void nccl_check(int rc, const char* what)
+void nccl_check(const Rccl& r, int rc, const char* what)
 {
-    if (rc != 0) fail(MRCNN_ERR_HIP, "%s failed: %s", what, rccl().GetErrorString ? rccl().GetErrorString(rc) : "?");
+    if (rc != 0) fail(MRCNN_ERR_HIP, "%s failed: %s", what, r.GetErrorString ? r.GetErrorString(rc) : "?");
 }
 
 void shard(int total, int world, int rank, int* lo, int* hi)
@@ -68,12 +91,91 @@ void shard(int total, int world, int rank, int* lo, int* hi)
     *hi = *lo + base + (rank < rem ? 1 : 0);
 }
 
+// ---- the layout of one exchange --------------------------------------------------------------------------------------
+constexpr int TRAILER = 4;        // floats: [status, images in the shard, 0, 0] (int32 bit patterns)
+struct Geometry {
+    size_t det_len, mask_len, rec;   // floats per image
+    int n_max;                       // images of the largest shard
+    size_t slot;                     // floats a rank sends: n_max records + trailer
+};
+Geometry geometry(int global_batch, int world, int max_det, int mask_size)
+{
+    Geometry g;
+    g.det_len = (size_t)max_det * 6;
+    g.mask_len = (size_t)max_det * mask_size * mask_size;
+    g.rec = g.det_len + g.mask_len;
+    g.n_max = (global_batch + world - 1) / world;
+    g.slot = (size_t)g.n_max * g.rec + TRAILER;
+    return g;
+}
+struct PlanEntry { int begin, end; size_t recv_off; };     // rank r: its images [begin, end); its slot starts at recv_off floats
+std::vector<PlanEntry> plan_entries(int global_batch, int world, const Geometry& g)
+{
+    std::vector<PlanEntry> p((size_t)world);
+    for (int r = 0; r < world; ++r) {
+        shard(global_batch, world, r, &p[r].begin, &p[r].end);
+        p[r].recv_off = (size_t)r * g.slot;
+    }
+    return p;
+}
+
+// pack / unpack are written once over a 2-D copy primitive: hipMemcpy2DAsync on the device path, memcpy rows on the host seam
+struct HostCopy {
+    void zero(float* dst, size_t n) const { memset(dst, 0, n * 4); }
+    void rows(float* dst, size_t dpitch, const float* src, size_t spitch, size_t width, size_t n) const
+    {
+        for (size_t i = 0; i < n; ++i) memcpy(dst + i * dpitch, src + i * spitch, width * 4);
+    }
+    void words(float* dst, const int32_t* w, int n) const { memcpy(dst, w, (size_t)n * 4); }
+};
+struct DeviceCopy {
+    hipStream_t s;
+    hipMemcpyKind in_kind, out_kind;
+    bool unpacking = false;
+    void zero(float* dst, size_t n) const { HIP_CHECK(hipMemsetAsync(dst, 0, n * 4, s)); }
+    void rows(float* dst, size_t dpitch, const float* src, size_t spitch, size_t width, size_t n) const
+    {
+        HIP_CHECK(hipMemcpy2DAsync(dst, dpitch * 4, src, spitch * 4, width * 4, n, unpacking ? out_kind : in_kind, s));
+    }
+    void words(float* dst, const int32_t* w, int n) const { HIP_CHECK(hipMemcpyAsync(dst, w, (size_t)n * 4, hipMemcpyHostToDevice, s)); }
+};
+
+// this rank's slot: records (zero-padded to n_max) + trailer.  status != 0: the records are sent as zeros.
+template <class Copy>
+void pack_slot(const Copy& c, const Geometry& g, int n_local, const float* det, const float* masks, const int32_t trailer[TRAILER], float* send)
+{
+    c.zero(send, g.slot);
+    if (n_local > 0 && trailer[0] == 0) {
+        c.rows(send, g.rec, det, g.det_len, g.det_len, (size_t)n_local);
+        c.rows(send + g.det_len, g.rec, masks, g.mask_len, g.mask_len, (size_t)n_local);
+    }
+    c.words(send + (size_t)g.n_max * g.rec, trailer, TRAILER);
+}
+// gathered slots → results in global image order, padding dropped
+template <class Copy>
+void unpack_slots(const Copy& c, const Geometry& g, const std::vector<PlanEntry>& plan, const float* recv, float* out_det, float* out_masks)
+{
+    for (const PlanEntry& e : plan) {
+        if (e.end == e.begin) continue;
+        const float* src = recv + e.recv_off;
+        c.rows(out_det + (size_t)e.begin * g.det_len, g.det_len, src, g.rec, g.det_len, (size_t)(e.end - e.begin));
+        c.rows(out_masks + (size_t)e.begin * g.mask_len, g.mask_len, src + g.det_len, g.rec, g.mask_len, (size_t)(e.end - e.begin));
+    }
+}
+
 }  // namespace
 
 struct mrcnn_dist {
     NcclComm comm = nullptr;
     int rank = 0, world = 1;
-    DevBuf send, recv, stage_det, stage_mask, out_det, out_mask;
+    hipStream_t gs = nullptr;                 // the exchange's own stream (async form)
+    hipEvent_t ev_ready = nullptr, ev_packed = nullptr;
+    DevBuf send, recv, stage_det, stage_mask, stage_img;
+    int32_t trailer[TRAILER] = {0, 0, 0, 0};  // host copy of what was packed (outlives the async H2D)
+    std::vector<int32_t> statuses;            // host copy of every rank's trailer after an exchange
+    bool pending = false;                     // an async exchange has been issued and not yet joined
+    Geometry g{};
+    std::vector<PlanEntry> plan;
 };
 
 extern "C" int mrcnn_dist_shard(int global_batch, int world, int rank, int* begin, int* end)
@@ -90,13 +192,53 @@ extern "C" int64_t mrcnn_dist_record_floats(int max_detections, int mask_size)
     return (int64_t)max_detections * 6 + (int64_t)max_detections * mask_size * mask_size;
 }
 
+extern "C" int mrcnn_dist_plan(int global_batch, int world, int max_detections, int mask_size, int64_t* table, int64_t* slot_floats)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(table && global_batch >= 0 && world >= 1 && max_detections >= 0 && mask_size >= 0, MRCNN_ERR_INVALID, "bad dist_plan argument");
+        const Geometry g = geometry(global_batch, world, max_detections, mask_size);
+        const auto plan = plan_entries(global_batch, world, g);
+        for (int r = 0; r < world; ++r) {
+            table[4 * r + 0] = plan[r].begin;
+            table[4 * r + 1] = plan[r].end;
+            table[4 * r + 2] = (int64_t)plan[r].recv_off;
+            table[4 * r + 3] = (int64_t)(plan[r].end - plan[r].begin) * (int64_t)g.rec;
+        }
+        if (slot_floats) *slot_floats = (int64_t)g.slot;
+    });
+}
+
+extern "C" int mrcnn_dist_simulate_host(int world, int global_batch, int max_detections, int mask_size, const float* const* detections,
+                                        const float* const* masks, const int32_t* status, float* out_detections, float* out_masks,
+                                        int32_t* status_out)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(detections && masks && out_detections && out_masks && world >= 1 && global_batch >= 1, MRCNN_ERR_INVALID,
+                      "bad dist_simulate_host argument");
+        const Geometry g = geometry(global_batch, world, max_detections, mask_size);
+        const auto plan = plan_entries(global_batch, world, g);
+        std::vector<float> gathered((size_t)world * g.slot, -1.0f);       // poisoned: every word must come from a pack
+        HostCopy c;
+        for (int r = 0; r < world; ++r) {
+            const int n = plan[r].end - plan[r].begin;
+            MRCNN_REQUIRE(n == 0 || (detections[r] && masks[r]), MRCNN_ERR_INVALID, "rank %d: null local results", r);
+            const int32_t tr[TRAILER] = {status ? status[r] : 0, n, 0, 0};
+            pack_slot(c, g, n, detections[r], masks[r], tr, gathered.data() + plan[r].recv_off);      // = rank r's ncclAllGather contribution
+        }
+        unpack_slots(c, g, plan, gathered.data(), out_detections, out_masks);
+        if (status_out)
+            for (int r = 0; r < world; ++r) memcpy(&status_out[r], gathered.data() + plan[r].recv_off + (size_t)g.n_max * g.rec, 4);
+    });
+}
+
 extern "C" int mrcnn_dist_unique_id(uint8_t* id128)
 {
     return guarded([&] {
         MRCNN_REQUIRE(id128, MRCNN_ERR_INVALID, "null id buffer");
         require_gpu();
         NcclUniqueId id;
-        nccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+        Rccl& r = rccl();
+        nccl_check(r, r.GetUniqueId(&id), "ncclGetUniqueId");
         memcpy(id128, id.internal, 128);
     });
 }
@@ -110,7 +252,11 @@ extern "C" int mrcnn_dist_init(int rank, int world, const uint8_t* id128, mrcnn_
         d->rank = rank; d->world = world;
         NcclUniqueId id;
         memcpy(id.internal, id128, 128);
-        nccl_check(rccl().CommInitRank(&d->comm, world, id, rank), "ncclCommInitRank");
+        Rccl& r = rccl();
+        nccl_check(r, r.CommInitRank(&d->comm, world, id, rank), "ncclCommInitRank");
+        HIP_CHECK(hipStreamCreateWithFlags(&d->gs, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&d->ev_packed, hipEventDisableTiming));
         *out = d.release();
     });
 }
@@ -118,44 +264,81 @@ extern "C" int mrcnn_dist_init(int rank, int world, const uint8_t* id128, mrcnn_
 extern "C" void mrcnn_dist_destroy(mrcnn_dist* d)
 {
     if (!d) return;
+    if (d->gs) (void)hipStreamSynchronize(d->gs);
     if (d->comm) (void)rccl().CommDestroy(d->comm);
+    if (d->ev_ready) (void)hipEventDestroy(d->ev_ready);
+    if (d->ev_packed) (void)hipEventDestroy(d->ev_packed);
+    if (d->gs) (void)hipStreamDestroy(d->gs);
     delete d;
 }
 
-// local results (n_local records, `in_space`) → every rank's records in global image order (`out_space`)
-static void gather_records(mrcnn_dist* d, Model& m, const float* det, const float* masks, int in_space, int global_batch, int out_space,
-                           float* out_det, float* out_masks)
+// Every rank's trailer after the exchange → raise on ALL ranks when any rank reported a failure.
+static void raise_remote_status(mrcnn_dist* d)
+{
+    for (int r = 0; r < d->world; ++r) {
+        const int st = d->statuses[(size_t)r * TRAILER];
+        if (st != 0)
+            fail(st > 0 && st <= MRCNN_ERR_CONFIG ? st : MRCNN_ERR_HIP,
+                 "rank %d of %d failed its local predict (status %d%s); the records of this batch are not valid on any rank", r, d->world, st,
+                 r == d->rank ? ": see this rank's earlier message" : "");
+    }
+}
+
+// local results (n_local records, `in_space`) → every rank's records in global image order (`out_space`).
+// Issued on stream `s`; `status` != 0 sends zeroed records.  Does not synchronise.
+static void issue_exchange(mrcnn_dist* d, Model& m, hipStream_t s, const float* det, const float* masks, int in_space, int global_batch,
+                           int out_space, float* out_det, float* out_masks, int status)
 {
     MRCNN_REQUIRE(m.kind == MRCNN_MODEL_MASKRCNN, MRCNN_ERR_INVALID, "all_gather_records needs the MaskRCNN model (record geometry)");
-    const int D = m.max_det, S = 2 * m.mask_pool;
-    const size_t det_len = (size_t)D * 6, mask_len = (size_t)D * S * S, rec = det_len + mask_len;
-    int lo, hi;
-    shard(global_batch, d->world, d->rank, &lo, &hi);
-    const int n_local = hi - lo, n_max = (global_batch + d->world - 1) / d->world;
-    MRCNN_REQUIRE(n_local == 0 || (det && masks), MRCNN_ERR_INVALID, "null local results");
-    hipStream_t s = m.stream;
-    // ---- pack: records of this rank, zero-padded to the largest shard ----------------------------------------------
-    if (d->send.bytes < (size_t)n_max * rec * 4) d->send.alloc((size_t)n_max * rec * 4);
-    if (d->recv.bytes < (size_t)d->world * n_max * rec * 4) d->recv.alloc((size_t)d->world * n_max * rec * 4);
-    HIP_CHECK(hipMemsetAsync(d->send.p, 0, (size_t)n_max * rec * 4, s));
-    if (n_local > 0) {
-        const hipMemcpyKind k = in_space != MRCNN_DEVICE ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
-        HIP_CHECK(hipMemcpy2DAsync(d->send.p, rec * 4, det, det_len * 4, det_len * 4, (size_t)n_local, k, s));
-        HIP_CHECK(hipMemcpy2DAsync(d->send.as<float>() + det_len, rec * 4, masks, mask_len * 4, mask_len * 4, (size_t)n_local, k, s));
-    }
-    // ---- the one collective of the path, on the model's stream -----------------------------------------------------
-    nccl_check(rccl().AllGather(d->send.p, d->recv.p, (size_t)n_max * rec, /*ncclFloat*/ 7, d->comm, s), "ncclAllGather");
-    // ---- unpack in global image order, padding dropped -------------------------------------------------------------
-    const hipMemcpyKind k = out_space != MRCNN_DEVICE ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-    for (int r = 0; r < d->world; ++r) {
-        int rlo, rhi;
-        shard(global_batch, d->world, r, &rlo, &rhi);
-        if (rhi == rlo) continue;
-        const float* src = d->recv.as<float>() + (size_t)r * n_max * rec;
-        HIP_CHECK(hipMemcpy2DAsync(out_det + (size_t)rlo * det_len, det_len * 4, src, rec * 4, det_len * 4, (size_t)(rhi - rlo), k, s));
-        HIP_CHECK(hipMemcpy2DAsync(out_masks + (size_t)rlo * mask_len, mask_len * 4, src + det_len, rec * 4, mask_len * 4, (size_t)(rhi - rlo), k, s));
-    }
-    HIP_CHECK(hipStreamSynchronize(s));
+    d->g = geometry(global_batch, d->world, m.max_det, 2 * m.mask_pool);
+    d->plan = plan_entries(global_batch, d->world, d->g);
+    const Geometry& g = d->g;
+    const int n_local = d->plan[d->rank].end - d->plan[d->rank].begin;
+    MRCNN_REQUIRE(status != 0 || n_local == 0 || (det && masks), MRCNN_ERR_INVALID, "null local results");
+    if (d->send.bytes < g.slot * 4) d->send.alloc(g.slot * 4);
+    if (d->recv.bytes < (size_t)d->world * g.slot * 4) d->recv.alloc((size_t)d->world * g.slot * 4);
+    d->trailer[0] = status; d->trailer[1] = n_local; d->trailer[2] = d->trailer[3] = 0;
+    DeviceCopy c{s, in_space != MRCNN_DEVICE ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
+                 out_space != MRCNN_DEVICE ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice};
+    pack_slot(c, g, n_local, det, masks, d->trailer, d->send.as<float>());
+    HIP_CHECK(hipEventRecord(d->ev_packed, s));
+    // ---- the one collective of the path ---------------------------------------------------------------------------
+    Rccl& r = rccl();
+    nccl_check(r, r.AllGather(d->send.p, d->recv.p, g.slot, /*ncclFloat*/ 7, d->comm, s), "ncclAllGather");
+    c.unpacking = true;
+    unpack_slots(c, g, d->plan, d->recv.as<float>(), out_det, out_masks);
+    // every rank's trailer → host (one strided copy)
+    d->statuses.assign((size_t)d->world * TRAILER, 0);
+    HIP_CHECK(hipMemcpy2DAsync(d->statuses.data(), TRAILER * 4, d->recv.as<float>() + (size_t)g.n_max * g.rec, g.slot * 4, TRAILER * 4,
+                               (size_t)d->world, hipMemcpyDeviceToHost, s));
+}
+
+extern "C" int mrcnn_dist_wait(mrcnn_dist* d)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(d, MRCNN_ERR_INVALID, "null dist handle");
+        if (!d->pending) return;
+        d->pending = false;
+        HIP_CHECK(hipStreamSynchronize(d->gs));
+        raise_remote_status(d);
+    });
+}
+
+extern "C" int mrcnn_dist_all_gather_records_async(mrcnn_dist* d, mrcnn_model* model, const float* det, const float* masks, int global_batch,
+                                                   float* out_det, float* out_masks)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(d && model && out_det && out_masks && global_batch >= 1, MRCNN_ERR_INVALID, "bad all_gather_records_async argument");
+        MRCNN_REQUIRE(!d->pending, MRCNN_ERR_INVALID, "an exchange is still pending: call mrcnn_dist_wait first");
+        Model& m = model->m;
+        // the exchange starts when the model's stream has produced the results ...
+        HIP_CHECK(hipEventRecord(d->ev_ready, m.stream));
+        HIP_CHECK(hipStreamWaitEvent(d->gs, d->ev_ready, 0));
+        issue_exchange(d, m, d->gs, det, masks, MRCNN_DEVICE, global_batch, MRCNN_DEVICE, out_det, out_masks, 0);
+        // ... and the model's stream may overwrite them (the next predict) once they are packed — not once they are exchanged
+        HIP_CHECK(hipStreamWaitEvent(m.stream, d->ev_packed, 0));
+        d->pending = true;
+    });
 }
 
 extern "C" int mrcnn_dist_all_gather_records(mrcnn_dist* d, mrcnn_model* model, const float* det, const float* masks, int global_batch,
@@ -163,7 +346,10 @@ extern "C" int mrcnn_dist_all_gather_records(mrcnn_dist* d, mrcnn_model* model, 
 {
     return guarded([&] {
         MRCNN_REQUIRE(d && model && out_det && out_masks && global_batch >= 1, MRCNN_ERR_INVALID, "bad all_gather_records argument");
-        gather_records(d, model->m, det, masks, memspace, global_batch, memspace, out_det, out_masks);
+        MRCNN_REQUIRE(!d->pending, MRCNN_ERR_INVALID, "an exchange is still pending: call mrcnn_dist_wait first");
+        issue_exchange(d, model->m, model->m.stream, det, masks, memspace, global_batch, memspace, out_det, out_masks, 0);
+        HIP_CHECK(hipStreamSynchronize(model->m.stream));
+        raise_remote_status(d);
     });
 }
 
@@ -171,28 +357,49 @@ extern "C" int mrcnn_maskrcnn_predict_sharded(mrcnn_dist* d, mrcnn_model* model,
                                               int memspace, float* detections, float* masks)
 {
     return guarded([&] {
+        // argument errors every rank sees identically (same call on every rank): raised before any work, on all ranks alike
         MRCNN_REQUIRE(d && model && rgb && detections && masks && global_batch >= 1, MRCNN_ERR_INVALID, "bad predict_sharded argument");
+        MRCNN_REQUIRE(!d->pending, MRCNN_ERR_INVALID, "an exchange is still pending: call mrcnn_dist_wait first");
         Model& m = model->m;
         MRCNN_REQUIRE(m.kind == MRCNN_MODEL_MASKRCNN, MRCNN_ERR_INVALID, "predict_sharded called on a non-MaskRCNN model");
+        const int n_max = (global_batch + d->world - 1) / d->world;
+        MRCNN_REQUIRE(n_max <= m.max_batch, MRCNN_ERR_SHAPE, "the largest shard (%d images of %d over %d ranks) exceeds the model's max_batch %d",
+                      n_max, global_batch, d->world, m.max_batch);
+        MRCNN_REQUIRE(height == m.H && width == m.W, MRCNN_ERR_SHAPE, "image is %dx%d, the model expects %dx%d", height, width, m.H, m.W);
         int lo, hi;
         shard(global_batch, d->world, d->rank, &lo, &hi);
         const int n = hi - lo;
-        MRCNN_REQUIRE(n <= m.max_batch, MRCNN_ERR_SHAPE, "shard of %d images exceeds the model's max_batch %d", n, m.max_batch);
         const int D = m.max_det, S = 2 * m.mask_pool;
-        // this rank's block of the batch → its results stay on the device between predict and the gather
-        const size_t nd = (size_t)(n > 0 ? n : 1) * D * 6 * 4, nm = (size_t)(n > 0 ? n : 1) * D * S * S * 4;
-        if (d->stage_det.bytes < nd) d->stage_det.alloc(nd);
-        if (d->stage_mask.bytes < nm) d->stage_mask.alloc(nm);
-        if (n > 0) {
-            const uint8_t* src = rgb + (size_t)lo * height * width * 3;
-            if (memspace == MRCNN_DEVICE) {
-                m.predict(src, n, height, width, MRCNN_DEVICE, d->stage_det.as<float>(), d->stage_mask.as<float>(), true);
-            } else {
-                if (d->out_det.bytes < (size_t)n * height * width * 3) d->out_det.alloc((size_t)n * height * width * 3);   // image staging
-                HIP_CHECK(hipMemcpy(d->out_det.p, src, (size_t)n * height * width * 3, hipMemcpyHostToDevice));
-                m.predict(d->out_det.as<uint8_t>(), n, height, width, MRCNN_DEVICE, d->stage_det.as<float>(), d->stage_mask.as<float>(), true);
+        // From here on a failure is LOCAL (a HIP error, the data-dependent fp16-range watchdog): it must not keep this rank out
+        // of the collective.  It becomes the status word of this rank's slot, and every rank raises after the gather.
+        int status = 0;
+        std::string local_msg;
+        try {
+            const size_t nd = (size_t)(n > 0 ? n : 1) * D * 6 * 4, nm = (size_t)(n > 0 ? n : 1) * D * S * S * 4;
+            if (d->stage_det.bytes < nd) d->stage_det.alloc(nd);
+            if (d->stage_mask.bytes < nm) d->stage_mask.alloc(nm);
+            if (n > 0) {
+                const uint8_t* src = rgb + (size_t)lo * height * width * 3;
+                if (memspace == MRCNN_DEVICE) {
+                    m.predict(src, n, height, width, MRCNN_DEVICE, d->stage_det.as<float>(), d->stage_mask.as<float>(), true);
+                } else {
+                    const size_t ib = (size_t)n * height * width * 3;
+                    if (d->stage_img.bytes < ib) d->stage_img.alloc(ib);
+                    HIP_CHECK(hipMemcpy(d->stage_img.p, src, ib, hipMemcpyHostToDevice));
+                    m.predict(d->stage_img.as<uint8_t>(), n, height, width, MRCNN_DEVICE, d->stage_det.as<float>(), d->stage_mask.as<float>(), true);
+                }
             }
+        } catch (const Error& e) {
+            status = e.code ? e.code : MRCNN_ERR_HIP;
+            local_msg = e.msg;
+        } catch (const std::exception& e) {
+            status = MRCNN_ERR_INVALID;
+            local_msg = e.what();
         }
-        gather_records(d, m, d->stage_det.as<float>(), d->stage_mask.as<float>(), MRCNN_DEVICE, global_batch, memspace, detections, masks);
+        issue_exchange(d, m, m.stream, d->stage_det.as<float>(), d->stage_mask.as<float>(), MRCNN_DEVICE, global_batch, memspace, detections, masks,
+                       status);
+        HIP_CHECK(hipStreamSynchronize(m.stream));
+        if (status != 0) fail(status, "rank %d: %s (the other ranks were told through the status word of this rank's slot)", d->rank, local_msg.c_str());
+        raise_remote_status(d);
     });
 }

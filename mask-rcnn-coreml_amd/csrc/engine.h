@@ -169,6 +169,11 @@ struct Model {
     DevBuf range_flag;          // 4 B: set by the conv epilogues in MRCNN_F16 / MRCNN_F32S when an activation leaves the fp16 range
     long range_overflows = 0;   // predicts that tripped it
     long graph_launches = 0;
+    // GPU time of the synchronous predicts of this handle (one event pair per call on the model's stream, read at the
+    // call's own synchronisation): "gpu_busy_us" / "predict_calls" of mrcnn_model_get_int — bench.py reports it live
+    hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;
+    double gpu_busy_ms = 0;
+    long predict_calls = 0;
     // Held by the stand-alone TimeDistributed*Layer plugins around stage → forward → unstage: every layer instance
     // shares the cached sub-model's head scratch (stage_in, h1/h2, cls6, feat, full) but launches on its own stream.
     std::mutex eval_mu;

@@ -543,6 +543,8 @@ void Model::drop_graphs()
 Model::~Model()
 {
     drop_graphs();
+    if (ev_p0) (void)hipEventDestroy(ev_p0);
+    if (ev_p1) (void)hipEventDestroy(ev_p1);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
 
@@ -836,6 +838,11 @@ void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, f
     MRCNN_REQUIRE(batch >= 1 && batch <= max_batch, MRCNN_ERR_SHAPE, "batch %d outside 1..%d", batch, max_batch);
     hipStream_t s = stream;
     const size_t img_bytes = (size_t)batch * H * W * 3;
+    if (!ev_p0) { HIP_CHECK(hipEventCreate(&ev_p0)); HIP_CHECK(hipEventCreate(&ev_p1)); }
+    hipStreamCaptureStatus outer_capture = hipStreamCaptureStatusNone;
+    HIP_CHECK(hipStreamIsCapturing(s, &outer_capture));
+    const bool timed_call = sync && outer_capture == hipStreamCaptureStatusNone;
+    if (timed_call) HIP_CHECK(hipEventRecord(ev_p0, s));
     HIP_CHECK(hipMemcpyAsync(d_rgb, rgb, img_bytes, memspace == MRCNN_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
 
     hipStreamCaptureStatus caller_capture = hipStreamCaptureStatusNone;
@@ -870,8 +877,15 @@ void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, f
     const hipMemcpyKind back = memspace == MRCNN_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     HIP_CHECK(hipMemcpyAsync(det_out, detections, (size_t)batch * max_det * 6 * 4, back, s));
     HIP_CHECK(hipMemcpyAsync(masks_out, mask_out, (size_t)batch * max_det * HW * 4, back, s));
+    if (timed_call) HIP_CHECK(hipEventRecord(ev_p1, s));
     if (sync) {
         HIP_CHECK(hipStreamSynchronize(s));
+        if (timed_call) {
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, ev_p0, ev_p1));
+            gpu_busy_ms += ms;
+            ++predict_calls;
+        }
         timer.finish();
         if (conv_profile.active) conv_profile.collect();
         if (mode != MRCNN_F32) {

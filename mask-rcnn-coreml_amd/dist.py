@@ -143,6 +143,46 @@ class NativeDist:
             self._lib.HOST if host else self._lib.DEVICE, ptr(out_det), ptr(out_mask)))
         return out_det, out_mask
 
+    def all_gather_records_async(self, model, det, mask, global_batch: int, out_det, out_mask):
+        """The same exchange on the handle's own stream behind the model's stream (torch CUDA tensors only): returns at
+        once; the model's next predict overlaps it.  Join with wait()."""
+        self._lib.check(self._lib.lib().mrcnn_dist_all_gather_records_async(
+            self._h, model._h, det.data_ptr(), mask.data_ptr(), global_batch, out_det.data_ptr(), out_mask.data_ptr()))
+
+    def wait(self):
+        self._lib.check(self._lib.lib().mrcnn_dist_wait(self._h))
+
+    @staticmethod
+    def plan(global_batch: int, world: int, max_det: int, mask_size: int):
+        """[(begin, end, slot offset in floats, record floats)] per rank and the slot size — host arithmetic of dist.hip."""
+        import ctypes as C
+        from . import _lib
+        table = (C.c_int64 * (4 * world))()
+        slot = C.c_int64(0)
+        _lib.check(_lib.lib().mrcnn_dist_plan(global_batch, world, max_det, mask_size, table, C.byref(slot)))
+        return [tuple(table[4 * r:4 * r + 4]) for r in range(world)], slot.value
+
+    @staticmethod
+    def simulate_host(dets, masks, global_batch: int, max_det: int, mask_size: int, status=None):
+        """dist.hip's pack -> all-gather (concatenation) -> unpack on host arrays: dets[r] / masks[r] = rank r's local results
+        (numpy float32).  Returns (detections, masks, statuses) of the whole batch as rank 0 would hold them."""
+        import ctypes as C
+        import numpy as np
+        from . import _lib
+        world = len(dets)
+        dk = [np.ascontiguousarray(d, np.float32) for d in dets]
+        mk = [np.ascontiguousarray(m, np.float32) for m in masks]
+        dp = (C.c_void_p * world)(*[a.ctypes.data if a.size else None for a in dk])
+        mp = (C.c_void_p * world)(*[a.ctypes.data if a.size else None for a in mk])
+        out_d = np.full((global_batch, max_det, 6), np.nan, np.float32)
+        out_m = np.full((global_batch, max_det, mask_size, mask_size), np.nan, np.float32)
+        st_in = None if status is None else np.ascontiguousarray(status, np.int32)
+        st_out = np.zeros(world, np.int32)
+        _lib.check(_lib.lib().mrcnn_dist_simulate_host(world, global_batch, max_det, mask_size, dp, mp,
+                                                       None if st_in is None else st_in.ctypes.data, out_d.ctypes.data, out_m.ctypes.data,
+                                                       st_out.ctypes.data))
+        return out_d, out_m, st_out
+
     def predict_sharded(self, model, images):
         """images: the GLOBAL batch (B,H,W,3) uint8, identical on every rank — numpy or torch CUDA tensor."""
         import numpy as np

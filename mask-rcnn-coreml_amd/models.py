@@ -110,6 +110,12 @@ class MaskRCNN(_Model):
         else:
             _lib.check(_lib.lib().mrcnn_maskrcnn_predict_async(self._h, images.data_ptr(), B, H, W, det.data_ptr(), mask.data_ptr()))
 
+    def predict_host_into(self, images: np.ndarray, det: np.ndarray, mask: np.ndarray):
+        """Host buffers in and out without allocation (pinned memory gives asynchronous PCIe copies): the H2D of the batch
+        and the D2H of the records are part of the call — bench.py's h2d_included leg."""
+        B, H, W, _ = images.shape
+        _lib.check(_lib.lib().mrcnn_maskrcnn_predict(self._h, images.ctypes.data, B, H, W, _lib.HOST, det.ctypes.data, mask.ctypes.data))
+
     def check_range(self) -> bool:
         """After predict_into(sync=False): synchronises the model's stream and reports whether the last predict left
         the fp16 range (its results are then not valid) — the async counterpart of the error predict() raises."""

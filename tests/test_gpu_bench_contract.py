@@ -39,6 +39,11 @@ def test_bench_json_contract():
     assert c["value"] < j["value"]
     assert j["dtype"] == "f32x3" and r_peak(j) == pytest.approx(2500.0 / 3, rel=1e-3)
     assert set(j["other_modes"]) == {"f32", "f32s", "f16"} and all(v["value"] > 0 for v in j["other_modes"].values())
+    assert all(v["steps"] >= 10 for v in j["other_modes"].values())
+    g = j["gpu_busy"]
+    assert 0 < g["gpu_seconds"] <= g["wall_seconds"] * 1.001 and g["predicts"] == j["steps"]       # measured in this run
+    assert j["h2d_included"]["value"] > 0 and j["h2d_included"]["value"] <= j["value"] * 1.05
+    assert "not measured in this run" in j["profiles_ref"]["note"].lower()
     p = j["parity_e2e"]
     assert p["images"] == 2 and set(p["modes"]) == {"f32", "f32x3", "f32s", "f16"}
     assert p["modes"]["f32x3"]["fraction"] >= 0.9 and p["modes"]["f32"]["fraction"] >= 0.9
@@ -46,6 +51,36 @@ def test_bench_json_contract():
 
 def r_peak(j):
     return j["roofline"]["peak"]
+
+
+def test_bench_gpus_1_without_torchrun_prints_n_gpus_1():
+    """The driver's N = 1 command line (`python bench.py --gpus 1 ...`, no torchrun) stays a single-process run."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline", "--no-other-modes"] + SMALL,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    j = _check(lines[0])
+    assert j["config"]["parallelism"] == "single"
+
+
+def test_bench_self_launch_covers_the_visible_gpus():
+    """`python bench.py --gpus N` with no torchrun environment launches its N ranks itself: with N GPUs an N-rank line
+    (parallelism dpN), otherwise a loud failure — never n_gpus: 1."""
+    import torch
+    n = 2
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--no-cpu-baseline", "--no-other-modes"] + SMALL,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    if torch.cuda.device_count() >= n:
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+        assert len(lines) == 1
+        j = _check(lines[0], n_gpus=n)
+        assert j["config"]["parallelism"] == f"dp{n}"
+    else:
+        assert r.returncode != 0 and not r.stdout.strip() and f"--gpus {n}" in r.stderr
 
 
 def test_bench_under_torchrun_with_rccl_leg():

@@ -203,3 +203,51 @@ def test_activation_tensor_beyond_4_gib(dtype, batch):
     if dtype == "f16":
         want = want.astype(np.float16).astype(np.float32)
     np.testing.assert_array_equal(y[1], np.broadcast_to(want, y[1].shape))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the split modes are not scale-invariant the way fp32 is: the curve, and the bound the documentation states
+# ---------------------------------------------------------------------------------------------------------------------
+SCALES = [0, -4, -8, -12, -16, -20]
+
+
+def split_scale_curve(dtype, shape=(2, 32, 32, 256, 128, 3), seed=3):
+    """max |err| / max |ref| of one convolution against an fp64 torch convolution, for the SAME post-ReLU-like tensor
+    multiplied by 2^e (an exact operation): [(e, relative error, bound)].  bound = what include/maskrcnn_hip.h documents for
+    the three-part split: every activation is carried exactly when |a| >= 0.5 and to 2^-24 ABSOLUTE (truncated toward
+    zero) below, so an output is off by at most 2^-24 * sum |w| over its taps — plus the fp32 summation noise every
+    fp32 engine has (taken as 2e-6 of the range, the bar of the other conv tests)."""
+    B, H, W, Ci, Co, k = shape
+    rng = np.random.default_rng(seed)
+    x = np.maximum(rng.standard_normal((B, H, W, Ci)), 0).astype(np.float32) * 4.0         # post-ReLU, O(1-10) like the trunk's
+    w = (rng.standard_normal((Co, k, k, Ci)) * np.sqrt(2.0 / (k * k * Ci))).astype(np.float16).astype(np.float32)
+    one, zero = np.ones(Co, np.float32), np.zeros(Co, np.float32)
+    wsum = np.abs(w.astype(np.float64)).reshape(Co, -1).sum(1).max()
+    out = []
+    for e in SCALES:
+        xs = np.ldexp(x, e).astype(np.float32)
+        got = conv(xs, w, k, 1, one, zero, None, act=0, dtype=dtype).astype(np.float64)
+        ref = torch_ref(xs, w, k, 1, one, zero, None, 0, dtype=dtype)
+        rng_ref = np.abs(ref).max()
+        out.append((e, float(np.abs(got - ref).max() / rng_ref), float(2.0 ** -24 * wsum / rng_ref + 2e-6)))
+    return out
+
+
+@pytest.mark.parametrize("dtype", ["f32x3", "f32s", "f32"])
+def test_split_modes_scale_curve_stays_inside_the_documented_bound(dtype):
+    """VERDICT r2 item 1(b) / ADVICE r2: the three-part split is exact only for 0.5 <= |a| < 65504; below, an activation is
+    carried to 2^-24 absolute.  The same tensor at 2^0 ... 2^-20: the fp32-MFMA mode is flat (control), the split modes follow
+    the documented bound (and must not be WORSE than it: that is what protects small-magnitude checkpoints from silent loss)."""
+    curve = split_scale_curve(dtype)
+    for e, err, bound in curve:
+        if dtype == "f32":
+            assert err < 2e-6, (e, err)                           # scale-invariant, like the reference's fp32
+        elif dtype == "f32x3":
+            assert err <= bound, (e, err, bound)
+        else:                                                     # two-part split: 2^-22 relative on top
+            assert err <= bound + 2.0 ** -21, (e, err, bound)
+    if dtype == "f32x3":
+        # at the trunk's own scale (O(1-10) activations) the split costs nothing measurable ...
+        assert curve[0][1] < 2e-6
+        # ... and the loss at tiny scales is real: were it to vanish, the documentation (and this test) should be revisited
+        assert curve[-1][1] > 10 * curve[0][1]

@@ -212,13 +212,15 @@ def test_engine_resnet101_256(pkg, orc, tmp_path_factory, weights_mod):
         _check_stages(pkg, orc, om, m, cfg, images, b, True, trunk)
 
 
-def test_engine_config3_resnet50_1024(pkg, orc, tmp_path_factory, weights_mod):
-    """BASELINE configs[2] per-GPU slice: ResNet50+FPN at 1024² (C4 = 6 blocks), batch 2."""
+@pytest.mark.parametrize("mode", ["f32x3", "f32"])
+def test_engine_config3_resnet50_1024(pkg, orc, tmp_path_factory, weights_mod, mode):
+    """BASELINE configs[2] per-GPU slice: ResNet50+FPN at 1024² (C4 = 6 blocks), batch 2 — in the headline mode (f32x3,
+    the mode profiles/*_bench_n1_resnet50.json is quoted in) and in the fp32-MFMA mode."""
     from oracle.network import load_oracle_model
     models = __import__("importlib").import_module("mask-rcnn-coreml_amd.models")
-    d, cfg = make_model_dir(tmp_path_factory, pkg, weights_mod, "r50full", architecture="resnet50")
+    d, cfg = make_model_dir(tmp_path_factory, pkg, weights_mod, "r50full" + mode, architecture="resnet50")
     om = load_oracle_model(d)
-    m = models.load_maskrcnn(d, max_batch=2)
+    m = models.load_maskrcnn(d, max_batch=2, compute_dtype=mode)
     images = rand_images(2, 1024, 1024, seed=11)
     m.predict(images)
     trunk = om.trunk(images[:1])
@@ -226,16 +228,18 @@ def test_engine_config3_resnet50_1024(pkg, orc, tmp_path_factory, weights_mod):
     _check_stages(pkg, orc, om, m, cfg, images, 1, False)
 
 
-def test_engine_config5_1536_two_classes(pkg, orc, tmp_path_factory, weights_mod):
+@pytest.mark.parametrize("mode", ["f32x3", "f32"])
+def test_engine_config5_1536_two_classes(pkg, orc, tmp_path_factory, weights_mod, mode):
     """BASELINE configs[4]: 1536×1536, num_classes = 2, pre_nms 12000 (NMS / ROIAlign stress):
-    A = 589 248 anchors, pyramid 384²..24², every stage after the trunk bit-exact on the GPU's taps."""
+    A = 589 248 anchors, pyramid 384²..24², every stage after the trunk bit-exact on the GPU's taps — in the headline
+    mode (f32x3, the mode profiles/*_config5_1536.json is quoted in) and in the fp32-MFMA mode."""
     from oracle.network import load_oracle_model
     models = __import__("importlib").import_module("mask-rcnn-coreml_amd.models")
-    d, cfg = make_model_dir(tmp_path_factory, pkg, weights_mod, "c5", architecture="resnet101",
+    d, cfg = make_model_dir(tmp_path_factory, pkg, weights_mod, "c5" + mode, architecture="resnet101",
                             input_image_shape=(1536, 1536, 3), num_classes=2, pre_nms_max_proposals=12000)
     assert cfg.num_anchors() == 589248
     om = load_oracle_model(d)
-    m = models.load_maskrcnn(d, max_batch=1)
+    m = models.load_maskrcnn(d, max_batch=1, compute_dtype=mode)
     images = rand_images(1, 1536, 1536, seed=13)
     m.predict(images)
     trunk = om.trunk(images)

@@ -61,7 +61,7 @@ def test_headline_batch8_full_size(pkg, orc, full_model, full_images, full_oracl
     pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None
 
 
-@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("mode", ["f32x3", "f32", "f16"])
 def test_config5_1536_batch2(pkg, orc, tmp_path_factory, weights_mod, mode):
     """BASELINE configs[4] (1536², 2 classes, pre_nms 12000) at batch 2: batch independence + staged parity on image 1."""
     from oracle.network import load_oracle_model
@@ -79,6 +79,33 @@ def test_config5_1536_batch2(pkg, orc, tmp_path_factory, weights_mod, mode):
         d1, m1 = m.predict(images[b:b + 1])
         np.testing.assert_array_equal(d1[0], det[b])
         np.testing.assert_array_equal(m1[0], mask[b])
+    pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None
+
+
+def test_headline_end_to_end_agreement_with_the_oracle(pkg, full_model):
+    """The end-to-end figure bench.py prints as parity_e2e, as a test: HIP predict in the headline
+    mode (f32x3) vs the CPU oracle's predict on 8 full-size images of the headline workload — EVERY detection of every
+    image must have a partner with the same class id and a box within 1e-4 (order-insensitive: scores that differ in the
+    last bits may swap neighbours), scores within 1e-5, masks (present on both sides) within 2e-4."""
+    import importlib
+    from oracle.network import load_oracle_model
+    models = importlib.import_module("mask-rcnn-coreml_amd.models")
+    ev = importlib.import_module("mask-rcnn-coreml_amd.evaluate")
+    d, cfg = full_model
+    images = rand_images(8, 1024, 1024, seed=31)
+    m = models.load_maskrcnn(d, max_batch=8, compute_dtype="f32x3")
+    hd, hk = m.predict(images)
+    om = load_oracle_model(d)
+    tot = matched = presence = 0
+    for b in range(8):
+        od, ok = om.predict(images[b:b + 1])
+        a = ev.detection_agreement(hd[b], od[0], 1e-4, hk[b], ok[0])
+        assert a["n_a"] == a["n_b"] == cfg.max_detections, (b, a)
+        assert a["matched"] == a["n_a"], f"image {b}: {a}"
+        assert a["max_score_diff"] < 1e-5 and a["max_mask_diff"] < 2e-4, (b, a)
+        tot += a["n_a"]; matched += a["matched"]; presence += a["mask_presence_mismatch"]
+    assert matched == tot == 8 * cfg.max_detections            # fraction == 1.0
+    assert presence <= 2                                        # the reference's removeZeros cliff (an exact-zero sample): rare
     pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None
 
 

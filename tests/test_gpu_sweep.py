@@ -126,7 +126,7 @@ def test_pyramid_roi_align_sweep(pkg, orc):
 
 def test_engine_config_sweep(pkg, orc, weights_mod, tmp_path_factory):
     """The fused engine on a dozen seeded small configurations — non-square inputs, class counts 2..81, proposal / detection
-    budgets from tiny to larger than the anchor count allows, loaded and sparse weights, batch 1..3, all three compute modes —
+    budgets from tiny to larger than the anchor count allows, loaded and sparse weights, batch 1..3, all four compute modes (the headline f32x3 first) —
     each through the full staged parity of test_gpu_engine (index / box stages bit-exact on the GPU's taps)."""
     import importlib
     from oracle.network import load_oracle_model
@@ -143,7 +143,7 @@ def test_engine_config_sweep(pkg, orc, weights_mod, tmp_path_factory):
         cfg = pkg.ModelConfig(**kw)
         d = str(tmp_path_factory.mktemp(f"sweep{case}"))
         weights_mod.save_synthetic_models(d, cfg, seed=100 + case, forced_load=bool(case % 3))
-        mode = ("f32", "f32s", "f16")[case % 3]
+        mode = ("f32x3", "f32", "f32s", "f16")[case % 4]
         seen_modes.add(mode)
         B = 1 + case % 3
         om = load_oracle_model(d)
@@ -159,4 +159,4 @@ def test_engine_config_sweep(pkg, orc, weights_mod, tmp_path_factory):
             np.testing.assert_array_equal(det[b], d_b)
             np.testing.assert_array_equal(mask[b].reshape(cfg.max_detections, -1), m_b)
         del m
-    assert seen_modes == {"f32", "f32s", "f16"}
+    assert seen_modes == {"f32x3", "f32", "f32s", "f16"}

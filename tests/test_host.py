@@ -407,3 +407,84 @@ def test_mask_to_u8_double_path_equals_float_path():
     L.check(L.lib().mrcnn_mask_to_u8_f64(md.ctypes.data, m.size, b.ctypes.data))
     np.testing.assert_array_equal(a, b)
     assert a[0] == 255 and a[1] == 127 and a[3] == 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# the native exchange (csrc/dist.hip) through its host seam, and bench.py's launcher
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_native_dist_layout_matches_the_torch_twin(world):
+    """csrc/dist.hip's pack -> all-gather -> unpack (the code the GPU path runs, copy primitive swapped for memcpy) at world
+    sizes 1-8 with even and uneven shards, against mask-rcnn-coreml_amd/dist.py's record layout and shard arithmetic —
+    the native path cannot run at world > 1 on the build machine."""
+    import torch
+    dmod = importlib.import_module("mask-rcnn-coreml_amd.dist")
+    D, S = 5, 4
+    rng = np.random.default_rng(world)
+    for global_batch in sorted({1, world, world + 1, 2 * world - 1 if world > 1 else 3, 8 * world, 8 * world + 3}):
+        det = rng.standard_normal((global_batch, D, 6)).astype(np.float32)
+        mask = rng.standard_normal((global_batch, D, S, S)).astype(np.float32)
+        plan, slot = dmod.NativeDist.plan(global_batch, world, D, S)
+        n_max = -(-global_batch // world)
+        rec = D * 6 + D * S * S
+        assert slot == n_max * rec + 4
+        bounds = [dmod.shard_bounds(global_batch, world, r) for r in range(world)]
+        assert [(b, e) for b, e, _, _ in plan] == bounds
+        assert [o for _, _, o, _ in plan] == [r * slot for r in range(world)]
+        assert [c for _, _, _, c in plan] == [(e - b) * rec for b, e in bounds]
+        for r in range(world):
+            assert dmod.NativeDist.shard(global_batch, world, r) == bounds[r]
+        locd = [det[b:e] for b, e in bounds]
+        locm = [mask[b:e] for b, e in bounds]
+        od, om, st = dmod.NativeDist.simulate_host(locd, locm, global_batch, D, S)
+        np.testing.assert_array_equal(od, det)
+        np.testing.assert_array_equal(om, mask)
+        assert not st.any()
+        # the torch twin's record layout: pack -> pad to the largest shard -> concatenate -> drop padding -> unpack
+        parts = []
+        for (b, e), d_, m_ in zip(bounds, locd, locm):
+            pad = torch.zeros((n_max, rec))
+            if e > b:
+                pad[: e - b] = dmod.pack_records(torch.from_numpy(d_), torch.from_numpy(m_))
+            parts.append(pad[: e - b])
+        td, tm = dmod.unpack_records(torch.cat(parts, 0), D, S)
+        np.testing.assert_array_equal(od, td.numpy())
+        np.testing.assert_array_equal(om, tm.numpy())
+
+
+def test_native_dist_failed_rank_still_contributes_a_slot():
+    """a rank whose local predict failed takes part in the collective with zeroed records and its status
+    word; every rank sees the status (and raises) instead of blocking in ncclAllGather."""
+    dmod = importlib.import_module("mask-rcnn-coreml_amd.dist")
+    D, S, world, gb = 3, 2, 4, 9
+    rng = np.random.default_rng(5)
+    det = rng.standard_normal((gb, D, 6)).astype(np.float32)
+    mask = rng.standard_normal((gb, D, S, S)).astype(np.float32)
+    bounds = [dmod.shard_bounds(gb, world, r) for r in range(world)]
+    status = np.array([0, 0, 5, 0], np.int32)        # rank 2: MRCNN_ERR_UNSUPPORTED (the fp16-range watchdog)
+    od, om, st = dmod.NativeDist.simulate_host([det[b:e] for b, e in bounds], [mask[b:e] for b, e in bounds], gb, D, S, status)
+    np.testing.assert_array_equal(st, status)
+    b2, e2 = bounds[2]
+    assert not od[b2:e2].any() and not om[b2:e2].any()          # zeroed, not garbage
+    keep = np.r_[0:b2, e2:gb]
+    np.testing.assert_array_equal(od[keep], det[keep])
+    np.testing.assert_array_equal(om[keep], mask[keep])
+
+
+def test_bench_gpus_n_fails_loudly_without_n_gpus():
+    """`python bench.py --gpus 2` is the driver's command line for N = 2: without two GPUs it must fail, not print an
+    n_gpus: 1 line; a --gpus / WORLD_SIZE mismatch is an error too."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs present")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0
+    assert not r.stdout.strip(), r.stdout                       # no JSON line
+    assert "--gpus 2" in r.stderr and "GPU" in r.stderr
+    env["WORLD_SIZE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and not r.stdout.strip() and "WORLD_SIZE" in r.stderr
