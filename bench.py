@@ -252,7 +252,7 @@ def main():
                 tail = {"f32": "2,2", "f16": "2,2", "f32s": "3,2", "f32x3": "3,3"}[args.dtype]
                 kname = {"128x128": f"k_conv_mfma_glds<{ktypes},128,1,2,4,2,{tail}>", "128x64": f"k_conv_mfma_glds<{ktypes},64,1,1,4,2,...>",
                          "128x32": f"k_conv_mfma_glds<{ktypes},32,1,1,4,1,...>", "128x128w4": f"k_conv_mfma_glds<{ktypes},128,1,4,4,1,{tail}>",
-                         "256x256pp": "k_conv_pp<0>"}[dom]
+                         "256x256pp": "k_conv_pp<0>", "128xNhalo": f"k_conv_halo<{parts},TN> (persistent 128 x 64*TN halo tiles)"}[dom]
                 out["roofline"] = {
                     "kernel": kname, "bound": "mfma",
                     "achieved": round(achieved, 2),

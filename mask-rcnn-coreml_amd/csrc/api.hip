@@ -803,6 +803,11 @@ extern "C" int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout
         d.OH = oh; d.OW = ow; d.Cout = cout; d.Npad = npad;
         d.out = dout.p; d.out_sP = cout; d.out_sB = (long)oh * ow * cout; d.act = ACT_RELU;
         Stream st;
+        DevBuf dwh;
+        if (ksize == 3 && ws == 2 && es == 4 && cin % 16 == 0 && npad % 64 == 0) {
+            conv_halo_pack(st.s, dw.p, npad, cin, dwh);
+            d.wgt_halo = dwh.p;
+        }
         hipEvent_t e0, e1;
         HIP_CHECK(hipEventCreate(&e0));
         HIP_CHECK(hipEventCreate(&e1));
@@ -880,6 +885,11 @@ extern "C" int mrcnn_conv2d_nhwc(const float* in, int batch, int h, int w, int c
         d.out = dout.p; d.out_sP = cout; d.out_sB = (long)oh * ow * cout; d.act = act;
         if (residual) { d.res = dres.p; d.res_sB = d.out_sB; d.res_sW = cout; d.res_sH = (long)ow * cout; }
         Stream st;
+        DevBuf dwh;
+        if (ksize == 3 && wdt != MRCNN_F32 && adt == MRCNN_F32 && cin % 16 == 0 && npad % 64 == 0) {
+            conv_halo_pack(st.s, dw.p, npad, cin, dwh);
+            d.wgt_halo = dwh.p;
+        }
         conv_forward(st.s, d);
         HIP_CHECK(hipStreamSynchronize(st.s));
         if (adt == MRCNN_F16) {

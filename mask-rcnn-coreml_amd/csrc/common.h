@@ -51,6 +51,19 @@ int guarded(F&& body)
     }
 }
 
+// roctx ranges with the reference's os_signpost names (ProposalLayer.swift:105-194, PyramidROIAlignLayer.swift:83-180,
+// DetectionLayer.swift:109-233, TimeDistributed*Layer.swift): rocprofv3 --marker-trace shows the stages of a predict by the
+// names Instruments shows for the reference.  The roctx library is bound at run time (librocprofiler-sdk-roctx.so.1, else
+// libroctx64.so.4); without it, or with MRCNN_ROCTX=0, the calls are no-ops.  Host-side ranges around the launches of a stage.
+void trace_push(const char* name);
+void trace_pop();
+struct TraceRange {
+    explicit TraceRange(const char* name) { trace_push(name); }
+    ~TraceRange() { trace_pop(); }
+    TraceRange(const TraceRange&) = delete;
+    TraceRange& operator=(const TraceRange&) = delete;
+};
+
 // Selects the current device and checks it is a gfx950 part; throws MRCNN_ERR_HIP otherwise.
 void require_gpu();
 

@@ -43,6 +43,7 @@ inline int mode_wgt(int mode) { return mode == MRCNN_F32 ? MRCNN_F32 : (mode == 
 
 struct PackedConv {
     DevBuf wgt, scale, shift;     // wgt in `wdtype`; scale/shift always fp32
+    DevBuf wgt_halo;              // 3x3 layers of the split modes: the same filters re-tiled for the halo kernel (conv_halo_pack)
     int Cin = 0, Cout = 0, KH = 1, KW = 1, Npad = 0;
     int dtype = MRCNN_F32;        // activations
     int wdtype = MRCNN_F32;       // filters (fp16 with fp32 activations = split mode, MRCNN_F32S)

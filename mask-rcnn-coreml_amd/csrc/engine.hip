@@ -8,6 +8,8 @@
 // fp32 with BatchNorm folded into a per-channel scale/shift; the pyramid P2..P5 stays resident for
 // both ROIAlign passes (the reference re-uploads 89 MB of textures per call,
 // PyramidROIAlignLayer.swift:110-118).
+#include <dlfcn.h>
+
 #include "engine.h"
 
 #include <math.h>
@@ -33,6 +35,29 @@ void set_error(const char* fmt, ...)
     g_last_error = buf;
 }
 const char* last_error() { return g_last_error.c_str(); }
+
+// ---- roctx (run-time bound) ----------------------------------------------------------------------------------------
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char* e = getenv("MRCNN_ROCTX");
+        if (e && atoi(e) == 0) return;
+        for (const char* n : {"librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+            void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            auto pu = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+            auto po = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (pu && po) { push = pu; pop = po; return; }
+        }
+    }
+};
+Roctx& roctx() { static Roctx r; return r; }
+}  // namespace
+void trace_push(const char* name) { if (roctx().push) (void)roctx().push(name); }
+void trace_pop() { if (roctx().pop) (void)roctx().pop(); }
 
 void fail(int code, const char* fmt, ...)
 {
@@ -262,6 +287,10 @@ PackedConv pack_conv_oihw(const MrcwFile& f, const std::string& conv, const std:
                 for (int x = 0; x < KW; ++x)
                     w[(((size_t)o * KH + y) * KW + x) * I + i] = k[(((size_t)o * I + i) * KH + y) * KW + x];
     upload_w(pc.wgt, w, pc.wdtype, pc.wdtype != pc.dtype, "MRCNN_F32S / MRCNN_F32X3");
+    if (KH == 3 && KW == 3 && pc.wdtype != pc.dtype && I % 16 == 0 && pc.Npad % 64 == 0) {
+        conv_halo_pack(nullptr, pc.wgt.p, pc.Npad, I, pc.wgt_halo);           // split modes: also in the halo kernel's tiling
+        HIP_CHECK(hipStreamSynchronize(nullptr));
+    }
     std::vector<float> sc, sh;
     fold_bn(f, conv, bn, O, pc.Npad, sc, sh);
     upload(pc.scale, sc);
@@ -363,6 +392,7 @@ void run_conv_dense(hipStream_t s, const PackedConv& pc, const void* in, int B, 
     d.in = in; d.B = B; d.H = H; d.W = W; d.Cin = pc.Cin;
     d.in_sW = pc.Cin; d.in_sH = (long)W * pc.Cin; d.in_sB = (long)H * W * pc.Cin;
     d.wgt = pc.wgt.p; d.KH = pc.KH; d.KW = pc.KW; d.stride = stride; d.padH = d.padW = pad;
+    d.wgt_halo = pc.wgt_halo.p;
     d.scale = pc.scale.as<float>(); d.shift = pc.shift.as<float>();
     d.OH = (H + 2 * pad - pc.KH) / stride + 1;
     d.OW = (W + 2 * pad - pc.KW) / stride + 1;
@@ -412,6 +442,7 @@ void ClassifierHead::forward(hipStream_t s, const void* pooled_nhwc, int n, floa
     run_conv_dense(s, fc1, pooled_nhwc, 1, 1, n, h1, 1, 0, ACT_RELU);
     run_conv_dense(s, fc2, h1, 1, 1, n, h2, 1, 0, ACT_RELU);
     run_conv_dense(s, fc3, h2, 1, 1, n, lb, 1, 0, ACT_NONE, nullptr, 1);
+    TraceRange tr("TimeDistributedClassifierLayer-ProcessOutput");
     softmax_rows_forward(s, lb, fc3.Cout, nc, n, probs);
     copy_columns_forward(s, lb, fc3.Cout, nc, 4 * nc, n, bbox);
     if (cls6_out) classifier_postprocess_forward(s, probs, bbox, nc, n, cls6_out, cls6_stride);
@@ -686,6 +717,7 @@ void Model::build_maskrcnn()
             d.in_sW = in.C; d.in_sH = (long)in.W * in.C; d.in_sB = in.sB();
             d.wdtype = pc->wdtype;
             d.wgt = pc->wgt.p; d.KH = pc->KH; d.KW = pc->KW; d.stride = stride; d.padH = d.padW = pad;
+            d.wgt_halo = pc->wgt_halo.p;
             d.scale = pc->scale.as<float>(); d.shift = pc->shift.as<float>();
             d.OH = out.H; d.OW = out.W; d.Cout = pc->Cout; d.Npad = pc->Npad;
             d.out = out.p; d.out_sP = out.C; d.out_sB = out.sB();
@@ -781,6 +813,7 @@ void Model::build_maskrcnn()
             d.in_sW = (long)sub * src.C; d.in_sH = (long)sub * src.W * src.C; d.in_sB = src.sB();
             d.wdtype = pc->wdtype;
             d.wgt = pc->wgt.p; d.KH = 3; d.KW = 3; d.stride = 1; d.padH = d.padW = 1;
+            d.wgt_halo = pc->wgt_halo.p;
             d.scale = pc->scale.as<float>(); d.shift = pc->shift.as<float>();
             d.OH = fh[l]; d.OW = fw[l]; d.Cout = 512; d.Npad = pc->Npad;
             d.out = rpn_feat; d.out_sP = 512; d.out_sB = (long)fh[l] * fw[l] * 512; d.act = ACT_RELU;
@@ -907,35 +940,54 @@ void Model::enqueue_pipeline(hipStream_t s, int batch)
     conv_set_range_flag(rflag);
     timer.begin(s);
     conv_set_profiler(conv_profile.active ? &conv_profile : nullptr);
-    for (auto& op : trunk_ops) op(s, batch);
+    {
+        TraceRange tr("MaskRCNN-Trunk");          // the Core ML graph itself: no signpost in the reference
+        for (auto& op : trunk_ops) op(s, batch);
+    }
     timer.mark(s, "Trunk");
     // ProposalLayer
     ProposalWorkspace pw = prop_ws; pw.B = batch;
-    proposal_forward(s, pw, rpn_probs, (long)A * 2, rpn_deltas, (long)A * 4, anchors.as<float>(), prop_std, prop_nms_thr, rois,
-                     (long)max_prop * 4, 4);
+    {
+        TraceRange tr("Proposal-Eval");
+        proposal_forward(s, pw, rpn_probs, (long)A * 2, rpn_deltas, (long)A * 4, anchors.as<float>(), prop_std, prop_nms_thr, rois,
+                         (long)max_prop * 4, 4);
+    }
     timer.mark(s, "Proposal-Eval");
     // PyramidROIAlign (classifier)
     PyramidMaps maps;
     for (int l = 0; l < 4; ++l) { maps.data[l] = P[l].p; maps.H[l] = P[l].H; maps.W[l] = P[l].W; maps.sB[l] = P[l].sB(); }
     const long prow = (long)cls_pool * cls_pool * 256;
-    roi_align_forward(s, maps, 256, 1, rois, (long)max_prop * 4, 4, max_prop, batch, cls_pool, roi_img_w, roi_img_h, pooled,
-                      (long)max_prop * prow, prow, dtype);
+    {
+        TraceRange tr("PyramidROIAlign-Eval");
+        roi_align_forward(s, maps, 256, 1, rois, (long)max_prop * 4, 4, max_prop, batch, cls_pool, roi_img_w, roi_img_h, pooled,
+                          (long)max_prop * prow, prow, dtype);
+    }
     timer.mark(s, "PyramidROIAlign-Eval");
     // TimeDistributedClassifier
-    cls_head.forward(s, pooled, batch * max_prop, cls6, 6);
+    {
+        TraceRange tr("TimeDistributedClassifierLayer-Eval");
+        cls_head.forward(s, pooled, batch * max_prop, cls6, 6);
+    }
     timer.mark(s, "TimeDistributedClassifierLayer-Eval");
     // DetectionLayer
     DetectionWorkspace dw = det_ws; dw.B = batch;
-    detection_forward(s, dw, rois, (long)max_prop * 4, 4, cls6, (long)max_prop * 6, det_std, det_score_thr, det_nms_thr, nc,
-                      detections, (long)max_det * 6, 6);
+    {
+        TraceRange tr("Detection-Eval");
+        detection_forward(s, dw, rois, (long)max_prop * 4, 4, cls6, (long)max_prop * 6, det_std, det_score_thr, det_nms_thr, nc,
+                          detections, (long)max_det * 6, 6);
+    }
     timer.mark(s, "Detection-Eval");
     // PyramidROIAlign (mask) on the detections' boxes
     const long mrow = (long)mask_pool * mask_pool * 256;
     // ... which also evaluates the mask layer's removeZeros predicate on the fp32 samples (before an fp16 store rounds them)
-    roi_align_forward(s, maps, 256, 1, detections, (long)max_det * 6, 6, max_det, batch, mask_pool, roi_img_w, roi_img_h, pooled_mask,
-                      (long)max_det * mrow, mrow, dtype, msel_ws.flags);
+    {
+        TraceRange tr("PyramidROIAlign-Eval");
+        roi_align_forward(s, maps, 256, 1, detections, (long)max_det * 6, 6, max_det, batch, mask_pool, roi_img_w, roi_img_h, pooled_mask,
+                          (long)max_det * mrow, mrow, dtype, msel_ws.flags);
+    }
     timer.mark(s, "PyramidROIAlign-Eval-Mask");
     // TimeDistributedMask
+    TraceRange tr_mask("TimeDistributedMask-Eval");
     const int HW = 4 * mask_pool * mask_pool;
     mask_valid_rows_forward(s, nullptr, (long)max_det * mrow, mrow, mrow, max_det, batch, msel_ws, dtype);
     // Rows the reference's mask layer never writes (an invalid row below the kept count,

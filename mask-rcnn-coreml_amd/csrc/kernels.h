@@ -96,6 +96,8 @@ struct ConvDesc {
     long in_sB = 0, in_sH = 0, in_sW = 0;
     // filter: packed [Npad][KH*KW*Cin], k contiguous (tap-major, channel-minor)
     const void* wgt = nullptr;
+    // the same filters re-tiled for the halo kernel (kernels_conv_halo.hip: conv_halo_pack); nullptr = not available
+    const void* wgt_halo = nullptr;
     int KH = 1, KW = 1, stride = 1, padH = 0, padW = 0;
     // epilogue: y = act(acc*scale[n] + shift[n] + residual)
     const float* scale = nullptr;
@@ -131,7 +133,8 @@ struct ConvDesc {
 // has been synchronised) folds the elapsed times into per-tile-shape totals.
 struct ConvProfile {
     struct Slot { long launches = 0; double ms = 0, flops = 0; };
-    Slot by_tile[6];                 // 0: 128x128, 1: 128x64, 2: 128x32, 3: 128x128 run by 4 waves of 32x128 (split modes, long K), 4: 256x256 ping-pong
+    Slot by_tile[6];                 // 0: 128x128, 1: 128x64, 2: 128x32, 3: 128x128 run by 4 waves of 32x128 (split modes, long K), 4: 256x256 ping-pong,
+                                     // 5: persistent halo tiles (3x3 stride 1, split modes)
     std::vector<hipEvent_t> pool;
     struct Shape { int M, N, K, tile; bool operator<(const Shape& o) const { return std::tie(M, N, K, tile) < std::tie(o.M, o.N, o.K, o.tile); } };
     std::map<Shape, Slot> by_shape;  // per GEMM shape (M = images·OH·OW, N = output columns, K = taps·Cin)
@@ -155,6 +158,13 @@ void conv_forward(hipStream_t s, const ConvDesc& d);
 // Test / measurement switches of the kernel choice ("conv_pp" 0|1, "conv_pp_split" 0|1, "conv_pp_min_tiles", "conv_pp_min_kt",
 // "conv_pp_min_fill" percent, "conv_pp_dbg" ablation bits); false = unknown key.
 bool conv_debug_set(const char* key, int value);
+// Halo kernel (kernels_conv_halo.hip): 3x3 stride-1 layers of the split modes.  conv_halo_pack re-tiles [Npad][9][Cin] fp16
+// filters (device) into its granule layout; conv_halo_eligible says whether a layer can run on it (a property of the layer's
+// geometry and mode only — never of the batch: the K order of the kernel differs from the 128-row kernel's).
+struct ConvArgs;
+void conv_halo_pack(hipStream_t s, const void* wgt_std, int Npad, int Cin, DevBuf& out);
+bool conv_halo_eligible(const ConvDesc& d);
+int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, int n_cus);
 
 // uint8 RGB (B,H,W,3) → fp32 (B, H+2*pad, W+2*pad, 4) minus mean, zero border, channel 3 = 0.
 void preprocess_forward(hipStream_t s, const uint8_t* rgb, int B, int H, int W, int pad, const float mean[3],

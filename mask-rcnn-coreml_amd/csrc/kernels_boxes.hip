@@ -631,7 +631,11 @@ void proposal_forward(hipStream_t s, const ProposalWorkspace& ws, const float* p
     HIP_CHECK(hipMemsetAsync(ws.hist, 0, (size_t)B * 3 * 4096 * 4, s));
     HIP_CHECK(hipMemsetAsync(ws.state, 0, (size_t)B * 8 * 4, s));
     dim3 g(ws.nblk, B);
+    // the roctx ranges carry the reference's signpost names for the step each group of launches replaces (ProposalLayer.swift:122-186)
+    trace_push("Proposal-StridedSlice");     // foreground scores -> order keys (fused with the first histogram)
     hipLaunchKernelGGL(k_keys_hist0, g, dim3(256), 0, s, probs, probs_sB, A, ws.keys, keys_sB, ws.hist);
+    trace_pop();
+    trace_push("Proposal-Sorting");          // radix select of the top K + sort of the survivors
     hipLaunchKernelGGL(k_select_scan, dim3(B), dim3(256), 0, s, ws.hist, ws.state, 0, K);
     hipLaunchKernelGGL(k_hist_pass<1>, g, dim3(256), 0, s, ws.keys, keys_sB, A, ws.state, ws.hist, ws.blockhist, ws.nblk);
     hipLaunchKernelGGL(k_select_scan, dim3(B), dim3(256), 0, s, ws.hist, ws.state, 1, K);
@@ -653,14 +657,19 @@ void proposal_forward(hipStream_t s, const ProposalWorkspace& ws, const float* p
     default: MRCNN_SORT(k_sort_decode_lds); break;          // Kpad < 1024
     }
 #undef MRCNN_SORT
+    trace_pop();                             // (k_sort_decode also covers Proposal-Gathering and Proposal-Compute: gather, x std, decode, clip)
     const long boxes_sB = (long)K * 4, mask_sB = (long)K * ws.W;
+    trace_push("Proposal-NMS");
     hipLaunchKernelGGL(k_nms_mask, dim3(ws.W, ws.W >= 16 ? 4 : 1, B), dim3(256), 0, s, ws.boxes, boxes_sB, (const int32_t*)nullptr, 0L,
                        (const int32_t*)nullptr, K, nms_thr, ws.nms_mask, mask_sB, ws.W);
     hipLaunchKernelGGL(k_nms_scan, dim3(B), dim3(256), (size_t)ws.max_keep * 4, s, ws.boxes, boxes_sB, (const int32_t*)nullptr, 0L,
                        (const int32_t*)nullptr, K, ws.nms_mask, mask_sB, ws.W, ws.max_keep, 0, ws.keep_idx,
                        (long)ws.max_keep, ws.keep_count);
+    trace_pop();
+    trace_push("Proposal-Copy");
     hipLaunchKernelGGL(k_write_rois, dim3(B), dim3(256), 0, s, ws.boxes, boxes_sB, ws.keep_idx, (long)ws.max_keep,
                        ws.keep_count, ws.max_keep, rois, rois_sB, row_stride);
+    trace_pop();
     HIP_CHECK(hipGetLastError());
 }
 

@@ -366,6 +366,7 @@ int conv_n_tile(int Cout)
 static int g_min_blocks = 448;   // narrow the N tile while the grid has fewer blocks than this: 7/8 of two blocks per CU (the
                                  // box head's 504 tiles of 128 columns beat 1008 of 64: +1.1 % end to end, tools/e2e_ab.py)
 static int g_direct = 1;         // 0: every layer through the LDS-staged epilogue; 1: fp16 tensors direct; 2: all modes direct (A/B, tests)
+static int g_halo = 1;        // 3x3 stride-1 layers of the split modes on the halo kernel (kernels_conv_halo.hip) when the filters come re-tiled
 static int g_tn4 = -1;       // split modes, 128x128 tile as 4 waves of 32x128: -1 by policy (conv_forward), 0 never, 1 always (tests)
 template <typename T, typename TW, int PARTS = 2>
 static void conv_launch(hipStream_t s, const ConvArgs& a, int bn, bool wide_waves = false)
@@ -421,6 +422,7 @@ bool conv_debug_set(const char* key, int value)
     else if (k == "conv_pp_min_fill") pp_policy().min_fill_pct = value;
     else if (k == "conv_pp_split") pp_policy().split = value;
     else if (k == "conv_tn4") g_tn4 = value;
+    else if (k == "conv_halo") g_halo = value;
     else if (k == "conv_direct") g_direct = value;
     else if (k == "conv_min_blocks") g_min_blocks = value;
     else return false;
@@ -493,6 +495,14 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     const bool wide_waves = split && bn == 128 && (g_tn4 < 0 ? a.Ktot / bk >= 64 : g_tn4 != 0);      // K >= 2048: the 3x3 layers
     ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
     const int e0 = prof ? prof_event(prof, s) : 0;
+    // 3x3 stride-1 layers of the split modes: the persistent halo kernel, whenever the layer qualifies — by its geometry and
+    // mode alone, so that a layer runs in ONE summation order whatever the batch (the kernel's K order is its own).
+    const bool halo = g_halo && d.wgt_halo && a.vec_ok && conv_halo_eligible(d);
+    if (halo) {
+        static int n_cus = [] { int dev = 0; hipDeviceProp_t p; (void)hipGetDevice(&dev); return hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }();
+        pp_bn = 0;
+        (void)conv_halo_forward(s, a, d, wdtype == MRCNN_F32X3 ? 3 : 2, n_cus);
+    } else
     if (pp_bn) conv_pp_launch(s, a, half ? 0 : (wdtype == MRCNN_F32X3 ? 3 : 2));
     else if (half) conv_launch<_Float16, _Float16>(s, a, bn);
     else if (split && wdtype == MRCNN_F32X3) conv_launch<float, _Float16, 3>(s, a, bn, wide_waves);
@@ -501,7 +511,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     if (prof) {
         const int e1 = prof_event(prof, s);
         const double k = d.algo_k > 0 ? d.algo_k : a.Ktot;
-        const int tile = pp_bn == 256 ? 4 : (wide_waves ? 3 : (bn == 128 ? 0 : (bn == 64 ? 1 : 2)));
+        const int tile = halo ? 5 : pp_bn == 256 ? 4 : (wide_waves ? 3 : (bn == 128 ? 0 : (bn == 64 ? 1 : 2)));
         prof->pending.push_back({tile, 2.0 * (double)a.M * (double)a.ncols * k, e0, e1, {a.M, a.ncols, a.Ktot, tile}});
     }
     HIP_CHECK(hipGetLastError());
