@@ -366,7 +366,8 @@ int conv_n_tile(int Cout)
 static int g_min_blocks = 448;   // narrow the N tile while the grid has fewer blocks than this: 7/8 of two blocks per CU (the
                                  // box head's 504 tiles of 128 columns beat 1008 of 64: +1.1 % end to end, tools/e2e_ab.py)
 static int g_direct = 1;         // 0: every layer through the LDS-staged epilogue; 1: fp16 tensors direct; 2: all modes direct (A/B, tests)
-static int g_halo = 1;        // 3x3 stride-1 layers of the split modes on the halo kernel (kernels_conv_halo.hip) when the filters come re-tiled
+static int env_int(const char* name, int dflt);
+static int g_halo = env_int("MRCNN_HALO", 1);        // 3x3 stride-1 layers of the split modes on the halo kernel (kernels_conv_halo.hip) when the filters come re-tiled
 static int g_tn4 = -1;       // split modes, 128x128 tile as 4 waves of 32x128: -1 by policy (conv_forward), 0 never, 1 always (tests)
 template <typename T, typename TW, int PARTS = 2>
 static void conv_launch(hipStream_t s, const ConvArgs& a, int bn, bool wide_waves = false)

@@ -4,10 +4,13 @@
 // Why: in the split modes a fp32 activation is turned into 2 / 3 fp16 parts in registers before it meets
 // the matrix cores.  The 128-row implicit-GEMM kernel (kernels_conv.hip) stages one (tap, 32 channels) slab per K step, so a
 // 3×3 layer fetches every input pixel NINE times from L2 (once per tap) and every wave column splits it again: the split
-// VALU was 18 % of the time of the large 3×3 layers and the L2 → LDS traffic 9× the input.  Here a tile's input region —
-// the rows above / below and the columns left / right of its 128 output pixels — is loaded once per 16-channel slab,
-// split once by the whole block on its way into LDS (fp16 hi / mid / lo planes), and the nine taps read SHIFTED windows of
-// those planes: 9× fewer activation loads, 9·WN× less split work, no VALU between the LDS reads and the MFMAs.
+// VALU was 18 % of the time of the large 3×3 layers and the L2 → LDS traffic 9× the input — and every K step ends in a block
+// barrier.  Here a tile's input region — the rows above / below and the columns left / right of its 128 output pixels — is
+// loaded once per 16-channel slab, split once by the whole block on its way into LDS (fp16 hi / mid / lo planes), and the nine
+// taps read SHIFTED windows of those planes; the filter fragments do not pass through LDS at all: the filters are re-tiled at
+// load into 1-KB granules in MFMA-fragment order (conv_halo_pack), so a fragment is ONE coalesced 1-KB load straight into
+// the registers of the wave that multiplies it (L2 / L1 hits: every CU walks the same granules).  Nothing a wave needs during
+// a slab's nine taps is produced by another wave, so there is ONE barrier per slab (108 MFMAs per wave) instead of one per step.
 //
 //   out[m][n] = Σ_h Σ_tap Σ_{c < 16} A[pixel(m) + tap][16 h + c] · W[n][tap][16 h + c]
 //
@@ -16,15 +19,14 @@
 // results do not depend on the batch — the sharding contract.  Per (h, tap) step and accumulator: hi·w, mid·w, lo·w, each
 // one v_mfma_f32_32x32x16_f16 (16 products + the fp32 accumulate).
 //
-// Data movement per 16-channel slab of a 128 × 256 tile:
+// Per 16-channel slab of a 128 × 256 tile (8 waves as 2 × 4, wave tile 64 × 64):
 //   activations  ≤ 528 input pixels × 64 B, buffer_load_dwordx4 into VGPRs one slab ahead (out-of-image pixels: an
 //                out-of-range offset, the hardware returns zeros = the zero padding), split in registers, ds_write_b64 into
 //                the other plane buffer while the nine taps of the current slab run;
-//   filters      9 steps × BN × 32 B, pre-tiled at load into 1-KB granules [32 columns][16 channels] in exactly the LDS image
-//                (conv_halo_pack), so a step's filter tile is BN/32 linear 1-KB global→LDS DMAs into a 4-slot ring;
-//   MFMAs        9 × 3 × 4 per wave (wave tile 32 × 128), fragments by ds_read_b128 (conflict-free half-swizzle).
-// One barrier per (h, tap) step (12 MFMAs per wave).  Blocks are persistent: one per CU, each XCD walks a contiguous run of
-// tiles with its 32 CUs on 32 consecutive tiles (vertical neighbours share their halo rows in that XCD's L2).
+//   filters      per step and wave two 1-KB fragment loads, two steps ahead (three register sets);
+//   MFMAs        9 × 3 × 4 per wave; activation fragments by ds_read_b128 (conflict-free half-swizzle), one step ahead.
+// Blocks are persistent: one per CU, each XCD walks a contiguous run of tiles with its 32 CUs on 32 consecutive tiles (vertical
+// neighbours share their halo rows in that XCD's L2).
 //
 // Epilogue: conv_epilogue_direct (conv_device.h) straight from the accumulators — the same arithmetic, in the same order,
 // as every other kernel of the family.
@@ -33,7 +35,6 @@
 namespace mrcnn {
 
 static constexpr int HALO_MAX_PX = 528;          // input pixels a tile may need (rows above/below + columns left/right included)
-static constexpr int HALO_RING = 4;              // filter-tile ring slots
 static constexpr unsigned HALO_OOB = 0xC0000000u;
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -74,26 +75,21 @@ template <int PARTS, int TN>
 __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
 {
     const ConvArgs& a = ha.a;
-    constexpr int BM = 128, WN = 2, BN = WN * TN * 32;
-    constexpr int NG = BN / 32;                           // filter granules (1 KB) per step
+    constexpr int BM = 128, WN = 4, TM = 2, BN = WN * TN * 32;
     constexpr int PLANE = HALO_MAX_PX * 32;               // bytes of one part of one slab
     constexpr int PBUF = PARTS * PLANE;                   // one plane buffer (all parts)
-    constexpr int RSLOT = BN * 32;                        // one ring slot
     constexpr int MAXPC = (HALO_MAX_PX * 4 + 511) / 512;  // 64-B pieces per thread per slab (5)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PBUF + HALO_RING * RSLOT + 2 * BN * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PBUF + 2 * 2 * BN * 4];
     unsigned char* const planes = smem;
-    unsigned char* const ring = smem + 2 * PBUF;
-    float* const s_tab = reinterpret_cast<float*>(smem + 2 * PBUF + HALO_RING * RSLOT);
+    float* const s_tab0 = reinterpret_cast<float*>(smem + 2 * PBUF);       // scale | shift of the tile's columns, by tile parity
 
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, kk = lane >> 5;
     const int ohw = a.OH * a.OW;
     const int NH = ha.NH, NS = NH * 9;
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
-    const bool has_b = wave < NG;                         // this wave issues one filter granule per step
 
     // ---- the tiles of this block: XCD x owns a contiguous run, its CUs take consecutive tiles -----------------------
     const int T = ha.n_tiles;
@@ -105,7 +101,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
         const int xcd = bid & 7, j = bid >> 3;
         const int lo = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
         const int cnt = q + (xcd < r8 ? 1 : 0);
-        const int per = nb >> 3;                          // blocks per XCD (nb is a multiple of 8, or nb == T < 8·… handled by the host)
+        const int per = nb >> 3;                          // blocks per XCD (the host launches a multiple of 8 blocks, or fewer than 8)
         t_first = lo + j; t_end = lo + cnt; t_step = per;
         if (nb < 8) { t_first = bid; t_end = T; t_step = nb; }
     }
@@ -120,12 +116,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
         srdB[3] = 0x00020000u;
     }
     const unsigned vlane16 = (unsigned)lane * 16u;
-    // fragment addresses that do not depend on the tile: filter rows of this wave's column tiles inside a ring slot
-    const unsigned b_lane = (unsigned)((wn * TN) * 1024 + l31 * 32 + ((kk ^ ((l31 >> 3) & 1)) << 4));
+    // measurement-only ablations (ha.a.dbg = 0 in production; mrcnn_debug_set("conv_pp_dbg")): 1 no filter loads in the main
+    // loop, 2 no barriers, 4 no activation-fragment reads, 8 no MFMAs, 16 no slab staging
+    const bool dbg_nodma = a.dbg & 1, dbg_nobar = a.dbg & 2, dbg_nords = a.dbg & 4, dbg_nomma = a.dbg & 8, dbg_nostage = a.dbg & 16;
 
-    for (int tile = t_first; tile < t_end; tile += t_step) {
+    int tile_par = 0;
+    for (int tile = t_first; tile < t_end; tile += t_step, tile_par ^= 1) {
         const int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
         const int m0 = mt * BM, n0 = nt * BN;
+        float* const s_tab = s_tab0 + tile_par * 2 * BN;
         // ---- geometry of the tile's input region (uniform) --------------------------------------------------------
         const int m_last = (m0 + BM - 1 < a.M ? m0 + BM - 1 : a.M - 1);
         const int b0 = m0 / ohw, rem0 = m0 - b0 * ohw, oh0 = rem0 / a.OW, ow0 = rem0 - oh0 * a.OW;
@@ -161,17 +160,21 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
             p_off[i] = ok ? (unsigned)(((long)(b - b0) * a.in_sB + (long)y * a.in_sH + (long)x * a.in_sW + qt * 4) * 4) : HALO_OOB;
             p_lds[i] = px < npx ? (unsigned)(px * 32 + (((qt >> 1) ^ ((px >> 3) & 1)) << 4) + (qt & 1) * 8) : 0xffffffffu;
         }
-        // ---- this lane's output pixel → index of its tap (0,0) input pixel in the region -----------------------------
-        int base_idx;
-        {
-            const int m = m0 + wm * 32 + l31;
+        // ---- this lane's two output pixels → index of their tap (0,0) input pixel in the region ------------------------
+        int base_idx[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * (TM * 32) + i * 32 + l31;
             const int mm = m < a.M ? m : a.M - 1;
             const int b = mm / ohw, rem = mm - b * ohw, oh = rem / a.OW, ow = rem - oh * a.OW;
-            base_idx = ha.single_row ? (ow - ow0) : (b * Hp + oh + 1 - gy_first) * pitch + ow;
+            base_idx[i] = ha.single_row ? (ow - ow0) : (b * Hp + oh + 1 - gy_first) * pitch + ow;
         }
-        unsigned sob = (unsigned)(((size_t)(n0 / 32 + wave) * NS) * 1024u);   // this wave's granule stream (has_b waves only)
+        // this wave's filter-fragment streams: granule (n0/32 + wn*TN + j), one KB per step
+        unsigned sob[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) sob[j] = (unsigned)(((size_t)(n0 / 32 + wn * TN + j) * NS) * 1024u);
 
-        // scale / shift of the tile's columns for the epilogue (read after many barriers)
+        // scale / shift of the tile's columns for the epilogue (double-buffered by tile parity: read after the main loop's barriers)
         if (t < BN / 2) {
             const int c = (t < BN / 4 ? t : t - BN / 4) * 4;
             const float* src = t < BN / 4 ? a.scale : a.shift;
@@ -195,96 +198,118 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
             }                                                                                                    \
         }                                                                                                        \
     }
-#define HALO_DMA_B(SLOT)                                                                                         \
+// filter fragments of one step: TN coalesced 1-KB loads into a register set (asm: counted by hand)
+#define HALO_BLOAD(BV, STEP_)                                                                                    \
     {                                                                                                            \
-        if (has_b) {                                                                                             \
-            const unsigned dst = lds0 + 2 * PBUF + (SLOT) * RSLOT + wave * 1024;                                 \
-            asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(vlane16), "s"(srdB), "s"(sob), "s"(dst) : "memory", "m0"); \
-            sob += 1024u;                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                         \
+            const unsigned so_ = sob[j] + (unsigned)(STEP_) * 1024u;                                             \
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(BV[j]) : "v"(vlane16), "s"(srdB), "s"(so_) : "memory"); \
         }                                                                                                        \
     }
+#define HALO_BPIN(BV) { _Pragma("unroll") for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(BV[j])); }
         static_assert(MAXPC == 5, "the staging statements are spelled out for five pieces per thread");
         u32x4 st[MAXPC];
+        u32x4 bv0[TN], bv1[TN], bv2[TN];
 
-        // ---- prologue: slab 0 into plane buffer 0, filter tiles of steps 0..RING-2 ------------------------------------
+        // ---- prologue: slab 0 into plane buffer 0, filter fragments of steps 0 and 1 ---------------------------------------
         HALO_LOADS()
         HALO_ADVANCE()
-        HALO_DMA_B(0)
-        if (NS > 1) HALO_DMA_B(1)
-        if (NS > 2) HALO_DMA_B(2)
+        HALO_BLOAD(bv0, 0)
+        if (NS > 1) HALO_BLOAD(bv1, 1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         HALO_PIN()
+        HALO_BPIN(bv0)
+        HALO_BPIN(bv1)
         HALO_WRITE(0)
         __syncthreads();
 
-        f32x16 acc[1][TN];
+        f32x16 acc[TM][TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[0][j][e] = 0.0f;
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
         // ---- main loop ----------------------------------------------------------------------------------------------
-        // vmcnt bookkeeping of a has_b wave (in issue order; every op is one wave instruction): per step one filter DMA, plus the
-        // five slab loads right behind the DMA of tap 0.  The barrier at the end of step s hands over the filter tile of step
-        // s + 1, issued RING - 2 = 2 steps earlier: the ops issued after it are the DMAs of steps s - 1 ... s (2) and, when the
-        // slab loads fall in between (taps 0..2), those five.  A wave without a DMA only has the five loads.
+        // Step s = (slab h, tap): the MFMAs run on activation set s & 1 and filter set s % 3 while the activation fragments of
+        // step s + 1 are read from LDS into the other set and the filter fragments of step s + 2 are requested from memory.
+        // vmcnt bookkeeping of a wave, in issue order: TN filter loads per step, the five slab loads right behind those of tap 0.
+        // Before step s + 1 multiplies, its filter fragments (requested in step s - 1) must have arrived: behind them come the
+        // TN loads of step s and, in taps 0 and 1, the five slab loads — which the wait of tap 2 therefore retires in every wave.
+        // ONE barrier per slab, after tap 7: the next slab's planes (written in taps 3-4 by every wave) are first read by the
+        // fragment prefetch of tap 8, and the buffer they replace was last read by the prefetch of the previous slab's tap 7.
+#define HALO_AFRAGS(AV, PB_, TAP_)                                                                               \
+    {                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                         \
+            const int idx_ = base_idx[i] + ((TAP_) / 3) * pitch + ((TAP_) % 3);                                  \
+            const unsigned a_addr_ = (unsigned)(idx_ << 5) + (unsigned)(((kk << 4) ^ ((idx_ << 1) & 16)));       \
+            _Pragma("unroll") for (int p = 0; p < PARTS; ++p) AV[i][p] = *reinterpret_cast<const uint4*>(planes + (PB_) * PBUF + p * PLANE + a_addr_); \
+        }                                                                                                        \
+    }
+#define HALO_STEP(AVC, AVN, BVC, BVNN, TAP, PB)                                                                  \
+    {                                                                                                            \
+        const bool more = step + 2 < NS && !dbg_nodma;                                                           \
+        if (more) HALO_BLOAD(BVNN, step + 2)                                                                     \
+        if ((TAP) == 0 && next_slab) { HALO_LOADS() HALO_ADVANCE() }                                             \
+        if (step + 1 < NS && !dbg_nords) {                                                                       \
+            if ((TAP) == 8) HALO_AFRAGS(AVN, (PB) ^ 1, 0)                                                        \
+            else HALO_AFRAGS(AVN, PB, ((TAP) + 1) % 9)                                                           \
+        }                                                                                                        \
+        if (!dbg_nomma) {                                                                                        \
+        _Pragma("unroll") for (int p = 0; p < PARTS; ++p)                                                        \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                       \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                   \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, BVC[j]), __builtin_bit_cast(f16x8, AVC[i][p]), acc[i][j], 0, 0, 0); \
+        }                                                                                                        \
+        if ((TAP) == 3 && next_slab) {                                                                           \
+            HALO_PIN()                                                                                           \
+            HALO_WRITE((PB) ^ 1)                                                                                 \
+        }                                                                                                        \
+        if ((TAP) <= 1 && next_slab) {                                                                           \
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TN + 5) : "memory");                              \
+            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                                                \
+        } else {                                                                                                 \
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TN) : "memory");                                  \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+        }                                                                                                        \
+        HALO_BPIN(bv0) HALO_BPIN(bv1) HALO_BPIN(bv2)                                                             \
+        if ((TAP) == 7 && !dbg_nobar) __syncthreads();                                                           \
+        ++step;                                                                                                  \
+    }
+        uint4 av0[TM][PARTS], av1[TM][PARTS];
+        HALO_AFRAGS(av0, 0, 0)
         int step = 0;
-        for (int h = 0; h < NH; ++h) {
-            const int pb = h & 1;
-            const bool next_slab = h + 1 < NH;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap, ++step) {
-                if (step + HALO_RING - 1 < NS) HALO_DMA_B((step + HALO_RING - 1) & (HALO_RING - 1))
-                if (tap == 0 && next_slab) { HALO_LOADS() HALO_ADVANCE() }
-                // fragments: this lane's pixel shifted by the tap, three parts; the wave's TN column tiles
-                const int idx = base_idx + (tap / 3) * pitch + (tap % 3);
-                const unsigned a_addr = (unsigned)(idx << 5) + (unsigned)(((kk << 4) ^ ((idx << 1) & 16)));
-                uint4 av[PARTS], bv[TN];
-#pragma unroll
-                for (int p = 0; p < PARTS; ++p) av[p] = *reinterpret_cast<const uint4*>(planes + pb * PBUF + p * PLANE + a_addr);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const uint4*>(ring + (step & (HALO_RING - 1)) * RSLOT + b_lane + j * 1024);
-#pragma unroll
-                for (int p = 0; p < PARTS; ++p)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bv[j]), __builtin_bit_cast(f16x8, av[p]), acc[0][j], 0, 0, 0);
-                if (tap == 4 && next_slab) {
-                    // the slab loads were retired by the counted wait of tap 3 at the latest (every wave): split and park
-                    // them in the other plane buffer, whose last reader finished five barriers ago
-                    HALO_PIN()
-                    HALO_WRITE(pb ^ 1)
-                }
-                // the filter tile of the next step must have landed (and at tap 3: the slab loads, in every wave)
-                const bool more = step + HALO_RING - 1 < NS;           // a DMA was issued this step
-                const bool more1 = step + HALO_RING - 2 < NS;          // ... and in the previous step
-                if (tap <= 2 && next_slab) {
-                    if (has_b && more && more1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-                    else if (has_b && (more || more1)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                    if (tap == 2) { /* next wait retires the loads */ }
-                } else {
-                    if (has_b && more && more1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                    else if (has_b && (more || more1)) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                __syncthreads();
+        for (int h = 0; h < NH; h += 2) {          // two slabs per iteration: 18 steps, the register sets rotate statically
+            {
+                const bool next_slab = !dbg_nostage;       // (NH is even: slab h + 1 exists)
+                HALO_STEP(av0, av1, bv0, bv2, 0, 0) HALO_STEP(av1, av0, bv1, bv0, 1, 0) HALO_STEP(av0, av1, bv2, bv1, 2, 0)
+                HALO_STEP(av1, av0, bv0, bv2, 3, 0) HALO_STEP(av0, av1, bv1, bv0, 4, 0) HALO_STEP(av1, av0, bv2, bv1, 5, 0)
+                HALO_STEP(av0, av1, bv0, bv2, 6, 0) HALO_STEP(av1, av0, bv1, bv0, 7, 0) HALO_STEP(av0, av1, bv2, bv1, 8, 0)
+            }
+            {
+                const bool next_slab = h + 2 < NH && !dbg_nostage;
+                HALO_STEP(av1, av0, bv0, bv2, 0, 1) HALO_STEP(av0, av1, bv1, bv0, 1, 1) HALO_STEP(av1, av0, bv2, bv1, 2, 1)
+                HALO_STEP(av0, av1, bv0, bv2, 3, 1) HALO_STEP(av1, av0, bv1, bv0, 4, 1) HALO_STEP(av0, av1, bv2, bv1, 5, 1)
+                HALO_STEP(av1, av0, bv0, bv2, 6, 1) HALO_STEP(av0, av1, bv1, bv0, 7, 1) HALO_STEP(av1, av0, bv2, bv1, 8, 1)
             }
         }
-#undef HALO_DMA_B
+#undef HALO_STEP
+#undef HALO_AFRAGS
+#undef HALO_BPIN
+#undef HALO_BLOAD
 #undef HALO_WRITE
 #undef HALO_PIN
 #undef HALO_ADVANCE
 #undef HALO_LOADS
 #undef HALO_LOAD
-        conv_epilogue_direct<float, BN, 1, TN>(a, acc, s_tab, m0 + wm * 32, n0, wn * TN * 32, lane);
-        __syncthreads();          // s_tab / plane buffer 0 are rewritten by the next tile's prologue
+        conv_epilogue_direct<float, BN, TM, TN>(a, acc, s_tab, m0 + wm * (TM * 32), n0, wn * TN * 32, lane);
     }
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// filter re-tiling: [Npad][9][Cin] fp16 (the family's packing) → granules [Npad/32][Cin/16][9][32 rows × 32 B], the 16-B halves
-// of a row swapped when (row >> 3) & 1 (the LDS image the kernel's ds_read_b128 expects: conflict-free)
+// filter re-tiling: [Npad][9][Cin] fp16 (the family's packing) → granules [Npad/32][Cin/16][9][1 KB] in MFMA-fragment order:
+// the 16 B of lane (l31, kk) — filter row 32 g + l31, channels 16 h + 8 kk .. + 8 — at byte 16 · (32 kk + l31)
 // ----------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_halo_pack(const uint4* __restrict__ src, int Npad, int Cin, uint4* __restrict__ dst)
 {
@@ -296,8 +321,7 @@ __global__ __launch_bounds__(256) void k_halo_pack(const uint4* __restrict__ src
         const int step = (int)(gs % (NH * 9));
         const int g = (int)(gs / (NH * 9));
         const int h = step / 9, tap = step - h * 9;
-        const int r = piece >> 1, pos = piece & 1;
-        const int half = pos ^ ((r >> 3) & 1);                    // the half stored at this position
+        const int r = piece & 31, half = piece >> 5;             // piece = lane of the wave that will load it
         const int n = g * 32 + r;
         dst[e] = src[(((long)n * 9 + tap) * Cin + 16 * h + 8 * half) / 8];
     }
@@ -328,7 +352,9 @@ bool conv_halo_eligible(const ConvDesc& d)
     const int wdtype = d.wdtype < 0 ? d.dtype : d.wdtype;
     const bool split = d.dtype == MRCNN_F32 && (wdtype == MRCNN_F16 || wdtype == MRCNN_F32X3);
     if (!split || d.KH != 3 || d.KW != 3 || d.stride != 1 || d.padH != 1 || d.padW != 1) return false;
-    if (d.OH != d.H || d.OW != d.W || d.Cin % 16 != 0 || d.Npad % 64 != 0 || d.Cout % 4 != 0) return false;
+    // an even number of slabs; 256 output columns or more: with 128 the wave tile is 64 x 32 and the activation-fragment reads per
+    // MFMA double — measured slower than the 128-row kernel (C3's 128 -> 128 layers: x0.92)
+    if (d.OH != d.H || d.OW != d.W || d.Cin % 32 != 0 || d.Npad % 256 != 0 || d.Cout % 4 != 0) return false;
     if (d.deconv2 || d.out2 || d.sel_partial || d.act == ACT_SIGMOID || d.res) return false;
     if (d.H >= 32760 || d.W >= 32760 || (double)d.in_sB * 8.0 >= 2.0e9) return false;
     return halo_region_bound(d.H, d.W) <= HALO_MAX_PX;
@@ -337,8 +363,7 @@ bool conv_halo_eligible(const ConvDesc& d)
 template <int PARTS>
 static void halo_launch(hipStream_t s, const HaloArgs& ha, int bn, int grid)
 {
-    if (bn == 256) hipLaunchKernelGGL((k_conv_halo<PARTS, 4>), dim3(grid), dim3(512), 0, s, ha);
-    else if (bn == 128) hipLaunchKernelGGL((k_conv_halo<PARTS, 2>), dim3(grid), dim3(512), 0, s, ha);
+    if (bn == 256) hipLaunchKernelGGL((k_conv_halo<PARTS, 2>), dim3(grid), dim3(512), 0, s, ha);
     else hipLaunchKernelGGL((k_conv_halo<PARTS, 1>), dim3(grid), dim3(512), 0, s, ha);
 }
 
@@ -348,8 +373,8 @@ int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, i
     HaloArgs ha;
     // tile width: the widest whose tiles fill the chip once (the K order, hence the result, does not depend on it)
     const int tiles_m = (a.M + 127) / 128;
-    int bn = d.Npad % 256 == 0 ? 256 : (d.Npad % 128 == 0 ? 128 : 64);
-    while (bn > 64 && (long)tiles_m * (d.Npad / bn) < n_cus) bn >>= 1;
+    int bn = d.Npad % 256 == 0 ? 256 : 128;
+    if (bn > 128 && (long)tiles_m * (d.Npad / bn) < n_cus) bn = 128;
     a.tiles_m = tiles_m;
     a.tiles_n = d.Npad / bn;
     a.direct = 1;
