@@ -367,6 +367,86 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x16 (
     if (a.range_flag && out_of_range) atomicOr(a.range_flag, 1);
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// conv_epilogue_wave (fp32 tensors): the wave's (TMS·32) × (TNS·32) accumulators through a WAVE-PRIVATE LDS tile of 32 × 32
+// outputs at a time — no block barrier — so that every store instruction writes FULL 128-B lines (8 pixel rows × 32
+// channels): scattered 16-B pieces (conv_epilogue_direct with fp32 tensors) issue 3× slower per instruction and reach 2.9
+// instead of 5.4 TB/s (tools/probes/vmem_probe.hip).  Same arithmetic, same order as the other epilogues: bit-identical.
+//   stage: this wave's 32 × 36 floats of LDS (rows padded by 16 B: the 16-B run writes of eight lanes fall in distinct
+//   banks); tab: scale[BN] | shift[BN] of the block's columns.  A wave's LDS writes and reads execute in order, so no wait
+//   is needed between the transposing write and the row-wise read-back.
+// ----------------------------------------------------------------------------------------------------------------
+template <int BN, int TMS, int TNS>
+__device__ __forceinline__ void conv_epilogue_wave(const ConvArgs& a, f32x16 (&acc)[TMS][TNS], float* stage, const float* tab, int row0, int n0,
+                                                   int colrel0, int lane)
+{
+    constexpr int SW = 36;                               // floats per staged row
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int ohw = a.OH * a.OW;
+    const float* const res = static_cast<const float*>(a.res);
+    float* const out = static_cast<float*>(a.out);
+    const bool dense_out = a.out_sB == (long)ohw * a.out_sP;
+    const bool dense_res = a.res_sB == (long)ohw * a.res_sW && a.res_shift == 0;
+    const bool relu = a.act == ACT_RELU;
+    const int rrow = lane >> 3, c4 = (lane & 7) * 4;     // read-back: eight lanes per row, four passes of eight rows
+    bool out_of_range = false;
+#pragma unroll
+    for (int i = 0; i < TMS; ++i) {
+        // rows of this 32-row slab the lane handles in the read-back: row = 8 * pass + rrow
+        long o_row[4], r_row[4];
+        bool ok[4];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int m = row0 + i * 32 + 8 * ps + rrow;
+            ok[ps] = m < a.M;
+            o_row[ps] = (long)m * a.out_sP; r_row[ps] = (long)m * a.res_sW;
+            if (!dense_out || (res && !dense_res)) {
+                const int mm = ok[ps] ? m : 0;
+                const int b = mm / ohw, pix = mm - b * ohw;
+                o_row[ps] = (long)b * a.out_sB + (long)pix * a.out_sP;
+                if (res) {
+                    if (a.res_shift) {
+                        const int oh = pix / a.OW, ow = pix - oh * a.OW;
+                        r_row[ps] = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
+                    } else r_row[ps] = (long)b * a.res_sB + (long)pix * a.res_sW;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TNS; ++j) {
+            const int cl = colrel0 + j * 32 + c4;          // column inside the block tile
+            const int n = n0 + cl;
+            const bool col_ok = n < a.ncols;
+            // the residual of the 32 × 32 piece is requested before the LDS round trip (its latency overlaps it)
+            float4 rv[4];
+            if (res) {
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    rv[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok[ps] && col_ok) rv[ps] = *reinterpret_cast<const float4*>(res + r_row[ps] + n);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(&stage[l31 * SW + 8 * q + 4 * kk]) =
+                    make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            const float4 sc = *reinterpret_cast<const float4*>(tab + cl), sh = *reinterpret_cast<const float4*>(tab + BN + cl);
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                float4 x = *reinterpret_cast<const float4*>(&stage[(8 * ps + rrow) * SW + c4]);
+                x.x = x.x * sc.x + sh.x; x.y = x.y * sc.y + sh.y; x.z = x.z * sc.z + sh.z; x.w = x.w * sc.w + sh.w;
+                if (res) { x.x += rv[ps].x; x.y += rv[ps].y; x.z += rv[ps].z; x.w += rv[ps].w; }
+                if (relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+                if (ok[ps] && col_ok) {
+                    out_of_range = out_of_range || !(fabsf(x.x) < 65504.0f) || !(fabsf(x.y) < 65504.0f) || !(fabsf(x.z) < 65504.0f) || !(fabsf(x.w) < 65504.0f);
+                    *reinterpret_cast<float4*>(out + o_row[ps] + n) = x;
+                }
+            }
+        }
+    }
+    if (a.range_flag && out_of_range) atomicOr(a.range_flag, 1);
+}
+
 // fp32 → (hi, lo) fp16 pair with hi + lo = a to ~2^-22 relative: hi = a rounded toward zero to fp16,
 // lo = (a - hi) rounded toward zero to fp16 (a - hi is exact in fp32; for |a| below ~1e-2 lo lands in the
 // fp16 subnormals, whose 2^-24 absolute step is far under the fp32 rounding noise of the sums it feeds).

@@ -28,8 +28,8 @@
 // Blocks are persistent: one per CU, each XCD walks a contiguous run of tiles with its 32 CUs on 32 consecutive tiles (vertical
 // neighbours share their halo rows in that XCD's L2).
 //
-// Epilogue: conv_epilogue_direct (conv_device.h) straight from the accumulators — the same arithmetic, in the same order,
-// as every other kernel of the family.
+// Epilogue: conv_epilogue_wave (conv_device.h) — wave-private LDS transpose, full-line stores — the same arithmetic, in the
+// same order, as every other kernel of the family.
 #include "conv_device.h"
 
 namespace mrcnn {
@@ -79,9 +79,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
     constexpr int PLANE = HALO_MAX_PX * 32;               // bytes of one part of one slab
     constexpr int PBUF = PARTS * PLANE;                   // one plane buffer (all parts)
     constexpr int MAXPC = (HALO_MAX_PX * 4 + 511) / 512;  // 64-B pieces per thread per slab (5)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PBUF + 2 * 2 * BN * 4];
+    constexpr int STAGE = 8 * 32 * 36 * 4;                // the epilogue's wave-private tiles: they live in plane buffer 1
+    constexpr int PLANES = 2 * PBUF > PBUF + STAGE ? 2 * PBUF : PBUF + STAGE;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PLANES + 2 * 2 * BN * 4];
     unsigned char* const planes = smem;
-    float* const s_tab0 = reinterpret_cast<float*>(smem + 2 * PBUF);       // scale | shift of the tile's columns, by tile parity
+    float* const s_tab0 = reinterpret_cast<float*>(smem + PLANES);         // scale | shift of the tile's columns, by tile parity
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -303,7 +305,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
 #undef HALO_ADVANCE
 #undef HALO_LOADS
 #undef HALO_LOAD
-        conv_epilogue_direct<float, BN, TM, TN>(a, acc, s_tab, m0 + wm * (TM * 32), n0, wn * TN * 32, lane);
+        // Epilogue through a wave-private 32 x 36-float tile inside plane buffer 1 (free since the last slab's barrier; the next
+        // tile's prologue only writes plane buffer 0 and the other s_tab, and its first write to buffer 1 comes after its own
+        // prologue barrier, i.e. after every wave has left this epilogue): full-line stores, no block barrier.
+        conv_epilogue_wave<BN, TM, TN>(a, acc, reinterpret_cast<float*>(planes + PBUF) + wave * (32 * 36), s_tab, m0 + wm * (TM * 32), n0,
+                                       wn * TN * 32, lane);
     }
 }
 
