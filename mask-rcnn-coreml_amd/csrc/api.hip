@@ -802,6 +802,12 @@ extern "C" int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout
         d.scale = ds.as<float>(); d.shift = db.as<float>();
         d.OH = oh; d.OW = ow; d.Cout = cout; d.Npad = npad;
         d.out = dout.p; d.out_sP = cout; d.out_sB = (long)oh * ow * cout; d.act = ACT_RELU;
+        DevBuf dres;
+        if (getenv("MRCNN_BENCH_RESIDUAL") && atoi(getenv("MRCNN_BENCH_RESIDUAL"))) {        // the bottleneck blocks' branch2c shape
+            dres.alloc(n_out * es);
+            HIP_CHECK(hipMemset(dres.p, 0, n_out * es));
+            d.res = dres.p; d.res_sB = d.out_sB; d.res_sW = cout; d.res_sH = (long)ow * cout;
+        }
         Stream st;
         DevBuf dwh;
         if (ksize == 3 && ws == 2 && es == 4 && cin % 16 == 0 && npad % 64 == 0) {

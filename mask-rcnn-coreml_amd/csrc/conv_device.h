@@ -122,7 +122,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
                 if (a.scale) sc[q] = *reinterpret_cast<const float4*>(a.scale + n + 4 * q);
                 if (a.shift) sh[q] = *reinterpret_cast<const float4*>(a.shift + n + 4 * q);
             }
+#ifdef MRCNN_CONV_ABLATE
+            if (res && !(a.dbg & 2048)) {
+#else
             if (res) {
+#endif
 #pragma unroll
                 for (int ps = 0; ps < NPASS; ++ps) {
                     const int m = m0 + rr + ps * RPP;
@@ -215,6 +219,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
                 long o;
                 if (a.deconv2) o = (long)b * a.out_sB + (long)(2 * oh + (qd >> 1)) * a.out_sH + (long)(2 * ow + (qd & 1)) * a.out_sW + co;
                 else o = (dense_out ? (long)m * a.out_sP : (long)b * a.out_sB + (long)pix * a.out_sP) + n;
+#ifdef MRCNN_CONV_ABLATE
+                if ((a.dbg & 4096) && v[0].x != 1.2345e33f) continue;
+#endif
                 if (a.out_f32) {
 #pragma unroll
                     for (int q = 0; q < NV; ++q) store4<float>(static_cast<float*>(a.out) + o + 4 * q, v[q]);

@@ -75,6 +75,13 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
     __shared__ __attribute__((aligned(16))) float s_tab[DIRECT_OK ? 2 * BN : 4];       // scale | shift of the block's columns (direct epilogue)
     const T* const in = static_cast<const T*>(a.in);
     const TW* const wgt = static_cast<const TW*>(a.wgt);
+#ifdef MRCNN_CONV_ABLATE
+    // experiment: de-phase the two blocks of a CU once, at the start of the launch (blocks 256..511 take the second slots)
+    if ((a.dbg >> 16) && blockIdx.x >= 256 && blockIdx.x < 512) {
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (unsigned long long)(a.dbg >> 16)) __builtin_amdgcn_s_sleep(16);      // units of 10 ns
+    }
+#endif
 
     const int nblocks = a.tiles_m * a.tiles_n;
     const int bid = blockIdx.x;
@@ -274,15 +281,22 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bv[G][j]), lo2, acc[i][j], 0, 0, 0); \
         }                                                                                                      \
     }
+#ifdef MRCNN_CONV_ABLATE      /* measurement build (make ablate): a.dbg 256 no MFMAs (split modes), 512 no DMA in the main loop, 1024 no epilogue, 2048 no residual, 4096 no stores */
+#define MRCNN_ABL_NODMA && !(a.dbg & 512)
+#define MRCNN_ABL_IFMMA if (!(a.dbg & 256))
+#else
+#define MRCNN_ABL_NODMA
+#define MRCNN_ABL_IFMMA
+#endif
 #define MRCNN_STEP(BUF, NBUF, KTV)                                                                             \
     {                                                                                                          \
-        const bool more = (KTV) + STAGES - 1 < KT;                                                             \
+        const bool more = (KTV) + STAGES - 1 < KT MRCNN_ABL_NODMA;                                             \
         if (more) MRCNN_DMA_TILE((KTV) + STAGES - 1, NBUF)                                                     \
         uint4 av[4][TM], bv[4][TN];                                                                            \
         if constexpr (SPLIT) {                                                                                 \
             MRCNN_KLOAD_SPLIT(0, BUF, ca0, ca1, cb0) MRCNN_KLOAD_SPLIT(1, BUF, ca2, ca3, cb1)                  \
             if constexpr (BN < 128) __builtin_amdgcn_sched_barrier(0);                                         \
-            MRCNN_KMATH_SPLIT(0) MRCNN_KMATH_SPLIT(1)                                                          \
+            MRCNN_ABL_IFMMA { MRCNN_KMATH_SPLIT(0) MRCNN_KMATH_SPLIT(1) }                                      \
         } else {                                                                                               \
             MRCNN_KLOAD(0, BUF, co0) MRCNN_KLOAD(1, BUF, co1) MRCNN_KLOAD(2, BUF, co2) MRCNN_KLOAD(3, BUF, co3) \
             if constexpr (BN < 128) __builtin_amdgcn_sched_barrier(0); /* keep the reads ahead of the MFMAs */ \
@@ -309,6 +323,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
 #undef MRCNN_GLDS_V
 #undef MRCNN_GLDS_S
 #undef MRCNN_SET_TAP
+#ifdef MRCNN_CONV_ABLATE
+    if (a.dbg & 1024) { if (a.dbg == 12345678) static_cast<float*>(a.out)[t] = acc[0][0][0]; return; }
+#endif
     if constexpr (DIRECT_OK) {
         if (direct) { conv_epilogue_direct<T, BN, TM, TN>(a, acc, s_tab, m0 + wm * TM * 32, n0, wn * TN * 32, lane); return; }
     }

@@ -23,8 +23,8 @@
 //   activations  ≤ 528 input pixels × 64 B, buffer_load_dwordx4 into VGPRs one slab ahead (out-of-image pixels: an
 //                out-of-range offset, the hardware returns zeros = the zero padding), split in registers, ds_write_b64 into
 //                the other plane buffer while the nine taps of the current slab run;
-//   filters      per step and wave two 1-KB fragment loads, two steps ahead (three register sets);
-//   MFMAs        9 × 3 × 4 per wave; activation fragments by ds_read_b128 (conflict-free half-swizzle), one step ahead.
+//   filters      per step and wave two 1-KB fragment loads, three steps ahead (four register sets);
+//   MFMAs        9 × 3 × 4 per wave; activation fragments by ds_read_b128 (conflict-free half-swizzle).
 // Blocks are persistent: one per CU, each XCD walks a contiguous run of tiles with its 32 CUs on 32 consecutive tiles (vertical
 // neighbours share their halo rows in that XCD's L2).
 //
@@ -160,6 +160,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
             const int x = col0 + c;
             const bool ok = px < npx && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W && b < a.B;
             p_off[i] = ok ? (unsigned)(((long)(b - b0) * a.in_sB + (long)y * a.in_sH + (long)x * a.in_sW + qt * 4) * 4) : HALO_OOB;
+            if (a.dbg & 32) p_off[i] = (unsigned)((px & 63) * 1024 + qt * 16);        // measurement only: a cache-hot source
             p_lds[i] = px < npx ? (unsigned)(px * 32 + (((qt >> 1) ^ ((px >> 3) & 1)) << 4) + (qt & 1) * 8) : 0xffffffffu;
         }
         // ---- this lane's two output pixels → index of their tap (0,0) input pixel in the region ------------------------
@@ -189,17 +190,16 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
 #define HALO_LOADS()  { HALO_LOAD(0) HALO_LOAD(1) HALO_LOAD(2) HALO_LOAD(3) HALO_LOAD(4) }
 #define HALO_ADVANCE() { _Pragma("unroll") for (int i = 0; i < MAXPC; ++i) p_off[i] += (p_off[i] < HALO_OOB ? 64u : 0u); }
 #define HALO_PIN()    asm volatile("" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]), "+v"(st[4]));
-#define HALO_WRITE(BUF)                                                                                          \
+#define HALO_WRITE1(BUF, I)                                                                                      \
     {                                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < MAXPC; ++i) {                                                      \
-            if (p_lds[i] != 0xffffffffu) {                                                                       \
-                u32x2 parts[PARTS];                                                                              \
-                split4<PARTS>(st[i], parts);                                                                     \
-                _Pragma("unroll") for (int p = 0; p < PARTS; ++p)                                                \
-                    *reinterpret_cast<u32x2*>(planes + (BUF) * PBUF + p * PLANE + p_lds[i]) = parts[p];          \
-            }                                                                                                    \
+        if (p_lds[I] != 0xffffffffu) {                                                                           \
+            u32x2 parts[PARTS];                                                                                  \
+            split4<PARTS>(st[I], parts);                                                                         \
+            _Pragma("unroll") for (int p = 0; p < PARTS; ++p)                                                    \
+                *reinterpret_cast<u32x2*>(planes + (BUF) * PBUF + p * PLANE + p_lds[I]) = parts[p];              \
         }                                                                                                        \
     }
+#define HALO_WRITE(BUF) { HALO_WRITE1(BUF, 0) HALO_WRITE1(BUF, 1) HALO_WRITE1(BUF, 2) HALO_WRITE1(BUF, 3) HALO_WRITE1(BUF, 4) }
 // filter fragments of one step: TN coalesced 1-KB loads into a register set (asm: counted by hand)
 #define HALO_BLOAD(BV, STEP_)                                                                                    \
     {                                                                                                            \
@@ -211,17 +211,19 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
 #define HALO_BPIN(BV) { _Pragma("unroll") for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(BV[j])); }
         static_assert(MAXPC == 5, "the staging statements are spelled out for five pieces per thread");
         u32x4 st[MAXPC];
-        u32x4 bv0[TN], bv1[TN], bv2[TN];
+        u32x4 bv0[TN], bv1[TN], bv2[TN], bv3[TN];
 
         // ---- prologue: slab 0 into plane buffer 0, filter fragments of steps 0 and 1 ---------------------------------------
         HALO_LOADS()
         HALO_ADVANCE()
         HALO_BLOAD(bv0, 0)
-        if (NS > 1) HALO_BLOAD(bv1, 1)
+        HALO_BLOAD(bv1, 1)
+        HALO_BLOAD(bv2, 2)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         HALO_PIN()
         HALO_BPIN(bv0)
         HALO_BPIN(bv1)
+        HALO_BPIN(bv2)
         HALO_WRITE(0)
         __syncthreads();
 
@@ -234,12 +236,13 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
         // ---- main loop ----------------------------------------------------------------------------------------------
-        // Step s = (slab h, tap): the MFMAs run on activation set s & 1 and filter set s % 3 while the activation fragments of
-        // step s + 1 are read from LDS into the other set and the filter fragments of step s + 2 are requested from memory.
+        // Step s = (slab h, tap): the MFMAs run on filter set s % 4 while the filter fragments of step s + 3 are requested from
+        // memory; once they are issued, the activation fragments of step s + 1 replace the ones just multiplied (the wave's
+        // partner on the SIMD owns the matrix pipe meanwhile).
         // vmcnt bookkeeping of a wave, in issue order: TN filter loads per step, the five slab loads right behind those of tap 0.
-        // Before step s + 1 multiplies, its filter fragments (requested in step s - 1) must have arrived: behind them come the
-        // TN loads of step s and, in taps 0 and 1, the five slab loads — which the wait of tap 2 therefore retires in every wave.
-        // ONE barrier per slab, after tap 7: the next slab's planes (written in taps 3-4 by every wave) are first read by the
+        // Before step s + 1 multiplies, its filter fragments (requested in step s - 2) must have arrived: behind them come the
+        // 2 TN loads of steps s - 1 and s and, in taps 0 to 2, the five slab loads — which the wait of tap 3 therefore retires.
+        // ONE barrier per slab, after tap 7: the next slab's planes (written in tap 4 by every wave) are first read by the
         // fragment prefetch of tap 8, and the buffer they replace was last read by the prefetch of the previous slab's tap 7.
 #define HALO_AFRAGS(AV, PB_, TAP_)                                                                               \
     {                                                                                                            \
@@ -249,58 +252,60 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
             _Pragma("unroll") for (int p = 0; p < PARTS; ++p) AV[i][p] = *reinterpret_cast<const uint4*>(planes + (PB_) * PBUF + p * PLANE + a_addr_); \
         }                                                                                                        \
     }
-#define HALO_STEP(AVC, AVN, BVC, BVNN, TAP, PB)                                                                  \
+#define HALO_STEP(BVC, BVN3, TAP, PB)                                                                            \
     {                                                                                                            \
-        const bool more = step + 2 < NS && !dbg_nodma;                                                           \
-        if (more) HALO_BLOAD(BVNN, step + 2)                                                                     \
+        const bool more = step + 3 < NS && !dbg_nodma, more1 = step + 2 < NS && !dbg_nodma;                      \
+        if (more) HALO_BLOAD(BVN3, step + 3)                                                                     \
         if ((TAP) == 0 && next_slab) { HALO_LOADS() HALO_ADVANCE() }                                             \
-        if (step + 1 < NS && !dbg_nords) {                                                                       \
-            if ((TAP) == 8) HALO_AFRAGS(AVN, (PB) ^ 1, 0)                                                        \
-            else HALO_AFRAGS(AVN, PB, ((TAP) + 1) % 9)                                                           \
-        }                                                                                                        \
         if (!dbg_nomma) {                                                                                        \
         _Pragma("unroll") for (int p = 0; p < PARTS; ++p)                                                        \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                       \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                   \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, BVC[j]), __builtin_bit_cast(f16x8, AVC[i][p]), acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, BVC[j]), __builtin_bit_cast(f16x8, av[i][p]), acc[i][j], 0, 0, 0); \
         }                                                                                                        \
-        if ((TAP) == 3 && next_slab) {                                                                           \
-            HALO_PIN()                                                                                           \
-            HALO_WRITE((PB) ^ 1)                                                                                 \
+        /* the fragments of the next step replace the ones just multiplied (the wave's partner on the SIMD owns the matrix \
+           pipe meanwhile): one register set */                                                                  \
+        if (step + 1 < NS && !dbg_nords) {                                                                       \
+            if ((TAP) == 8) HALO_AFRAGS(av, (PB) ^ 1, 0)                                                         \
+            else HALO_AFRAGS(av, PB, ((TAP) + 1) % 9)                                                            \
         }                                                                                                        \
-        if ((TAP) <= 1 && next_slab) {                                                                           \
-            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TN + 5) : "memory");                              \
+        /* the next slab, piece by piece over taps 4..7 (a burst in one step would leave both waves of a SIMD in VALU) */    \
+        if ((TAP) == 4 && next_slab) { HALO_PIN() HALO_WRITE1((PB) ^ 1, 0) HALO_WRITE1((PB) ^ 1, 1) }            \
+        if ((TAP) == 5 && next_slab) HALO_WRITE1((PB) ^ 1, 2)                                                    \
+        if ((TAP) == 6 && next_slab) HALO_WRITE1((PB) ^ 1, 3)                                                    \
+        if ((TAP) == 7 && next_slab) HALO_WRITE1((PB) ^ 1, 4)                                                    \
+        if ((TAP) <= 2 && next_slab) {                                                                           \
+            if (more && more1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TN + 5) : "memory");                 \
+            else if (more1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TN + 5) : "memory");                        \
             else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                                                \
         } else {                                                                                                 \
-            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TN) : "memory");                                  \
+            if (more && more1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TN) : "memory");                     \
+            else if (more1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TN) : "memory");                            \
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
         }                                                                                                        \
-        HALO_BPIN(bv0) HALO_BPIN(bv1) HALO_BPIN(bv2)                                                             \
+        HALO_BPIN(bv0) HALO_BPIN(bv1) HALO_BPIN(bv2) HALO_BPIN(bv3)                                              \
         if ((TAP) == 7 && !dbg_nobar) __syncthreads();                                                           \
         ++step;                                                                                                  \
     }
-        uint4 av0[TM][PARTS], av1[TM][PARTS];
-        HALO_AFRAGS(av0, 0, 0)
+#define HALO_SLAB(B0, B1, B2, B3, PB)                                                                            \
+    HALO_STEP(B0, B3, 0, PB) HALO_STEP(B1, B0, 1, PB) HALO_STEP(B2, B1, 2, PB) HALO_STEP(B3, B2, 3, PB) HALO_STEP(B0, B3, 4, PB) \
+    HALO_STEP(B1, B0, 5, PB) HALO_STEP(B2, B1, 6, PB) HALO_STEP(B3, B2, 7, PB) HALO_STEP(B0, B3, 8, PB)
+        uint4 av[TM][PARTS];
+        HALO_AFRAGS(av, 0, 0)
         int step = 0;
-        for (int h = 0; h < NH; h += 2) {          // two slabs per iteration: 18 steps, the register sets rotate statically
-            {
-                const bool next_slab = !dbg_nostage;       // (NH is even: slab h + 1 exists)
-                HALO_STEP(av0, av1, bv0, bv2, 0, 0) HALO_STEP(av1, av0, bv1, bv0, 1, 0) HALO_STEP(av0, av1, bv2, bv1, 2, 0)
-                HALO_STEP(av1, av0, bv0, bv2, 3, 0) HALO_STEP(av0, av1, bv1, bv0, 4, 0) HALO_STEP(av1, av0, bv2, bv1, 5, 0)
-                HALO_STEP(av0, av1, bv0, bv2, 6, 0) HALO_STEP(av1, av0, bv1, bv0, 7, 0) HALO_STEP(av0, av1, bv2, bv1, 8, 0)
-            }
-            {
-                const bool next_slab = h + 2 < NH && !dbg_nostage;
-                HALO_STEP(av1, av0, bv0, bv2, 0, 1) HALO_STEP(av0, av1, bv1, bv0, 1, 1) HALO_STEP(av1, av0, bv2, bv1, 2, 1)
-                HALO_STEP(av0, av1, bv0, bv2, 3, 1) HALO_STEP(av1, av0, bv1, bv0, 4, 1) HALO_STEP(av0, av1, bv2, bv1, 5, 1)
-                HALO_STEP(av1, av0, bv0, bv2, 6, 1) HALO_STEP(av0, av1, bv1, bv0, 7, 1) HALO_STEP(av1, av0, bv2, bv1, 8, 1)
-            }
+        for (int h = 0; h < NH; h += 4) {          // four slabs per iteration: 36 steps, the four filter register sets rotate statically
+            { const bool next_slab = !dbg_nostage;                 HALO_SLAB(bv0, bv1, bv2, bv3, 0) }      // steps 0.. 8: sets 0 1 2 3 0 1 2 3 0
+            { const bool next_slab = !dbg_nostage;                 HALO_SLAB(bv1, bv2, bv3, bv0, 1) }      // steps 9..17: sets 1 2 3 0 ...
+            { const bool next_slab = !dbg_nostage;                 HALO_SLAB(bv2, bv3, bv0, bv1, 0) }
+            { const bool next_slab = h + 4 < NH && !dbg_nostage;   HALO_SLAB(bv3, bv0, bv1, bv2, 1) }
         }
+#undef HALO_SLAB
 #undef HALO_STEP
 #undef HALO_AFRAGS
 #undef HALO_BPIN
 #undef HALO_BLOAD
 #undef HALO_WRITE
+#undef HALO_WRITE1
 #undef HALO_PIN
 #undef HALO_ADVANCE
 #undef HALO_LOADS
@@ -358,9 +363,9 @@ bool conv_halo_eligible(const ConvDesc& d)
     const int wdtype = d.wdtype < 0 ? d.dtype : d.wdtype;
     const bool split = d.dtype == MRCNN_F32 && (wdtype == MRCNN_F16 || wdtype == MRCNN_F32X3);
     if (!split || d.KH != 3 || d.KW != 3 || d.stride != 1 || d.padH != 1 || d.padW != 1) return false;
-    // an even number of slabs; 256 output columns or more: with 128 the wave tile is 64 x 32 and the activation-fragment reads per
+    // slabs in fours (the main loop is unrolled by four slabs); 256 output columns or more: with 128 the wave tile is 64 x 32 and the activation-fragment reads per
     // MFMA double — measured slower than the 128-row kernel (C3's 128 -> 128 layers: x0.92)
-    if (d.OH != d.H || d.OW != d.W || d.Cin % 32 != 0 || d.Npad % 256 != 0 || d.Cout % 4 != 0) return false;
+    if (d.OH != d.H || d.OW != d.W || d.Cin % 64 != 0 || d.Npad % 256 != 0 || d.Cout % 4 != 0) return false;
     if (d.deconv2 || d.out2 || d.sel_partial || d.act == ACT_SIGMOID || d.res) return false;
     if (d.H >= 32760 || d.W >= 32760 || (double)d.in_sB * 8.0 >= 2.0e9) return false;
     return halo_region_bound(d.H, d.W) <= HALO_MAX_PX;
