@@ -186,6 +186,15 @@ MRCNN_API int mrcnn_model_enable_graph(mrcnn_model* model, int on);
  * is batch 1).  memspace says where image/detections/masks live (host or device). */
 MRCNN_API int mrcnn_maskrcnn_predict(mrcnn_model* model, const uint8_t* rgb, int batch, int height,
                                      int width, int memspace, float* detections, float* masks);
+/* `.scaleFit` inside predict (VNCoreMLRequest.imageCropAndScaleOption = .scaleFit, EvaluateCommand.swift:152-157,
+ * ViewController.swift:45): images of ANY size height×width (the same for the whole batch) are letterboxed — aspect-preserving
+ * bilinear resize, centred, black borders: exactly mrcnn_letterbox_rgb's pixels — into the model's input size INSIDE the
+ * pre-processing kernel; the results equal mrcnn_letterbox_rgb + mrcnn_maskrcnn_predict bit for bit.  Boxes come back normalized
+ * in the letterboxed frame, like the reference's (EvaluateCommand.swift:203-248); mrcnn_unletterbox_boxes maps rows
+ * (y1,x1,y2,x2,...) of `stride` floats back to the source image's normalized frame (host arithmetic, in place). */
+MRCNN_API int mrcnn_maskrcnn_predict_scalefit(mrcnn_model* model, const uint8_t* rgb, int batch, int height, int width, int memspace,
+                                              float* detections, float* masks);
+MRCNN_API int mrcnn_unletterbox_boxes(float* detections, int64_t n, int64_t stride, int src_h, int src_w, int model_h, int model_w);
 /* Same, but only enqueues on the model's stream (no synchronisation); device buffers only. */
 MRCNN_API int mrcnn_maskrcnn_predict_async(mrcnn_model* model, const uint8_t* rgb, int batch, int height,
                                            int width, float* detections, float* masks);

@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = [
     "mrcnn_dist_unique_id", "mrcnn_dist_init", "mrcnn_dist_destroy", "mrcnn_dist_shard", "mrcnn_dist_record_floats",
     "mrcnn_dist_all_gather_records", "mrcnn_maskrcnn_predict_sharded", "mrcnn_mask_to_u8_f64",
     "mrcnn_dist_all_gather_records_async", "mrcnn_dist_wait", "mrcnn_dist_plan", "mrcnn_dist_simulate_host",
+    "mrcnn_maskrcnn_predict_scalefit", "mrcnn_unletterbox_boxes",
 ]
 
 
@@ -106,6 +107,8 @@ def lib():
     L.mrcnn_model_destroy.restype = None
     L.mrcnn_model_set_stream.argtypes = [vp, vp]
     L.mrcnn_maskrcnn_predict.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.mrcnn_maskrcnn_predict_scalefit.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.mrcnn_unletterbox_boxes.argtypes = [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
     L.mrcnn_maskrcnn_predict_async.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
     L.mrcnn_classifier_predict.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
     L.mrcnn_mask_predict.argtypes = [vp, vp, C.c_int, C.c_int, vp]

@@ -538,6 +538,31 @@ extern "C" int mrcnn_maskrcnn_predict(mrcnn_model* model, const uint8_t* rgb, in
         model->m.predict(rgb, batch, height, width, memspace, detections, masks, true);
     });
 }
+extern "C" int mrcnn_maskrcnn_predict_scalefit(mrcnn_model* model, const uint8_t* rgb, int batch, int height, int width, int memspace,
+                                               float* detections, float* masks)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model, MRCNN_ERR_INVALID, "null model");
+        model->m.predict(rgb, batch, height, width, memspace, detections, masks, true, true);
+    });
+}
+extern "C" int mrcnn_unletterbox_boxes(float* detections, int64_t n, int64_t stride, int h, int w, int H, int W)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(detections && n >= 0 && stride >= 4, MRCNN_ERR_INVALID, "bad unletterbox argument");
+        int nh, nw, py, px;
+        MRCNN_REQUIRE(mrcnn_letterbox_geometry(h, w, H, W, &nh, &nw, &py, &px) == MRCNN_OK, MRCNN_ERR_INVALID, "bad letterbox geometry");
+        // normalized coordinates follow Matterport's norm_boxes: pixel = n * (size - 1), far edge + 1 (anchors, mask paste)
+        const double sy = (double)h / nh, sx = (double)w / nw, hy = h > 1 ? h - 1 : 1, wx = w > 1 ? w - 1 : 1;
+        auto clip = [](double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); };
+        for (int64_t i = 0; i < n; ++i) {
+            float* d = detections + i * stride;
+            const double y1 = ((double)d[0] * (H - 1) - py) * sy, x1 = ((double)d[1] * (W - 1) - px) * sx;
+            const double y2 = ((double)d[2] * (H - 1) + 1.0 - py) * sy, x2 = ((double)d[3] * (W - 1) + 1.0 - px) * sx;
+            d[0] = (float)clip(y1 / hy); d[1] = (float)clip(x1 / wx); d[2] = (float)clip((y2 - 1.0) / hy); d[3] = (float)clip((x2 - 1.0) / wx);
+        }
+    });
+}
 extern "C" int mrcnn_maskrcnn_predict_async(mrcnn_model* model, const uint8_t* rgb, int batch, int height, int width,
                                             float* detections, float* masks)
 {

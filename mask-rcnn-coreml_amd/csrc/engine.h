@@ -147,6 +147,8 @@ struct Model {
     struct Tap { void* base; long per_image; int dtype; };
     std::map<std::string, Tap> taps;    // name → (base, per-image elements, element type)
     uint8_t* d_rgb = nullptr;
+    void* stem_in = nullptr;          // the stem's zero-padded NHWC4 / NHWC8 staging tensor (written by the pre-processing op = trunk_ops[0])
+    DevBuf fit_src;                   // predict_scalefit: the source images on the device
     float *rpn_logits = nullptr, *rpn_probs = nullptr, *rpn_deltas = nullptr, *rois = nullptr;
     float *cls6 = nullptr, *detections = nullptr, *mask_out = nullptr;
     void *pooled = nullptr, *pooled_mask = nullptr;     // compute dtype
@@ -182,8 +184,10 @@ struct Model {
     ~Model();
     void load(int kind, const std::string& path, int max_batch, int dtype);
     void build_maskrcnn();
-    void predict(const uint8_t* rgb, int batch, int h, int w, int memspace, float* det, float* masks, bool sync);
-    void enqueue_pipeline(hipStream_t s, int batch);    // d_rgb → detections / mask_out, launches only
+    // fit = true: the images are h×w of ANY size, letterboxed into the model's H×W inside the pre-processing kernel (.scaleFit)
+    void predict(const uint8_t* rgb, int batch, int h, int w, int memspace, float* det, float* masks, bool sync, bool fit = false);
+    // d_rgb (or, with fit geometry, fit_src) → detections / mask_out, launches only
+    void enqueue_pipeline(hipStream_t s, int batch, const int* fit = nullptr);
     void drop_graphs();
     void read_tensor(const std::string& name, int image, float* dst, int64_t cap, int64_t* count);
 };

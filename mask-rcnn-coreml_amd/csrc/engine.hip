@@ -732,6 +732,7 @@ void Model::build_maskrcnn()
         const int Hp = H + 6, Wp = W + 6;
         const int pxc = dt == MRCNN_F16 ? 8 : 4;
         void* x0 = ar.alloc_b((size_t)Bm * Hp * Wp * 16 + 256);
+        stem_in = x0;
         {
             const float m3[3] = {mean[0], mean[1], mean[2]};
             uint8_t* src = d_rgb;
@@ -869,26 +870,35 @@ void Model::build_maskrcnn()
     taps["cls_bbox"] = {cls_head.bbox, (long)max_prop * nc * 4, MRCNN_F32};
 }
 
-void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, float* det_out, float* masks_out, bool sync)
+void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, float* det_out, float* masks_out, bool sync, bool fit)
 {
     MRCNN_REQUIRE(kind == MRCNN_MODEL_MASKRCNN, MRCNN_ERR_INVALID, "predict called on a non-MaskRCNN model");
     MRCNN_REQUIRE(rgb && det_out && masks_out, MRCNN_ERR_INVALID, "null buffer");
-    MRCNN_REQUIRE(h == H && w == W, MRCNN_ERR_SHAPE, "image is %dx%d, the model expects %dx%d", h, w, H, W);
+    MRCNN_REQUIRE(fit ? (h > 0 && w > 0 && h < 32768 && w < 32768) : (h == H && w == W), MRCNN_ERR_SHAPE,
+                  "image is %dx%d, the model expects %dx%d (mrcnn_maskrcnn_predict_scalefit letterboxes any size)", h, w, H, W);
     MRCNN_REQUIRE(batch >= 1 && batch <= max_batch, MRCNN_ERR_SHAPE, "batch %d outside 1..%d", batch, max_batch);
     hipStream_t s = stream;
-    const size_t img_bytes = (size_t)batch * H * W * 3;
+    int fitgeo[6] = {h, w, 0, 0, 0, 0};
+    if (fit) {
+        MRCNN_REQUIRE(mrcnn_letterbox_geometry(h, w, H, W, &fitgeo[2], &fitgeo[3], &fitgeo[4], &fitgeo[5]) == MRCNN_OK, MRCNN_ERR_INVALID, "bad letterbox geometry");
+        const size_t need = (size_t)batch * h * w * 3;
+        if (fit_src.bytes < need) { HIP_CHECK(hipStreamSynchronize(s)); fit_src.alloc(need); drop_graphs(); }
+    }
+    const size_t img_bytes = (size_t)batch * h * w * 3;
+    uint8_t* const img_dst = fit ? fit_src.as<uint8_t>() : d_rgb;
     if (!ev_p0) { HIP_CHECK(hipEventCreate(&ev_p0)); HIP_CHECK(hipEventCreate(&ev_p1)); }
     hipStreamCaptureStatus outer_capture = hipStreamCaptureStatusNone;
     HIP_CHECK(hipStreamIsCapturing(s, &outer_capture));
     const bool timed_call = sync && outer_capture == hipStreamCaptureStatusNone;
     if (timed_call) HIP_CHECK(hipEventRecord(ev_p0, s));
-    HIP_CHECK(hipMemcpyAsync(d_rgb, rgb, img_bytes, memspace == MRCNN_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(img_dst, rgb, img_bytes, memspace == MRCNN_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
 
     hipStreamCaptureStatus caller_capture = hipStreamCaptureStatusNone;
     if (use_graph) HIP_CHECK(hipStreamIsCapturing(s, &caller_capture));
-    const bool plain = !use_graph || timer.enabled || conv_profile.active || caller_capture != hipStreamCaptureStatusNone;
+    // (the scale-fit geometry is a launch argument of the first kernel: such calls are not replayed from a captured graph)
+    const bool plain = !use_graph || fit || timer.enabled || conv_profile.active || caller_capture != hipStreamCaptureStatusNone;
     if (plain) {
-        enqueue_pipeline(s, batch);
+        enqueue_pipeline(s, batch, fit ? fitgeo : nullptr);
     } else {
         GraphSlot& g = graphs[batch];
         if (!g.exec && g.eager_runs++ == 0) {
@@ -939,7 +949,7 @@ void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, f
     }
 }
 
-void Model::enqueue_pipeline(hipStream_t s, int batch)
+void Model::enqueue_pipeline(hipStream_t s, int batch, const int* fit)
 {
     int* const rflag = mode != MRCNN_F32 ? range_flag.as<int>() : nullptr;
     if (rflag) HIP_CHECK(hipMemsetAsync(rflag, 0, sizeof(int), s));
@@ -948,7 +958,12 @@ void Model::enqueue_pipeline(hipStream_t s, int batch)
     conv_set_profiler(conv_profile.active ? &conv_profile : nullptr);
     {
         TraceRange tr("MaskRCNN-Trunk");          // the Core ML graph itself: no signpost in the reference
-        for (auto& op : trunk_ops) op(s, batch);
+        size_t first = 0;
+        if (fit) {      // .scaleFit: letterbox + mean subtraction in one kernel, instead of trunk_ops[0] (d_rgb → stem_in)
+            preprocess_scalefit_forward(s, fit_src.as<uint8_t>(), batch, fit[0], fit[1], H, W, fit[2], fit[3], fit[4], fit[5], 3, mean, stem_in, dtype);
+            first = 1;
+        }
+        for (size_t i = first; i < trunk_ops.size(); ++i) trunk_ops[i](s, batch);
     }
     timer.mark(s, "Trunk");
     // ProposalLayer

@@ -74,6 +74,9 @@ void roi_align_forward(hipStream_t s, const PyramidMaps& maps, int C, int layout
 
 // `.scaleFit` letterbox of an RGB8 image into an H×W canvas (content nh×nw at offset (py,px)).
 void letterbox_forward(hipStream_t s, const uint8_t* src, int h, int w, uint8_t* dst, int H, int W, int nh, int nw, int py, int px);
+// The same resampling fused with the mean subtraction, straight into the stem's padded staging tensor (B images of h×w).
+void preprocess_scalefit_forward(hipStream_t s, const uint8_t* src, int B, int h, int w, int H, int W, int nh, int nw, int py, int px, int pad,
+                                 const float mean[3], void* out, int dtype);
 // Full-resolution binary instance masks from the 28×28 sigmoid masks (resize to box + threshold).
 void paste_masks_forward(hipStream_t s, const float* det, long det_stride, const float* masks, int n, int S, int H, int W,
                          float thr, uint8_t* out);

@@ -258,6 +258,31 @@ void paste_masks_forward(hipStream_t s, const float* det, long det_stride, const
 // (half-pixel centres, edge clamp, round-half-up to 8 bit) centred in an H×W canvas, black borders.
 // Vision's resampler is closed source → convention unpinned.
 // ------------------------------------------------------------------------------------------------
+// One letterboxed pixel (the arithmetic k_letterbox and the fused pre-processing share: the two must agree to the bit)
+__device__ __forceinline__ void letterbox_pixel(const uint8_t* __restrict__ src, int h, int w, int nh, int nw, float ry, float rx, int y, int x,
+                                                uint8_t (&r)[3])
+{
+    r[0] = r[1] = r[2] = 0;
+    if ((unsigned)y < (unsigned)nh && (unsigned)x < (unsigned)nw) {
+        float sy = ((float)y + 0.5f) * ry - 0.5f, sx = ((float)x + 0.5f) * rx - 0.5f;
+        sy = fminf(fmaxf(sy, 0.0f), (float)(h - 1));
+        sx = fminf(fmaxf(sx, 0.0f), (float)(w - 1));
+        const int ya = (int)floorf(sy), yb = min(ya + 1, h - 1), xa = (int)floorf(sx), xb = min(xa + 1, w - 1);
+        const float fy = sy - (float)ya, fx = sx - (float)xa;
+        const uint8_t* a = src + ((long)ya * w + xa) * 3;
+        const uint8_t* b = src + ((long)ya * w + xb) * 3;
+        const uint8_t* c = src + ((long)yb * w + xa) * 3;
+        const uint8_t* d = src + ((long)yb * w + xb) * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float top = (float)a[k] + ((float)b[k] - (float)a[k]) * fx;
+            const float bot = (float)c[k] + ((float)d[k] - (float)c[k]) * fx;
+            const float v = top + (bot - top) * fy;
+            r[k] = (uint8_t)floorf(v + 0.5f);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_letterbox(const uint8_t* __restrict__ src, int h, int w, uint8_t* __restrict__ dst,
                                                    int H, int W, int nh, int nw, int py, int px)
 {
@@ -265,30 +290,54 @@ __global__ __launch_bounds__(256) void k_letterbox(const uint8_t* __restrict__ s
     const float ry = (float)h / (float)nh, rx = (float)w / (float)nw;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const int Y = (int)(e / W), X = (int)(e - (long)Y * W);
-        const int y = Y - py, x = X - px;
-        uint8_t o0 = 0, o1 = 0, o2 = 0;
-        if ((unsigned)y < (unsigned)nh && (unsigned)x < (unsigned)nw) {
-            float sy = ((float)y + 0.5f) * ry - 0.5f, sx = ((float)x + 0.5f) * rx - 0.5f;
-            sy = fminf(fmaxf(sy, 0.0f), (float)(h - 1));
-            sx = fminf(fmaxf(sx, 0.0f), (float)(w - 1));
-            const int ya = (int)floorf(sy), yb = min(ya + 1, h - 1), xa = (int)floorf(sx), xb = min(xa + 1, w - 1);
-            const float fy = sy - (float)ya, fx = sx - (float)xa;
-            const uint8_t* a = src + ((long)ya * w + xa) * 3;
-            const uint8_t* b = src + ((long)ya * w + xb) * 3;
-            const uint8_t* c = src + ((long)yb * w + xa) * 3;
-            const uint8_t* d = src + ((long)yb * w + xb) * 3;
-            uint8_t r[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float top = (float)a[k] + ((float)b[k] - (float)a[k]) * fx;
-                const float bot = (float)c[k] + ((float)d[k] - (float)c[k]) * fx;
-                const float v = top + (bot - top) * fy;
-                r[k] = (uint8_t)floorf(v + 0.5f);
-            }
-            o0 = r[0]; o1 = r[1]; o2 = r[2];
-        }
-        dst[e * 3 + 0] = o0; dst[e * 3 + 1] = o1; dst[e * 3 + 2] = o2;
+        uint8_t r[3];
+        letterbox_pixel(src, h, w, nh, nw, ry, rx, Y - py, X - px, r);
+        dst[e * 3 + 0] = r[0]; dst[e * 3 + 1] = r[1]; dst[e * 3 + 2] = r[2];
     }
+}
+
+// `.scaleFit` fused into the network's input staging (EvaluateCommand.swift:152-157): source images of any
+// size h×w → the letterboxed 8-bit value (exactly k_letterbox's) minus the channel mean, into the zero-padded NHWC4 (fp32) /
+// NHWC8 (fp16) tensor the stem reads — the H×W×3 letterboxed image is never materialised.
+template <typename T>
+__global__ __launch_bounds__(256) void k_preprocess_scalefit(const uint8_t* __restrict__ src, int B, int h, int w, int H, int W, int nh, int nw,
+                                                             int py, int px, int pad, float mr, float mg, float mb, void* __restrict__ out)
+{
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const long total = (long)B * Hp * Wp;
+    const float ry = (float)h / (float)nh, rx = (float)w / (float)nw;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int X = (int)(e % Wp) - pad;
+        const int Y = (int)((e / Wp) % Hp) - pad;
+        const int b = (int)(e / ((long)Wp * Hp));
+        float r = 0.f, g = 0.f, bl = 0.f;
+        if ((unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W) {
+            uint8_t v[3];
+            letterbox_pixel(src + (long)b * h * w * 3, h, w, nh, nw, ry, rx, Y - py, X - px, v);
+            r = (float)v[0] - mr; g = (float)v[1] - mg; bl = (float)v[2] - mb;
+        }
+        if constexpr (sizeof(T) == 4) {
+            reinterpret_cast<float4*>(out)[e] = make_float4(r, g, bl, 0.f);
+        } else {
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            h8 hv;
+            hv[0] = (_Float16)r; hv[1] = (_Float16)g; hv[2] = (_Float16)bl;
+            hv[3] = hv[4] = hv[5] = hv[6] = hv[7] = (_Float16)0.f;
+            reinterpret_cast<h8*>(out)[e] = hv;
+        }
+    }
+}
+
+void preprocess_scalefit_forward(hipStream_t s, const uint8_t* src, int B, int h, int w, int H, int W, int nh, int nw, int py, int px, int pad,
+                                 const float mean[3], void* out, int dtype)
+{
+    const long total = (long)B * (H + 2 * pad) * (W + 2 * pad);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dtype == MRCNN_F16)
+        hipLaunchKernelGGL(k_preprocess_scalefit<_Float16>, dim3(grid), dim3(256), 0, s, src, B, h, w, H, W, nh, nw, py, px, pad, mean[0], mean[1], mean[2], out);
+    else
+        hipLaunchKernelGGL(k_preprocess_scalefit<float>, dim3(grid), dim3(256), 0, s, src, B, h, w, H, W, nh, nw, py, px, pad, mean[0], mean[1], mean[2], out);
+    HIP_CHECK(hipGetLastError());
 }
 
 void letterbox_forward(hipStream_t s, const uint8_t* src, int h, int w, uint8_t* dst, int H, int W, int nh, int nw, int py, int px)

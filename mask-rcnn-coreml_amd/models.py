@@ -101,6 +101,16 @@ class MaskRCNN(_Model):
                                                      mask.data_ptr()))
         return det, mask
 
+    def predict_scalefit(self, images: np.ndarray):
+        """images (B,h,w,3) uint8 of ANY size: `.scaleFit` letterbox fused into the pre-processing kernel, then predict.
+        Boxes are normalized in the letterboxed frame (evaluate.unletterbox_boxes / mrcnn_unletterbox_boxes map them back)."""
+        imgs = np.ascontiguousarray(images, dtype=np.uint8)
+        B, h, w, _ = imgs.shape
+        det = np.empty((B, self.max_detections, 6), dtype=np.float32)
+        mask = np.empty((B, self.max_detections, self.mask_size, self.mask_size), dtype=np.float32)
+        _lib.check(_lib.lib().mrcnn_maskrcnn_predict_scalefit(self._h, imgs.ctypes.data, B, h, w, _lib.HOST, det.ctypes.data, mask.ctypes.data))
+        return det, mask
+
     def predict_into(self, images, det, mask, sync: bool = True):
         """Device tensors in, pre-allocated device tensors out (bench loop: no allocation, optional no sync)."""
         B, H, W, _ = images.shape

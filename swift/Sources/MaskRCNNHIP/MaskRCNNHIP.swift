@@ -17,6 +17,27 @@ public final class MaskRCNNConfig {
     public var compiledMaskModelURL: URL? { didSet { _ = mrcnn_config_set_mask_path(compiledMaskModelURL?.path) } }
 }
 
+/// Compute mode of the convolutions (`compute_dtype` of mrcnn_model_load; include/maskrcnn_hip.h).
+public enum ComputeMode {
+    /// fp32 tensors, exact-fp32 MFMA (`v_mfma_f32_32x32x2_f32`): the scale-invariant baseline.
+    case f32
+    /// fp32 tensors; products on the fp16 matrix cores from a THREE-part split of the activation (exact for 0.5 <= |a| < 65504,
+    /// the activation carried to 2^-24 absolute below): the mode `bench.py` reports.
+    case f32x3
+    /// fp32 tensors; two-part split (22 of 24 significand bits).
+    case f32s
+    /// fp16 tensors and fp16 MFMA, fp32 accumulate, fp32 box path and outputs (BASELINE configs[3]).
+    case f16
+    var raw: Int32 {
+        switch self {
+        case .f32: return Int32(MRCNN_F32.rawValue)
+        case .f32x3: return Int32(MRCNN_F32X3.rawValue)
+        case .f32s: return Int32(MRCNN_F32S.rawValue)
+        case .f16: return Int32(MRCNN_F16.rawValue)
+        }
+    }
+}
+
 /// Replaces the Xcode-generated `MaskRCNN` class (Example/Source/ViewController.swift:37).
 public final class MaskRCNN {
     private var handle: OpaquePointer?
@@ -25,9 +46,8 @@ public final class MaskRCNN {
     public let width: Int32
     public let height: Int32
 
-    public init(contentsOf url: URL, maxBatch: Int32 = 1, halfPrecision: Bool = false) throws {
-        try check(mrcnn_model_load(Int32(MRCNN_MODEL_MASKRCNN.rawValue), url.path, maxBatch,
-                                   Int32(halfPrecision ? MRCNN_F16.rawValue : MRCNN_F32.rawValue), &handle))
+    public init(contentsOf url: URL, maxBatch: Int32 = 1, computeMode: ComputeMode = .f32x3) throws {
+        try check(mrcnn_model_load(Int32(MRCNN_MODEL_MASKRCNN.rawValue), url.path, maxBatch, computeMode.raw, &handle))
         var v: Int64 = 0
         try check(mrcnn_model_get_int(handle, "max_detections", &v)); maxDetections = Int(v)
         try check(mrcnn_model_get_int(handle, "mask_size", &v)); maskSide = Int(v)
@@ -36,12 +56,24 @@ public final class MaskRCNN {
     }
     deinit { mrcnn_model_destroy(handle) }
 
-    /// `image`: RGB8, width x height of the model (letterbox first: `mrcnn_letterbox_rgb` = `.scaleFit`).
+    /// `image`: RGB8, width x height of the model.
     /// Returns the two outputs of the reference graph: "detections" (maxDet x 6) and "mask" (maxDet x 28 x 28).
     public func prediction(image rgb: UnsafePointer<UInt8>) throws -> (detections: [Float], mask: [Float]) {
         var det = [Float](repeating: 0, count: maxDetections * 6)
         var msk = [Float](repeating: 0, count: maxDetections * maskSide * maskSide)
         try check(mrcnn_maskrcnn_predict(handle, rgb, 1, height, width, Int32(MRCNN_HOST.rawValue), &det, &msk))
+        return (det, msk)
+    }
+
+    /// `image`: RGB8 of ANY size — what `VNCoreMLRequest` with `.scaleFit` does for the reference (EvaluateCommand.swift:152-157,
+    /// ViewController.swift:45): the letterbox runs inside the engine's pre-processing kernel.  Boxes are normalized in the
+    /// letterboxed frame, like the reference's; `unletterboxed` maps them back to the source image.
+    public func prediction(image rgb: UnsafePointer<UInt8>, width w: Int32, height h: Int32, unletterboxed: Bool = false) throws
+        -> (detections: [Float], mask: [Float]) {
+        var det = [Float](repeating: 0, count: maxDetections * 6)
+        var msk = [Float](repeating: 0, count: maxDetections * maskSide * maskSide)
+        try check(mrcnn_maskrcnn_predict_scalefit(handle, rgb, 1, h, w, Int32(MRCNN_HOST.rawValue), &det, &msk))
+        if unletterboxed { try check(mrcnn_unletterbox_boxes(&det, Int64(maxDetections), 6, h, w, height, width)) }
         return (det, msk)
     }
 }

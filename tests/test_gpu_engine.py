@@ -560,3 +560,40 @@ def test_engine_joins_a_callers_graph_capture(pkg, small_model):
     torch.cuda.synchronize()
     np.testing.assert_array_equal(det_d.cpu().numpy(), ref_b[0])
     np.testing.assert_array_equal(mask_d.cpu().numpy(), ref_b[1])
+
+
+@pytest.mark.parametrize("mode", ["f32x3", "f16"])
+def test_predict_scalefit_equals_letterbox_then_predict(pkg, small_model, mode):
+    """mrcnn_maskrcnn_predict_scalefit (`.scaleFit` of EvaluateCommand.swift:152-157 inside predict): images of
+    any size — landscape, portrait, smaller and larger than the model, and exactly the model's size — give bit for bit what
+    mrcnn_letterbox_rgb followed by mrcnn_maskrcnn_predict gives; mrcnn_unletterbox_boxes equals the Python mirror."""
+    import ctypes as C
+    models = __import__("importlib").import_module("mask-rcnn-coreml_amd.models")
+    ev = __import__("importlib").import_module("mask-rcnn-coreml_amd.evaluate")
+    L = __import__("importlib").import_module("mask-rcnn-coreml_amd._lib")
+    d, cfg = small_model
+    H, W = cfg.image_height, cfg.image_width
+    m = models.load_maskrcnn(d, max_batch=3, compute_dtype=mode)
+    rng = np.random.default_rng(41)
+    for (h, w, B) in ((96, 160, 2), (300, 200, 3), (H, W, 1), (37, 53, 2)):
+        imgs = rng.integers(0, 256, (B, h, w, 3), dtype=np.uint8)
+        det, mask = m.predict_scalefit(imgs)
+        boxed = np.stack([ev.letterbox(imgs[b], H, W) for b in range(B)])
+        if (h, w) == (H, W):
+            np.testing.assert_array_equal(boxed, imgs)                  # the identity case really is the identity
+        det0, mask0 = m.predict(boxed)
+        np.testing.assert_array_equal(det, det0)
+        np.testing.assert_array_equal(mask, mask0)
+        un = det[0].copy()
+        L.check(L.lib().mrcnn_unletterbox_boxes(un.ctypes.data, un.shape[0], 6, h, w, H, W))
+        np.testing.assert_allclose(un[:, :4], ev.unletterbox_boxes(det[0], h, w, H, W)[:, :4].astype(np.float32), rtol=0, atol=1e-7)
+        np.testing.assert_array_equal(un[:, 4:], det[0][:, 4:])
+    # a plain predict in between sees no state of the scale-fit path
+    img = rng.integers(0, 256, (1, H, W, 3), dtype=np.uint8)
+    d1, k1 = m.predict(img)
+    d2, k2 = m.predict_scalefit(img)
+    np.testing.assert_array_equal(d1, d2)
+    np.testing.assert_array_equal(k1, k2)
+    with pytest.raises(L.MrcnnError):
+        m.predict(rng.integers(0, 256, (1, 64, 64, 3), dtype=np.uint8))      # the exact-size entry still refuses other sizes
+    pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None
