@@ -139,6 +139,7 @@ struct Model {
     // weights
     std::map<std::string, PackedConv> convs;
     DevBuf anchors;
+    DevBuf rpn_head_frag;             // split modes: the RPN heads' filters in the halo kernel's head-fragment order (conv_halo_pack_head)
     ClassifierHead cls_head;
     MaskHead mask_head;
     // activations

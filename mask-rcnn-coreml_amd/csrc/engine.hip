@@ -696,6 +696,10 @@ void Model::build_maskrcnn()
         convs[n] = pack_conv_oihw(f, n, "", mode);
     convs["rpn_heads"] = pack_stacked_1x1(f, {"rpn_class_raw", "rpn_bbox_pred"}, mode);
     MRCNN_REQUIRE(convs["rpn_heads"].Cout == 6 * na, MRCNN_ERR_IO, "RPN head width %d != 6*anchors_per_location", convs["rpn_heads"].Cout);
+    if (convs["rpn_heads"].wdtype != convs["rpn_heads"].dtype && convs["rpn_heads"].Npad == 32) {       // split modes: heads fused into the shared 3x3 layer
+        conv_halo_pack_head(nullptr, convs["rpn_heads"].wgt.p, 32, convs["rpn_heads"].Cin, rpn_head_frag);
+        HIP_CHECK(hipStreamSynchronize(nullptr));
+    }
 
     // ---- activation plan (pass 0 sizes the arena, pass 1 binds pointers and records the ops) ------
     const int Bm = max_batch;
@@ -824,7 +828,6 @@ void Model::build_maskrcnn()
             d.scale = pc->scale.as<float>(); d.shift = pc->shift.as<float>();
             d.OH = fh[l]; d.OW = fw[l]; d.Cout = 512; d.Npad = pc->Npad;
             d.out = rpn_feat; d.out_sP = 512; d.out_sB = (long)fh[l] * fw[l] * 512; d.act = ACT_RELU;
-            add([d](hipStream_t s, int batch) { ConvDesc x = d; x.B = batch; conv_forward(s, x); });
             const PackedConv* hc = &convs.at("rpn_heads");
             ConvDesc e;
             e.dtype = dt; e.out_f32 = 1;      // the box path consumes fp32 (ProposalLayer.swift:108-109)
@@ -835,7 +838,21 @@ void Model::build_maskrcnn()
             e.OH = fh[l]; e.OW = fw[l]; e.Cout = hc->Cout; e.Npad = hc->Npad;
             e.out = rpn_logits + lvl_off[l] * 2; e.out_sP = 2 * na; e.out_sB = (long)A * 2;
             e.out2 = rpn_deltas + lvl_off[l] * 4; e.out2_sP = 4 * na; e.out2_sB = (long)A * 4; e.n_split = 2 * na;
-            add([e](hipStream_t s, int batch) { ConvDesc x = e; x.B = batch; conv_forward(s, x); });
+            // Levels whose geometry qualifies (a property of the level, not of the batch: P2..P4 at 1024²) run the two heads INSIDE
+            // the shared 3x3 layer's epilogue: the 512-channel tensor — 1.07 GB at P2, batch 8 — is neither
+            // written nor read back, and the head launches disappear.  Switched off with the halo kernel itself: the two launches.
+            ConvDesc f = d;
+            f.B = 1;
+            f.head_w = rpn_head_frag.p; f.head_bias = hc->shift.as<float>();
+            f.head_out = rpn_logits + lvl_off[l] * 2; f.head_out_sP = 2 * na; f.head_out_sB = (long)A * 2;
+            f.head_out2 = rpn_deltas + lvl_off[l] * 4; f.head_out2_sP = 4 * na; f.head_out2_sB = (long)A * 4;
+            f.head_split = 2 * na; f.head_cols = 6 * na;
+            const bool fuse = rpn_head_frag.p && d.wgt_halo && conv_halo_head_eligible(f);
+            add([d, e, f, fuse](hipStream_t s, int batch) {
+                if (fuse && conv_halo_enabled()) { ConvDesc x = f; x.B = batch; conv_forward(s, x); return; }
+                ConvDesc x = d; x.B = batch; conv_forward(s, x);
+                ConvDesc y = e; y.B = batch; conv_forward(s, y);
+            });
         }
         {
             float* lg = rpn_logits; float* pr = rpn_probs; const long per = A;

@@ -129,6 +129,15 @@ struct ConvDesc {
     const float* sel_w = nullptr;
     const int32_t* sel_cid = nullptr;
     float* sel_partial = nullptr;
+    // halo kernel only — a 1x1 head fused into this layer's epilogue (the RPN's class / box heads on the shared 3x3 layer): the
+    // layer's own output is not stored; head_out gets head columns [0, head_split), head_out2 the columns [head_split, head_cols),
+    // each + head_bias.  head_w = conv_halo_pack_head of the [32][Cout] head filters.  conv_halo_head_eligible says whether the
+    // layer can run fused (a property of its geometry only); conv_forward fails loudly when it cannot.
+    const void* head_w = nullptr;
+    const float* head_bias = nullptr;
+    float* head_out = nullptr; float* head_out2 = nullptr;
+    long head_out_sB = 0, head_out_sP = 0, head_out2_sB = 0, head_out2_sP = 0;
+    int head_split = 0, head_cols = 0;
 };
 
 // Live per-kernel profile of the conv family: when a profiler is active on the calling thread every
@@ -166,7 +175,10 @@ bool conv_debug_set(const char* key, int value);
 // geometry and mode only — never of the batch: the K order of the kernel differs from the 128-row kernel's).
 struct ConvArgs;
 void conv_halo_pack(hipStream_t s, const void* wgt_std, int Npad, int Cin, DevBuf& out);
+void conv_halo_pack_head(hipStream_t s, const void* wgt_std, int Npad, int Cin, DevBuf& out);
 bool conv_halo_eligible(const ConvDesc& d);
+bool conv_halo_head_eligible(const ConvDesc& d);
+bool conv_halo_enabled();                   // the run-time switch mrcnn_debug_set("conv_halo") / MRCNN_HALO
 int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, int n_cus);
 
 // uint8 RGB (B,H,W,3) → fp32 (B, H+2*pad, W+2*pad, 4) minus mean, zero border, channel 3 = 0.

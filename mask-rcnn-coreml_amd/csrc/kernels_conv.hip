@@ -430,6 +430,7 @@ static PpPolicy& pp_policy()
                          env_int("MRCNN_PP_MIN_FILL", 85), env_int("MRCNN_PP_SPLIT", 0)};
     return p;
 }
+bool conv_halo_enabled() { return g_halo != 0; }
 bool conv_debug_set(const char* key, int value)
 {
     const std::string k = key;
@@ -516,6 +517,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     // 3x3 stride-1 layers of the split modes: the persistent halo kernel, whenever the layer qualifies — by its geometry and
     // mode alone, so that a layer runs in ONE summation order whatever the batch (the kernel's K order is its own).
     const bool halo = g_halo && d.wgt_halo && a.vec_ok && conv_halo_eligible(d);
+    MRCNN_REQUIRE(!d.head_w || (halo && conv_halo_head_eligible(d)), MRCNN_ERR_INVALID, "conv: a fused head needs the halo kernel (layer not eligible, or switched off)");
     if (halo) {
         static int n_cus = [] { int dev = 0; hipDeviceProp_t p; (void)hipGetDevice(&dev); return hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }();
         pp_bn = 0;

@@ -46,6 +46,13 @@ struct HaloArgs {
     int NH;                      // 16-channel slabs = Cin / 16
     int single_row;              // OW % 128 == 0: a tile lies inside one image row (cropped halo, pitch 130)
     int n_tiles;
+    // fused 1x1 head (RPN: rpn_class_raw | rpn_bbox_pred on the ReLU'd output of this 3x3 layer): the layer's
+    // own output is NOT stored; head_out / head_out2 receive columns [0, head_split) / [head_split, head_cols) + head_bias
+    const void* head_w;          // conv_halo_pack_head layout (nullptr: no head)
+    const float* head_bias;      // [32]
+    float* head_out; float* head_out2;
+    long head_out_sB, head_out_sP, head_out2_sB, head_out2_sP;
+    int head_split, head_cols;
 };
 
 // 4 fp32 → PARTS × 4 fp16 (the same round-toward-zero chain as split_hi_mid_lo / split_hi_lo of conv_device.h)
@@ -71,7 +78,7 @@ __device__ __forceinline__ void split4(const u32x4 v, u32x2 (&out)[PARTS])
     }
 }
 
-template <int PARTS, int TN>
+template <int PARTS, int TN, bool HEAD = false>
 __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
 {
     const ConvArgs& a = ha.a;
@@ -80,10 +87,14 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
     constexpr int PBUF = PARTS * PLANE;                   // one plane buffer (all parts)
     constexpr int MAXPC = (HALO_MAX_PX * 4 + 511) / 512;  // 64-B pieces per thread per slab (5)
     constexpr int STAGE = 8 * 32 * 36 * 4;                // the epilogue's wave-private tiles: they live in plane buffer 1
-    constexpr int PLANES = 2 * PBUF > PBUF + STAGE ? 2 * PBUF : PBUF + STAGE;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[PLANES + 2 * 2 * BN * 4];
+    constexpr int HPART = 4 * 128 * 32 * 4;               // HEAD: the four wave columns' partial head sums of a tile (they live in the planes)
+    constexpr int HRUN = HEAD ? 128 * 32 * 4 : 0;         // HEAD: running head sum of the M tile over its N tiles
+    constexpr int PLANES_ = 2 * PBUF > PBUF + STAGE ? 2 * PBUF : PBUF + STAGE;
+    constexpr int PLANES = HEAD && HPART > PLANES_ ? HPART : PLANES_;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PLANES + 2 * 2 * BN * 4 + HRUN];
     unsigned char* const planes = smem;
     float* const s_tab0 = reinterpret_cast<float*>(smem + PLANES);         // scale | shift of the tile's columns, by tile parity
+    float* const h_run = reinterpret_cast<float*>(smem + PLANES + 2 * 2 * BN * 4);
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -94,7 +105,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
     const int NH = ha.NH, NS = NH * 9;
 
     // ---- the tiles of this block: XCD x owns a contiguous run, its CUs take consecutive tiles -----------------------
-    const int T = ha.n_tiles;
+    // (HEAD: the unit handed to a block is an M tile; its N tiles run back to back on the same block, which sums the head over them)
+    const int T = HEAD ? a.tiles_m : ha.n_tiles;
+    const int n_inner = HEAD ? a.tiles_n : 1;
     const int nb = gridDim.x;
     const int bid = blockIdx.x;
     int t_first, t_end, t_step;
@@ -123,8 +136,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
     const bool dbg_nodma = a.dbg & 1, dbg_nobar = a.dbg & 2, dbg_nords = a.dbg & 4, dbg_nomma = a.dbg & 8, dbg_nostage = a.dbg & 16;
 
     int tile_par = 0;
-    for (int tile = t_first; tile < t_end; tile += t_step, tile_par ^= 1) {
-        const int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
+    for (int unit = t_first; unit < t_end; unit += t_step)
+    for (int inner = 0; inner < n_inner; ++inner, tile_par ^= 1) {
+        const int mt = HEAD ? unit : unit / a.tiles_n, nt = HEAD ? inner : unit - mt * a.tiles_n;
         const int m0 = mt * BM, n0 = nt * BN;
         float* const s_tab = s_tab0 + tile_par * 2 * BN;
         // ---- geometry of the tile's input region (uniform) --------------------------------------------------------
@@ -313,8 +327,87 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
         // Epilogue through a wave-private 32 x 36-float tile inside plane buffer 1 (free since the last slab's barrier; the next
         // tile's prologue only writes plane buffer 0 and the other s_tab, and its first write to buffer 1 comes after its own
         // prologue barrier, i.e. after every wave has left this epilogue): full-line stores, no block barrier.
-        conv_epilogue_wave<BN, TM, TN>(a, acc, reinterpret_cast<float*>(planes + PBUF) + wave * (32 * 36), s_tab, m0 + wm * (TM * 32), n0,
-                                       wn * TN * 32, lane);
+        if constexpr (!HEAD) {
+            conv_epilogue_wave<BN, TM, TN>(a, acc, reinterpret_cast<float*>(planes + PBUF) + wave * (32 * 36), s_tab, m0 + wm * (TM * 32), n0,
+                                           wn * TN * 32, lane);
+        } else {
+            // ---- fused head: y = act(acc * scale + shift) stays in registers; head[pixel][0..32) += y[pixel][64 channels] . Wh ----
+            // The accumulator layout IS an MFMA activation fragment up to a permutation of the 16 channels of a K group
+            // (lane (pixel, kk), slot s <-> channel 16 g + 4 kk + (s & 3) + 8 (s >> 2)); the head filters are packed with the
+            // same permutation (conv_halo_pack_head), so no data moves: split in registers, multiply.
+            // Summation order (the definition of the fused head, the same for every batch): per wave, K groups ascending, parts
+            // hi / mid / lo; then wave columns 0..3, then N tiles ascending, then the bias.
+            const bool relu = a.act == ACT_RELU;
+            bool out_of_range = false;
+            f32x16 hp[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) hp[i][e] = 0.0f;
+            const unsigned hw_off = (unsigned)(((n0 + wn * TN * 32) / 16) * 1024);         // this wave's first K group of the head
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const uint4 wf = *reinterpret_cast<const uint4*>(static_cast<const char*>(ha.head_w) + hw_off + (j * 2 + g) * 1024 + lane * 16);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        u32x4 v0, v1;
+#pragma unroll
+                        for (int q2 = 0; q2 < 2; ++q2) {
+                            const int cl = wn * TN * 32 + j * 32 + 8 * (2 * g + q2) + 4 * kk;
+                            const float4 sc = *reinterpret_cast<const float4*>(s_tab + cl), sh = *reinterpret_cast<const float4*>(s_tab + BN + cl);
+                            float x[4] = {acc[i][j][8 * g + 4 * q2 + 0] * sc.x + sh.x, acc[i][j][8 * g + 4 * q2 + 1] * sc.y + sh.y,
+                                          acc[i][j][8 * g + 4 * q2 + 2] * sc.z + sh.z, acc[i][j][8 * g + 4 * q2 + 3] * sc.w + sh.w};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                if (relu) x[r] = fmaxf(x[r], 0.f);
+                                out_of_range = out_of_range || !(fabsf(x[r]) < 65504.0f);
+                                if (q2 == 0) v0[r] = __float_as_uint(x[r]); else v1[r] = __float_as_uint(x[r]);
+                            }
+                        }
+                        u32x2 p0[PARTS], p1[PARTS];
+                        split4<PARTS>(v0, p0);
+                        split4<PARTS>(v1, p1);
+#pragma unroll
+                        for (int p = 0; p < PARTS; ++p) {
+                            const u32x4 af = {p0[p][0], p0[p][1], p1[p][0], p1[p][1]};
+                            hp[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf), __builtin_bit_cast(f16x8, af), hp[i], 0, 0, 0);
+                        }
+                    }
+                }
+            if (a.range_flag && out_of_range) atomicOr(a.range_flag, 1);
+            // partial sums of the four wave columns -> LDS (the planes: nobody reads them after the last slab's barrier)
+            float* const part = reinterpret_cast<float*>(planes);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(&part[((wn * 128) + wm * (TM * 32) + i * 32 + l31) * 32 + 8 * q + 4 * kk]) =
+                        make_float4(hp[i][4 * q], hp[i][4 * q + 1], hp[i][4 * q + 2], hp[i][4 * q + 3]);
+            __syncthreads();
+            const bool last = inner == n_inner - 1;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int o = t + 512 * k, row = o >> 5, col = o & 31;
+                float sum = inner == 0 ? 0.0f : h_run[o];
+                sum += part[(0 * 128 + row) * 32 + col];
+                sum += part[(1 * 128 + row) * 32 + col];
+                sum += part[(2 * 128 + row) * 32 + col];
+                sum += part[(3 * 128 + row) * 32 + col];
+                if (!last) h_run[o] = sum;
+                else {
+                    const int m = m0 + row;
+                    if (m < a.M && col < ha.head_cols) {
+                        const float y = sum + ha.head_bias[col];
+                        const int b = m / ohw, pix = m - b * ohw;
+                        if (col < ha.head_split) ha.head_out[(long)b * ha.head_out_sB + (long)pix * ha.head_out_sP + col] = y;
+                        else ha.head_out2[(long)b * ha.head_out2_sB + (long)pix * ha.head_out2_sP + (col - ha.head_split)] = y;
+                    }
+                }
+            }
+            __syncthreads();          // the partials (= the planes) are rewritten by the next tile's prologue
+        }
     }
 }
 
@@ -336,6 +429,27 @@ __global__ __launch_bounds__(256) void k_halo_pack(const uint4* __restrict__ src
         const int n = g * 32 + r;
         dst[e] = src[(((long)n * 9 + tap) * Cin + 16 * h + 8 * half) / 8];
     }
+}
+
+// head filters [32][Cin] fp16 (rows = head columns) -> [Cin/16][1 KB]: lane (n, kk), slot s holds W[n][16 G + 4 kk + (s & 3) + 8 (s >> 2)]
+// — the K permutation under which an accumulator of the main kernel is an activation fragment (k_conv_halo's head epilogue)
+__global__ __launch_bounds__(256) void k_halo_pack_head(const uint16_t* __restrict__ src, int Cin, uint16_t* __restrict__ dst)
+{
+    const long total = (long)(Cin / 16) * 64 * 8;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int sl = (int)(e & 7), lane = (int)((e >> 3) & 63);
+        const int G = (int)(e >> 9);
+        const int n = lane & 31, kk = lane >> 5;
+        dst[e] = src[(long)n * Cin + 16 * G + 4 * kk + (sl & 3) + 8 * (sl >> 2)];
+    }
+}
+
+void conv_halo_pack_head(hipStream_t s, const void* wgt_std, int Npad, int Cin, DevBuf& out)
+{
+    MRCNN_REQUIRE(Npad == 32 && Cin % 16 == 0, MRCNN_ERR_SHAPE, "halo head packing: Npad %d (must be 32) / Cin %d", Npad, Cin);
+    out.alloc((size_t)32 * Cin * 2);
+    hipLaunchKernelGGL(k_halo_pack_head, dim3(64), dim3(256), 0, s, static_cast<const uint16_t*>(wgt_std), Cin, static_cast<uint16_t*>(out.p));
+    HIP_CHECK(hipGetLastError());
 }
 
 void conv_halo_pack(hipStream_t s, const void* wgt_std, int Npad, int Cin, DevBuf& out)
@@ -374,8 +488,17 @@ bool conv_halo_eligible(const ConvDesc& d)
 template <int PARTS>
 static void halo_launch(hipStream_t s, const HaloArgs& ha, int bn, int grid)
 {
-    if (bn == 256) hipLaunchKernelGGL((k_conv_halo<PARTS, 2>), dim3(grid), dim3(512), 0, s, ha);
+    if (ha.head_w) hipLaunchKernelGGL((k_conv_halo<PARTS, 2, true>), dim3(grid), dim3(512), 0, s, ha);
+    else if (bn == 256) hipLaunchKernelGGL((k_conv_halo<PARTS, 2>), dim3(grid), dim3(512), 0, s, ha);
     else hipLaunchKernelGGL((k_conv_halo<PARTS, 1>), dim3(grid), dim3(512), 0, s, ha);
+}
+
+// A fused head needs 256-column tiles (the head's K groups are walked per wave column) and enough M tiles to occupy the chip
+// at ANY batch the layer may see — a property of the layer, not of the call: at least 32 M tiles per image.
+bool conv_halo_head_eligible(const ConvDesc& d)
+{
+    return conv_halo_eligible(d) && d.Npad % 256 == 0 && d.Npad == d.Cout && ((long)d.OH * d.OW) % 128 == 0 && (long)d.OH * d.OW >= 4096 &&
+           d.head_cols >= 1 && d.head_cols <= 32 && d.head_split >= 0 && d.head_split <= d.head_cols;
 }
 
 // a: filled by conv_forward (M, strides, epilogue fields, vec_ok checked by the caller); returns the N tile used
@@ -385,7 +508,7 @@ int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, i
     // tile width: the widest whose tiles fill the chip once (the K order, hence the result, does not depend on it)
     const int tiles_m = (a.M + 127) / 128;
     int bn = d.Npad % 256 == 0 ? 256 : 128;
-    if (bn > 128 && (long)tiles_m * (d.Npad / bn) < n_cus) bn = 128;
+    if (bn > 128 && (long)tiles_m * (d.Npad / bn) < n_cus && !d.head_w) bn = 128;
     a.tiles_m = tiles_m;
     a.tiles_n = d.Npad / bn;
     a.direct = 1;
@@ -394,7 +517,11 @@ int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, i
     ha.NH = d.Cin / 16;
     ha.single_row = d.W % 128 == 0 ? 1 : 0;
     ha.n_tiles = a.tiles_m * a.tiles_n;
-    int grid = ha.n_tiles < n_cus ? ha.n_tiles : n_cus;
+    ha.head_w = d.head_w; ha.head_bias = d.head_bias; ha.head_out = d.head_out; ha.head_out2 = d.head_out2;
+    ha.head_out_sB = d.head_out_sB; ha.head_out_sP = d.head_out_sP; ha.head_out2_sB = d.head_out2_sB; ha.head_out2_sP = d.head_out2_sP;
+    ha.head_split = d.head_split; ha.head_cols = d.head_cols;
+    const int units = d.head_w ? a.tiles_m : ha.n_tiles;
+    int grid = units < n_cus ? units : n_cus;
     if (grid >= 8) grid &= ~7;                  // a multiple of 8: every XCD runs the same number of blocks
     if (parts == 3) halo_launch<3>(s, ha, bn, grid);
     else halo_launch<2>(s, ha, bn, grid);
