@@ -14,7 +14,7 @@ Weights are seeded synthetic weights of the exact architecture ("forced full loa
 
 Default compute mode: f32x3 — fp32 tensors, fp32 accumulation, products formed on the fp16 matrix cores from a three-part
 fp16 split of the activation × the fp16-stored filter: an activation with 0.5 <= |a| < 65504 is carried EXACTLY (all 24
-significand bits, so a*w is the exact product), a smaller one to 2^-24 ABSOLUTE (truncated toward zero: the third part
+significand bits, so a*w is the exact product), a smaller one to 2^-25 ABSOLUTE (rounded to nearest: the third part
 reaches the fp16 subnormal step) — unlike fp32 the mode is not scale-invariant; tests/test_gpu_conv_kernels.py pins the
 curve (profiles/r03_split_scale_curve.txt).  On this workload (activations O(1-100)): against an fp64 evaluation of the same
 graph it is CLOSER than the fp32-MFMA engine of round 1 (profiles/r02_fp64_trunk_parity.json) and it matches the CPU
@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--dtype", default="f32x3", choices=["f32", "f16", "f32s", "f32x3"],
                     help="compute mode of the convolutions.  f32x3 (default): fp32 tensors, products a*w formed on the "
                          "fp16 matrix cores from a three-part split of the fp32 activation against the fp16-stored filter "
-                         "(task.py:90; exact for 0.5 <= |a| < 65504, the activation carried to 2^-24 absolute below), fp32 accumulate — measured closer to an fp64 evaluation than the fp32-MFMA engine "
+                         "(task.py:90; exact for 0.5 <= |a| < 65504, the activation carried to 2^-25 absolute below), fp32 accumulate — measured closer to an fp64 evaluation than the fp32-MFMA engine "
                          "(profiles/r02_fp64_trunk_parity.json), 100 %% end-to-end agreement with the CPU oracle (parity_e2e); "
                          "f32: v_mfma_f32_32x32x2_f32 (round-1 headline, now under other_modes); f32s: two-part split; "
                          "f16: fp16 tensors + fp16 MFMA (BASELINE configs[3])")
@@ -222,7 +222,7 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "dtype_note": {"f32x3": "fp32 tensors and accumulation; products a*w formed on the fp16 MFMA from a 3-part split of the activation "
                                     "(the filters are fp16 in the artefact, task.py:90): exact for 0.5 <= |a| < 65504, the activation "
-                                    "carried to 2^-24 absolute (truncated) below — not scale-invariant like fp32; curve: "
+                                    "carried to 2^-25 absolute (rounded to nearest) below — not scale-invariant like fp32; curve: "
                                     "profiles/r03_split_scale_curve.txt",
                            "f32": "fp32 tensors, v_mfma_f32_32x32x2_f32", "f32s": "fp32 tensors, 2-part split of the activations (22 of 24 bits)",
                            "f16": "fp16 tensors, fp16 MFMA, fp32 accumulate; box path and outputs fp32"}[args.dtype],
@@ -315,7 +315,7 @@ def main():
                                                      "f32s": "fp32 tensors, two fp16 MFMA passes over a hi/lo split of the activations "
                                                              "(fp32-grade: parity-tested at the fp32 tolerances)",
                                                      "f32x3": "fp32 tensors, three fp16 MFMA passes over a three-part split of the "
-                                                              "activations (exact for 0.5 <= |a| < 65504, 2^-24 absolute below)"}[mode]}
+                                                              "activations (exact for 0.5 <= |a| < 65504, 2^-25 absolute below)"}[mode]}
                 del mm
         if n_gpus == 1:
             # the same step with the batch in pinned host memory: H2D of the images and D2H of the records inside the timing

@@ -156,9 +156,9 @@ typedef struct mrcnn_model mrcnn_model;
  * what the converter writes; an artefact with genuine fp32 filters is refused in this mode).  MRCNN_F32X3 is the same
  * with THREE parts — three MFMA passes instead of two.  The bound that holds: an activation with 0.5 <= |a| < 65504 is
  * represented exactly (its product with an fp16 filter is then exact and only the fp32 summation order differs from an fp32
- * engine); a smaller one is carried to 2^-24 ABSOLUTE, truncated toward zero (the third part reaches the fp16 subnormal
+ * engine); a smaller one is carried to 2^-25 ABSOLUTE, rounded to nearest (the third part reaches the fp16 subnormal
  * step; this also relies on the MFMA not flushing fp16 subnormals, which gfx950 does not), i.e. about 14 significant bits
- * at |a| = 1e-3.  An output is therefore off by at most 2^-24 * sum|w| beyond fp32 summation noise: invisible while a layer's
+ * at |a| = 1e-3.  An output is therefore off by at most 2^-25 * sum|w| beyond fp32 summation noise: invisible while a layer's
  * activations are O(1) or larger (every tensor of a BatchNorm-folded trunk), but unlike fp32 the mode is NOT scale-invariant —
  * a model whose activations are uniformly tiny should be loaded with MRCNN_F32 (tests/test_gpu_conv_kernels.py,
  * profiles/r03_split_scale_curve.txt).

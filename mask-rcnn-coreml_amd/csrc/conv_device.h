@@ -454,8 +454,21 @@ __device__ __forceinline__ void conv_epilogue_wave(const ConvArgs& a, f32x16 (&a
     if (a.range_flag && out_of_range) atomicOr(a.range_flag, 1);
 }
 
-// fp32 → (hi, lo) fp16 pair with hi + lo = a to ~2^-22 relative: hi = a rounded toward zero to fp16,
-// lo = (a - hi) rounded toward zero to fp16 (a - hi is exact in fp32; for |a| below ~1e-2 lo lands in the
+// two fp32 → packed fp16, ROUND TO NEAREST EVEN (v_cvt_pk_f16_f32; the builtin pack conversion truncates).  Every part of the
+// splits below is rounded to nearest: the parts of an activation that cannot be carried exactly leave a two-sided, unbiased
+// error (half the one-sided error of truncation).
+// (A vector conversion, which hipcc lowers to the one instruction: written as inline asm the compiler does not pad the
+// VALU-write -> MFMA-read hazard behind it and the matrix cores read a stale register — NaNs in the three-part kernels.)
+__device__ __forceinline__ uint32_t cvt_pk_rne(float x, float y)
+{
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {x, y};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+
+// fp32 → (hi, lo) fp16 pair with hi + lo = a to 2^-23 relative: hi = a rounded to nearest fp16,
+// lo = (a - hi) rounded to nearest fp16 (a - hi is exact in fp32; for |a| below ~1e-2 lo lands in the
 // fp16 subnormals, whose 2^-24 absolute step is far under the fp32 rounding noise of the sums it feeds).
 // fp16 × fp16 products are exact in the MFMA's fp32 accumulate, so hi·w + lo·w reproduces the fp32 product
 // a·w for fp16-exact filters w.  |a| must stay below 65504 (as in any fp16 GPU path of the reference).
@@ -466,20 +479,20 @@ __device__ __forceinline__ void split_hi_lo(const uint4 u0, const uint4 u1, f16x
     uint32_t hw[4], lw[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const uint32_t h2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a[2 * p], a[2 * p + 1]));
+        const uint32_t h2 = cvt_pk_rne(a[2 * p], a[2 * p + 1]);
         // r = a - hi in ONE mixed-precision FMA (fp16 half of h2 × -1.0 + a): saves the widening conversion
         float r0, r1;
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h2), "v"(a[2 * p]));
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h2), "v"(a[2 * p + 1]));
         hw[p] = h2;
-        lw[p] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+        lw[p] = cvt_pk_rne(r0, r1);
     }
     hi = __builtin_bit_cast(f16x8, uint4{hw[0], hw[1], hw[2], hw[3]});
     lo = __builtin_bit_cast(f16x8, uint4{lw[0], lw[1], lw[2], lw[3]});
 }
 
 // Three-part variant (MRCNN_F32X3): hi + mid + lo carries all 24 significand bits — exact for 0.5 <= |a| < 65504, and to
-// 2^-24 absolute below (where the last part reaches the fp16 subnormal step and is truncated toward zero): for |a| >= 0.5
+// 2^-25 absolute below (where the last part reaches the fp16 subnormal step and is rounded to nearest): for |a| >= 0.5
 // the fp32 product a·w is reproduced exactly; the bound for smaller activations is the one include/maskrcnn_hip.h states
 // and tests/test_gpu_conv_kernels.py::test_split_modes_scale_curve_stays_inside_the_documented_bound pins.
 __device__ __forceinline__ void split_hi_mid_lo(const uint4 u0, const uint4 u1, f16x8& hi, f16x8& mid, f16x8& lo)
@@ -489,16 +502,16 @@ __device__ __forceinline__ void split_hi_mid_lo(const uint4 u0, const uint4 u1, 
     uint32_t hw[4], mw[4], lw[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const uint32_t h2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a[2 * p], a[2 * p + 1]));
+        const uint32_t h2 = cvt_pk_rne(a[2 * p], a[2 * p + 1]);
         float r0, r1, q0, q1;
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h2), "v"(a[2 * p]));
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h2), "v"(a[2 * p + 1]));
-        const uint32_t m2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+        const uint32_t m2 = cvt_pk_rne(r0, r1);
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(q0) : "v"(m2), "v"(r0));
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(q1) : "v"(m2), "v"(r1));
         hw[p] = h2;
         mw[p] = m2;
-        lw[p] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(q0, q1));
+        lw[p] = cvt_pk_rne(q0, q1);
     }
     hi = __builtin_bit_cast(f16x8, uint4{hw[0], hw[1], hw[2], hw[3]});
     mid = __builtin_bit_cast(f16x8, uint4{mw[0], mw[1], mw[2], mw[3]});

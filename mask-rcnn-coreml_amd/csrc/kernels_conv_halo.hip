@@ -55,25 +55,25 @@ struct HaloArgs {
     int head_split, head_cols;
 };
 
-// 4 fp32 → PARTS × 4 fp16 (the same round-toward-zero chain as split_hi_mid_lo / split_hi_lo of conv_device.h)
+// 4 fp32 → PARTS × 4 fp16 (the same round-to-nearest chain as split_hi_mid_lo / split_hi_lo of conv_device.h)
 template <int PARTS>
 __device__ __forceinline__ void split4(const u32x4 v, u32x2 (&out)[PARTS])
 {
     const float a[4] = {__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        const uint32_t h2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a[2 * p], a[2 * p + 1]));
+        const uint32_t h2 = cvt_pk_rne(a[2 * p], a[2 * p + 1]);
         float r0, r1;
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h2), "v"(a[2 * p]));
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h2), "v"(a[2 * p + 1]));
-        const uint32_t m2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+        const uint32_t m2 = cvt_pk_rne(r0, r1);
         out[0][p] = h2;
         out[1][p] = m2;
         if constexpr (PARTS == 3) {
             float q0, q1;
             asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(q0) : "v"(m2), "v"(r0));
             asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(q1) : "v"(m2), "v"(r1));
-            out[2][p] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(q0, q1));
+            out[2][p] = cvt_pk_rne(q0, q1);
         }
     }
 }

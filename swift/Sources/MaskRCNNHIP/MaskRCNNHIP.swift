@@ -22,7 +22,7 @@ public enum ComputeMode {
     /// fp32 tensors, exact-fp32 MFMA (`v_mfma_f32_32x32x2_f32`): the scale-invariant baseline.
     case f32
     /// fp32 tensors; products on the fp16 matrix cores from a THREE-part split of the activation (exact for 0.5 <= |a| < 65504,
-    /// the activation carried to 2^-24 absolute below): the mode `bench.py` reports.
+    /// the activation carried to 2^-25 absolute below): the mode `bench.py` reports.
     case f32x3
     /// fp32 tensors; two-part split (22 of 24 significand bits).
     case f32s

@@ -236,8 +236,8 @@ SCALES = [0, -4, -8, -12, -16, -20]
 def split_scale_curve(dtype, shape=(2, 32, 32, 256, 128, 3), seed=3):
     """max |err| / max |ref| of one convolution against an fp64 torch convolution, for the SAME post-ReLU-like tensor
     multiplied by 2^e (an exact operation): [(e, relative error, bound)].  bound = what include/maskrcnn_hip.h documents for
-    the three-part split: every activation is carried exactly when |a| >= 0.5 and to 2^-24 ABSOLUTE (truncated toward
-    zero) below, so an output is off by at most 2^-24 * sum |w| over its taps — plus the fp32 summation noise every
+    the three-part split: every activation is carried exactly when |a| >= 0.5 and to 2^-25 ABSOLUTE (rounded to
+    nearest) below, so an output is off by at most 2^-25 * sum |w| over its taps (the test grants 2^-24) — plus the fp32 summation noise every
     fp32 engine has (taken as 2e-6 of the range, the bar of the other conv tests)."""
     B, H, W, Ci, Co, k = shape
     rng = np.random.default_rng(seed)
@@ -258,7 +258,7 @@ def split_scale_curve(dtype, shape=(2, 32, 32, 256, 128, 3), seed=3):
 @pytest.mark.parametrize("dtype", ["f32x3", "f32s", "f32"])
 def test_split_modes_scale_curve_stays_inside_the_documented_bound(dtype):
     """VERDICT r2 item 1(b) / ADVICE r2: the three-part split is exact only for 0.5 <= |a| < 65504; below, an activation is
-    carried to 2^-24 absolute.  The same tensor at 2^0 ... 2^-20: the fp32-MFMA mode is flat (control), the split modes follow
+    carried to 2^-25 absolute.  The same tensor at 2^0 ... 2^-20: the fp32-MFMA mode is flat (control), the split modes follow
     the documented bound (and must not be WORSE than it: that is what protects small-magnitude checkpoints from silent loss)."""
     curve = split_scale_curve(dtype)
     for e, err, bound in curve:
