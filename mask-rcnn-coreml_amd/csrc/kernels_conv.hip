@@ -327,7 +327,15 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
     if (a.dbg & 1024) { if (a.dbg == 12345678) static_cast<float*>(a.out)[t] = acc[0][0][0]; return; }
 #endif
     if constexpr (DIRECT_OK) {
-        if (direct) { conv_epilogue_direct<T, BN, TM, TN>(a, acc, s_tab, m0 + wm * TM * 32, n0, wn * TN * 32, lane); return; }
+        if (direct) {
+            if constexpr (sizeof(T) == 4) {
+                // fp32 tensors (a.direct == 2): through a wave-private 32 x 36-float LDS tile (the operand ring is free: the K loop
+                // ended in a barrier) — full-line stores without the two block barriers of the staged epilogue
+                static_assert(WM * WN * 32 * 36 * 4 <= SMEM, "wave-private epilogue tiles fit in the operand ring");
+                conv_epilogue_wave<BN, TM, TN>(a, acc, reinterpret_cast<float*>(smem) + wave * (32 * 36), s_tab, m0 + wm * TM * 32, n0, wn * TN * 32, lane);
+            } else conv_epilogue_direct<T, BN, TM, TN>(a, acc, s_tab, m0 + wm * TM * 32, n0, wn * TN * 32, lane);
+            return;
+        }
     }
     conv_epilogue<T, BN, TM, TN, WM, WN, CPASS>(a, acc, smem, m0, n0);
 }
@@ -380,10 +388,11 @@ int conv_n_tile(int Cout)
     return 32;
 }
 
+static int env_int(const char* name, int dflt);
 static int g_min_blocks = 448;   // narrow the N tile while the grid has fewer blocks than this: 7/8 of two blocks per CU (the
                                  // box head's 504 tiles of 128 columns beat 1008 of 64: +1.1 % end to end, tools/e2e_ab.py)
-static int g_direct = 1;         // 0: every layer through the LDS-staged epilogue; 1: fp16 tensors direct; 2: all modes direct (A/B, tests)
-static int env_int(const char* name, int dflt);
+static int g_direct = env_int("MRCNN_DIRECT", 2);   // 0: every layer through the block-staged epilogue; 1: fp16 tensors straight from the accumulators;
+                                 // 2: also fp32 tensors through wave-private LDS tiles (conv_epilogue_wave)
 static int g_halo = env_int("MRCNN_HALO", 1);        // 3x3 stride-1 layers of the split modes on the halo kernel (kernels_conv_halo.hip) when the filters come re-tiled
 static int g_tn4 = -1;       // split modes, 128x128 tile as 4 waves of 32x128: -1 by policy (conv_forward), 0 never, 1 always (tests)
 template <typename T, typename TW, int PARTS = 2>
@@ -493,9 +502,11 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
                (!d.deconv2 || (d.Cout % cpt == 0 && d.out_sH % cpt == 0 && d.out_sW % cpt == 0));
     a.tiles_n = d.Npad / bn;
     MRCNN_REQUIRE(!d.sel_partial || (bn == 128 && a.vec_ok), MRCNN_ERR_INVALID, "conv: the selected-class mode needs the 128-wide vector epilogue");
-    // Direct epilogue: fp16 tensors only by default (g_direct = 1).  With fp32 tensors a lane's 16-B store holds four channels of
-    // one pixel — 64 scattered pieces per store instruction — and the LDS-staged full-row stores win by 1.4 % end to end
-    // (tools/e2e_ab.py f32x3 conv_direct 0 1); with fp16 tensors (eight channels per store) the direct form wins by 0.9 %.
+    // Epilogue without block barriers wherever the layer allows (g_direct = 2): fp16 tensors straight from the accumulators
+    // (eight channels per 16-B store: +0.9 % end to end over the block-staged form); fp32 tensors through wave-private LDS
+    // tiles (conv_epilogue_wave: full-line stores — a lane's own 16-B store would hold four channels of one pixel, 64 scattered
+    // pieces per instruction, which lost 1.4 % — without the two barriers of the block-staged form: +1.6 % end to end,
+    // tools/e2e_direct_ab.sh, round 3).
     a.direct = (g_direct && (half || g_direct > 1) && a.vec_ok && !d.out2 && !d.deconv2 && d.act != ACT_SIGMOID && (!half || !a.out_f32)) ? 1 : 0;
     // Layers with a large GEMM: the 256×256 persistent ping-pong kernel (kernels_conv_pp.hip), one block per CU — when the
     // tiles fill whole rounds of the chip well enough (a static walk: the last round costs as much as a full one).

@@ -158,7 +158,7 @@ def test_direct_epilogue_equals_the_lds_staged_epilogue_bitwise(shape, dtype):
         L.check(lib.mrcnn_debug_set(b"conv_direct", 2))
         y1 = conv(x, w, k, stride, scale, shift, res, 1, dtype)
     finally:
-        L.check(lib.mrcnn_debug_set(b"conv_direct", 1))
+        L.check(lib.mrcnn_debug_set(b"conv_direct", 2))
         L.check(lib.mrcnn_debug_set(b"conv_pp", 1))
         L.check(lib.mrcnn_debug_set(b"conv_halo", 1))
     np.testing.assert_array_equal(y1, y0)
