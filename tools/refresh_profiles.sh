@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerates everything under profiles/ for round $1 (default r02) on a GPU box:
-#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r02'
+#   gpurun --timeout 3000 -- 'bash tools/refresh_profiles.sh r03'
 # Outputs land in gpurun_out/profiles_<round>/ (merged back by gpurun); copy them into profiles/ and commit.
 # Counter passes follow MI355X_MICROARCH.md: --pmc in its own run with --kernel-trace only, FETCH_SIZE and WRITE_SIZE separately.
 set -u
-RND=${1:-r02}
+RND=${1:-r03}
 MODES=${2:-"f32x3 f16 f32s f32"}
 R=$(pwd)
 OUT=$R/gpurun_out/profiles_$RND
@@ -40,13 +40,15 @@ json.dump({"kernel": k, "launches_sampled": conv[k]["launches_sampled"], "hbm_by
 PY
 done
 cd $R
-for dt in f16 f32x3; do timeout 300 python tools/conv_ab.py 3 10 1 $dt > $OUT/${RND}_conv_ab_$dt.txt 2>/dev/null; done
-timeout 200 python tools/pp_ablate.py 0 > $OUT/${RND}_pp_ablate_f16.txt 2>/dev/null
-timeout 200 python tools/pp_ktfit.py 512 > $OUT/${RND}_pp_ktfit_f16.txt 2>/dev/null
-[ -x tools/probes/dma_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-inline-asm -o tools/probes/dma_probe tools/probes/dma_probe.hip 2>/dev/null
-[ -x tools/probes/dma_probe ] && timeout 120 ./tools/probes/dma_probe 4096 > $OUT/${RND}_dma_probe.txt 2>&1
-bash tools/pp_clock_probe.sh f16 "0 4 8 12 256" > $OUT/${RND}_pp_clock_f16.txt 2>&1
-bash tools/pp_clock_probe.sh f32x3 "0 4 8 12 256" > $OUT/${RND}_pp_clock_f32x3.txt 2>&1
+timeout 300 python tools/conv_ab.py 3 10 1 f16 > $OUT/${RND}_conv_ab_f16.txt 2>/dev/null
+for dt in f32x3 f32s; do timeout 300 python tools/halo_ab.py 3 10 $dt 2>/dev/null | grep -v amdgpu > $OUT/${RND}_halo_ab_$dt.txt; done
+timeout 200 python tools/halo_ablate.py f32x3 2>/dev/null | grep -v amdgpu > $OUT/${RND}_halo_ablate_f32x3.txt
+bash tools/pmc_halo_probe.sh f32x3 "8 256 256 256 512 3 1" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD" "FETCH_SIZE" "WRITE_SIZE" > $OUT/${RND}_pmc_probe_rpn3x3_f32x3.txt 2>&1
+[ -x tools/probes/vmem_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/probes/vmem_probe tools/probes/vmem_probe.hip 2>/dev/null
+[ -x tools/probes/vmem_probe ] && timeout 120 ./tools/probes/vmem_probe 2048 > $OUT/${RND}_vmem_probe.txt 2>&1
+python tools/split_scale_curve.py 2>/dev/null | grep -v amdgpu > $OUT/${RND}_split_scale_curve.txt
+# stage-attributed trace: roctx ranges with the reference's signpost names (marker trace + kernel trace, no counters)
+( cd /tmp && rm -rf /tmp/mk && timeout 300 rocprofv3 --marker-trace --kernel-trace --stats --output-format csv -d /tmp/mk -o m -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-modes --no-kernel-events > /dev/null 2> $OUT/marker.err; f=$(find /tmp/mk -name "*marker*stats*.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${RND}_marker_stats_f32x3.csv; f=$(find /tmp/mk -name "*marker_api_trace.csv" | head -1); [ -n "$f" ] && head -80 $f > $OUT/${RND}_marker_trace_head_f32x3.csv )
 timeout 200 bash tools/power_probe.sh > $OUT/${RND}_power_probe.txt 2>&1
 timeout 200 bash tools/mfma_power.sh > $OUT/${RND}_mfma_power.txt 2>&1
 timeout 400 python tools/fp64_trunk_parity.py --out $OUT/${RND}_fp64_trunk_parity.json > $OUT/fp64.log 2>&1
@@ -57,7 +59,7 @@ python bench.py --steps 5 --warmup 2 --size 1536 --num-classes 2 --pre-nms 12000
 for b in 1 2 4 16 32; do python bench.py --steps 10 --warmup 3 --batch $b --no-cpu-baseline --no-other-modes --no-kernel-events > $OUT/${RND}_bench_n1_batch$b.json 2>/dev/null; done
 # 64-image end-to-end agreement with the CPU oracle (about 6 minutes of host time)
 python bench.py --steps 5 --warmup 2 --e2e-images 64 --no-kernel-events 2>/dev/null | python -c "import json,sys; print(json.dumps(json.loads(sys.stdin.read())['parity_e2e'], indent=1))" > $OUT/${RND}_parity_e2e_64.json
-timeout 900 python tools/soak_determinism.py 100 > $OUT/${RND}_soak_determinism.txt 2>&1
+timeout 900 python tools/soak_determinism.py 200 > $OUT/${RND}_soak_determinism.txt 2>&1
 # the default bench line last: it reports the counters / probe figures of THIS refresh (bench.py reads them from profiles/)
 cp $OUT/${RND}_pmc_traffic_*.json $OUT/${RND}_mfma_power.txt $R/profiles/ 2>/dev/null
 python bench.py --steps 10 --warmup 3 > $OUT/${RND}_bench_n1.json 2> $OUT/bench_default.err
