@@ -336,7 +336,9 @@ MRCNN_API int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout,
  * "conv_pp_dbg"; "conv_tn4" -1|0|1: split modes, 128x128 tile as 4 waves of 32x128 by policy | never | always; "conv_min_blocks": the grid
  * size below which the N tile is narrowed; "conv_direct" 0|1|2: epilogue straight from the accumulators never | fp16 tensors | always; "mask_fused" 0|1: the mask head's
  * deconvolution + selected-class 1x1 as two launches over a materialised tensor | fused — results within fp32 summation noise): every choice must give
- * bit-identical results — the tile shape depends on the batch size and per-image results must not. */
+ * bit-identical results — the tile shape depends on the batch size and per-image results must not.  Further knobs: "conv_halo" 0|1 the
+ * persistent halo kernel of the 3x3 layers of the split modes (its K order is its own: results differ from "0" by summation noise).
+ * The switches are PROCESS-WIDE test / measurement knobs: not thread-safe; a choice captured in a hipGraph stays captured. */
 MRCNN_API int mrcnn_conv2d_nhwc(const float* in, int batch, int h, int w, int cin, const float* filters, int cout,
                                 int ksize, int stride, const float* scale, const float* shift, const float* residual,
                                 int act, int dtype, float* out);
