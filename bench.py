@@ -252,7 +252,7 @@ def main():
                 tail = {"f32": "2,2", "f16": "2,2", "f32s": "3,2", "f32x3": "3,3"}[args.dtype]
                 kname = {"128x128": f"k_conv_mfma_glds<{ktypes},128,1,2,4,2,{tail}>", "128x64": f"k_conv_mfma_glds<{ktypes},64,1,1,4,2,...>",
                          "128x32": f"k_conv_mfma_glds<{ktypes},32,1,1,4,1,...>", "128x128w4": f"k_conv_mfma_glds<{ktypes},128,1,4,4,1,{tail}>",
-                         "256x256pp": "k_conv_pp<0>", "128xNhalo": f"k_conv_halo<{parts},TN> (persistent 128 x 64*TN halo tiles)"}[dom]
+                         "256x256pp": "k_conv_pp<0>", "128xNhalo": f"k_conv_halo<{parts},TN,HEAD> (persistent 128 x 128*TN halo tiles; instantiations <{parts},2,false>, <{parts},2,true> = fused RPN heads, <{parts},1,false>)"}[dom]
                 out["roofline"] = {
                     "kernel": kname, "bound": "mfma",
                     "achieved": round(achieved, 2),
@@ -260,7 +260,7 @@ def main():
                     "flops_counted": "algorithmic (2*M*N*K of the convolution)" + (
                         f"; the kernel EXECUTES {parts} fp16 MFMA flops per algorithmic flop ({round(achieved * parts, 1)} of "
                         f"{PEAK_FP16_MFMA_TFLOPS} TFLOP/s), so the peak for algorithmic flops is 1/{parts} of the fp16 MFMA peak" if parts > 1 else ""),
-                    "traffic": pmc_traffic(args.dtype),
+                    "traffic": pmc_traffic(args.dtype, dom),
                     "traffic_note": "from profiles_ref (separate rocprofv3 --pmc passes of this command, committed): not of this run",
                     "launches_per_step": launches // ev_steps, "event_steps": ev_steps,
                     "avg_launch_ms": round(ms / launches, 4),
@@ -276,7 +276,7 @@ def main():
                 }
                 out["profiles_ref"] = {
                     "note": "constants read from committed files under profiles/ — NOT measured in this run",
-                    "traffic_bytes_per_launch_dominant_kernel": pmc_traffic(args.dtype), "traffic_source": pmc_traffic_source(args.dtype),
+                    "traffic_bytes_per_launch_dominant_kernel": pmc_traffic(args.dtype, dom), "traffic_source": pmc_traffic_source(args.dtype),
                     "sustained_peak": sustained_peak(args.dtype, parts, achieved)}
         # images of the end-to-end parity leg (the oracle sees the same ones): seed 1 stream, after this rank's bench batch
         n_e2e = 0 if (n_gpus != 1 or args.no_cpu_baseline) else max(args.e2e_images, 0)
@@ -362,10 +362,26 @@ def sustained_peak(dtype, parts, achieved):
     return None
 
 
-def pmc_traffic(dtype):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command in this
-    compute mode (profiles/r02_pmc_traffic_<dtype>.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled
-    per MI355X_MICROARCH.md §HBM).  PMC collection cannot run inside the timed process, hence a committed value."""
+CLASS_KERNELS = {"128xNhalo": ("k_conv_halo<",), "256x256pp": ("k_conv_pp<",), "128x128": (", 128, 1, 2, 4, 2,",), "128x64": (", 64, 1, 1, 4, 2,",),
+                 "128x32": (", 32, 1, 1, 4, 1,",), "128x128w4": (", 128, 1, 4, 4, 1,",)}
+
+
+def pmc_traffic(dtype, tile_class=None):
+    """HBM bytes per launch of the dominant kernel CLASS (a tile class may be several template instantiations: the halo kernel
+    with and without the fused head, 256- and 128-column tiles), launch-weighted, from the committed rocprofv3 PMC passes of THIS
+    command in this compute mode (profiles/rNN_pmc_kernels_<dtype>.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE
+    doubled per MI355X_MICROARCH.md §HBM).  PMC collection cannot run inside the timed process, hence a committed value."""
+    if tile_class in CLASS_KERNELS:
+        for rnd in ("r03",):
+            try:
+                with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_kernels_{dtype}.json")) as f:
+                    ks = json.load(f)["kernels"]
+                sel = [v for k, v in ks.items() if any(tag in k for tag in CLASS_KERNELS[tile_class]) and k.startswith("k_conv") and "hbm_bytes_per_launch" in v]
+                n = sum(v["launches_sampled"] for v in sel)
+                if n:
+                    return round(sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in sel) / n)
+            except Exception:
+                pass
     for name in (f"r03_pmc_traffic_{dtype}.json", f"r02_pmc_traffic_{dtype}.json", "r01_pmc_traffic.json" if dtype == "f32" else None):
         if not name:
             continue
@@ -378,7 +394,7 @@ def pmc_traffic(dtype):
 
 
 def pmc_traffic_source(dtype):
-    for name in (f"r03_pmc_traffic_{dtype}.json", f"r02_pmc_traffic_{dtype}.json", "r01_pmc_traffic.json" if dtype == "f32" else None):
+    for name in (f"r03_pmc_kernels_{dtype}.json", f"r03_pmc_traffic_{dtype}.json", f"r02_pmc_traffic_{dtype}.json", "r01_pmc_traffic.json" if dtype == "f32" else None):
         if name and os.path.exists(os.path.join(ROOT, "profiles", name)):
             return "profiles/" + name
     return None
