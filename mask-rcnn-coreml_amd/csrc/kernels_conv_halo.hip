@@ -78,12 +78,12 @@ __device__ __forceinline__ void split4(const u32x4 v, u32x2 (&out)[PARTS])
     }
 }
 
-template <int PARTS, int TN, bool HEAD = false>
+template <int PARTS, int TN, bool HEAD = false, bool DBG = false>
 __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
 {
     const ConvArgs& a = ha.a;
     constexpr int BM = 128, WN = 4, TM = 2, BN = WN * TN * 32;
-    constexpr int PLANE = HALO_MAX_PX * 32;               // bytes of one part of one slab
+    constexpr int PLANE = (HALO_MAX_PX + 1) * 32;         // bytes of one part of one slab (+ one dump slot: pieces beyond the region write there, unconditionally)
     constexpr int PBUF = PARTS * PLANE;                   // one plane buffer (all parts)
     constexpr int MAXPC = (HALO_MAX_PX * 4 + 511) / 512;  // 64-B pieces per thread per slab (5)
     constexpr int STAGE = 8 * 32 * 36 * 4;                // the epilogue's wave-private tiles: they live in plane buffer 1
@@ -133,7 +133,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
     const unsigned vlane16 = (unsigned)lane * 16u;
     // measurement-only ablations (ha.a.dbg = 0 in production; mrcnn_debug_set("conv_pp_dbg")): 1 no filter loads in the main
     // loop, 2 no barriers, 4 no activation-fragment reads, 8 no MFMAs, 16 no slab staging
-    const bool dbg_nodma = a.dbg & 1, dbg_nobar = a.dbg & 2, dbg_nords = a.dbg & 4, dbg_nomma = a.dbg & 8, dbg_nostage = a.dbg & 16;
+    // (compiled in only in the DBG instantiation, which the launcher picks when a.dbg != 0: the production loop carries no switch)
+    const int dbg = DBG ? a.dbg : 0;
+    const bool dbg_nodma = dbg & 1, dbg_nobar = dbg & 2, dbg_nords = dbg & 4, dbg_nomma = dbg & 8, dbg_nostage = dbg & 16;
+    const bool dbg_noloads = dbg & 64, dbg_nosplit = dbg & 128, dbg_nowrite = dbg & 256;       // 64 no slab loads, 128 no split, 256 no plane writes
 
     int tile_par = 0;
     for (int unit = t_first; unit < t_end; unit += t_step)
@@ -174,8 +177,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
             const int x = col0 + c;
             const bool ok = px < npx && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W && b < a.B;
             p_off[i] = ok ? (unsigned)(((long)(b - b0) * a.in_sB + (long)y * a.in_sH + (long)x * a.in_sW + qt * 4) * 4) : HALO_OOB;
-            if (a.dbg & 32) p_off[i] = (unsigned)((px & 63) * 1024 + qt * 16);        // measurement only: a cache-hot source
-            p_lds[i] = px < npx ? (unsigned)(px * 32 + (((qt >> 1) ^ ((px >> 3) & 1)) << 4) + (qt & 1) * 8) : 0xffffffffu;
+            if (DBG && (a.dbg & 32)) p_off[i] = (unsigned)((px & 63) * 1024 + qt * 16);        // measurement only: a cache-hot source
+            p_lds[i] = px < npx ? (unsigned)(px * 32 + (((qt >> 1) ^ ((px >> 3) & 1)) << 4) + (qt & 1) * 8) : (unsigned)(HALO_MAX_PX * 32 + qt * 8);
         }
         // ---- this lane's two output pixels → index of their tap (0,0) input pixel in the region ------------------------
         int base_idx[TM];
@@ -206,9 +209,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
 #define HALO_PIN()    asm volatile("" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]), "+v"(st[4]));
 #define HALO_WRITE1(BUF, I)                                                                                      \
     {                                                                                                            \
-        if (p_lds[I] != 0xffffffffu) {                                                                           \
-            u32x2 parts[PARTS];                                                                                  \
-            split4<PARTS>(st[I], parts);                                                                         \
+        u32x2 parts[PARTS];                                                                                      \
+        if (DBG && dbg_nosplit) { _Pragma("unroll") for (int p = 0; p < PARTS; ++p) { parts[p][0] = st[I][0]; parts[p][1] = st[I][p]; } } \
+        else split4<PARTS>(st[I], parts);                                                                        \
+        if (DBG && dbg_nowrite) { _Pragma("unroll") for (int p = 0; p < PARTS; ++p) asm volatile("" ::"v"(parts[p])); } \
+        else {                                                                                                   \
             _Pragma("unroll") for (int p = 0; p < PARTS; ++p)                                                    \
                 *reinterpret_cast<u32x2*>(planes + (BUF) * PBUF + p * PLANE + p_lds[I]) = parts[p];              \
         }                                                                                                        \
@@ -268,18 +273,18 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
     }
 #define HALO_STEP(BVC, BVN3, TAP, PB)                                                                            \
     {                                                                                                            \
-        const bool more = step + 3 < NS && !dbg_nodma, more1 = step + 2 < NS && !dbg_nodma;                      \
-        if (more) HALO_BLOAD(BVN3, step + 3)                                                                     \
-        if ((TAP) == 0 && next_slab) { HALO_LOADS() HALO_ADVANCE() }                                             \
-        if (!dbg_nomma) {                                                                                        \
+        /* the filter fragments of step + 3 (past the end: the last step's again — the loop carries no tail case) */  \
+        if (!(DBG && dbg_nodma)) HALO_BLOAD(BVN3, step + 3 < NS ? step + 3 : NS - 1)                             \
+        if ((TAP) == 0 && next_slab && !(DBG && dbg_noloads)) { HALO_LOADS() HALO_ADVANCE() }                    \
+        if (!(DBG && dbg_nomma)) {                                                                               \
         _Pragma("unroll") for (int p = 0; p < PARTS; ++p)                                                        \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                       \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                   \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, BVC[j]), __builtin_bit_cast(f16x8, av[i][p]), acc[i][j], 0, 0, 0); \
         }                                                                                                        \
         /* the fragments of the next step replace the ones just multiplied (the wave's partner on the SIMD owns the matrix \
-           pipe meanwhile): one register set */                                                                  \
-        if (step + 1 < NS && !dbg_nords) {                                                                       \
+           pipe meanwhile): one register set; past the last step the read is harmless */                         \
+        if (!(DBG && dbg_nords)) {                                                                               \
             if ((TAP) == 8) HALO_AFRAGS(av, (PB) ^ 1, 0)                                                         \
             else HALO_AFRAGS(av, PB, ((TAP) + 1) % 9)                                                            \
         }                                                                                                        \
@@ -288,17 +293,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
         if ((TAP) == 5 && next_slab) HALO_WRITE1((PB) ^ 1, 2)                                                    \
         if ((TAP) == 6 && next_slab) HALO_WRITE1((PB) ^ 1, 3)                                                    \
         if ((TAP) == 7 && next_slab) HALO_WRITE1((PB) ^ 1, 4)                                                    \
-        if ((TAP) <= 2 && next_slab) {                                                                           \
-            if (more && more1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TN + 5) : "memory");                 \
-            else if (more1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TN + 5) : "memory");                        \
-            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                                                \
-        } else {                                                                                                 \
-            if (more && more1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TN) : "memory");                     \
-            else if (more1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TN) : "memory");                            \
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
-        }                                                                                                        \
+        if (DBG && (dbg_nodma || dbg_noloads)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  \
+        else if ((TAP) <= 2 && next_slab) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TN + 5) : "memory");      \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TN) : "memory");                                       \
         HALO_BPIN(bv0) HALO_BPIN(bv1) HALO_BPIN(bv2) HALO_BPIN(bv3)                                              \
-        if ((TAP) == 7 && !dbg_nobar) __syncthreads();                                                           \
+        if ((TAP) == 7 && !(DBG && dbg_nobar)) __syncthreads();                                                  \
         ++step;                                                                                                  \
     }
 #define HALO_SLAB(B0, B1, B2, B3, PB)                                                                            \
@@ -488,6 +487,7 @@ bool conv_halo_eligible(const ConvDesc& d)
 template <int PARTS>
 static void halo_launch(hipStream_t s, const HaloArgs& ha, int bn, int grid)
 {
+    if (ha.a.dbg && !ha.head_w && bn == 256 && PARTS == 3) { hipLaunchKernelGGL((k_conv_halo<3, 2, false, true>), dim3(grid), dim3(512), 0, s, ha); return; }   // ablations (tools/halo_ablate.py)
     if (ha.head_w) hipLaunchKernelGGL((k_conv_halo<PARTS, 2, true>), dim3(grid), dim3(512), 0, s, ha);
     else if (bn == 256) hipLaunchKernelGGL((k_conv_halo<PARTS, 2>), dim3(grid), dim3(512), 0, s, ha);
     else hipLaunchKernelGGL((k_conv_halo<PARTS, 1>), dim3(grid), dim3(512), 0, s, ha);

@@ -8,7 +8,8 @@ lib = L.lib()
 dt = sys.argv[1] if len(sys.argv) > 1 else "f32x3"
 DT = {"f32s": L.F32S, "f32x3": L.F32X3}[dt]
 shape = [int(x) for x in sys.argv[2:9]] if len(sys.argv) > 8 else [8, 256, 256, 256, 512, 3, 1]
-names = {0: "shipped", 32: "slab loads from a cache-hot source", 1: "no filter DMA", 2: "no barriers", 4: "no fragment reads", 8: "no MFMAs", 16: "no slab staging",
+names = {0: "shipped", 32: "slab loads from a cache-hot source", 64: "no slab loads (split + writes of stale registers)", 128: "no split (raw bits written)",
+         256: "no plane writes (loads + split only)", 64 + 128: "no loads, no split (writes only)", 64 + 256: "no loads, no writes (split only)", 128 + 256: "loads only", 1: "no filter DMA", 2: "no barriers", 4: "no fragment reads", 8: "no MFMAs", 16: "no slab staging",
          17: "no DMA, no staging", 3: "no DMA, no barriers", 19: "no DMA/staging/barriers", 23: "MFMAs only", 12: "no reads, no MFMAs (DMA + staging + barriers)"}
 for rnd in range(2):
     for dbg, nm in names.items():
