@@ -312,6 +312,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
             { const bool next_slab = !dbg_nostage;                 HALO_SLAB(bv2, bv3, bv0, bv1, 0) }
             { const bool next_slab = h + 4 < NH && !dbg_nostage;   HALO_SLAB(bv3, bv0, bv1, bv2, 1) }
         }
+        // the loop's last three steps requested filter fragments nobody multiplies (no tail case in the loop): they must have
+        // landed before the epilogue reuses their registers
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        HALO_BPIN(bv0) HALO_BPIN(bv1) HALO_BPIN(bv2) HALO_BPIN(bv3)
 #undef HALO_SLAB
 #undef HALO_STEP
 #undef HALO_AFRAGS
@@ -467,8 +471,10 @@ static int halo_region_bound(int H, int W)
 {
     if (W % 128 == 0) return 3 * 130;
     const int rows_touched = (127 + W - 1) / W + 1;
-    const bool straddle = ((long)H * W) % 128 != 0;               // a tile may span two images: two zero rows in between
-    return (rows_touched + (straddle ? 2 : 0) + 2) * (W + 2);
+    // a tile may span several images (two zero rows between consecutive ones): at most this many boundaries inside 128 pixels
+    const long ohw = (long)H * W;
+    const int boundaries = ohw % 128 == 0 ? 0 : (int)((127 + ohw - 1) / ohw);
+    return (rows_touched + 2 * boundaries + 2) * (W + 2);
 }
 
 bool conv_halo_eligible(const ConvDesc& d)
