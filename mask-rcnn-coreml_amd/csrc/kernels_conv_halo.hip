@@ -78,11 +78,12 @@ __device__ __forceinline__ void split4(const u32x4 v, u32x2 (&out)[PARTS])
     }
 }
 
-template <int PARTS, int TN, bool HEAD = false, bool DBG = false>
+template <int PARTS, int TN, bool HEAD = false, bool DBG = false, int TM = 2>       // TM = 1: 64-row tiles for grids that would not fill the chip
 __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
 {
     const ConvArgs& a = ha.a;
-    constexpr int BM = 128, WN = 4, TM = 2, BN = WN * TN * 32;
+    static_assert(!HEAD || TM == 2, "the fused head reduces over 128-row tiles");
+    constexpr int BM = 2 * TM * 32, WN = 4, BN = WN * TN * 32;
     constexpr int PLANE = (HALO_MAX_PX + 1) * 32;         // bytes of one part of one slab (+ one dump slot: pieces beyond the region write there, unconditionally)
     constexpr int PBUF = PARTS * PLANE;                   // one plane buffer (all parts)
     constexpr int MAXPC = (HALO_MAX_PX * 4 + 511) / 512;  // 64-B pieces per thread per slab (5)
@@ -491,12 +492,13 @@ bool conv_halo_eligible(const ConvDesc& d)
 }
 
 template <int PARTS>
-static void halo_launch(hipStream_t s, const HaloArgs& ha, int bn, int grid)
+static void halo_launch(hipStream_t s, const HaloArgs& ha, int bm, int bn, int grid)
 {
     if (ha.a.dbg && !ha.head_w && bn == 256 && PARTS == 3) { hipLaunchKernelGGL((k_conv_halo<3, 2, false, true>), dim3(grid), dim3(512), 0, s, ha); return; }   // ablations (tools/halo_ablate.py)
     if (ha.head_w) hipLaunchKernelGGL((k_conv_halo<PARTS, 2, true>), dim3(grid), dim3(512), 0, s, ha);
     else if (bn == 256) hipLaunchKernelGGL((k_conv_halo<PARTS, 2>), dim3(grid), dim3(512), 0, s, ha);
-    else hipLaunchKernelGGL((k_conv_halo<PARTS, 1>), dim3(grid), dim3(512), 0, s, ha);
+    else if (bm == 128) hipLaunchKernelGGL((k_conv_halo<PARTS, 1>), dim3(grid), dim3(512), 0, s, ha);
+    else hipLaunchKernelGGL((k_conv_halo<PARTS, 1, false, false, 1>), dim3(grid), dim3(512), 0, s, ha);
 }
 
 // A fused head needs 256-column tiles (the head's K groups are walked per wave column) and enough M tiles to occupy the chip
@@ -511,10 +513,14 @@ bool conv_halo_head_eligible(const ConvDesc& d)
 int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, int n_cus)
 {
     HaloArgs ha;
-    // tile width: the widest whose tiles fill the chip once (the K order, hence the result, does not depend on it)
-    const int tiles_m = (a.M + 127) / 128;
-    int bn = d.Npad % 256 == 0 ? 256 : 128;
-    if (bn > 128 && (long)tiles_m * (d.Npad / bn) < n_cus && !d.head_w) bn = 128;
+    // tile shape: the largest whose tiles occupy the chip (the K order, hence the result, does not depend on it): 128 x 256,
+    // then 128 x 128, then — small grids: batch 1, the top pyramid levels — 64 x 128
+    int bm = 128, bn = d.Npad % 256 == 0 ? 256 : 128;
+    if (!d.head_w) {
+        if (bn > 128 && (long)((a.M + 127) / 128) * (d.Npad / bn) < n_cus) bn = 128;
+        if (bn == 128 && (long)((a.M + 127) / 128) * (d.Npad / bn) * 4 < (long)n_cus * 3) bm = 64;
+    }
+    const int tiles_m = (a.M + bm - 1) / bm;
     a.tiles_m = tiles_m;
     a.tiles_n = d.Npad / bn;
     a.direct = 1;
@@ -529,8 +535,8 @@ int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, i
     const int units = d.head_w ? a.tiles_m : ha.n_tiles;
     int grid = units < n_cus ? units : n_cus;
     if (grid >= 8) grid &= ~7;                  // a multiple of 8: every XCD runs the same number of blocks
-    if (parts == 3) halo_launch<3>(s, ha, bn, grid);
-    else halo_launch<2>(s, ha, bn, grid);
+    if (parts == 3) halo_launch<3>(s, ha, bm, bn, grid);
+    else halo_launch<2>(s, ha, bm, bn, grid);
     return bn;
 }
 
