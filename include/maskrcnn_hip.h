@@ -334,7 +334,7 @@ MRCNN_API int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout,
  * (MRCNN_F16: the fp16 values the layer stores, widened).  mrcnn_debug_set switches kernel-selection policy knobs for A/B tests
  * ("conv_pp" 0|1: the 256-row ping-pong fp16 kernels; "conv_pp_min_tiles", "conv_pp_min_kt", "conv_pp_min_fill", "conv_pp_split",
  * "conv_pp_dbg"; "conv_tn4" -1|0|1: split modes, 128x128 tile as 4 waves of 32x128 by policy | never | always; "conv_min_blocks": the grid
- * size below which the N tile is narrowed; "conv_direct" 0|1|2: epilogue straight from the accumulators never | fp16 tensors | always; "mask_fused" 0|1: the mask head's
+ * size below which the N tile is narrowed; "conv_direct" 0|1|2|3: epilogue without block barriers never | fp16 tensors straight from the accumulators | + fp32 tensors through wave-private LDS tiles | + the fp16 tensors of the 128-column kernel (default 3; all four bit-identical); "mask_fused" 0|1: the mask head's
  * deconvolution + selected-class 1x1 as two launches over a materialised tensor | fused — results within fp32 summation noise): every choice must give
  * bit-identical results — the tile shape depends on the batch size and per-image results must not.  Further knobs: "conv_halo" 0|1 the
  * persistent halo kernel of the 3x3 layers of the split modes (its K order is its own: results differ from "0" by summation noise).

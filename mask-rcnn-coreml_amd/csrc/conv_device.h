@@ -454,6 +454,93 @@ __device__ __forceinline__ void conv_epilogue_wave(const ConvArgs& a, f32x16 (&a
     if (a.range_flag && out_of_range) atomicOr(a.range_flag, 1);
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// conv_epilogue_wave_h (fp16 tensors, wave tiles of 32·TMS × 64): the same idea for 2-byte outputs — a row of the wave tile is
+// 64 channels = ONE 128-B line, so both 32 × 32 pieces of a row slab go through the wave's private LDS tile (32 × 68 floats)
+// together and the read-back moves eight channels per lane: residual loads and stores of 8 full lines per instruction, where
+// conv_epilogue_direct issues 64-B store pieces and 8-B residual pieces (3× slower to issue per CU, tools/probes/vmem_probe.hip).
+// Same arithmetic in the same order (scale/shift, + residual, ReLU in fp32, ONE rounding): bit-identical.
+// ----------------------------------------------------------------------------------------------------------------
+template <int BN, int TMS>
+__device__ __forceinline__ void conv_epilogue_wave_h(const ConvArgs& a, f32x16 (&acc)[TMS][2], float* stage, const float* tab, int row0, int n0,
+                                                     int colrel0, int lane)
+{
+    constexpr int SW = 68;                               // floats per staged row (64 + 4: the transposing 16-B writes of 16 lanes fall in distinct banks)
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int ohw = a.OH * a.OW;
+    const _Float16* const res = static_cast<const _Float16*>(a.res);
+    _Float16* const out = static_cast<_Float16*>(a.out);
+    const bool dense_out = a.out_sB == (long)ohw * a.out_sP;
+    const bool dense_res = a.res_sB == (long)ohw * a.res_sW && a.res_shift == 0;
+    const bool relu = a.act == ACT_RELU;
+    const int rrow = lane >> 3, c8 = (lane & 7) * 8;     // read-back: eight lanes per row (one line), four passes of eight rows
+    const int cl = colrel0 + c8;                         // column inside the block tile
+    const int n = n0 + cl;
+    const bool col_ok = n < a.ncols;
+    const float4 sc0 = *reinterpret_cast<const float4*>(tab + cl), sc1 = *reinterpret_cast<const float4*>(tab + cl + 4);
+    const float4 sh0 = *reinterpret_cast<const float4*>(tab + BN + cl), sh1 = *reinterpret_cast<const float4*>(tab + BN + cl + 4);
+    bool out_of_range = false;
+#pragma unroll
+    for (int i = 0; i < TMS; ++i) {
+        long o_row[4], r_row[4];
+        bool ok[4];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int m = row0 + i * 32 + 8 * ps + rrow;
+            ok[ps] = m < a.M;
+            o_row[ps] = (long)m * a.out_sP; r_row[ps] = (long)m * a.res_sW;
+            if (!dense_out || (res && !dense_res)) {
+                const int mm = ok[ps] ? m : 0;
+                const int b = mm / ohw, pix = mm - b * ohw;
+                o_row[ps] = (long)b * a.out_sB + (long)pix * a.out_sP;
+                if (res) {
+                    if (a.res_shift) {
+                        const int oh = pix / a.OW, ow = pix - oh * a.OW;
+                        r_row[ps] = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
+                    } else r_row[ps] = (long)b * a.res_sB + (long)pix * a.res_sW;
+                }
+            }
+        }
+        // the residual of the slab is requested before the LDS round trip (and before any store: `res` may alias `out`)
+        uint4 rv[4];
+        if (res) {
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                rv[ps] = make_uint4(0u, 0u, 0u, 0u);
+                if (ok[ps] && col_ok) rv[ps] = *reinterpret_cast<const uint4*>(res + r_row[ps] + n);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(&stage[l31 * SW + j * 32 + 8 * q + 4 * kk]) =
+                    make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            float4 x = *reinterpret_cast<const float4*>(&stage[(8 * ps + rrow) * SW + c8]);
+            float4 y = *reinterpret_cast<const float4*>(&stage[(8 * ps + rrow) * SW + c8 + 4]);
+            x.x = x.x * sc0.x + sh0.x; x.y = x.y * sc0.y + sh0.y; x.z = x.z * sc0.z + sh0.z; x.w = x.w * sc0.w + sh0.w;
+            y.x = y.x * sc1.x + sh1.x; y.y = y.y * sc1.y + sh1.y; y.z = y.z * sc1.z + sh1.z; y.w = y.w * sc1.w + sh1.w;
+            if (res) {
+                const f16x8 h = __builtin_bit_cast(f16x8, rv[ps]);
+                x.x += (float)h[0]; x.y += (float)h[1]; x.z += (float)h[2]; x.w += (float)h[3];
+                y.x += (float)h[4]; y.y += (float)h[5]; y.z += (float)h[6]; y.w += (float)h[7];
+            }
+            if (relu) {
+                x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f);
+                y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
+            }
+            if (ok[ps] && col_ok) {
+                out_of_range = out_of_range || !(fabsf(x.x) < 65504.0f) || !(fabsf(x.y) < 65504.0f) || !(fabsf(x.z) < 65504.0f) || !(fabsf(x.w) < 65504.0f) ||
+                               !(fabsf(y.x) < 65504.0f) || !(fabsf(y.y) < 65504.0f) || !(fabsf(y.z) < 65504.0f) || !(fabsf(y.w) < 65504.0f);
+                store8h(out + o_row[ps] + n, x, y);
+            }
+        }
+    }
+    if (a.range_flag && out_of_range) atomicOr(a.range_flag, 1);
+}
+
 // two fp32 → packed fp16, ROUND TO NEAREST EVEN (v_cvt_pk_f16_f32; the builtin pack conversion truncates).  Every part of the
 // splits below is rounded to nearest: the parts of an activation that cannot be carried exactly leave a two-sided, unbiased
 // error (half the one-sided error of truncation).

@@ -69,7 +69,11 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
     static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
     constexpr int NLOADS = SPLIT ? AP : AP + BP;                // DMA instructions per tile per thread (SPLIT: waves past BN/16 issue no filter DMA)
     constexpr int SMEM_OPS = STAGES * (A_STAGE + B_STAGE);      // ring of operand buffers
-    constexpr int SMEM = SMEM_OPS > C_BYTES ? SMEM_OPS : C_BYTES;
+    // fp16 tensors, 32 x 64 wave tiles: the wave-private epilogue stages 32 x 68 floats per wave (conv_epilogue_wave_h)
+    constexpr bool WAVE_H = sizeof(T) == 2 && TN == 2 && BN == 128 && CPASS == 1;
+    constexpr int WAVE_H_BYTES = WAVE_H ? WM * WN * 32 * 68 * 4 : 0;
+    constexpr int SMEM_ = SMEM_OPS > C_BYTES ? SMEM_OPS : C_BYTES;
+    constexpr int SMEM = SMEM_ > WAVE_H_BYTES ? SMEM_ : WAVE_H_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     constexpr bool DIRECT_OK = CPASS == 1 && BN >= 64;                 // (the 32-wide tiles fill the LDS of two blocks to the byte)
     __shared__ __attribute__((aligned(16))) float s_tab[DIRECT_OK ? 2 * BN : 4];       // scale | shift of the block's columns (direct epilogue)
@@ -333,7 +337,16 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
                 // ended in a barrier) — full-line stores without the two block barriers of the staged epilogue
                 static_assert(WM * WN * 32 * 36 * 4 <= SMEM, "wave-private epilogue tiles fit in the operand ring");
                 conv_epilogue_wave<BN, TM, TN>(a, acc, reinterpret_cast<float*>(smem) + wave * (32 * 36), s_tab, m0 + wm * TM * 32, n0, wn * TN * 32, lane);
-            } else conv_epilogue_direct<T, BN, TM, TN>(a, acc, s_tab, m0 + wm * TM * 32, n0, wn * TN * 32, lane);
+            } else {
+                if constexpr (WAVE_H) {
+                    // fp16 tensors (a.direct == 2): a row of the 32 x 64 wave tile is one 128-B line — full-line residual loads and stores
+                    if (a.direct == 2) {
+                        conv_epilogue_wave_h<BN, TM>(a, acc, reinterpret_cast<float*>(smem) + wave * (32 * 68), s_tab, m0 + wm * TM * 32, n0, wn * TN * 32, lane);
+                        return;
+                    }
+                }
+                conv_epilogue_direct<T, BN, TM, TN>(a, acc, s_tab, m0 + wm * TM * 32, n0, wn * TN * 32, lane);
+            }
             return;
         }
     }
@@ -391,8 +404,9 @@ int conv_n_tile(int Cout)
 static int env_int(const char* name, int dflt);
 static int g_min_blocks = 448;   // narrow the N tile while the grid has fewer blocks than this: 7/8 of two blocks per CU (the
                                  // box head's 504 tiles of 128 columns beat 1008 of 64: +1.1 % end to end, tools/e2e_ab.py)
-static int g_direct = env_int("MRCNN_DIRECT", 2);   // 0: every layer through the block-staged epilogue; 1: fp16 tensors straight from the accumulators;
-                                 // 2: also fp32 tensors through wave-private LDS tiles (conv_epilogue_wave)
+static int g_direct = env_int("MRCNN_DIRECT", 3);   // 0: every layer through the block-staged epilogue; 1: fp16 tensors straight from the accumulators;
+                                 // 2: also fp32 tensors through wave-private LDS tiles (conv_epilogue_wave); 3: also the fp16 tensors of the
+                                 // 128-column kernel (conv_epilogue_wave_h: full-line residual loads and stores; +3.6 % end to end in fp16 mode)
 static int g_halo = env_int("MRCNN_HALO", 1);        // 3x3 stride-1 layers of the split modes on the halo kernel (kernels_conv_halo.hip) when the filters come re-tiled
 static int g_tn4 = -1;       // split modes, 128x128 tile as 4 waves of 32x128: -1 by policy (conv_forward), 0 never, 1 always (tests)
 template <typename T, typename TW, int PARTS = 2>
@@ -502,12 +516,14 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
                (!d.deconv2 || (d.Cout % cpt == 0 && d.out_sH % cpt == 0 && d.out_sW % cpt == 0));
     a.tiles_n = d.Npad / bn;
     MRCNN_REQUIRE(!d.sel_partial || (bn == 128 && a.vec_ok), MRCNN_ERR_INVALID, "conv: the selected-class mode needs the 128-wide vector epilogue");
-    // Epilogue without block barriers wherever the layer allows (g_direct = 2): fp16 tensors straight from the accumulators
-    // (eight channels per 16-B store: +0.9 % end to end over the block-staged form); fp32 tensors through wave-private LDS
-    // tiles (conv_epilogue_wave: full-line stores — a lane's own 16-B store would hold four channels of one pixel, 64 scattered
-    // pieces per instruction, which lost 1.4 % — without the two barriers of the block-staged form: +1.6 % end to end,
-    // tools/e2e_direct_ab.sh, round 3).
+    // Epilogue without block barriers wherever the layer allows: fp32 tensors through wave-private LDS tiles (conv_epilogue_wave:
+    // full-line stores — a lane's own 16-B store would hold four channels of one pixel, 64 scattered pieces per instruction, which
+    // lost 1.4 % — without the two barriers of the block-staged form: +1.6 % end to end, tools/e2e_direct_ab.sh, round 3); fp16
+    // tensors of the 128-column kernel the same way (conv_epilogue_wave_h: a row of the 32 x 64 wave tile is one 128-B line;
+    // +3.6 % end to end in fp16 mode over the form below, tools/e2e_ab.py f16 conv_direct 2 3), the narrower fp16 tiles straight
+    // from the accumulators (conv_epilogue_direct: 32-B pieces per pixel and store, +0.9 % over the block-staged form).
     a.direct = (g_direct && (half || g_direct > 1) && a.vec_ok && !d.out2 && !d.deconv2 && d.act != ACT_SIGMOID && (!half || !a.out_f32)) ? 1 : 0;
+    if (a.direct && half && g_direct > 2) a.direct = 2;      // fp16 tensors through wave-private tiles where the wave tile is 32 x 64 (the 128-column kernel)
     // Layers with a large GEMM: the 256×256 persistent ping-pong kernel (kernels_conv_pp.hip), one block per CU — when the
     // tiles fill whole rounds of the chip well enough (a static walk: the last round costs as much as a full one).
     int pp_bn = 0;

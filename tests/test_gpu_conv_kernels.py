@@ -134,9 +134,12 @@ def test_wide_wave_variant_equals_the_eight_wave_tile_bitwise(shape, dtype):
     np.testing.assert_array_equal(y1, y0)
 
 
+DIRECT_DEFAULT = 3      # MRCNN_DIRECT of kernels_conv.hip
+
+
 @pytest.mark.parametrize("dtype", ["f16", "f32", "f32s", "f32x3"])
 @pytest.mark.parametrize("shape", [(2, 64, 64, 256, 256, 1, 1, True), (1, 72, 56, 128, 300, 3, 1, True), (3, 40, 40, 64, 128, 1, 2, False),
-                                   (1, 33, 47, 192, 64, 3, 1, True)])
+                                   (1, 33, 47, 192, 64, 3, 1, True), (1, 33, 47, 192, 136, 3, 1, True)])
 def test_direct_epilogue_equals_the_lds_staged_epilogue_bitwise(shape, dtype):
     """The epilogue straight from the (transposed) accumulators — the default for fp16 tensors — against the LDS-staged
     full-row form (the default for fp32 tensors), forced either way in every mode: ragged M, ragged N (vector stores still
@@ -157,11 +160,14 @@ def test_direct_epilogue_equals_the_lds_staged_epilogue_bitwise(shape, dtype):
         y0 = conv(x, w, k, stride, scale, shift, res, 1, dtype)
         L.check(lib.mrcnn_debug_set(b"conv_direct", 2))
         y1 = conv(x, w, k, stride, scale, shift, res, 1, dtype)
+        L.check(lib.mrcnn_debug_set(b"conv_direct", 3))      # fp16 tensors through wave-private tiles (128-column kernel)
+        y2 = conv(x, w, k, stride, scale, shift, res, 1, dtype)
     finally:
-        L.check(lib.mrcnn_debug_set(b"conv_direct", 2))
+        L.check(lib.mrcnn_debug_set(b"conv_direct", DIRECT_DEFAULT))
         L.check(lib.mrcnn_debug_set(b"conv_pp", 1))
         L.check(lib.mrcnn_debug_set(b"conv_halo", 1))
     np.testing.assert_array_equal(y1, y0)
+    np.testing.assert_array_equal(y2, y0)
     ref = torch_ref(x, w, k, stride, scale, shift, res, 1, dtype if dtype != "f32" else "f32s")
     if dtype == "f32":          # exact-fp32 MFMA on fp32 filters: the reference must not round the filters to fp16
         import torch
