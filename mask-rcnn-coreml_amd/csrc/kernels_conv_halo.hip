@@ -25,6 +25,7 @@
 //                the other plane buffer while the nine taps of the current slab run;
 //   filters      per step and wave two 1-KB fragment loads, three steps ahead (four register sets);
 //   MFMAs        9 × 3 × 4 per wave; activation fragments by ds_read_b128 (conflict-free half-swizzle).
+// Grids that would not fill the chip run 128 × 128 or 64 × 128 tiles (TN = 1, TM = 1: conv_halo_forward) — same K order, same bits.
 // Blocks are persistent: one per CU, each XCD walks a contiguous run of tiles with its 32 CUs on 32 consecutive tiles (vertical
 // neighbours share their halo rows in that XCD's L2).
 //
