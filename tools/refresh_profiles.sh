@@ -40,6 +40,11 @@ json.dump({"kernel": k, "launches_sampled": conv[k]["launches_sampled"], "hbm_by
 PY
 done
 cd $R
+# MODES_ONLY=1: refresh the per-mode files of $MODES only (a kernel of one mode changed after the round's full refresh)
+if [ "${MODES_ONLY:-0}" = 1 ]; then
+  for dt in $MODES; do [ $dt = f32x3 ] || cut -c1-200 $OUT/${RND}_bench_n1_$dt.json; cat $OUT/${RND}_pmc_kernels_$dt.txt; done
+  exit 0
+fi
 timeout 300 python tools/conv_ab.py 3 10 1 f16 > $OUT/${RND}_conv_ab_f16.txt 2>/dev/null
 for dt in f32x3 f32s; do timeout 300 python tools/halo_ab.py 3 10 $dt 2>/dev/null | grep -v amdgpu > $OUT/${RND}_halo_ab_$dt.txt; done
 timeout 200 python tools/halo_ablate.py f32x3 2>/dev/null | grep -v amdgpu > $OUT/${RND}_halo_ablate_f32x3.txt
