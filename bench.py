@@ -224,7 +224,7 @@ def main():
                                     "(the filters are fp16 in the artefact, task.py:90): exact for 0.5 <= |a| < 65504, the activation "
                                     "carried to 2^-25 absolute (rounded to nearest) below — not scale-invariant like fp32; curve: "
                                     "profiles/r03_split_scale_curve.txt",
-                           "f32": "fp32 tensors, v_mfma_f32_32x32x2_f32", "f32s": "fp32 tensors, 2-part split of the activations (22 of 24 bits)",
+                           "f32": "fp32 tensors, v_mfma_f32_32x32x2_f32", "f32s": "fp32 tensors, 2-part split of the activations (23 of 24 bits, nearest rounding)",
                            "f16": "fp16 tensors, fp16 MFMA, fp32 accumulate; box path and outputs fp32"}[args.dtype],
             "config": {"workload": (f"BASELINE configs[1]: " if (args.arch, args.size, args.num_classes, args.pre_nms, B) == ("resnet101", 1024, 81, 6000, 8) else "")
                                    + f"{args.arch}+FPN {args.size}x{args.size}, batch {B} per GPU, "
