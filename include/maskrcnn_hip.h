@@ -242,6 +242,10 @@ MRCNN_API int mrcnn_maskrcnn_predict_sharded(mrcnn_dist* dist, mrcnn_model* mode
 MRCNN_API int mrcnn_dist_all_gather_records_async(mrcnn_dist* dist, mrcnn_model* model, const float* detections, const float* masks,
                                                   int global_batch, float* out_detections, float* out_masks);
 MRCNN_API int mrcnn_dist_wait(mrcnn_dist* dist);
+/* Which RCCL this library bound (dist.hip binds it at run time): 1 = the copy the process had already mapped (e.g. the one
+ * PyTorch ships under the soname librccl.so.1 — taken first, so that a process holds ONE RCCL), 0 = its own dlopen of
+ * librccl.so.1, -1 = RCCL could not be loaded.  Loads RCCL when it is not bound yet; needs no GPU. */
+MRCNN_API int mrcnn_dist_rccl_shared(void);
 MRCNN_API int mrcnn_dist_plan(int global_batch, int world, int max_detections, int mask_size, int64_t* table, int64_t* slot_floats);
 MRCNN_API int mrcnn_dist_simulate_host(int world, int global_batch, int max_detections, int mask_size, const float* const* detections,
                                        const float* const* masks, const int32_t* status, float* out_detections, float* out_masks,
@@ -280,6 +284,39 @@ MRCNN_API int mrcnn_model_read_tensor(mrcnn_model* model, const char* name, int 
  * (counted in "range_overflows" like the synchronous path).  Always 0 in MRCNN_F32. */
 MRCNN_API int mrcnn_model_check_range(mrcnn_model* model, int* tripped);
 
+/* ---------------------------------------------------------------------------------------------
+ * Scale-aware split — what makes MRCNN_F32X3 / MRCNN_F32S fp32-grade at ANY activation scale.
+ * The split modes carry an fp32 activation exactly while 0.5 <= |a| < 65504 and to 2^-25 ABSOLUTE below, so a checkpoint
+ * whose tensors sit at 1e-3 would lose accuracy (and one at 1e5 would trip the range watchdog) where the reference's CPU path
+ * — fp32 activations, fp16 weights (Conversion/task.py:90) — is scale-free.  Every tensor a split convolution reads belongs to
+ * a GROUP with an exponent e: it is STORED as 2^e * value, an exact operation folded at no run-time cost into the producer's
+ * BatchNorm scale / shift and undone in the consumer's (ReLU, max-pool, the bilinear sampler and the residual add commute).
+ * With every e = 0 (the state after mrcnn_model_load) nothing changes.
+ *   mrcnn_model_calibrate_split  one predict on the given images collects max |a| per group, picks e with max |a| * 2^e in
+ *                          [2^11, 2^12) (16x head room under the fp16 range, everything above 2^-13 of the maximum exact), and a
+ *                          second predict verifies the choice and counts the inputs a split still cannot carry exactly;
+ *                          apply = 0 only diagnoses (exponents untouched).  Outputs, taps and every stage after the convolutions
+ *                          are in true scale either way; results are bit-identical for any batch split as before.
+ *   mrcnn_model_get_int    "split_small_inputs" (non-zero inputs below 2^-8 of their tensor's maximum), "split_inexact_inputs"
+ *                          (non-zero stored inputs below 0.5: carried to 2^-25 absolute, i.e. <= 2^-36 of the maximum once
+ *                          calibrated), "split_inputs_counted", "split_min_exponent" / "split_max_exponent", "split_calibrated",
+ *                          "split_groups" — next to "range_overflows"
+ *   mrcnn_model_split_group_stat   per group: name, exponent, max |a|, the three counters
+ *   mrcnn_model_get/set_split_exponents   the exponents as a vector (one per group, 0 for the groups fp32 arithmetic consumes):
+ *                          a sharded job calibrates on one rank — or offline — and sets the same vector on every rank.
+ * MRCNN_F32 and MRCNN_F16 models return MRCNN_ERR_UNSUPPORTED from calibrate / set. */
+typedef struct mrcnn_split_group_stat {
+    char    name[48];
+    int32_t exponent;
+    int32_t fixed;            /* 1: consumed by fp32 arithmetic (logits, deltas, probabilities): exponent stays 0 */
+    float   absmax;           /* max |a| of the true values over the calibration images */
+    int64_t small_inputs, inexact_inputs, inputs_counted;
+} mrcnn_split_group_stat;
+MRCNN_API int mrcnn_model_calibrate_split(mrcnn_model* model, const uint8_t* rgb, int batch, int height, int width, int memspace, int apply);
+MRCNN_API int mrcnn_model_split_group_stat(mrcnn_model* model, int index, mrcnn_split_group_stat* out);
+MRCNN_API int mrcnn_model_get_split_exponents(mrcnn_model* model, int32_t* exponents, int capacity, int* count);
+MRCNN_API int mrcnn_model_set_split_exponents(mrcnn_model* model, const int32_t* exponents, int count);
+
 /* PyramidROIAlign (PyramidROIAlignLayer.swift:79-181) on the engine's own layout: four NHWC maps (H_l, W_l, C),
  * dtype MRCNN_F32 or MRCNN_F16; rois rows (y1,x1,y2,x2,...) of `roi_stride` floats; out (n_rois, pool, pool, C)
  * in the maps' dtype.  row_flags (optional, n_rois int32): the removeZeros predicate the mask layer applies to a
@@ -298,51 +335,10 @@ MRCNN_API int mrcnn_roi_align_nhwc(const void* const maps[4], const int heights[
 MRCNN_API int mrcnn_model_enable_timing(mrcnn_model* model, int on);
 MRCNN_API int mrcnn_model_stage_ms(mrcnn_model* model, const char* stage, float* ms);
 
-/* Live per-kernel profile of the convolution family during predict (bench.py roofline leg): when
- * enabled every conv launch is bracketed by HIP events on the model's stream.  tile: 0 = the
- * 128x128 kernel, 1 = 128x64, 2 = 128x32, 3 = 128x128 run by four waves of 32x128 (split modes, K >= 2048), 4 = 256x256 ping-pong.  enable(1) opens a measurement window (totals reset);
- * enable(0) closes it and the totals stay readable — the events cost ~2 % (fp32) / ~13 % (fp16) of a step,
- * so bench.py opens the window for the first steps of its timed region only.
- * total_flops is ALGORITHMIC work (2*M*N*K of the convolution, padding excluded). */
-MRCNN_API int mrcnn_model_conv_profile_enable(mrcnn_model* model, int on);
-MRCNN_API int mrcnn_model_conv_profile_get(mrcnn_model* model, int tile, int64_t* launches, double* total_ms,
-                                           double* total_flops);
-/* The same totals broken down by GEMM shape (M = images*OH*OW, N = output columns, K = taps*Cin): writes at
- * most `capacity` records, *count = number of distinct shapes seen (call with capacity 0 to size the buffer). */
-typedef struct mrcnn_conv_shape_stat {
-    int32_t M, N, K, tile;
-    int64_t launches;
-    double total_ms, total_flops;
-} mrcnn_conv_shape_stat;
-MRCNN_API int mrcnn_model_conv_profile_shapes(mrcnn_model* model, mrcnn_conv_shape_stat* out, int capacity, int* count);
-
-/* ---------------------------------------------------------------------------------------------
- * Convolution micro-benchmark hook (bench.py roofline leg): runs one convolution of the trunk's
- * kernel family on synthetic data resident in HBM and reports the average kernel time measured
- * with HIP events on the launching stream.
- * --------------------------------------------------------------------------------------------- */
-MRCNN_API int mrcnn_bench_conv(int batch, int h, int w, int cin, int cout, int ksize, int stride,
-                               int iters, float* avg_ms, double* flops);
-/* Same with an explicit element type (MRCNN_F32 | MRCNN_F16, fp32 accumulate). */
-MRCNN_API int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout, int ksize, int stride,
-                                     int iters, int dtype, float* avg_ms, double* flops);
-
-/* One convolution of the engine's kernel family on caller (host) data — the unit the parity tests of the kernels use:
- * in (B,H,W,Cin) NHWC fp32, filters (Cout, k, k, Cin) fp32 (k = 1 | 3, 'same' padding k/2), optional per-channel
- * scale/shift (folded BatchNorm + bias), optional residual (B,OH,OW,Cout), act 0 none | 1 ReLU | 2 sigmoid;
- * dtype = compute mode (inputs are converted to it on the host, round-to-nearest); out (B,OH,OW,Cout) fp32
- * (MRCNN_F16: the fp16 values the layer stores, widened).  mrcnn_debug_set switches kernel-selection policy knobs for A/B tests
- * ("conv_pp" 0|1: the 256-row ping-pong fp16 kernels; "conv_pp_min_tiles", "conv_pp_min_kt", "conv_pp_min_fill", "conv_pp_split",
- * "conv_pp_dbg"; "conv_tn4" -1|0|1: split modes, 128x128 tile as 4 waves of 32x128 by policy | never | always; "conv_min_blocks": the grid
- * size below which the N tile is narrowed; "conv_direct" 0|1|2|3: epilogue without block barriers never | fp16 tensors straight from the accumulators | + fp32 tensors through wave-private LDS tiles | + the fp16 tensors of the 128-column kernel (default 3; all four bit-identical); "mask_fused" 0|1: the mask head's
- * deconvolution + selected-class 1x1 as two launches over a materialised tensor | fused — results within fp32 summation noise): every choice must give
- * bit-identical results — the tile shape depends on the batch size and per-image results must not.  Further knobs: "conv_halo" 0|1 the
- * persistent halo kernel of the 3x3 layers of the split modes (its K order is its own: results differ from "0" by summation noise).
- * The switches are PROCESS-WIDE test / measurement knobs: not thread-safe; a choice captured in a hipGraph stays captured. */
-MRCNN_API int mrcnn_conv2d_nhwc(const float* in, int batch, int h, int w, int cin, const float* filters, int cout,
-                                int ksize, int stride, const float* scale, const float* shift, const float* residual,
-                                int act, int dtype, float* out);
-MRCNN_API int mrcnn_debug_set(const char* key, int value);
+/* Test and measurement entry points (the convolution micro-benchmark hook, the per-kernel live profile, the
+ * single-convolution parity entry and the process-wide kernel-selection knobs) are exported by the same library but
+ * declared in include/maskrcnn_hip_test.h: they are not part of the drop-in surface — nothing in the reference's
+ * interface (ProposalLayer.swift:52-103, MaskRCNNConfig.swift:10-18) is a debug knob. */
 
 /* ---------------------------------------------------------------------------------------------
  * Result decoding — Detection.detectionsFromFeatureValue (Sources/Mask-RCNN-CoreML/

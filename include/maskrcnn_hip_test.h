@@ -1,0 +1,70 @@
+/*
+ * maskrcnn_hip_test.h — TEST AND MEASUREMENT entry points of libmaskrcnn_hip.so.
+ *
+ * Not part of the drop-in surface (include/maskrcnn_hip.h): these are what tests/, tools/ and bench.py use to run one
+ * convolution of the kernel family on caller data, to time a layer shape, to read the live per-kernel profile of a
+ * predict, and to switch kernel-selection policy for A/B comparisons.  The switches are PROCESS-WIDE and not
+ * thread-safe; a production host never calls anything declared here.
+ */
+#ifndef MASKRCNN_HIP_TEST_H
+#define MASKRCNN_HIP_TEST_H
+
+#include "maskrcnn_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Live per-kernel profile of the convolution family during predict (bench.py roofline leg): when
+ * enabled every conv launch is bracketed by HIP events on the model's stream.  tile: 0 = the
+ * 128x128 kernel, 1 = 128x64, 2 = 128x32, 3 = 128x128 run by four waves of 32x128 (split modes, K >= 2048), 4 = 256x256 ping-pong,
+ * 5 = the persistent halo tiles of the 3x3 layers of the split modes (kernels_conv_halo.hip).  enable(1) opens a measurement window (totals reset);
+ * enable(0) closes it and the totals stay readable — the events cost ~2 % (fp32) / ~13 % (fp16) of a step,
+ * so bench.py opens the window for the first steps of its timed region only.
+ * total_flops is ALGORITHMIC work (2*M*N*K of the convolution, padding excluded). */
+MRCNN_API int mrcnn_model_conv_profile_enable(mrcnn_model* model, int on);
+MRCNN_API int mrcnn_model_conv_profile_get(mrcnn_model* model, int tile, int64_t* launches, double* total_ms,
+                                           double* total_flops);
+/* The same totals broken down by GEMM shape (M = images*OH*OW, N = output columns, K = taps*Cin): writes at
+ * most `capacity` records, *count = number of distinct shapes seen (call with capacity 0 to size the buffer). */
+typedef struct mrcnn_conv_shape_stat {
+    int32_t M, N, K, tile;
+    int64_t launches;
+    double total_ms, total_flops;
+} mrcnn_conv_shape_stat;
+MRCNN_API int mrcnn_model_conv_profile_shapes(mrcnn_model* model, mrcnn_conv_shape_stat* out, int capacity, int* count);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolution micro-benchmark hook (bench.py roofline leg): runs one convolution of the trunk's
+ * kernel family on synthetic data resident in HBM and reports the average kernel time measured
+ * with HIP events on the launching stream.
+ * --------------------------------------------------------------------------------------------- */
+MRCNN_API int mrcnn_bench_conv(int batch, int h, int w, int cin, int cout, int ksize, int stride,
+                               int iters, float* avg_ms, double* flops);
+/* Same with an explicit element type (MRCNN_F32 | MRCNN_F16, fp32 accumulate). */
+MRCNN_API int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout, int ksize, int stride,
+                                     int iters, int dtype, float* avg_ms, double* flops);
+
+/* One convolution of the engine's kernel family on caller (host) data — the unit the parity tests of the kernels use:
+ * in (B,H,W,Cin) NHWC fp32, filters (Cout, k, k, Cin) fp32 (k = 1 | 3, 'same' padding k/2), optional per-channel
+ * scale/shift (folded BatchNorm + bias), optional residual (B,OH,OW,Cout), act 0 none | 1 ReLU | 2 sigmoid;
+ * dtype = compute mode (inputs are converted to it on the host, round-to-nearest); out (B,OH,OW,Cout) fp32
+ * (MRCNN_F16: the fp16 values the layer stores, widened).  mrcnn_debug_set switches kernel-selection policy knobs for A/B tests
+ * ("conv_pp" 0|1: the 256-row ping-pong fp16 kernels; "conv_pp_min_tiles", "conv_pp_min_kt", "conv_pp_min_fill", "conv_pp_split",
+ * "conv_pp_dbg"; "conv_tn4" -1|0|1: split modes, 128x128 tile as 4 waves of 32x128 by policy | never | always; "conv_min_blocks": the grid
+ * size below which the N tile is narrowed; "conv_direct" 0|1|2|3: epilogue without block barriers never | fp16 tensors straight from the accumulators | + fp32 tensors through wave-private LDS tiles | + the fp16 tensors of the 128-column kernel (default 3; all four bit-identical); "mask_fused" 0|1: the mask head's
+ * deconvolution + selected-class 1x1 as two launches over a materialised tensor | fused — results within fp32 summation noise): every choice must give
+ * bit-identical results — the tile shape depends on the batch size and per-image results must not.  Further knobs: "conv_halo" 0|1 the
+ * persistent halo kernel of the 3x3 layers of the split modes (its K order is its own: results differ from "0" by summation noise);
+ * "halo_geo" 0|1: its round-3 tile geometries | two-row tiles, region-sized staging, conflict-free LDS pitch (bit-identical).
+ * The switches are PROCESS-WIDE test / measurement knobs: not thread-safe; a choice captured in a hipGraph stays captured. */
+MRCNN_API int mrcnn_conv2d_nhwc(const float* in, int batch, int h, int w, int cin, const float* filters, int cout,
+                                int ksize, int stride, const float* scale, const float* shift, const float* residual,
+                                int act, int dtype, float* out);
+MRCNN_API int mrcnn_debug_set(const char* key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* MASKRCNN_HIP_TEST_H */

@@ -18,22 +18,27 @@ HOST, DEVICE = 0, 1
 PARAM_INT, PARAM_DOUBLE, PARAM_STRING = 0, 1, 2
 MODEL_MASKRCNN, MODEL_CLASSIFIER, MODEL_MASK = 0, 1, 2
 
+# declared in include/maskrcnn_hip.h (the drop-in surface)
 EXPORTED_SYMBOLS = [
-    "mrcnn_last_error", "mrcnn_version", "mrcnn_device_count",
-    "mrcnn_config_set_anchors_path", "mrcnn_config_set_classifier_path", "mrcnn_config_set_mask_path",
-    "mrcnn_config_get_anchors_path", "mrcnn_config_get_classifier_path", "mrcnn_config_get_mask_path",
-    "mrcnn_layer_create", "mrcnn_layer_set_weight_data", "mrcnn_layer_output_shapes", "mrcnn_layer_evaluate",
-    "mrcnn_layer_destroy", "mrcnn_iou",
-    "mrcnn_model_load", "mrcnn_model_destroy", "mrcnn_model_set_stream", "mrcnn_maskrcnn_predict",
+    "mrcnn_last_error", "mrcnn_version", "mrcnn_device_count", "mrcnn_config_set_anchors_path",
+    "mrcnn_config_set_classifier_path", "mrcnn_config_set_mask_path", "mrcnn_config_get_anchors_path",
+    "mrcnn_config_get_classifier_path", "mrcnn_config_get_mask_path", "mrcnn_layer_create",
+    "mrcnn_layer_set_weight_data", "mrcnn_layer_output_shapes", "mrcnn_layer_evaluate", "mrcnn_layer_destroy",
+    "mrcnn_iou", "mrcnn_model_load", "mrcnn_model_destroy", "mrcnn_model_set_stream", "mrcnn_maskrcnn_predict",
     "mrcnn_maskrcnn_predict_async", "mrcnn_classifier_predict", "mrcnn_mask_predict", "mrcnn_model_get_int",
-    "mrcnn_model_read_tensor", "mrcnn_model_enable_timing", "mrcnn_model_stage_ms", "mrcnn_bench_conv",
-    "mrcnn_model_conv_profile_enable", "mrcnn_model_conv_profile_get", "mrcnn_model_conv_profile_shapes", "mrcnn_model_enable_graph", "mrcnn_bench_conv_dtype",
-    "mrcnn_detections_decode", "mrcnn_mask_to_u8", "mrcnn_paste_masks", "mrcnn_generate_anchors", "mrcnn_letterbox_geometry", "mrcnn_letterbox_rgb",
-    "mrcnn_model_check_range", "mrcnn_roi_align_nhwc", "mrcnn_conv2d_nhwc", "mrcnn_debug_set",
+    "mrcnn_model_read_tensor", "mrcnn_model_enable_timing", "mrcnn_model_stage_ms", "mrcnn_model_enable_graph",
+    "mrcnn_detections_decode", "mrcnn_mask_to_u8", "mrcnn_paste_masks", "mrcnn_generate_anchors",
+    "mrcnn_letterbox_geometry", "mrcnn_letterbox_rgb", "mrcnn_model_check_range", "mrcnn_model_calibrate_split", "mrcnn_model_split_group_stat",
+    "mrcnn_model_get_split_exponents", "mrcnn_model_set_split_exponents", "mrcnn_roi_align_nhwc",
     "mrcnn_dist_unique_id", "mrcnn_dist_init", "mrcnn_dist_destroy", "mrcnn_dist_shard", "mrcnn_dist_record_floats",
     "mrcnn_dist_all_gather_records", "mrcnn_maskrcnn_predict_sharded", "mrcnn_mask_to_u8_f64",
-    "mrcnn_dist_all_gather_records_async", "mrcnn_dist_wait", "mrcnn_dist_plan", "mrcnn_dist_simulate_host",
+    "mrcnn_dist_all_gather_records_async", "mrcnn_dist_wait", "mrcnn_dist_rccl_shared", "mrcnn_dist_plan", "mrcnn_dist_simulate_host",
     "mrcnn_maskrcnn_predict_scalefit", "mrcnn_unletterbox_boxes",
+]
+# declared in include/maskrcnn_hip_test.h (test / measurement entry points of the same library)
+TEST_SYMBOLS = [
+    "mrcnn_bench_conv", "mrcnn_bench_conv_dtype", "mrcnn_model_conv_profile_enable", "mrcnn_model_conv_profile_get",
+    "mrcnn_model_conv_profile_shapes", "mrcnn_conv2d_nhwc", "mrcnn_debug_set",
 ]
 
 
@@ -54,6 +59,11 @@ class Tensor(C.Structure):          # mrcnn_tensor
 
 class Param(C.Structure):           # mrcnn_param
     _fields_ = [("key", C.c_char_p), ("type", C.c_int32), ("i", C.c_int64), ("d", C.c_double), ("s", C.c_char_p)]
+
+
+class SplitGroupStat(C.Structure):   # mrcnn_split_group_stat
+    _fields_ = [("name", C.c_char * 48), ("exponent", C.c_int32), ("fixed", C.c_int32), ("absmax", C.c_float),
+                ("small_inputs", C.c_int64), ("inexact_inputs", C.c_int64), ("inputs_counted", C.c_int64)]
 
 
 class DetectionRecord(C.Structure):  # mrcnn_detection
@@ -133,6 +143,12 @@ def lib():
     L.mrcnn_conv2d_nhwc.argtypes = [vp] + [C.c_int] * 4 + [vp] + [C.c_int] * 3 + [vp, vp, vp, C.c_int, C.c_int, vp]
     L.mrcnn_debug_set.argtypes = [cp, C.c_int]
     L.mrcnn_model_check_range.argtypes = [vp, ip]
+    L.mrcnn_model_calibrate_split.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.mrcnn_model_split_group_stat.argtypes = [vp, C.c_int, C.POINTER(SplitGroupStat)]
+    L.mrcnn_model_get_split_exponents.argtypes = [vp, vp, C.c_int, ip]
+    L.mrcnn_model_set_split_exponents.argtypes = [vp, vp, C.c_int]
+    L.mrcnn_dist_rccl_shared.argtypes = []
+    L.mrcnn_dist_rccl_shared.restype = C.c_int
     L.mrcnn_dist_unique_id.argtypes = [vp]
     L.mrcnn_dist_init.argtypes = [C.c_int, C.c_int, vp, C.POINTER(vp)]
     L.mrcnn_dist_destroy.argtypes = [vp]

@@ -557,6 +557,9 @@ extern "C" int mrcnn_unletterbox_boxes(float* detections, int64_t n, int64_t str
         auto clip = [](double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); };
         for (int64_t i = 0; i < n; ++i) {
             float* d = detections + i * stride;
+            // zero-padded rows (DetectionLayer.swift:224-230 pads the output to maxDetections rows) stay all-zero: mapped through
+            // the letterbox an all-zero box would come out with a non-zero far edge and read as a detection
+            if (d[0] == 0.f && d[1] == 0.f && d[2] == 0.f && d[3] == 0.f) continue;
             const double y1 = ((double)d[0] * (H - 1) - py) * sy, x1 = ((double)d[1] * (W - 1) - px) * sx;
             const double y2 = ((double)d[2] * (H - 1) + 1.0 - py) * sy, x2 = ((double)d[3] * (W - 1) + 1.0 - px) * sx;
             d[0] = (float)clip(y1 / hy); d[1] = (float)clip(x1 / wx); d[2] = (float)clip((y2 - 1.0) / hy); d[3] = (float)clip((x2 - 1.0) / wx);
@@ -640,11 +643,77 @@ extern "C" int mrcnn_model_get_int(mrcnn_model* model, const char* key, int64_t*
         else if (k == "pre_nms_count") *value = m.K;
         else if (k == "mask_size") *value = 2 * m.mask_pool;
         else if (k == "range_overflows") *value = m.range_overflows;
+        // scale-aware split (mrcnn_model_calibrate_split): totals over the tensor groups of the last calibrate / diagnose pass
+        else if (k == "split_groups") *value = (int64_t)m.sgroups.size();
+        else if (k == "split_calibrated") *value = m.split_calibrated ? 1 : 0;
+        else if (k == "split_small_inputs" || k == "split_inexact_inputs" || k == "split_inputs_counted" || k == "split_min_exponent" ||
+                 k == "split_max_exponent") {
+            long long small = 0, inexact = 0, counted = 0;
+            int lo = 0, hi = 0;
+            bool first = true;
+            for (const auto& g : m.sgroups) {
+                if (g.fixed) continue;
+                small += g.small; inexact += g.inexact; counted += g.counted;
+                if (first || g.exp < lo) lo = g.exp;
+                if (first || g.exp > hi) hi = g.exp;
+                first = false;
+            }
+            *value = k == "split_small_inputs" ? small : k == "split_inexact_inputs" ? inexact : k == "split_inputs_counted" ? counted :
+                     k == "split_min_exponent" ? lo : hi;
+        }
         else if (k == "graph_launches") *value = m.graph_launches;
         else if (k == "gpu_busy_us") *value = (int64_t)(m.gpu_busy_ms * 1e3);
         else if (k == "predict_calls") *value = m.predict_calls;
         else if (k == "graph_enabled") *value = m.use_graph ? 1 : 0;
         else *value = m.file.get_int(k);
+    });
+}
+
+extern "C" int mrcnn_model_calibrate_split(mrcnn_model* model, const uint8_t* rgb, int batch, int height, int width, int memspace, int apply)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model && rgb, MRCNN_ERR_INVALID, "bad calibrate_split argument");
+        model->m.calibrate_split(rgb, batch, height, width, memspace, apply != 0);
+    });
+}
+extern "C" int mrcnn_model_split_group_stat(mrcnn_model* model, int index, mrcnn_split_group_stat* out)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model && out && index >= 0 && index < (int)model->m.sgroups.size(), MRCNN_ERR_INVALID, "bad split_group_stat argument");
+        const SplitGroup& g = model->m.sgroups[(size_t)index];
+        memset(out, 0, sizeof *out);
+        snprintf(out->name, sizeof out->name, "%s", g.name.c_str());
+        out->exponent = g.exp; out->fixed = g.fixed ? 1 : 0; out->absmax = g.absmax;
+        out->small_inputs = g.small; out->inexact_inputs = g.inexact; out->inputs_counted = g.counted;
+    });
+}
+extern "C" int mrcnn_model_get_split_exponents(mrcnn_model* model, int32_t* exponents, int capacity, int* count)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model && count, MRCNN_ERR_INVALID, "bad get_split_exponents argument");
+        const int n = (int)model->m.sgroups.size();
+        *count = n;
+        if (!exponents) return;
+        MRCNN_REQUIRE(capacity >= n, MRCNN_ERR_SHAPE, "get_split_exponents: %d groups, buffer holds %d", n, capacity);
+        for (int i = 0; i < n; ++i) exponents[i] = model->m.sgroups[(size_t)i].exp;
+    });
+}
+extern "C" int mrcnn_model_set_split_exponents(mrcnn_model* model, const int32_t* exponents, int count)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model && exponents, MRCNN_ERR_INVALID, "bad set_split_exponents argument");
+        Model& m = model->m;
+        MRCNN_REQUIRE(m.kind == MRCNN_MODEL_MASKRCNN && count == (int)m.sgroups.size(), MRCNN_ERR_SHAPE, "set_split_exponents: the model has %d groups, %d given",
+                      (int)m.sgroups.size(), count);
+        MRCNN_REQUIRE(m.mode == MRCNN_F32S || m.mode == MRCNN_F32X3, MRCNN_ERR_UNSUPPORTED, "set_split_exponents: only the split modes use exponents");
+        for (int i = 0; i < count; ++i) {
+            MRCNN_REQUIRE(exponents[i] >= -60 && exponents[i] <= 60, MRCNN_ERR_INVALID, "exponent %d of group %d out of range", exponents[i], i);
+            MRCNN_REQUIRE(!m.sgroups[(size_t)i].fixed || exponents[i] == 0, MRCNN_ERR_INVALID, "group %d ('%s') is consumed by fp32 arithmetic: its exponent is 0",
+                          i, m.sgroups[(size_t)i].name.c_str());
+        }
+        for (int i = 0; i < count; ++i) m.sgroups[(size_t)i].exp = exponents[i];
+        m.apply_split_exponents();
+        m.split_calibrated = true;
     });
 }
 
@@ -835,7 +904,7 @@ extern "C" int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout
         }
         Stream st;
         DevBuf dwh;
-        if (ksize == 3 && ws == 2 && es == 4 && cin % 16 == 0 && npad % 64 == 0) {
+        if (ksize == 3 && ws == 2 && es == 4 && conv_halo_packable(ksize, ksize, cin, npad)) {
             conv_halo_pack(st.s, dw.p, npad, cin, dwh);
             d.wgt_halo = dwh.p;
         }
@@ -860,10 +929,12 @@ extern "C" int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout
 // One convolution of the engine's kernel family on caller data (parity tests of the kernels themselves: every tile
 // shape / pipeline variant must give bit-identical results, since the choice depends on the batch size)
 // ================================================================================================
+static int g_conv2d_alias_res = 0;      // mrcnn_conv2d_nhwc writes its output in place over the residual (tests of the in-place contract)
 extern "C" int mrcnn_debug_set(const char* key, int value)
 {
     return guarded([&] {
         MRCNN_REQUIRE(key, MRCNN_ERR_INVALID, "null key");
+        if (strcmp(key, "conv2d_alias_res") == 0) { g_conv2d_alias_res = value; return; }
         MRCNN_REQUIRE(conv_debug_set(key, value) || engine_debug_set(key, value), MRCNN_ERR_INVALID, "unknown debug key '%s'", key);
     });
 }
@@ -915,20 +986,25 @@ extern "C" int mrcnn_conv2d_nhwc(const float* in, int batch, int h, int w, int c
         d.OH = oh; d.OW = ow; d.Cout = cout; d.Npad = npad;
         d.out = dout.p; d.out_sP = cout; d.out_sB = (long)oh * ow * cout; d.act = act;
         if (residual) { d.res = dres.p; d.res_sB = d.out_sB; d.res_sW = cout; d.res_sH = (long)ow * cout; }
+        // mrcnn_debug_set("conv2d_alias_res", 1): the output is written IN PLACE over the residual, the way the engine runs every
+        // bottleneck block's branch2c (engine.hip: `to = sc`).  The contract every epilogue must keep (ConvDesc::res in kernels.h):
+        // a residual element is loaded by the thread that stores the output element at the same address, before that store.
+        if (residual && g_conv2d_alias_res) d.out = dres.p;
         Stream st;
         DevBuf dwh;
-        if (ksize == 3 && wdt != MRCNN_F32 && adt == MRCNN_F32 && cin % 16 == 0 && npad % 64 == 0) {
+        if (ksize == 3 && wdt != MRCNN_F32 && adt == MRCNN_F32 && conv_halo_packable(ksize, ksize, cin, npad)) {
             conv_halo_pack(st.s, dw.p, npad, cin, dwh);
             d.wgt_halo = dwh.p;
         }
         conv_forward(st.s, d);
         HIP_CHECK(hipStreamSynchronize(st.s));
+        const void* const result = d.out;
         if (adt == MRCNN_F16) {
             std::vector<_Float16> t(n_out);
-            HIP_CHECK(hipMemcpy(t.data(), dout.p, n_out * 2, hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(t.data(), result, n_out * 2, hipMemcpyDeviceToHost));
             for (size_t i = 0; i < n_out; ++i) out[i] = (float)t[i];
         } else {
-            HIP_CHECK(hipMemcpy(out, dout.p, n_out * 4, hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(out, result, n_out * 4, hipMemcpyDeviceToHost));
         }
     });
 }

@@ -6,6 +6,7 @@
 #include <string>
 
 #include "../../include/maskrcnn_hip.h"
+#include "../../include/maskrcnn_hip_test.h"     // test / measurement entry points (same library, separate header)
 
 namespace mrcnn {
 

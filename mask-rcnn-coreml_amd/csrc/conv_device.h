@@ -379,15 +379,18 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x16 (
 // outputs at a time — no block barrier — so that every store instruction writes FULL 128-B lines (8 pixel rows × 32
 // channels): scattered 16-B pieces (conv_epilogue_direct with fp32 tensors) issue 3× slower per instruction and reach 2.9
 // instead of 5.4 TB/s (tools/probes/vmem_probe.hip).  Same arithmetic, same order as the other epilogues: bit-identical.
-//   stage: this wave's 32 × 36 floats of LDS (rows padded by 16 B: the 16-B run writes of eight lanes fall in distinct
-//   banks); tab: scale[BN] | shift[BN] of the block's columns.  A wave's LDS writes and reads execute in order, so no wait
+//   stage: this wave's LDS tile, used as 32 rows × 32 floats with the 16-B chunk c of row r stored at chunk c ^ (r & 7)
+//   (round 4; rounds 2-3 padded the rows to 36 floats, which keeps the transposing ds_write_b128 conflict-free but makes
+//   every read-back ds_read_b128 a 2-way conflict under the instruction's real lane groups {0-3,12-15,20-27} / {4-11,16-19,
+//   28-31} — MI355X_MICROARCH.md §LDS; tools/lds_bank_model.py enumerates both layouts: 32 vs 16 LDS cycles per 32 × 32
+//   piece); tab: scale[BN] | shift[BN] of the block's columns.  A wave's LDS writes and reads execute in order, so no wait
 //   is needed between the transposing write and the row-wise read-back.
 // ----------------------------------------------------------------------------------------------------------------
 template <int BN, int TMS, int TNS>
 __device__ __forceinline__ void conv_epilogue_wave(const ConvArgs& a, f32x16 (&acc)[TMS][TNS], float* stage, const float* tab, int row0, int n0,
                                                    int colrel0, int lane)
 {
-    constexpr int SW = 36;                               // floats per staged row
+    constexpr int SW = 32;                               // floats per staged row (unpadded: XOR-swizzled 16-B chunks)
     const int l31 = lane & 31, kk = lane >> 5;
     const int ohw = a.OH * a.OW;
     const float* const res = static_cast<const float*>(a.res);
@@ -435,12 +438,12 @@ __device__ __forceinline__ void conv_epilogue_wave(const ConvArgs& a, f32x16 (&a
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<float4*>(&stage[l31 * SW + 8 * q + 4 * kk]) =
+                *reinterpret_cast<float4*>(&stage[l31 * SW + (((2 * q + kk) ^ (l31 & 7)) << 2)]) =
                     make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
             const float4 sc = *reinterpret_cast<const float4*>(tab + cl), sh = *reinterpret_cast<const float4*>(tab + BN + cl);
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
-                float4 x = *reinterpret_cast<const float4*>(&stage[(8 * ps + rrow) * SW + c4]);
+                float4 x = *reinterpret_cast<const float4*>(&stage[(8 * ps + rrow) * SW + (((lane & 7) ^ rrow) << 2)]);
                 x.x = x.x * sc.x + sh.x; x.y = x.y * sc.y + sh.y; x.z = x.z * sc.z + sh.z; x.w = x.w * sc.w + sh.w;
                 if (res) { x.x += rv[ps].x; x.y += rv[ps].y; x.z += rv[ps].z; x.w += rv[ps].w; }
                 if (relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
@@ -465,7 +468,7 @@ template <int BN, int TMS>
 __device__ __forceinline__ void conv_epilogue_wave_h(const ConvArgs& a, f32x16 (&acc)[TMS][2], float* stage, const float* tab, int row0, int n0,
                                                      int colrel0, int lane)
 {
-    constexpr int SW = 68;                               // floats per staged row (64 + 4: the transposing 16-B writes of 16 lanes fall in distinct banks)
+    constexpr int SW = 64;                               // floats per staged row; 16-B chunk c of row r lives at chunk c ^ (r & 7): conflict-free transposing writes AND read-back (round 4, as conv_epilogue_wave)
     const int l31 = lane & 31, kk = lane >> 5;
     const int ohw = a.OH * a.OW;
     const _Float16* const res = static_cast<const _Float16*>(a.res);
@@ -514,12 +517,12 @@ __device__ __forceinline__ void conv_epilogue_wave_h(const ConvArgs& a, f32x16 (
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<float4*>(&stage[l31 * SW + j * 32 + 8 * q + 4 * kk]) =
+                *reinterpret_cast<float4*>(&stage[l31 * SW + (((j * 8 + 2 * q + kk) ^ (l31 & 7)) << 2)]) =
                     make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
-            float4 x = *reinterpret_cast<const float4*>(&stage[(8 * ps + rrow) * SW + c8]);
-            float4 y = *reinterpret_cast<const float4*>(&stage[(8 * ps + rrow) * SW + c8 + 4]);
+            float4 x = *reinterpret_cast<const float4*>(&stage[(8 * ps + rrow) * SW + (((2 * (lane & 7)) ^ rrow) << 2)]);
+            float4 y = *reinterpret_cast<const float4*>(&stage[(8 * ps + rrow) * SW + (((2 * (lane & 7) + 1) ^ rrow) << 2)]);
             x.x = x.x * sc0.x + sh0.x; x.y = x.y * sc0.y + sh0.y; x.z = x.z * sc0.z + sh0.z; x.w = x.w * sc0.w + sh0.w;
             y.x = y.x * sc1.x + sh1.x; y.y = y.y * sc1.y + sh1.y; y.z = y.z * sc1.z + sh1.z; y.w = y.w * sc1.w + sh1.w;
             if (res) {

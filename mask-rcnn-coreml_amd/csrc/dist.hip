@@ -44,6 +44,8 @@ struct Rccl {
     int (*GetUniqueId)(NcclUniqueId*) = nullptr;
     int (*CommInitRank)(NcclComm*, int, NcclUniqueId, int) = nullptr;
     int (*CommDestroy)(NcclComm) = nullptr;
+    int (*CommAbort)(NcclComm) = nullptr;          // optional (last resort of a rank that cannot take part in a collective)
+    bool shared = false;                           // the copy the process had already mapped (RTLD_NOLOAD), e.g. PyTorch's
     int (*AllGather)(const void*, void*, size_t, int, NcclComm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
@@ -55,10 +57,19 @@ Rccl& rccl()
     if (r.lib) return r;
     // resolved into a local table first: a missing symbol must not leave a half-bound table behind
     Rccl t;
+    // ONE RCCL per process: a copy the host has already mapped — torch's process group loads one under the
+    // same soname — is taken first (RTLD_NOLOAD: succeeds only when the library is resident); only a process without one
+    // loads its own.  MRCNN_RCCL_PRIVATE=1 skips the first step (tests).
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    const char* priv = getenv("MRCNN_RCCL_PRIVATE");
+    if (!(priv && atoi(priv) != 0))
+        for (const char* n : names) {
+            t.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+            if (t.lib) { t.shared = true; break; }
+        }
     for (const char* n : names) {
-        t.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (t.lib) break;
+        t.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     }
     MRCNN_REQUIRE(t.lib, MRCNN_ERR_CONFIG, "cannot load RCCL (librccl.so.1): %s", dlerror());
     const char* missing = nullptr;
@@ -72,6 +83,7 @@ Rccl& rccl()
     t.CommDestroy = reinterpret_cast<decltype(t.CommDestroy)>(sym("ncclCommDestroy"));
     t.AllGather = reinterpret_cast<decltype(t.AllGather)>(sym("ncclAllGather"));
     t.GetErrorString = reinterpret_cast<decltype(t.GetErrorString)>(sym("ncclGetErrorString"));
+    t.CommAbort = reinterpret_cast<decltype(t.CommAbort)>(dlsym(t.lib, "ncclCommAbort"));      // optional
     if (missing) {
         dlclose(t.lib);
         fail(MRCNN_ERR_CONFIG, "RCCL lacks %s", missing);
@@ -231,6 +243,13 @@ extern "C" int mrcnn_dist_simulate_host(int world, int global_batch, int max_det
     });
 }
 
+extern "C" int mrcnn_dist_rccl_shared(void)
+{
+    int shared = -1;
+    (void)guarded([&] { shared = rccl().shared ? 1 : 0; });
+    return shared;
+}
+
 extern "C" int mrcnn_dist_unique_id(uint8_t* id128)
 {
     return guarded([&] {
@@ -284,33 +303,64 @@ static void raise_remote_status(mrcnn_dist* d)
     }
 }
 
+// Buffers of an exchange.  Their sizes depend only on arguments every rank passes alike (record geometry, global batch, world),
+// so an allocation failure here is the same failure on every rank — it happens BEFORE the window in which a rank-local error
+// would leave the others alone in the collective.
+static void reserve_exchange(mrcnn_dist* d, const Geometry& g)
+{
+    if (d->send.bytes < g.slot * 4) d->send.alloc(g.slot * 4);
+    if (d->recv.bytes < (size_t)d->world * g.slot * 4) d->recv.alloc((size_t)d->world * g.slot * 4);
+    if (d->statuses.size() != (size_t)d->world * TRAILER) d->statuses.assign((size_t)d->world * TRAILER, 0);    // never re-assigned under an in-flight D2H
+}
+
 // local results (n_local records, `in_space`) → every rank's records in global image order (`out_space`).
 // Issued on stream `s`; `status` != 0 sends zeroed records.  Does not synchronise.
+// The contract: once the arguments every rank sees alike have been checked, NOTHING rank-local may keep this
+// rank out of ncclAllGather — a rank-local error (null results, a failing pack copy after a sticky HIP error) becomes the status
+// word of a zeroed slot; only when even that cannot be enqueued is the communicator aborted (ncclCommAbort: the peers' collective
+// then fails instead of blocking for ever) and the error raised.  *enqueued is set as soon as work targets d's buffers.
 static void issue_exchange(mrcnn_dist* d, Model& m, hipStream_t s, const float* det, const float* masks, int in_space, int global_batch,
-                           int out_space, float* out_det, float* out_masks, int status)
+                           int out_space, float* out_det, float* out_masks, int status, bool* enqueued = nullptr)
 {
     MRCNN_REQUIRE(m.kind == MRCNN_MODEL_MASKRCNN, MRCNN_ERR_INVALID, "all_gather_records needs the MaskRCNN model (record geometry)");
     d->g = geometry(global_batch, d->world, m.max_det, 2 * m.mask_pool);
     d->plan = plan_entries(global_batch, d->world, d->g);
     const Geometry& g = d->g;
     const int n_local = d->plan[d->rank].end - d->plan[d->rank].begin;
-    MRCNN_REQUIRE(status != 0 || n_local == 0 || (det && masks), MRCNN_ERR_INVALID, "null local results");
-    if (d->send.bytes < g.slot * 4) d->send.alloc(g.slot * 4);
-    if (d->recv.bytes < (size_t)d->world * g.slot * 4) d->recv.alloc((size_t)d->world * g.slot * 4);
-    d->trailer[0] = status; d->trailer[1] = n_local; d->trailer[2] = d->trailer[3] = 0;
+    reserve_exchange(d, g);
+    // ---- from here on: rank-local failures travel as the status word ------------------------------------------------
+    std::string local_msg;
+    if (status == 0 && n_local > 0 && !(det && masks)) { status = MRCNN_ERR_INVALID; local_msg = "null local results"; }
     DeviceCopy c{s, in_space != MRCNN_DEVICE ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
                  out_space != MRCNN_DEVICE ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice};
-    pack_slot(c, g, n_local, det, masks, d->trailer, d->send.as<float>());
+    if (enqueued) *enqueued = true;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        d->trailer[0] = status; d->trailer[1] = n_local; d->trailer[2] = d->trailer[3] = 0;
+        try {
+            pack_slot(c, g, n_local, det, masks, d->trailer, d->send.as<float>());
+            break;
+        } catch (const Error& e) {
+            (void)hipGetLastError();
+            if (attempt == 1) {          // not even a zeroed slot can be enqueued: release the peers, then raise
+                Rccl& r = rccl();
+                if (r.CommAbort && d->comm) { (void)r.CommAbort(d->comm); d->comm = nullptr; }
+                fail(e.code ? e.code : MRCNN_ERR_HIP, "rank %d cannot take part in the all-gather (%s); communicator aborted", d->rank, e.msg.c_str());
+            }
+            status = e.code ? e.code : MRCNN_ERR_HIP;      // second attempt: zeroed records + this status
+            local_msg = e.msg;
+        }
+    }
     HIP_CHECK(hipEventRecord(d->ev_packed, s));
     // ---- the one collective of the path ---------------------------------------------------------------------------
     Rccl& r = rccl();
+    MRCNN_REQUIRE(d->comm, MRCNN_ERR_INVALID, "the communicator of this handle was aborted by an earlier failure");
     nccl_check(r, r.AllGather(d->send.p, d->recv.p, g.slot, /*ncclFloat*/ 7, d->comm, s), "ncclAllGather");
     c.unpacking = true;
     unpack_slots(c, g, d->plan, d->recv.as<float>(), out_det, out_masks);
     // every rank's trailer → host (one strided copy)
-    d->statuses.assign((size_t)d->world * TRAILER, 0);
     HIP_CHECK(hipMemcpy2DAsync(d->statuses.data(), TRAILER * 4, d->recv.as<float>() + (size_t)g.n_max * g.rec, g.slot * 4, TRAILER * 4,
                                (size_t)d->world, hipMemcpyDeviceToHost, s));
+    if (!local_msg.empty()) set_error("rank %d: %s (sent as the status word of this rank's slot)", d->rank, local_msg.c_str());
 }
 
 extern "C" int mrcnn_dist_wait(mrcnn_dist* d)
@@ -334,10 +384,18 @@ extern "C" int mrcnn_dist_all_gather_records_async(mrcnn_dist* d, mrcnn_model* m
         // the exchange starts when the model's stream has produced the results ...
         HIP_CHECK(hipEventRecord(d->ev_ready, m.stream));
         HIP_CHECK(hipStreamWaitEvent(d->gs, d->ev_ready, 0));
-        issue_exchange(d, m, d->gs, det, masks, MRCNN_DEVICE, global_batch, MRCNN_DEVICE, out_det, out_masks, 0);
+        bool enqueued = false;
+        try {
+            issue_exchange(d, m, d->gs, det, masks, MRCNN_DEVICE, global_batch, MRCNN_DEVICE, out_det, out_masks, 0, &enqueued);
+        } catch (...) {
+            // work may already target d's buffers and the caller's outputs: join it before the error leaves (a later exchange
+            // must never re-use them under an in-flight copy — ADVICE r3)
+            if (enqueued) (void)hipStreamSynchronize(d->gs);
+            throw;
+        }
+        d->pending = true;
         // ... and the model's stream may overwrite them (the next predict) once they are packed — not once they are exchanged
         HIP_CHECK(hipStreamWaitEvent(m.stream, d->ev_packed, 0));
-        d->pending = true;
     });
 }
 

@@ -43,6 +43,7 @@ inline int mode_wgt(int mode) { return mode == MRCNN_F32 ? MRCNN_F32 : (mode == 
 
 struct PackedConv {
     DevBuf wgt, scale, shift;     // wgt in `wdtype`; scale/shift always fp32
+    std::vector<float> h_scale, h_shift;   // host copies of scale / shift (the scale-aware split derives per-op copies from them)
     DevBuf wgt_halo;              // 3x3 layers of the split modes: the same filters re-tiled for the halo kernel (conv_halo_pack)
     int Cin = 0, Cout = 0, KH = 1, KW = 1, Npad = 0;
     int dtype = MRCNN_F32;        // activations
@@ -56,6 +57,29 @@ struct Tensor4 {   // dense NHWC activation (element type = the model's compute 
 };
 
 using Op = std::function<void(hipStream_t, int /*batch*/)>;
+
+// ---- scale-aware split (round 4) ----------------------------------------------------------------------
+// The split modes carry an activation exactly only while 0.5 <= |a| < 65504 (below: 2^-25 absolute).  Every tensor a split
+// convolution reads therefore belongs to a GROUP with an exponent e: the tensor is stored as 2^e * (its true value), an exact
+// operation folded into the producer's scale / shift (scale' = scale * 2^(e_out - e_in), shift' = shift * 2^e_out), undone by
+// the consumer the same way.  ReLU, max-pool, the bilinear sampler and the residual add (tensors of one residual chain share a
+// group) commute with it, so with every e = 0 nothing changes and with calibrated exponents the mode is fp32-grade at any
+// activation scale.  Exponents are chosen by Model::calibrate_split from one predict (max |a| * 2^e in [2^11, 2^12): 16x head
+// room under the fp16 range the watchdog guards) or set by the host (identical on every rank of a sharded job).
+struct SplitGroup {
+    std::string name;
+    int exp = 0;
+    bool fixed = false;            // consumed by non-split arithmetic (logits, box deltas, probabilities): stays 0
+    float absmax = 0.f;            // of the true values, over the calibration batch
+    long long small = 0, inexact = 0, counted = 0;   // diagnostics of the last calibrate / diagnose pass (elements)
+};
+struct ScaledOp {                  // a convolution whose scale / shift carry the exponents of its input / output groups
+    const PackedConv* pc = nullptr;
+    int g_in = 0, g_out = 0;
+    DevBuf scale, shift;           // the per-op copies the launch reads (rewritten in place by apply_split_exponents)
+};
+// called after a layer has been enqueued while a calibration pass is active (group, tensor, elements)
+using SplitObserver = std::function<void(hipStream_t, int, const void*, size_t)>;
 
 struct Arena {
     char* base = nullptr;
@@ -85,6 +109,9 @@ struct ClassifierHead {
     void *h1 = nullptr, *h2 = nullptr, *stage_in = nullptr;           // compute dtype
     float *lb = nullptr, *probs = nullptr, *bbox = nullptr, *cls6 = nullptr;
     int mode = MRCNN_F32;          // compute mode the head was loaded with (MRCNN_F32 | MRCNN_F16 | MRCNN_F32S)
+    ScaledOp sop[3];               // fc1 / fc2 / fc3 with the exponents of pooled → h1 → h2 → logits (0)
+    int grp[3] = {-1, -1, -1};     // split groups of pooled, h1, h2 (owned by the model; -1 = stand-alone head, exponent 0)
+    SplitObserver observe;
     void load(const MrcwFile& f, int capacity_rows, int mode);
     // pooled: n rows of pool*pool*C elements in (h,w,c) order, contiguous, compute dtype.
     void forward(hipStream_t s, const void* pooled_nhwc, int n, float* cls6_out, long cls6_stride);
@@ -99,6 +126,9 @@ struct MaskHead {
     void *t0 = nullptr, *t1 = nullptr, *feat = nullptr, *stage_in = nullptr;   // compute dtype
     float* full = nullptr;
     int mode = MRCNN_F32;          // compute mode the head was loaded with (MRCNN_F32 | MRCNN_F16 | MRCNN_F32S)
+    ScaledOp sop[5];               // conv1..4 + the deconvolution, exponents pooled_mask → t1 → t2 → t3 → t4 → 0
+    int grp[5] = {-1, -1, -1, -1, -1};   // split groups of pooled_mask and of the four 3x3 outputs
+    SplitObserver observe;
     void load(const MrcwFile& f, int capacity_rows, int mode);
     // pooled: n rows of 14*14*C NHWC → feat (n, 28*28, C) = ReLU(deconv)
     // sel_partial != nullptr: the deconvolution leaves the selected-class partial dots instead of feat (ConvDesc::sel_partial)
@@ -145,7 +175,7 @@ struct Model {
     // activations
     DevBuf arena;
     std::vector<Op> trunk_ops;
-    struct Tap { void* base; long per_image; int dtype; };
+    struct Tap { void* base; long per_image; int dtype; int group = -1; };     // group >= 0: stored as 2^e * value (read_tensor undoes it)
     std::map<std::string, Tap> taps;    // name → (base, per-image elements, element type)
     uint8_t* d_rgb = nullptr;
     void* stem_in = nullptr;          // the stem's zero-padded NHWC4 / NHWC8 staging tensor (written by the pre-processing op = trunk_ops[0])
@@ -170,6 +200,20 @@ struct Model {
     struct GraphSlot { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int eager_runs = 0; };
     std::map<int, GraphSlot> graphs;
     bool use_graph = false;
+    // ---- scale-aware split ------------------------------------------------------------------------------------------
+    std::vector<SplitGroup> sgroups;
+    std::vector<std::unique_ptr<ScaledOp>> sops;       // the trunk's convolutions (stable addresses: the ops hold pointers)
+    int g_P[4] = {-1, -1, -1, -1}, g_rpn[5] = {-1, -1, -1, -1, -1}, g_pooled = -1, g_pooled_mask = -1;
+    int calib_phase = 0;              // 0 off | 1 collect max |a| per group | 2 count the inputs the split cannot carry exactly
+    DevBuf calib_buf;                 // per group: uint32 max bits | 3 x uint64 counters
+    bool split_calibrated = false;
+    int new_split_group(const std::string& name, bool fixed = false);
+    ScaledOp* new_scaled_op(const PackedConv* pc, int g_in, int g_out);
+    void apply_split_exponents();     // rewrites every op's scale / shift copy from the groups' exponents (synchronises the stream)
+    void observe_split(hipStream_t s, int group, const void* x, size_t n);
+    // one predict with every exponent 0 collecting max |a| per group, exponents chosen, (apply) a second predict that verifies
+    // the choice and counts the inputs a split still cannot carry exactly; apply = false: diagnose only, exponents untouched
+    void calibrate_split(const uint8_t* rgb, int batch, int h, int w, int memspace, bool apply);
     DevBuf range_flag;          // 4 B: set by the conv epilogues in MRCNN_F16 / MRCNN_F32S when an activation leaves the fp16 range
     long range_overflows = 0;   // predicts that tripped it
     long graph_launches = 0;
@@ -196,7 +240,8 @@ struct Model {
 // Helpers shared with api.hip
 PackedConv pack_conv_oihw(const MrcwFile& f, const std::string& conv, const std::string& bn, int dtype);
 void run_conv_dense(hipStream_t s, const PackedConv& pc, const void* in, int B, int H, int W, void* out, int stride,
-                    int pad, int act, const void* res = nullptr, int out_f32 = 0);
+                    int pad, int act, const void* res = nullptr, int out_f32 = 0, const ScaledOp* sop = nullptr);
+void init_scaled_op(ScaledOp& op, const PackedConv* pc, int g_in, int g_out);      // allocates the copies = the base scale / shift
 
 }  // namespace mrcnn
 

@@ -287,7 +287,7 @@ PackedConv pack_conv_oihw(const MrcwFile& f, const std::string& conv, const std:
                 for (int x = 0; x < KW; ++x)
                     w[(((size_t)o * KH + y) * KW + x) * I + i] = k[(((size_t)o * I + i) * KH + y) * KW + x];
     upload_w(pc.wgt, w, pc.wdtype, pc.wdtype != pc.dtype, "MRCNN_F32S / MRCNN_F32X3");
-    if (KH == 3 && KW == 3 && pc.wdtype != pc.dtype && I % 16 == 0 && pc.Npad % 64 == 0) {
+    if (pc.wdtype != pc.dtype && conv_halo_packable(KH, KW, I, pc.Npad)) {
         conv_halo_pack(nullptr, pc.wgt.p, pc.Npad, I, pc.wgt_halo);           // split modes: also in the halo kernel's tiling
         HIP_CHECK(hipStreamSynchronize(nullptr));
     }
@@ -295,6 +295,7 @@ PackedConv pack_conv_oihw(const MrcwFile& f, const std::string& conv, const std:
     fold_bn(f, conv, bn, O, pc.Npad, sc, sh);
     upload(pc.scale, sc);
     upload(pc.shift, sh);
+    pc.h_scale = sc; pc.h_shift = sh;
     return pc;
 }
 
@@ -325,6 +326,7 @@ static PackedConv pack_conv1(const MrcwFile& f, int dtype)
     fold_bn(f, "conv1", "bn_conv1", O, pc.Npad, sc, sh);
     upload(pc.scale, sc);
     upload(pc.shift, sh);
+    pc.h_scale = sc; pc.h_shift = sh;
     return pc;
 }
 
@@ -356,6 +358,7 @@ static PackedConv pack_stacked_1x1(const MrcwFile& f, const std::vector<std::str
     upload_w(pc.wgt, w, pc.wdtype, pc.wdtype != pc.dtype, "MRCNN_F32S / MRCNN_F32X3");
     upload(pc.scale, sc);
     upload(pc.shift, sh);
+    pc.h_scale = sc; pc.h_shift = sh;
     return pc;
 }
 
@@ -380,12 +383,21 @@ static PackedConv pack_deconv2(const MrcwFile& f, const std::string& name, int d
     upload_w(pc.wgt, w, pc.wdtype, pc.wdtype != pc.dtype, "MRCNN_F32S / MRCNN_F32X3");
     upload(pc.scale, sc);
     upload(pc.shift, sh);
+    pc.h_scale = sc; pc.h_shift = sh;
     return pc;
+}
+
+// A convolution's own copy of its scale / shift (= the folded BatchNorm + bias until exponents are applied)
+void init_scaled_op(ScaledOp& op, const PackedConv* pc, int g_in, int g_out)
+{
+    op.pc = pc; op.g_in = g_in; op.g_out = g_out;
+    upload(op.scale, pc->h_scale);
+    upload(op.shift, pc->h_shift);
 }
 
 // Dense NHWC conv helper (in: B×H×W×Cin, out: B×OH×OW×Cout).
 void run_conv_dense(hipStream_t s, const PackedConv& pc, const void* in, int B, int H, int W, void* out, int stride,
-                    int pad, int act, const void* res, int out_f32)
+                    int pad, int act, const void* res, int out_f32, const ScaledOp* sop)
 {
     ConvDesc d;
     d.dtype = pc.dtype; d.wdtype = pc.wdtype; d.out_f32 = out_f32;
@@ -393,7 +405,7 @@ void run_conv_dense(hipStream_t s, const PackedConv& pc, const void* in, int B, 
     d.in_sW = pc.Cin; d.in_sH = (long)W * pc.Cin; d.in_sB = (long)H * W * pc.Cin;
     d.wgt = pc.wgt.p; d.KH = pc.KH; d.KW = pc.KW; d.stride = stride; d.padH = d.padW = pad;
     d.wgt_halo = pc.wgt_halo.p;
-    d.scale = pc.scale.as<float>(); d.shift = pc.shift.as<float>();
+    d.scale = sop ? sop->scale.as<float>() : pc.scale.as<float>(); d.shift = sop ? sop->shift.as<float>() : pc.shift.as<float>();
     d.OH = (H + 2 * pad - pc.KH) / stride + 1;
     d.OW = (W + 2 * pad - pc.KW) / stride + 1;
     d.Cout = pc.Cout; d.Npad = pc.Npad;
@@ -432,6 +444,9 @@ void ClassifierHead::load(const MrcwFile& f, int capacity_rows, int dtype_)
         stage_in = ar.alloc_e((size_t)cap * pool * pool * C, dtype);
         if (pass == 0) { arena.alloc(ar.off); ar.base = arena.as<char>(); }
     }
+    init_scaled_op(sop[0], &fc1, -1, -1);
+    init_scaled_op(sop[1], &fc2, -1, -1);
+    init_scaled_op(sop[2], &fc3, -1, -1);
 }
 
 void ClassifierHead::forward(hipStream_t s, const void* pooled_nhwc, int n, float* cls6_out, long cls6_stride)
@@ -439,9 +454,11 @@ void ClassifierHead::forward(hipStream_t s, const void* pooled_nhwc, int n, floa
     MRCNN_REQUIRE(n <= cap, MRCNN_ERR_SHAPE, "classifier head: %d rows exceed capacity %d", n, cap);
     if (n <= 0) return;
     // rows are "pixels" of a 1×n image
-    run_conv_dense(s, fc1, pooled_nhwc, 1, 1, n, h1, 1, 0, ACT_RELU);
-    run_conv_dense(s, fc2, h1, 1, 1, n, h2, 1, 0, ACT_RELU);
-    run_conv_dense(s, fc3, h2, 1, 1, n, lb, 1, 0, ACT_NONE, nullptr, 1);
+    run_conv_dense(s, fc1, pooled_nhwc, 1, 1, n, h1, 1, 0, ACT_RELU, nullptr, 0, &sop[0]);
+    if (observe) observe(s, grp[1], h1, (size_t)n * fc1.Cout);
+    run_conv_dense(s, fc2, h1, 1, 1, n, h2, 1, 0, ACT_RELU, nullptr, 0, &sop[1]);
+    if (observe) observe(s, grp[2], h2, (size_t)n * fc2.Cout);
+    run_conv_dense(s, fc3, h2, 1, 1, n, lb, 1, 0, ACT_NONE, nullptr, 1, &sop[2]);
     TraceRange tr("TimeDistributedClassifierLayer-ProcessOutput");
     softmax_rows_forward(s, lb, fc3.Cout, nc, n, probs);
     copy_columns_forward(s, lb, fc3.Cout, nc, 4 * nc, n, bbox);
@@ -475,6 +492,8 @@ void MaskHead::load(const MrcwFile& f, int capacity_rows, int dtype_)
         stage_in = ar.alloc_e((size_t)cap * hw * C, dtype);
         if (pass == 0) { arena.alloc(ar.off); ar.base = arena.as<char>(); }
     }
+    for (int i = 0; i < 4; ++i) init_scaled_op(sop[i], &conv[i], -1, -1);
+    init_scaled_op(sop[4], &deconv, -1, -1);
 }
 
 // process-wide A/B switch of the fused mask tail (tests, tools/e2e_ab.py): mrcnn_debug_set("mask_fused", 0 | 1)
@@ -489,17 +508,22 @@ void MaskHead::forward_features(hipStream_t s, const void* pooled_nhwc, int n, c
 {
     MRCNN_REQUIRE(n <= cap, MRCNN_ERR_SHAPE, "mask head: %d rows exceed capacity %d", n, cap);
     if (n <= 0) return;
-    run_conv_dense(s, conv[0], pooled_nhwc, n, pool, pool, t0, 1, 1, ACT_RELU);
-    run_conv_dense(s, conv[1], t0, n, pool, pool, t1, 1, 1, ACT_RELU);
-    run_conv_dense(s, conv[2], t1, n, pool, pool, t0, 1, 1, ACT_RELU);
-    run_conv_dense(s, conv[3], t0, n, pool, pool, t1, 1, 1, ACT_RELU);
+    const size_t te = (size_t)n * pool * pool * C;
+    run_conv_dense(s, conv[0], pooled_nhwc, n, pool, pool, t0, 1, 1, ACT_RELU, nullptr, 0, &sop[0]);
+    if (observe) observe(s, grp[1], t0, te);
+    run_conv_dense(s, conv[1], t0, n, pool, pool, t1, 1, 1, ACT_RELU, nullptr, 0, &sop[1]);
+    if (observe) observe(s, grp[2], t1, te);
+    run_conv_dense(s, conv[2], t1, n, pool, pool, t0, 1, 1, ACT_RELU, nullptr, 0, &sop[2]);
+    if (observe) observe(s, grp[3], t0, te);
+    run_conv_dense(s, conv[3], t0, n, pool, pool, t1, 1, 1, ACT_RELU, nullptr, 0, &sop[3]);
+    if (observe) observe(s, grp[4], t1, te);
     ConvDesc d;
     const int Co = deconv.Cout;
     d.dtype = dtype;
     d.in = t1; d.B = n; d.H = pool; d.W = pool; d.Cin = deconv.Cin;
     d.in_sW = deconv.Cin; d.in_sH = (long)pool * deconv.Cin; d.in_sB = (long)pool * pool * deconv.Cin;
     d.wdtype = deconv.wdtype;
-    d.wgt = deconv.wgt.p; d.scale = deconv.scale.as<float>(); d.shift = deconv.shift.as<float>();
+    d.wgt = deconv.wgt.p; d.scale = sop[4].scale.as<float>(); d.shift = sop[4].shift.as<float>();
     d.OH = pool; d.OW = pool; d.Cout = Co; d.Npad = deconv.Npad;
     d.deconv2 = 1; d.act = ACT_RELU;
     d.out = feat; d.out_sW = Co; d.out_sH = (long)2 * pool * Co; d.out_sB = (long)4 * pool * pool * Co;
@@ -704,17 +728,24 @@ void Model::build_maskrcnn()
     // ---- activation plan (pass 0 sizes the arena, pass 1 binds pointers and records the ops) ------
     const int Bm = max_batch;
     Arena ar;
+    Model* const self = this;
     for (int pass = 0; pass < 2; ++pass) {
         ar.off = 0;
         trunk_ops.clear();
         taps.clear();
+        sgroups.clear();
+        sops.clear();
         const bool real = pass == 1;
         const int dt = dtype;
         auto T = [&](int h, int w, int c) { Tensor4 t; t.H = h; t.W = w; t.C = c; t.p = ar.alloc_e((size_t)Bm * h * w * c, dt); return t; };
         auto add = [&](Op op) { if (real) trunk_ops.push_back(std::move(op)); };
+        // split groups (engine.h: SplitGroup): g_in / g_out of every convolution; a residual rides in the output's group
+        const int g_img = new_split_group("image", true);        // pixel - mean: written by the pre-processing kernel, exponent 0
+        const int g_zero = new_split_group("outputs", true);      // logits, box deltas, probabilities: consumed by fp32 arithmetic
         auto conv_op = [&](const std::string& name, const Tensor4& in, const Tensor4& out, int stride, int pad, int act,
-                           const Tensor4* res, int res_shift) {
+                           const Tensor4* res, int res_shift, int g_in, int g_out) {
             const PackedConv* pc = &convs.at(name);
+            ScaledOp* const so = real ? new_scaled_op(pc, g_in, g_out) : nullptr;
             ConvDesc d;
             d.dtype = dt;
             d.in = in.p; d.H = in.H; d.W = in.W; d.Cin = pc->Cin;
@@ -722,12 +753,16 @@ void Model::build_maskrcnn()
             d.wdtype = pc->wdtype;
             d.wgt = pc->wgt.p; d.KH = pc->KH; d.KW = pc->KW; d.stride = stride; d.padH = d.padW = pad;
             d.wgt_halo = pc->wgt_halo.p;
-            d.scale = pc->scale.as<float>(); d.shift = pc->shift.as<float>();
+            d.scale = so ? so->scale.as<float>() : nullptr; d.shift = so ? so->shift.as<float>() : nullptr;
             d.OH = out.H; d.OW = out.W; d.Cout = pc->Cout; d.Npad = pc->Npad;
             d.out = out.p; d.out_sP = out.C; d.out_sB = out.sB();
             d.act = act;
             if (res) { d.res = res->p; d.res_sB = res->sB(); d.res_sH = (long)res->W * res->C; d.res_sW = res->C; d.res_shift = res_shift; }
-            add([d](hipStream_t s, int batch) { ConvDesc x = d; x.B = batch; conv_forward(s, x); });
+            const size_t per_image = (size_t)out.sB();
+            add([d, self, g_out, per_image](hipStream_t s, int batch) {
+                ConvDesc x = d; x.B = batch; conv_forward(s, x);
+                if (self->calib_phase) self->observe_split(s, g_out, d.out, per_image * batch);
+            });
         };
 
         d_rgb = (uint8_t*)ar.alloc_b((size_t)Bm * H * W * 3);
@@ -744,6 +779,7 @@ void Model::build_maskrcnn()
             add([=](hipStream_t s, int batch) { preprocess_forward(s, src, batch, h, w, 3, m3, x0, dt); });
         }
         Tensor4 c1 = T(H / 2, W / 2, 64);
+        const int g_c1 = new_split_group("C1");                  // conv1's output and its max-pooled version (max-pool commutes with the scaling)
         {
             const PackedConv* pc = &convs.at("conv1");
             ConvDesc d;
@@ -752,11 +788,17 @@ void Model::build_maskrcnn()
             d.in_sW = pxc; d.in_sH = (long)Wp * pxc; d.in_sB = (long)Hp * Wp * pxc;
             d.wdtype = pc->wdtype;
             d.wgt = pc->wgt.p; d.KH = 7; d.KW = 1; d.stride = 2; d.padH = d.padW = 0;
-            d.scale = pc->scale.as<float>(); d.shift = pc->shift.as<float>();
+            ScaledOp* const so = real ? new_scaled_op(pc, g_img, g_c1) : nullptr;
+            d.scale = so ? so->scale.as<float>() : nullptr; d.shift = so ? so->shift.as<float>() : nullptr;
             d.OH = c1.H; d.OW = c1.W; d.Cout = pc->Cout; d.Npad = pc->Npad;
             d.out = c1.p; d.out_sP = c1.C; d.out_sB = c1.sB(); d.act = ACT_RELU;
             d.algo_k = 147;   // 7*7*3 real taps (the packed row is padded to 7*32)
-            add([d](hipStream_t s, int batch) { ConvDesc x = d; x.B = batch; conv_forward(s, x); });
+            const size_t per_image = (size_t)c1.sB();
+            const int g = g_c1;
+            add([d, self, g, per_image](hipStream_t s, int batch) {
+                ConvDesc x = d; x.B = batch; conv_forward(s, x);
+                if (self->calib_phase) self->observe_split(s, g, d.out, per_image * batch);
+            });
         }
         Tensor4 x = T(H / 4, W / 4, 64);
         {
@@ -765,46 +807,55 @@ void Model::build_maskrcnn()
         }
         Tensor4 Cf[6];
         const int f1s[6] = {0, 0, 64, 128, 256, 512}, f3s[6] = {0, 0, 256, 512, 1024, 2048};
+        int g_x = g_c1;                                           // group of the running tensor x
+        int g_C[6] = {-1, -1, -1, -1, -1, -1};
         for (int st = 2; st <= 5; ++st) {
             Tensor4 stage_ta, stage_tb;
+            // every block output of a stage shares ONE group: the blocks add their shortcut in place (res == out)
+            const int g_stage = new_split_group("C" + std::to_string(st));
             for (auto& b : blocks[st]) {
                 const std::string p = std::to_string(st) + b;
                 const bool first = b == "a";
                 const int stride = (first && st > 2) ? 2 : 1;
                 const int oh = x.H / stride, ow = x.W / stride;
                 if (first) { stage_ta = T(oh, ow, f1s[st]); stage_tb = T(oh, ow, f1s[st]); }      // the branch tensors are reused by every block of the stage
+                const int g_a = new_split_group("res" + p + "_branch2a"), g_b = new_split_group("res" + p + "_branch2b");
                 Tensor4 ta = stage_ta;
-                conv_op("res" + p + "_branch2a", x, ta, stride, 0, ACT_RELU, nullptr, 0);
+                conv_op("res" + p + "_branch2a", x, ta, stride, 0, ACT_RELU, nullptr, 0, g_x, g_a);
                 Tensor4 tb = stage_tb;
-                conv_op("res" + p + "_branch2b", ta, tb, 1, 1, ACT_RELU, nullptr, 0);
+                conv_op("res" + p + "_branch2b", ta, tb, 1, 1, ACT_RELU, nullptr, 0, g_a, g_b);
                 Tensor4 sc = x;
                 if (first) {
                     sc = T(oh, ow, f3s[st]);
-                    conv_op("res" + p + "_branch1", x, sc, stride, 0, ACT_NONE, nullptr, 0);
+                    conv_op("res" + p + "_branch1", x, sc, stride, 0, ACT_NONE, nullptr, 0, g_x, g_stage);
                 }
                 // The block's output overwrites its shortcut IN PLACE (branch2c reads a residual element and writes the output
                 // element at the same address, from the same thread; nothing reads the shortcut afterwards): a stage then cycles
                 // through x + two branch tensors — 200 MB for C4 at batch 8, inside the 256 MB Infinity Cache — instead of
                 // streaming a fresh 134 MB tensor per block through HBM.
                 Tensor4 to = sc;
-                conv_op("res" + p + "_branch2c", tb, to, 1, 0, ACT_RELU, &sc, 0);
+                conv_op("res" + p + "_branch2c", tb, to, 1, 0, ACT_RELU, &sc, 0, g_b, g_stage);
                 x = to;
+                g_x = g_stage;
             }
             Cf[st] = x;
+            g_C[st] = g_stage;
         }
         // FPN: lateral 1×1 (+ nearest 2× upsample of the level above, fused as a shifted residual), then 3×3
         Tensor4 L5 = T(Cf[5].H, Cf[5].W, 256), L4 = T(Cf[4].H, Cf[4].W, 256), L3 = T(Cf[3].H, Cf[3].W, 256), L2 = T(Cf[2].H, Cf[2].W, 256);
-        conv_op("fpn_c5p5", Cf[5], L5, 1, 0, ACT_NONE, nullptr, 0);
-        conv_op("fpn_c4p4", Cf[4], L4, 1, 0, ACT_NONE, &L5, 1);
-        conv_op("fpn_c3p3", Cf[3], L3, 1, 0, ACT_NONE, &L4, 1);
-        conv_op("fpn_c2p2", Cf[2], L2, 1, 0, ACT_NONE, &L3, 1);
+        const int g_L = new_split_group("fpn_lateral");           // L5..L2 add each other (top-down): one group
+        conv_op("fpn_c5p5", Cf[5], L5, 1, 0, ACT_NONE, nullptr, 0, g_C[5], g_L);
+        conv_op("fpn_c4p4", Cf[4], L4, 1, 0, ACT_NONE, &L5, 1, g_C[4], g_L);
+        conv_op("fpn_c3p3", Cf[3], L3, 1, 0, ACT_NONE, &L4, 1, g_C[3], g_L);
+        conv_op("fpn_c2p2", Cf[2], L2, 1, 0, ACT_NONE, &L3, 1, g_C[2], g_L);
         const Tensor4 Ls[4] = {L2, L3, L4, L5};
         const char* pn[4] = {"fpn_p2", "fpn_p3", "fpn_p4", "fpn_p5"};
         const char* tn[4] = {"P2", "P3", "P4", "P5"};
         for (int l = 0; l < 4; ++l) {
             P[l] = T(Ls[l].H, Ls[l].W, 256);
-            conv_op(pn[l], Ls[l], P[l], 1, 1, ACT_NONE, nullptr, 0);
-            taps[tn[l]] = {P[l].p, P[l].sB(), dt};
+            g_P[l] = new_split_group(tn[l]);
+            conv_op(pn[l], Ls[l], P[l], 1, 1, ACT_NONE, nullptr, 0, g_L, g_P[l]);
+            taps[tn[l]] = {P[l].p, P[l].sB(), dt, g_P[l]};
             MRCNN_REQUIRE(P[l].H == fh[l] && P[l].W == fw[l], MRCNN_ERR_SHAPE, "pyramid level %d shape mismatch", l + 2);
         }
         // RPN on P2..P6 (P6 = P5 sub-sampled by 2: read in place through doubled strides)
@@ -818,6 +869,8 @@ void Model::build_maskrcnn()
             const Tensor4& src = P[l < 4 ? l : 3];
             const int sub = l < 4 ? 1 : 2;
             const PackedConv* pc = &convs.at("rpn_conv_shared");
+            g_rpn[l] = new_split_group("rpn_feat_P" + std::to_string(l + 2));
+            ScaledOp* const so_d = real ? new_scaled_op(pc, g_P[l < 4 ? l : 3], g_rpn[l]) : nullptr;
             ConvDesc d;
             d.dtype = dt;
             d.in = src.p; d.H = fh[l]; d.W = fw[l]; d.Cin = 256;
@@ -825,16 +878,17 @@ void Model::build_maskrcnn()
             d.wdtype = pc->wdtype;
             d.wgt = pc->wgt.p; d.KH = 3; d.KW = 3; d.stride = 1; d.padH = d.padW = 1;
             d.wgt_halo = pc->wgt_halo.p;
-            d.scale = pc->scale.as<float>(); d.shift = pc->shift.as<float>();
+            d.scale = so_d ? so_d->scale.as<float>() : nullptr; d.shift = so_d ? so_d->shift.as<float>() : nullptr;
             d.OH = fh[l]; d.OW = fw[l]; d.Cout = 512; d.Npad = pc->Npad;
             d.out = rpn_feat; d.out_sP = 512; d.out_sB = (long)fh[l] * fw[l] * 512; d.act = ACT_RELU;
             const PackedConv* hc = &convs.at("rpn_heads");
+            ScaledOp* const so_e = real ? new_scaled_op(hc, g_rpn[l], g_zero) : nullptr;     // the separate head launch undoes the exponent in its scale
             ConvDesc e;
             e.dtype = dt; e.out_f32 = 1;      // the box path consumes fp32 (ProposalLayer.swift:108-109)
             e.in = rpn_feat; e.H = fh[l]; e.W = fw[l]; e.Cin = 512;
             e.in_sW = 512; e.in_sH = (long)fw[l] * 512; e.in_sB = (long)fh[l] * fw[l] * 512;
             e.wdtype = hc->wdtype;
-            e.wgt = hc->wgt.p; e.scale = hc->scale.as<float>(); e.shift = hc->shift.as<float>();
+            e.wgt = hc->wgt.p; e.scale = so_e ? so_e->scale.as<float>() : nullptr; e.shift = so_e ? so_e->shift.as<float>() : nullptr;
             e.OH = fh[l]; e.OW = fw[l]; e.Cout = hc->Cout; e.Npad = hc->Npad;
             e.out = rpn_logits + lvl_off[l] * 2; e.out_sP = 2 * na; e.out_sB = (long)A * 2;
             e.out2 = rpn_deltas + lvl_off[l] * 4; e.out2_sP = 4 * na; e.out2_sB = (long)A * 4; e.n_split = 2 * na;
@@ -848,9 +902,18 @@ void Model::build_maskrcnn()
             f.head_out2 = rpn_deltas + lvl_off[l] * 4; f.head_out2_sP = 4 * na; f.head_out2_sB = (long)A * 4;
             f.head_split = 2 * na; f.head_cols = 6 * na;
             const bool fuse = rpn_head_frag.p && d.wgt_halo && conv_halo_head_eligible(f);
-            add([d, e, f, fuse](hipStream_t s, int batch) {
-                if (fuse && conv_halo_enabled()) { ConvDesc x = f; x.B = batch; conv_forward(s, x); return; }
+            const int g_r = g_rpn[l];
+            const size_t per_image = (size_t)fh[l] * fw[l] * 512;
+            add([d, e, f, fuse, self, g_r, per_image](hipStream_t s, int batch) {
+                // (a calibration pass needs the 512-channel tensor: it runs the two-launch form)
+                if (fuse && conv_halo_enabled() && !self->calib_phase) {
+                    ConvDesc x = f; x.B = batch;
+                    x.head_mul = ldexpf(1.0f, -self->sgroups[(size_t)g_r].exp);       // the fused heads see 2^e * relu(...): undone on their sums (exact)
+                    conv_forward(s, x);
+                    return;
+                }
                 ConvDesc x = d; x.B = batch; conv_forward(s, x);
+                if (self->calib_phase) self->observe_split(s, g_r, d.out, per_image * batch);
                 ConvDesc y = e; y.B = batch; conv_forward(s, y);
             });
         }
@@ -865,10 +928,12 @@ void Model::build_maskrcnn()
         pooled_mask = ar.alloc_e((size_t)Bm * max_det * mask_pool * mask_pool * 256, dt);
         mask_out = ar.alloc_f((size_t)Bm * max_det * 4 * mask_pool * mask_pool);
         taps["rois"] = {rois, (long)max_prop * 4, MRCNN_F32};
-        taps["pooled"] = {pooled, (long)max_prop * cls_pool * cls_pool * 256, dt};
+        g_pooled = new_split_group("pooled");
+        g_pooled_mask = new_split_group("pooled_mask");
+        taps["pooled"] = {pooled, (long)max_prop * cls_pool * cls_pool * 256, dt, g_pooled};
         taps["cls6"] = {cls6, (long)max_prop * 6, MRCNN_F32};
         taps["detections"] = {detections, (long)max_det * 6, MRCNN_F32};
-        taps["pooled_mask"] = {pooled_mask, (long)max_det * mask_pool * mask_pool * 256, dt};
+        taps["pooled_mask"] = {pooled_mask, (long)max_det * mask_pool * mask_pool * 256, dt, g_pooled_mask};
         taps["mask"] = {mask_out, (long)max_det * 4 * mask_pool * mask_pool, MRCNN_F32};
         void* pws = ar.alloc_b(ProposalWorkspace::bytes(Bm, A, K, max_prop));
         void* dws = ar.alloc_b(DetectionWorkspace::bytes(Bm, max_prop, max_det));
@@ -881,10 +946,184 @@ void Model::build_maskrcnn()
             prop_ws.bind(pws, Bm, A, K, max_prop);
             det_ws.bind(dws, Bm, max_prop, max_det);
         }
+        if (real) {
+            // the heads' layers: pooled → h1 → h2 → logits (0);  pooled_mask → t1..t4 → deconvolution output (0: its consumer is an fp32 dot)
+            cls_head.grp[0] = g_pooled; cls_head.grp[1] = new_split_group("cls_h1"); cls_head.grp[2] = new_split_group("cls_h2");
+            mask_head.grp[0] = g_pooled_mask;
+            for (int i = 1; i <= 4; ++i) mask_head.grp[i] = new_split_group("mask_t" + std::to_string(i));
+            for (int i = 0; i < 3; ++i) { cls_head.sop[i].g_in = cls_head.grp[i]; cls_head.sop[i].g_out = i < 2 ? cls_head.grp[i + 1] : g_zero; }
+            for (int i = 0; i < 5; ++i) { mask_head.sop[i].g_in = mask_head.grp[i]; mask_head.sop[i].g_out = i < 4 ? mask_head.grp[i + 1] : g_zero; }
+            cls_head.observe = [self](hipStream_t s, int g, const void* x, size_t n) { if (self->calib_phase) self->observe_split(s, g, x, n); };
+            mask_head.observe = cls_head.observe;
+        }
         if (pass == 0) { arena.alloc(ar.off); ar.base = arena.as<char>(); }
+    }
+    calib_buf.alloc(sgroups.size() * 32);
+    HIP_CHECK(hipMemset(calib_buf.p, 0, sgroups.size() * 32));
+    if (const char* e = getenv("MRCNN_SPLIT_EXP")) {          // measurement / tests: one exponent for every non-fixed group
+        for (auto& g : sgroups) if (!g.fixed) g.exp = atoi(e);
+        apply_split_exponents();
     }
     taps["cls_probs"] = {cls_head.probs, (long)max_prop * nc, MRCNN_F32};
     taps["cls_bbox"] = {cls_head.bbox, (long)max_prop * nc * 4, MRCNN_F32};
+}
+
+// ------------------------------------------------------------------------------------------------
+// scale-aware split (engine.h: SplitGroup)
+// ------------------------------------------------------------------------------------------------
+int Model::new_split_group(const std::string& name, bool fixed)
+{
+    SplitGroup g;
+    g.name = name; g.fixed = fixed;
+    sgroups.push_back(g);
+    return (int)sgroups.size() - 1;
+}
+
+ScaledOp* Model::new_scaled_op(const PackedConv* pc, int g_in, int g_out)
+{
+    sops.emplace_back(new ScaledOp);
+    init_scaled_op(*sops.back(), pc, g_in, g_out);
+    return sops.back().get();
+}
+
+// max |x| of a tensor (phase 1) / how many of its non-zero elements the three-part split cannot carry exactly (phase 2):
+// slot = [uint32 bits of the maximum | pad | small | inexact | counted] (32 B per group)
+__global__ __launch_bounds__(256) void k_split_observe(const float* __restrict__ x, size_t n, int phase, float small_thr, unsigned* __restrict__ slot)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    float mx = 0.f;
+    unsigned long long small = 0, inexact = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float a = fabsf(x[i]);
+        if (phase == 1) mx = fmaxf(mx, a);
+        else if (a != 0.f) { small += a < small_thr; inexact += a < 0.5f; }
+    }
+    __shared__ float s_mx[256];
+    __shared__ unsigned long long s_a[256], s_b[256];
+    s_mx[threadIdx.x] = mx; s_a[threadIdx.x] = small; s_b[threadIdx.x] = inexact;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            s_mx[threadIdx.x] = fmaxf(s_mx[threadIdx.x], s_mx[threadIdx.x + w]);
+            s_a[threadIdx.x] += s_a[threadIdx.x + w];
+            s_b[threadIdx.x] += s_b[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (phase == 1) atomicMax(slot, __float_as_uint(s_mx[0]));        // non-negative floats order like their bit patterns (NaN / inf sort above everything: reported)
+        else {
+            unsigned long long* c = reinterpret_cast<unsigned long long*>(slot + 2);
+            atomicAdd(c, s_a[0]);
+            atomicAdd(c + 1, s_b[0]);
+            if (blockIdx.x == 0) atomicAdd(c + 2, (unsigned long long)n);
+        }
+    }
+}
+
+void Model::observe_split(hipStream_t s, int group, const void* x, size_t n)
+{
+    if (!calib_phase || group < 0 || n == 0 || dtype != MRCNN_F32) return;
+    const SplitGroup& g = sgroups[(size_t)group];
+    if (g.fixed) return;
+    // phase 2 sees the stored (scaled) tensor: "small" = below 2^-8 of the group's maximum, "inexact" = below 0.5
+    const float small_thr = ldexpf(g.absmax, g.exp - 8);
+    const int grid = (int)((n + 256 * 16 - 1) / (256 * 16) < 2048 ? (n + 256 * 16 - 1) / (256 * 16) : 2048);
+    hipLaunchKernelGGL(k_split_observe, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, static_cast<const float*>(x), n, calib_phase, small_thr,
+                       calib_buf.as<unsigned>() + (size_t)group * 8);
+    HIP_CHECK(hipGetLastError());
+}
+
+void Model::apply_split_exponents()
+{
+    HIP_CHECK(hipStreamSynchronize(stream));
+    drop_graphs();                                   // the fused heads' multiplier and the samplers' are launch arguments
+    auto ex = [&](int g) { return g >= 0 ? sgroups[(size_t)g].exp : 0; };
+    auto refresh = [&](ScaledOp& op) {
+        const int ds = ex(op.g_out) - ex(op.g_in), eo = ex(op.g_out);
+        std::vector<float> sc(op.pc->h_scale), sh(op.pc->h_shift);
+        for (auto& v : sc) v = ldexpf(v, ds);        // exact: a power of two (a folded BatchNorm scale is nowhere near the fp32 range limits)
+        for (auto& v : sh) v = ldexpf(v, eo);
+        HIP_CHECK(hipMemcpy(op.scale.p, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(op.shift.p, sh.data(), sh.size() * 4, hipMemcpyHostToDevice));
+    };
+    for (auto& op : sops) refresh(*op);
+    for (auto& op : cls_head.sop) refresh(op);
+    for (auto& op : mask_head.sop) refresh(op);
+}
+
+void Model::calibrate_split(const uint8_t* rgb, int batch, int h, int w, int memspace, bool apply)
+{
+    MRCNN_REQUIRE(kind == MRCNN_MODEL_MASKRCNN, MRCNN_ERR_INVALID, "calibrate_split called on a non-MaskRCNN model");
+    MRCNN_REQUIRE(mode == MRCNN_F32S || mode == MRCNN_F32X3, MRCNN_ERR_UNSUPPORTED,
+                  "calibrate_split: only the split modes (MRCNN_F32S, MRCNN_F32X3) carry activations through fp16 parts; this model is scale-invariant as it is");
+    const size_t G = sgroups.size();
+    std::vector<float> det((size_t)batch * max_det * 6), msk((size_t)batch * max_det * 4 * mask_pool * mask_pool);
+    std::vector<unsigned> raw(G * 8);
+    std::vector<int> saved(G);
+    for (size_t g = 0; g < G; ++g) saved[g] = sgroups[g].exp;
+    auto run = [&](int phase) {
+        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(hipMemset(calib_buf.p, 0, G * 32));
+        calib_phase = phase;
+        try {
+            predict(rgb, batch, h, w, memspace, det.data(), msk.data(), true);
+        } catch (...) {
+            calib_phase = 0;
+            throw;
+        }
+        calib_phase = 0;
+        HIP_CHECK(hipMemcpy(raw.data(), calib_buf.p, G * 32, hipMemcpyDeviceToHost));
+    };
+    try {
+        // ---- phase 1: true magnitudes.  Every exponent 0 — or, when an activation of THIS model leaves the fp16 range there
+        // (the watchdog fails the predict: its maxima would be garbage), one uniform negative exponent that keeps it inside ----
+        int base = 0;
+        for (;;) {
+            for (auto& g : sgroups) g.exp = g.fixed ? 0 : base;
+            apply_split_exponents();
+            try {
+                run(1);
+                break;
+            } catch (const Error& e) {
+                if (e.code != MRCNN_ERR_UNSUPPORTED || base <= -24) throw;
+                base -= 6;
+            }
+        }
+        for (size_t g = 0; g < G; ++g) {
+            float mx;
+            memcpy(&mx, &raw[g * 8], 4);
+            mx = ldexpf(mx, -sgroups[g].exp);               // stored = 2^e * value
+            sgroups[g].absmax = mx;
+            MRCNN_REQUIRE(mx == mx && mx < 3.0e38f, MRCNN_ERR_UNSUPPORTED, "calibrate_split: tensor group '%s' holds inf / NaN", sgroups[g].name.c_str());
+        }
+        // ---- exponents: max |a| * 2^e in [2^11, 2^12) — 16x head room below the fp16 range, 0.5 = 2^-13 of the maximum exact ----
+        std::vector<int> chosen(G, 0);
+        for (size_t g = 0; g < G; ++g) {
+            if (sgroups[g].fixed || !(sgroups[g].absmax > 0.f)) continue;
+            int k = 0;
+            (void)frexpf(sgroups[g].absmax, &k);           // absmax = m * 2^k, 0.5 <= m < 1
+            int e = 12 - k;
+            chosen[g] = e < -24 ? -24 : (e > 48 ? 48 : e);
+        }
+        // ---- phase 2: with the chosen exponents — verifies them (range watchdog) and counts what a split still cannot carry ----
+        for (size_t g = 0; g < G; ++g) sgroups[g].exp = chosen[g];
+        apply_split_exponents();
+        run(2);
+        for (size_t g = 0; g < G; ++g) {
+            unsigned long long c[3];
+            memcpy(c, &raw[g * 8 + 2], 24);
+            sgroups[g].small = (long long)c[0]; sgroups[g].inexact = (long long)c[1]; sgroups[g].counted = (long long)c[2];
+        }
+        if (!apply) {
+            for (size_t g = 0; g < G; ++g) sgroups[g].exp = saved[g];
+            apply_split_exponents();
+        } else split_calibrated = true;
+    } catch (...) {
+        for (size_t g = 0; g < G; ++g) sgroups[g].exp = saved[g];
+        apply_split_exponents();
+        throw;
+    }
 }
 
 void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, float* det_out, float* masks_out, bool sync, bool fit)
@@ -913,7 +1152,7 @@ void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, f
     hipStreamCaptureStatus caller_capture = hipStreamCaptureStatusNone;
     if (use_graph) HIP_CHECK(hipStreamIsCapturing(s, &caller_capture));
     // (the scale-fit geometry is a launch argument of the first kernel: such calls are not replayed from a captured graph)
-    const bool plain = !use_graph || fit || timer.enabled || conv_profile.active || caller_capture != hipStreamCaptureStatusNone;
+    const bool plain = !use_graph || fit || timer.enabled || conv_profile.active || calib_phase || caller_capture != hipStreamCaptureStatusNone;
     if (plain) {
         enqueue_pipeline(s, batch, fit ? fitgeo : nullptr);
     } else {
@@ -994,11 +1233,15 @@ void Model::enqueue_pipeline(hipStream_t s, int batch, const int* fit)
     // PyramidROIAlign (classifier)
     PyramidMaps maps;
     for (int l = 0; l < 4; ++l) { maps.data[l] = P[l].p; maps.H[l] = P[l].H; maps.W[l] = P[l].W; maps.sB[l] = P[l].sB(); }
+    // the pyramid levels may sit at different split exponents: the sampler brings each to the exponent of its output (exact)
+    auto level_muls = [&](int g_out) { for (int l = 0; l < 4; ++l) maps.mul[l] = ldexpf(1.0f, sgroups[(size_t)g_out].exp - sgroups[(size_t)g_P[l]].exp); };
     const long prow = (long)cls_pool * cls_pool * 256;
     {
         TraceRange tr("PyramidROIAlign-Eval");
+        level_muls(g_pooled);
         roi_align_forward(s, maps, 256, 1, rois, (long)max_prop * 4, 4, max_prop, batch, cls_pool, roi_img_w, roi_img_h, pooled,
                           (long)max_prop * prow, prow, dtype);
+        if (calib_phase) observe_split(s, g_pooled, pooled, (size_t)batch * max_prop * prow);
     }
     timer.mark(s, "PyramidROIAlign-Eval");
     // TimeDistributedClassifier
@@ -1020,8 +1263,10 @@ void Model::enqueue_pipeline(hipStream_t s, int batch, const int* fit)
     // ... which also evaluates the mask layer's removeZeros predicate on the fp32 samples (before an fp16 store rounds them)
     {
         TraceRange tr("PyramidROIAlign-Eval");
+        level_muls(g_pooled_mask);
         roi_align_forward(s, maps, 256, 1, detections, (long)max_det * 6, 6, max_det, batch, mask_pool, roi_img_w, roi_img_h, pooled_mask,
                           (long)max_det * mrow, mrow, dtype, msel_ws.flags);
+        if (calib_phase) observe_split(s, g_pooled_mask, pooled_mask, (size_t)batch * max_det * mrow);
     }
     timer.mark(s, "PyramidROIAlign-Eval-Mask");
     // TimeDistributedMask
@@ -1101,6 +1346,9 @@ void Model::read_tensor(const std::string& name, int image, float* dst, int64_t 
     } else {
         HIP_CHECK(hipMemcpy(dst, static_cast<const float*>(it->second.base) + (size_t)image * n, (size_t)n * 4, hipMemcpyDeviceToHost));
     }
+    // a tensor of a split group is stored as 2^e * value: hand out the value (exact)
+    const int e = it->second.group >= 0 ? sgroups[(size_t)it->second.group].exp : 0;
+    if (e != 0) for (long i = 0; i < n; ++i) dst[i] = ldexpf(dst[i], -e);
 }
 
 }  // namespace mrcnn

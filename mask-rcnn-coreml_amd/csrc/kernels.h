@@ -64,6 +64,8 @@ struct PyramidMaps {
     const void* data[4];
     int H[4], W[4];
     long sB[4];          // batch stride in elements
+    float mul[4] = {1.f, 1.f, 1.f, 1.f};   // NHWC kernel: every sample of level l is multiplied by mul[l] — exact powers of two that bring
+                                           // levels stored at different split exponents to the output's (engine.h: SplitGroup)
 };
 // layout_nhwc = 1: maps are (B,H,W,C) and out is (B,n,P,P,C); 0: maps (B,C,H,W), out (B,n,C,P,P).
 // dtype: element type of the maps and of the output (MRCNN_F16 only with layout_nhwc = 1).
@@ -105,6 +107,10 @@ struct ConvDesc {
     // epilogue: y = act(acc*scale[n] + shift[n] + residual)
     const float* scale = nullptr;
     const float* shift = nullptr;
+    // `res` MAY ALIAS `out` (the engine writes every bottleneck block's output in place over its shortcut).  Contract of every
+    // epilogue form: the residual element at an address is loaded by the SAME thread that stores the output element there, and
+    // before that store; no epilogue may prefetch residual elements another thread (or a later pass) stores over.  Pinned by
+    // tests/test_gpu_conv_kernels.py::test_every_epilogue_is_safe_in_place_over_its_residual.
     const void* res = nullptr;
     long res_sB = 0, res_sH = 0, res_sW = 0;
     int res_shift = 0;           // residual read at (oh >> res_shift, ow >> res_shift): nearest 2× upsample when 1
@@ -138,6 +144,7 @@ struct ConvDesc {
     float* head_out = nullptr; float* head_out2 = nullptr;
     long head_out_sB = 0, head_out_sP = 0, head_out2_sB = 0, head_out2_sP = 0;
     int head_split = 0, head_cols = 0;
+    float head_mul = 1.f;        // the head's sums are multiplied by this before the bias (2^-e of this layer's output group: exact)
 };
 
 // Live per-kernel profile of the conv family: when a profiler is active on the calling thread every
@@ -179,6 +186,8 @@ void conv_halo_pack_head(hipStream_t s, const void* wgt_std, int Npad, int Cin, 
 bool conv_halo_eligible(const ConvDesc& d);
 bool conv_halo_head_eligible(const ConvDesc& d);
 bool conv_halo_enabled();                   // the run-time switch mrcnn_debug_set("conv_halo") / MRCNN_HALO
+bool conv_halo_debug_set(const char* key, int value);     // "halo_geo" 0 = the round-3 tile geometries (A/B, bit-identity tests) | 1
+bool conv_halo_packable(int KH, int KW, int Cin, int Npad);   // the filter shapes conv_halo_eligible can accept (re-tile only those)
 int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, int n_cus);
 
 // uint8 RGB (B,H,W,3) → fp32 (B, H+2*pad, W+2*pad, 4) minus mean, zero border, channel 3 = 0.

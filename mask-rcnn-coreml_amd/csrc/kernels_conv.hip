@@ -467,7 +467,7 @@ bool conv_debug_set(const char* key, int value)
     else if (k == "conv_halo") g_halo = value;
     else if (k == "conv_direct") g_direct = value;
     else if (k == "conv_min_blocks") g_min_blocks = value;
-    else return false;
+    else return conv_halo_debug_set(key, value);
     return true;
 }
 

@@ -33,10 +33,19 @@
 // same order, as every other kernel of the family.
 #include "conv_device.h"
 
+#include <stdlib.h>
+#include <string>
+
 namespace mrcnn {
 
-static constexpr int HALO_MAX_PX = 528;          // input pixels a tile may need (rows above/below + columns left/right included)
+static int env_int_halo(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
+static constexpr int HALO_MAX_SLOT = 640;        // LDS pixel slots of one plane (region rows x LDS pitch <= this)
 static constexpr unsigned HALO_OOB = 0xC0000000u;
+// Tile geometries (HaloArgs::geo) — which 64 / 128 output pixels a tile owns.  The K order, hence every output bit, is the same in all.
+enum { HALO_GEO_LINEAR = 0,      // BM consecutive output pixels (any W; tiles may span rows and straddle images)
+       HALO_GEO_ROW = 1,         // BM consecutive pixels inside ONE image row (OW % BM == 0): region 3 x (BM + 2)
+       HALO_GEO_2ROWS = 2 };     // 2 rows x 64 columns (BM = 128, OW % 64 == 0, OH % 2 == 0): region 4 x 66 = 264 pixels instead of 3 x 130 = 390
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -45,7 +54,13 @@ struct HaloArgs {
     ConvArgs a;
     const void* wgt_halo;        // conv_halo_pack layout
     int NH;                      // 16-channel slabs = Cin / 16
-    int single_row;              // OW % 128 == 0: a tile lies inside one image row (cropped halo, pitch 130)
+    int geo;                     // HALO_GEO_*
+    int ecols;                   // region columns staged per region row (W + 2, or the cropped BM + 2 / 66)
+    int pitch;                   // LDS pixel slots per region row (>= ecols; HALO_GEO_LINEAR pads it so that a wave's 32 pixels keep
+                                 // distinct slots mod 16 across a row wrap: conflict-free ds_read_b128, halo_lds_pitch)
+    int img_skew;                // HALO_GEO_LINEAR: extra slots per image boundary inside the region, so that consecutive output pixels keep
+                                 // consecutive slots mod 16 across the boundary too (2 W + skew = 0 mod 16)
+    int tiles_row, tiles_img;    // HALO_GEO_2ROWS: 64-column blocks per row, tiles per image
     int n_tiles;
     // fused 1x1 head (RPN: rpn_class_raw | rpn_bbox_pred on the ReLU'd output of this 3x3 layer): the layer's
     // own output is NOT stored; head_out / head_out2 receive columns [0, head_split) / [head_split, head_cols) + head_bias
@@ -54,6 +69,7 @@ struct HaloArgs {
     float* head_out; float* head_out2;
     long head_out_sB, head_out_sP, head_out2_sB, head_out2_sP;
     int head_split, head_cols;
+    float head_mul;              // head sums * head_mul + bias (ConvDesc::head_mul)
 };
 
 // 4 fp32 → PARTS × 4 fp16 (the same round-to-nearest chain as split_hi_mid_lo / split_hi_lo of conv_device.h)
@@ -79,15 +95,19 @@ __device__ __forceinline__ void split4(const u32x4 v, u32x2 (&out)[PARTS])
     }
 }
 
-template <int PARTS, int TN, bool HEAD = false, bool DBG = false, int TM = 2>       // TM = 1: 64-row tiles for grids that would not fill the chip
+// MAXPC = 16-B staging pieces per thread and slab: the region of a tile (rows x ecols pixels x 4 pieces) must fit MAXPC x 512.
+// Every thread loads, splits and parks MAXPC pieces per slab whether the region needs them or not, so the launcher picks the
+// smallest that fits: 2 (<= 256 pixels: the mask head, C5, the top pyramid levels), 3 (<= 384: the 4 x 66 regions of C4 and of
+// the two-row tiles — rounds 1-3 staged 5 pieces for all of them), 5 (anything up to 640).
+template <int PARTS, int TN, bool HEAD = false, bool DBG = false, int TM = 2, int MAXPC = 5>       // TM = 1: 64-row tiles for grids that would not fill the chip
 __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
 {
     const ConvArgs& a = ha.a;
     static_assert(!HEAD || TM == 2, "the fused head reduces over 128-row tiles");
+    static_assert(MAXPC >= 2 && MAXPC <= 5, "staging pieces per thread");
     constexpr int BM = 2 * TM * 32, WN = 4, BN = WN * TN * 32;
-    constexpr int PLANE = (HALO_MAX_PX + 1) * 32;         // bytes of one part of one slab (+ one dump slot: pieces beyond the region write there, unconditionally)
+    constexpr int PLANE = (HALO_MAX_SLOT + 1) * 32;       // bytes of one part of one slab (+ one dump slot: pieces beyond the region write there, unconditionally)
     constexpr int PBUF = PARTS * PLANE;                   // one plane buffer (all parts)
-    constexpr int MAXPC = (HALO_MAX_PX * 4 + 511) / 512;  // 64-B pieces per thread per slab (5)
     constexpr int STAGE = 8 * 32 * 36 * 4;                // the epilogue's wave-private tiles: they live in plane buffer 1
     constexpr int HPART = 4 * 128 * 32 * 4;               // HEAD: the four wave columns' partial head sums of a tile (they live in the planes)
     constexpr int HRUN = HEAD ? 128 * 32 * 4 : 0;         // HEAD: running head sum of the M tile over its N tiles
@@ -144,19 +164,31 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
     for (int unit = t_first; unit < t_end; unit += t_step)
     for (int inner = 0; inner < n_inner; ++inner, tile_par ^= 1) {
         const int mt = HEAD ? unit : unit / a.tiles_n, nt = HEAD ? inner : unit - mt * a.tiles_n;
-        const int m0 = mt * BM, n0 = nt * BN;
+        const int n0 = nt * BN;
         float* const s_tab = s_tab0 + tile_par * 2 * BN;
         // ---- geometry of the tile's input region (uniform) --------------------------------------------------------
-        const int m_last = (m0 + BM - 1 < a.M ? m0 + BM - 1 : a.M - 1);
-        const int b0 = m0 / ohw, rem0 = m0 - b0 * ohw, oh0 = rem0 / a.OW, ow0 = rem0 - oh0 * a.OW;
-        const int b1 = m_last / ohw, rem1 = m_last - b1 * ohw, oh1 = rem1 / a.OW;
         const int Hp = a.H + 2;
-        const int gy_first = b0 * Hp + oh0 + 1;                           // padded global row of the first output pixel
-        const int gy_last = b1 * Hp + oh1 + 1;
-        const int pitch = ha.single_row ? 130 : a.W + 2;
-        const int col0 = ha.single_row ? ow0 - 1 : -1;                    // input column of buffer column 0
-        const int rows = gy_last - gy_first + 3;
-        const int npx = rows * pitch;                                     // <= HALO_MAX_PX (host-checked bound)
+        const int pitch = ha.pitch, ecols = ha.ecols;
+        int m0, b0, gy_first, col0, rows;                 // m0: first output pixel (linear M index) of the tile — of its first row in HALO_GEO_2ROWS
+        if (ha.geo == HALO_GEO_2ROWS) {
+            b0 = mt / ha.tiles_img;
+            const int r = mt - b0 * ha.tiles_img, rp = r / ha.tiles_row, cb = r - rp * ha.tiles_row;
+            m0 = b0 * ohw + 2 * rp * a.OW + 64 * cb;
+            gy_first = b0 * Hp + 2 * rp + 1;
+            col0 = 64 * cb - 1;
+            rows = 4;
+        } else {
+            m0 = mt * BM;
+            const int m_last = (m0 + BM - 1 < a.M ? m0 + BM - 1 : a.M - 1);
+            b0 = m0 / ohw;
+            const int rem0 = m0 - b0 * ohw, oh0 = rem0 / a.OW, ow0 = rem0 - oh0 * a.OW;
+            const int b1 = m_last / ohw, rem1 = m_last - b1 * ohw, oh1 = rem1 / a.OW;
+            gy_first = b0 * Hp + oh0 + 1;                                 // padded global row of the first output pixel
+            const int gy_last = b1 * Hp + oh1 + 1;
+            col0 = ha.geo == HALO_GEO_ROW ? ow0 - 1 : -1;                 // input column of region column 0
+            rows = gy_last - gy_first + 3;
+        }
+        const int npx = rows * ecols;                                     // staged pixels: <= MAXPC * 128 (host-checked), rows * pitch <= HALO_MAX_SLOT
         // activations through a buffer resource that starts at image b0 and covers the (at most two) images the tile touches
         srd_t srdA;
         {
@@ -173,23 +205,33 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
         for (int i = 0; i < MAXPC; ++i) {
             const int j = t + 512 * i;
             const int px = j >> 2, qt = j & 3;
-            const int r = px / pitch, c = px - r * pitch;
+            const int r = px / ecols, c = px - r * ecols;
             const int gy = gy_first - 1 + r;
             const int b = gy / Hp, y = gy - b * Hp - 1;
             const int x = col0 + c;
             const bool ok = px < npx && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W && b < a.B;
             p_off[i] = ok ? (unsigned)(((long)(b - b0) * a.in_sB + (long)y * a.in_sH + (long)x * a.in_sW + qt * 4) * 4) : HALO_OOB;
             if (DBG && (a.dbg & 32)) p_off[i] = (unsigned)((px & 63) * 1024 + qt * 16);        // measurement only: a cache-hot source
-            p_lds[i] = px < npx ? (unsigned)(px * 32 + (((qt >> 1) ^ ((px >> 3) & 1)) << 4) + (qt & 1) * 8) : (unsigned)(HALO_MAX_PX * 32 + qt * 8);
+            const int slot = r * pitch + c + (b - b0) * ha.img_skew;
+            p_lds[i] = px < npx ? (unsigned)(slot * 32 + (((qt >> 1) ^ ((slot >> 3) & 1)) << 4) + (qt & 1) * 8) : (unsigned)(HALO_MAX_SLOT * 32 + qt * 8);
         }
-        // ---- this lane's two output pixels → index of their tap (0,0) input pixel in the region ------------------------
+        // ---- this lane's output pixels → slot of their tap (0,0) input pixel in the region; the wave's first output row -----
         int base_idx[TM];
+        int wave_row0;                                    // linear M index of the wave's first output pixel (its TM * 32 pixels are consecutive)
+        if (ha.geo == HALO_GEO_2ROWS) {
+            wave_row0 = m0 + wm * a.OW;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * (TM * 32) + i * 32 + l31;
-            const int mm = m < a.M ? m : a.M - 1;
-            const int b = mm / ohw, rem = mm - b * ohw, oh = rem / a.OW, ow = rem - oh * a.OW;
-            base_idx[i] = ha.single_row ? (ow - ow0) : (b * Hp + oh + 1 - gy_first) * pitch + ow;
+            for (int i = 0; i < TM; ++i) base_idx[i] = wm * pitch + i * 32 + l31;
+        } else {
+            wave_row0 = m0 + wm * (TM * 32);
+            const int ow0 = col0 + 1;                     // HALO_GEO_ROW: the tile's first column
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = wave_row0 + i * 32 + l31;
+                const int mm = m < a.M ? m : a.M - 1;
+                const int b = mm / ohw, rem = mm - b * ohw, oh = rem / a.OW, ow = rem - oh * a.OW;
+                base_idx[i] = ha.geo == HALO_GEO_ROW ? (ow - ow0) : (b * Hp + oh + 1 - gy_first) * pitch + ow + (b - b0) * ha.img_skew;
+            }
         }
         // this wave's filter-fragment streams: granule (n0/32 + wn*TN + j), one KB per step
         unsigned sob[TN];
@@ -205,12 +247,14 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
                 src ? *reinterpret_cast<const float4*>(src + n0 + c) : make_float4(fill, fill, fill, fill);
         }
 
-#define HALO_LOAD(I) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(st[I]) : "v"(p_off[I]), "s"(srdA) : "memory");
+#define HALO_LOAD(I) if constexpr ((I) < MAXPC) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(st[(I) < MAXPC ? (I) : 0]) : "v"(p_off[(I) < MAXPC ? (I) : 0]), "s"(srdA) : "memory");
 #define HALO_LOADS()  { HALO_LOAD(0) HALO_LOAD(1) HALO_LOAD(2) HALO_LOAD(3) HALO_LOAD(4) }
 #define HALO_ADVANCE() { _Pragma("unroll") for (int i = 0; i < MAXPC; ++i) p_off[i] += (p_off[i] < HALO_OOB ? 64u : 0u); }
-#define HALO_PIN()    asm volatile("" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]), "+v"(st[4]));
-#define HALO_WRITE1(BUF, I)                                                                                      \
-    {                                                                                                            \
+#define HALO_PIN1(I)  if constexpr ((I) < MAXPC) asm volatile("" : "+v"(st[(I) < MAXPC ? (I) : 0]));
+#define HALO_PIN()    { HALO_PIN1(0) HALO_PIN1(1) HALO_PIN1(2) HALO_PIN1(3) HALO_PIN1(4) }
+#define HALO_WRITE1(BUF, I_)                                                                                     \
+    if constexpr ((I_) < MAXPC) {                                                                                \
+        constexpr int I = (I_) < MAXPC ? (I_) : 0;                                                               \
         u32x2 parts[PARTS];                                                                                      \
         if (DBG && dbg_nosplit) { _Pragma("unroll") for (int p = 0; p < PARTS; ++p) { parts[p][0] = st[I][0]; parts[p][1] = st[I][p]; } } \
         else split4<PARTS>(st[I], parts);                                                                        \
@@ -230,7 +274,6 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
         }                                                                                                        \
     }
 #define HALO_BPIN(BV) { _Pragma("unroll") for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(BV[j])); }
-        static_assert(MAXPC == 5, "the staging statements are spelled out for five pieces per thread");
         u32x4 st[MAXPC];
         u32x4 bv0[TN], bv1[TN], bv2[TN], bv3[TN];
 
@@ -291,12 +334,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
             else HALO_AFRAGS(av, PB, ((TAP) + 1) % 9)                                                            \
         }                                                                                                        \
         /* the next slab, piece by piece over taps 4..7 (a burst in one step would leave both waves of a SIMD in VALU) */    \
-        if ((TAP) == 4 && next_slab) { HALO_PIN() HALO_WRITE1((PB) ^ 1, 0) HALO_WRITE1((PB) ^ 1, 1) }            \
-        if ((TAP) == 5 && next_slab) HALO_WRITE1((PB) ^ 1, 2)                                                    \
-        if ((TAP) == 6 && next_slab) HALO_WRITE1((PB) ^ 1, 3)                                                    \
-        if ((TAP) == 7 && next_slab) HALO_WRITE1((PB) ^ 1, 4)                                                    \
+        if ((TAP) == 4 && next_slab) { HALO_PIN() HALO_WRITE1((PB) ^ 1, 0) HALO_WRITE1((PB) ^ 1, 4) }            \
+        if ((TAP) == 5 && next_slab) HALO_WRITE1((PB) ^ 1, 1)                                                    \
+        if ((TAP) == 6 && next_slab) HALO_WRITE1((PB) ^ 1, 2)                                                    \
+        if ((TAP) == 7 && next_slab) HALO_WRITE1((PB) ^ 1, 3)                                                    \
         if (DBG && (dbg_nodma || dbg_noloads)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  \
-        else if ((TAP) <= 2 && next_slab) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TN + 5) : "memory");      \
+        else if ((TAP) <= 2 && next_slab) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TN + MAXPC) : "memory");  \
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TN) : "memory");                                       \
         HALO_BPIN(bv0) HALO_BPIN(bv1) HALO_BPIN(bv2) HALO_BPIN(bv3)                                              \
         if ((TAP) == 7 && !(DBG && dbg_nobar)) __syncthreads();                                                  \
@@ -326,6 +369,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
 #undef HALO_WRITE
 #undef HALO_WRITE1
 #undef HALO_PIN
+#undef HALO_PIN1
 #undef HALO_ADVANCE
 #undef HALO_LOADS
 #undef HALO_LOAD
@@ -333,7 +377,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
         // tile's prologue only writes plane buffer 0 and the other s_tab, and its first write to buffer 1 comes after its own
         // prologue barrier, i.e. after every wave has left this epilogue): full-line stores, no block barrier.
         if constexpr (!HEAD) {
-            conv_epilogue_wave<BN, TM, TN>(a, acc, reinterpret_cast<float*>(planes + PBUF) + wave * (32 * 36), s_tab, m0 + wm * (TM * 32), n0,
+            conv_epilogue_wave<BN, TM, TN>(a, acc, reinterpret_cast<float*>(planes + PBUF) + wave * (32 * 36), s_tab, wave_row0, n0,
                                            wn * TN * 32, lane);
         } else {
             // ---- fused head: y = act(acc * scale + shift) stays in registers; head[pixel][0..32) += y[pixel][64 channels] . Wh ----
@@ -402,9 +446,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
                 sum += part[(3 * 128 + row) * 32 + col];
                 if (!last) h_run[o] = sum;
                 else {
-                    const int m = m0 + row;
+                    const int m = ha.geo == HALO_GEO_2ROWS ? m0 + (row >> 6) * a.OW + (row & 63) : m0 + row;
                     if (m < a.M && col < ha.head_cols) {
-                        const float y = sum + ha.head_bias[col];
+                        const float y = sum * ha.head_mul + ha.head_bias[col];
                         const int b = m / ohw, pix = m - b * ohw;
                         if (col < ha.head_split) ha.head_out[(long)b * ha.head_out_sB + (long)pix * ha.head_out_sP + col] = y;
                         else ha.head_out2[(long)b * ha.head_out2_sB + (long)pix * ha.head_out2_sP + (col - ha.head_split)] = y;
@@ -468,15 +512,59 @@ void conv_halo_pack(hipStream_t s, const void* wgt_std, int Npad, int Cin, DevBu
     HIP_CHECK(hipGetLastError());
 }
 
-// Largest input region (pixels) any tile of this geometry needs; > HALO_MAX_PX → the layer stays on the 128-row kernel.
-static int halo_region_bound(int H, int W)
+// ---- tile geometry (host) -------------------------------------------------------------------------------------------
+// Rows of the input region a tile of bm CONSECUTIVE output pixels may touch (HALO_GEO_LINEAR): the rows its pixels lie in, one
+// above and one below, and two zero rows per image boundary inside the tile.
+static int halo_linear_rows(int H, int W, int bm)
 {
-    if (W % 128 == 0) return 3 * 130;
-    const int rows_touched = (127 + W - 1) / W + 1;
-    // a tile may span several images (two zero rows between consecutive ones): at most this many boundaries inside 128 pixels
+    const int rows_touched = (bm - 1 + W - 1) / W + 1;
     const long ohw = (long)H * W;
-    const int boundaries = ohw % 128 == 0 ? 0 : (int)((127 + ohw - 1) / ohw);
-    return (rows_touched + 2 * boundaries + 2) * (W + 2);
+    const int boundaries = ohw % bm == 0 ? 0 : (int)((bm - 1 + ohw - 1) / ohw);
+    return rows_touched + 2 * boundaries + 2;
+}
+
+static int g_halo_geo = env_int_halo("MRCNN_HALO_GEO", 1);     // 0: the round-3 geometries (one-row 3 x 130 regions, five staging pieces, pitch W + 2) — A/B and bit-identity tests
+
+struct HaloGeo { int geo, ecols, pitch, img_skew, tiles_row, tiles_img, rows, maxpc; bool ok; };
+
+// Geometry of the tiles of a layer for block tiles of bm rows.  Which geometry is used never changes a result: every tile sums
+// its K in the same (slab, tap, part) order.
+static HaloGeo halo_geometry(int H, int W, int bm)
+{
+    HaloGeo g{};
+    int slots_extra = 0;
+    if (g_halo_geo == 0) {              // round 3
+        const bool row = W % 128 == 0;
+        g.geo = row ? HALO_GEO_ROW : HALO_GEO_LINEAR;
+        g.ecols = g.pitch = row ? 130 : W + 2;
+        g.rows = row ? 3 : halo_linear_rows(H, W, bm);
+        g.maxpc = 5;
+        g.ok = g.rows * g.ecols <= 528;
+        return g;
+    }
+    if (bm == 128 && W % 64 == 0 && W >= 128 && H % 2 == 0) {
+        g.geo = HALO_GEO_2ROWS; g.ecols = g.pitch = 66; g.rows = 4;
+        g.tiles_row = W / 64; g.tiles_img = (H / 2) * g.tiles_row;
+    } else if (W % bm == 0) {
+        g.geo = HALO_GEO_ROW; g.ecols = g.pitch = bm + 2; g.rows = 3;
+    } else {
+        g.geo = HALO_GEO_LINEAR; g.ecols = W + 2; g.rows = halo_linear_rows(H, W, bm);
+        // a wave's 32 consecutive output pixels wrap into the next region row when W % 32 != 0 and their slot index jumps by
+        // pitch - W: a multiple of 16 keeps the 16 lanes of every ds_read_b128 group on distinct 16-B slots of the 256-B bank row
+        // (the mask head's W = 14 with pitch 16 was a 2-way conflict on every fragment read: tools/lds_bank_model.py)
+        // ... and across an image boundary inside a tile (three region rows further: the two zero rows between images) the slot
+        // index jumps by 3 pitch - W + 1: img_skew extra slots per boundary make that = 1 mod 16 as well
+        g.pitch = W % 32 == 0 ? W + 2 : W + 16;
+        const long ohw = (long)H * W;
+        const int boundaries = ohw % bm == 0 ? 0 : (int)((bm - 1 + ohw - 1) / ohw);
+        g.img_skew = g.pitch == W + 16 ? (16 - (2 * W) % 16) % 16 : 0;
+        if (g.rows * g.pitch + boundaries * g.img_skew > HALO_MAX_SLOT) { g.pitch = W + 2; g.img_skew = 0; }
+        slots_extra = boundaries * g.img_skew;
+    }
+    const int px = g.rows * g.ecols;
+    g.maxpc = px <= 256 ? 2 : px <= 384 ? 3 : 5;
+    g.ok = px <= 640 && g.rows * g.pitch + slots_extra <= HALO_MAX_SLOT;
+    return g;
 }
 
 bool conv_halo_eligible(const ConvDesc& d)
@@ -489,17 +577,47 @@ bool conv_halo_eligible(const ConvDesc& d)
     if (d.OH != d.H || d.OW != d.W || d.Cin % 64 != 0 || d.Npad % 256 != 0 || d.Cout % 4 != 0) return false;
     if (d.deconv2 || d.out2 || d.sel_partial || d.act == ACT_SIGMOID || d.res) return false;
     if (d.H >= 32760 || d.W >= 32760 || (double)d.in_sB * 8.0 >= 2.0e9) return false;
-    return halo_region_bound(d.H, d.W) <= HALO_MAX_PX;
+    // A property of the layer, never of the batch: both tile heights the launcher may pick must have a geometry that fits.
+    // (Round 3 asked for a region of <= 528 pixels of 128 consecutive output pixels; that bound is kept for the geometries it
+    // admitted, so no layer changes its kernel — hence its K order — between rounds except the ones the two-row tiles ADD:
+    // W % 64 == 0 with even H, e.g. the 192-wide P3 level of 1536² inputs.)
+    const bool legacy_ok = (d.W % 128 == 0 ? 3 * 130 : halo_linear_rows(d.H, d.W, 128) * (d.W + 2)) <= 528;
+    if (g_halo_geo == 0) return legacy_ok;
+    const bool rows2_ok = d.W % 64 == 0 && d.H % 2 == 0;
+    return (legacy_ok || rows2_ok) && halo_geometry(d.H, d.W, 128).ok && halo_geometry(d.H, d.W, 64).ok;
+}
+
+template <int PARTS, int TN, bool HEAD, int TM>
+static void halo_launch_pc(hipStream_t s, const HaloArgs& ha, int maxpc, int grid)
+{
+    if (maxpc == 2) {
+        if constexpr (!HEAD) hipLaunchKernelGGL((k_conv_halo<PARTS, TN, HEAD, false, TM, 2>), dim3(grid), dim3(512), 0, s, ha);
+        else hipLaunchKernelGGL((k_conv_halo<PARTS, TN, HEAD, false, TM, 3>), dim3(grid), dim3(512), 0, s, ha);        // (no fused level has a region this small)
+    } else if (maxpc == 3) hipLaunchKernelGGL((k_conv_halo<PARTS, TN, HEAD, false, TM, 3>), dim3(grid), dim3(512), 0, s, ha);
+    else hipLaunchKernelGGL((k_conv_halo<PARTS, TN, HEAD, false, TM, 5>), dim3(grid), dim3(512), 0, s, ha);
 }
 
 template <int PARTS>
-static void halo_launch(hipStream_t s, const HaloArgs& ha, int bm, int bn, int grid)
+static void halo_launch(hipStream_t s, const HaloArgs& ha, int bm, int bn, int maxpc, int grid)
 {
-    if (ha.a.dbg && !ha.head_w && bn == 256 && PARTS == 3) { hipLaunchKernelGGL((k_conv_halo<3, 2, false, true>), dim3(grid), dim3(512), 0, s, ha); return; }   // ablations (tools/halo_ablate.py)
-    if (ha.head_w) hipLaunchKernelGGL((k_conv_halo<PARTS, 2, true>), dim3(grid), dim3(512), 0, s, ha);
-    else if (bn == 256) hipLaunchKernelGGL((k_conv_halo<PARTS, 2>), dim3(grid), dim3(512), 0, s, ha);
-    else if (bm == 128) hipLaunchKernelGGL((k_conv_halo<PARTS, 1>), dim3(grid), dim3(512), 0, s, ha);
-    else hipLaunchKernelGGL((k_conv_halo<PARTS, 1, false, false, 1>), dim3(grid), dim3(512), 0, s, ha);
+    if (ha.a.dbg && !ha.head_w && bn == 256 && PARTS == 3) {           // ablations (tools/halo_ablate.py)
+        if (maxpc <= 3) hipLaunchKernelGGL((k_conv_halo<3, 2, false, true, 2, 3>), dim3(grid), dim3(512), 0, s, ha);
+        else hipLaunchKernelGGL((k_conv_halo<3, 2, false, true, 2, 5>), dim3(grid), dim3(512), 0, s, ha);
+        return;
+    }
+    if (ha.head_w) halo_launch_pc<PARTS, 2, true, 2>(s, ha, maxpc, grid);
+    else if (bn == 256) halo_launch_pc<PARTS, 2, false, 2>(s, ha, maxpc, grid);
+    else if (bm == 128) halo_launch_pc<PARTS, 1, false, 2>(s, ha, maxpc, grid);
+    else halo_launch_pc<PARTS, 1, false, 1>(s, ha, maxpc, grid);
+}
+
+// the filter shapes conv_halo_eligible can accept: only those are re-tiled at load (engine.hip: pack_conv_oihw)
+bool conv_halo_packable(int KH, int KW, int Cin, int Npad) { return KH == 3 && KW == 3 && Cin % 64 == 0 && Npad % 256 == 0; }
+
+bool conv_halo_debug_set(const char* key, int value)
+{
+    if (std::string(key) == "halo_geo") { g_halo_geo = value; return true; }
+    return false;
 }
 
 // A fused head needs 256-column tiles (the head's K groups are walked per wave column) and enough M tiles to occupy the chip
@@ -528,16 +646,18 @@ int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, i
     ha.a = a;
     ha.wgt_halo = d.wgt_halo;
     ha.NH = d.Cin / 16;
-    ha.single_row = d.W % 128 == 0 ? 1 : 0;
+    const HaloGeo g = halo_geometry(d.H, d.W, bm);
+    MRCNN_REQUIRE(g.ok, MRCNN_ERR_SHAPE, "halo kernel: no tile geometry for %dx%d (conv_halo_eligible should have said so)", d.H, d.W);
+    ha.geo = g.geo; ha.ecols = g.ecols; ha.pitch = g.pitch; ha.img_skew = g.img_skew; ha.tiles_row = g.tiles_row; ha.tiles_img = g.tiles_img;
     ha.n_tiles = a.tiles_m * a.tiles_n;
     ha.head_w = d.head_w; ha.head_bias = d.head_bias; ha.head_out = d.head_out; ha.head_out2 = d.head_out2;
     ha.head_out_sB = d.head_out_sB; ha.head_out_sP = d.head_out_sP; ha.head_out2_sB = d.head_out2_sB; ha.head_out2_sP = d.head_out2_sP;
-    ha.head_split = d.head_split; ha.head_cols = d.head_cols;
+    ha.head_split = d.head_split; ha.head_cols = d.head_cols; ha.head_mul = d.head_mul;
     const int units = d.head_w ? a.tiles_m : ha.n_tiles;
     int grid = units < n_cus ? units : n_cus;
     if (grid >= 8) grid &= ~7;                  // a multiple of 8: every XCD runs the same number of blocks
-    if (parts == 3) halo_launch<3>(s, ha, bm, bn, grid);
-    else halo_launch<2>(s, ha, bm, bn, grid);
+    if (parts == 3) halo_launch<3>(s, ha, bm, bn, g.maxpc, grid);
+    else halo_launch<2>(s, ha, bm, bn, g.maxpc, grid);
     return bn;
 }
 

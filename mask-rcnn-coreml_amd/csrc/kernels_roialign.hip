@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void k_roi_align_nhwc(PyramidMaps maps, int C,
     int all_nonzero = 1;
     const int H = maps.H[g.level], W = maps.W[g.level];
     const T* m = static_cast<const T*>(maps.data[g.level]) + (size_t)b * maps.sB[g.level];
+    const float mul = maps.mul[g.level];               // 1, or the exact power of two between this level's split exponent and the output's
     for (int e = t; e < total; e += 256) {
         const int cq = e % C4, pt = e / C4;
         const int py = pt / P, px = pt % P;
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256) void k_roi_align_nhwc(PyramidMaps maps, int C,
             v.y = bilerp(tl.y, tr.y, bl.y, br.y, s.lx, s.ly);
             v.z = bilerp(tl.z, tr.z, bl.z, br.z, s.lx, s.ly);
             v.w = bilerp(tl.w, tr.w, bl.w, br.w, s.lx, s.ly);
+            v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
         }
         all_nonzero &= (v.x != 0.0f && v.y != 0.0f && v.z != 0.0f && v.w != 0.0f) ? 1 : 0;
         st4<T>(o + ((size_t)pt * C4 + cq) * 4, v);

@@ -52,6 +52,10 @@ def unletterbox_boxes(detections: np.ndarray, h: int, w: int, H: int, W: int) ->
     d[:, 1] = np.clip(x1 / wx, 0.0, 1.0)
     d[:, 2] = np.clip((y2 - 1.0) / hy, 0.0, 1.0)
     d[:, 3] = np.clip((x2 - 1.0) / wx, 0.0, 1.0)
+    # zero-padded rows stay all-zero (like mrcnn_unletterbox_boxes): an all-zero box mapped through the letterbox would come out
+    # with a non-zero far edge and read as a detection to a consumer that finds the padding by all-zero rows
+    pad = ~np.any(np.asarray(detections, dtype=np.float64)[:, :4] != 0.0, axis=1)
+    d[pad, :4] = 0.0
     return d
 
 

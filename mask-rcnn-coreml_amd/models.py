@@ -133,6 +133,44 @@ class MaskRCNN(_Model):
         _lib.check(_lib.lib().mrcnn_model_check_range(self._h, C.byref(t)))
         return bool(t.value)
 
+    # -- scale-aware split (include/maskrcnn_hip.h: mrcnn_model_calibrate_split) ----------------------
+    def calibrate_split(self, images, apply: bool = True) -> Dict[str, int]:
+        """One calibration predict on `images` (numpy (B,H,W,3) uint8 or a CUDA tensor): a power-of-two pre-scale per tensor
+        group so that the split modes carry every activation like fp32 whatever the checkpoint's scale.  apply=False only
+        diagnoses.  Returns the totals of the pass (see split_report for the per-group view)."""
+        if isinstance(images, np.ndarray):
+            imgs = np.ascontiguousarray(images, dtype=np.uint8)
+            B, H, W, _ = imgs.shape
+            _lib.check(_lib.lib().mrcnn_model_calibrate_split(self._h, imgs.ctypes.data, B, H, W, _lib.HOST, int(apply)))
+        else:
+            B, H, W, _ = images.shape
+            _lib.check(_lib.lib().mrcnn_model_calibrate_split(self._h, images.data_ptr(), B, H, W, _lib.DEVICE, int(apply)))
+        return {k: self.get_int(k) for k in ("split_small_inputs", "split_inexact_inputs", "split_inputs_counted", "split_min_exponent",
+                                             "split_max_exponent", "split_calibrated")}
+
+    def split_report(self):
+        """[{name, exponent, fixed, absmax, small_inputs, inexact_inputs, inputs_counted}] per tensor group."""
+        out = []
+        st = _lib.SplitGroupStat()
+        for i in range(self.get_int("split_groups")):
+            _lib.check(_lib.lib().mrcnn_model_split_group_stat(self._h, i, C.byref(st)))
+            out.append({"name": st.name.decode(), "exponent": int(st.exponent), "fixed": bool(st.fixed), "absmax": float(st.absmax),
+                        "small_inputs": int(st.small_inputs), "inexact_inputs": int(st.inexact_inputs), "inputs_counted": int(st.inputs_counted)})
+        return out
+
+    @property
+    def split_exponents(self) -> np.ndarray:
+        n = C.c_int(0)
+        _lib.check(_lib.lib().mrcnn_model_get_split_exponents(self._h, None, 0, C.byref(n)))
+        e = np.zeros(n.value, np.int32)
+        _lib.check(_lib.lib().mrcnn_model_get_split_exponents(self._h, e.ctypes.data, e.size, C.byref(n)))
+        return e
+
+    @split_exponents.setter
+    def split_exponents(self, exps):
+        e = np.ascontiguousarray(exps, dtype=np.int32)
+        _lib.check(_lib.lib().mrcnn_model_set_split_exponents(self._h, e.ctypes.data, e.size))
+
     # -- parity / profiling hooks -------------------------------------------------------------------
     def read_tensor(self, name: str, image_index: int = 0) -> np.ndarray:
         cnt = C.c_int64(0)

@@ -46,6 +46,12 @@ public final class MaskRCNN {
     public let width: Int32
     public let height: Int32
 
+    /// `computeMode` defaults to `.f32x3`: fp32 tensors whose products are formed on the fp16 matrix cores from a three-part split
+    /// (2.5x the exact-fp32 mode).  Two things differ from `.f32` and a host must know them: (1) the mode carries activations
+    /// below 0.5 to 2^-25 ABSOLUTE rather than 2^-24 relative — call `calibrateSplit` once (a power-of-two pre-scale per tensor,
+    /// folded into the layers at no run-time cost) to make it fp32-grade at any activation scale; (2) an activation that leaves
+    /// the fp16 range (|v| >= 65504) fails the predict with MRCNN_ERR_UNSUPPORTED ("load the model with MRCNN_F32") instead of
+    /// returning a wrong result.  `.f32` has neither property.
     public init(contentsOf url: URL, maxBatch: Int32 = 1, computeMode: ComputeMode = .f32x3) throws {
         try check(mrcnn_model_load(Int32(MRCNN_MODEL_MASKRCNN.rawValue), url.path, maxBatch, computeMode.raw, &handle))
         var v: Int64 = 0
@@ -53,6 +59,12 @@ public final class MaskRCNN {
         try check(mrcnn_model_get_int(handle, "mask_size", &v)); maskSide = Int(v)
         try check(mrcnn_model_get_int(handle, "image_width", &v)); width = Int32(v)
         try check(mrcnn_model_get_int(handle, "image_height", &v)); height = Int32(v)
+    }
+    /// Source compatibility with the first version of this shim (`halfPrecision: Bool`): `true` = `.f16`, `false` = `.f32`
+    /// (the exact-fp32 engine that initialiser used to select — NOT the new `.f32x3` default).
+    @available(*, deprecated, message: "use init(contentsOf:maxBatch:computeMode:); false maps to .f32, true to .f16")
+    public convenience init(contentsOf url: URL, maxBatch: Int32 = 1, halfPrecision: Bool) throws {
+        try self.init(contentsOf: url, maxBatch: maxBatch, computeMode: halfPrecision ? .f16 : .f32)
     }
     deinit { mrcnn_model_destroy(handle) }
 

@@ -31,7 +31,7 @@ def _build_example(tmp_path, name="maskrcnn_predict"):
 
 def test_header_is_plain_c_and_cxx(tmp_path):
     src = tmp_path / "use.c"
-    src.write_text('#include "maskrcnn_hip.h"\nint main(void) { mrcnn_tensor t; mrcnn_param p; mrcnn_detection d; mrcnn_conv_shape_stat s;'
+    src.write_text('#include "maskrcnn_hip.h"\n#include "maskrcnn_hip_test.h"\nint main(void) { mrcnn_tensor t; mrcnn_param p; mrcnn_detection d; mrcnn_conv_shape_stat s;'
                    ' (void)t; (void)p; (void)d; (void)s; return (int)MRCNN_OK; }\n')
     for cc, std in (("gcc", "-std=c99"), ("gcc", "-std=c11"), ("g++", "-std=c++17")):
         lang = ["-x", "c++"] if cc == "g++" else []
@@ -41,6 +41,8 @@ def test_header_is_plain_c_and_cxx(tmp_path):
     hdr = open(os.path.join(INC, "maskrcnn_hip.h")).read()
     import re
     assert sorted(re.findall(r"^#include\s+(\S+)", hdr, re.M)) == ["<stddef.h>", "<stdint.h>"]     # no HIP / C++ / torch headers
+    thdr = open(os.path.join(INC, "maskrcnn_hip_test.h")).read()
+    assert re.findall(r"^#include\s+(\S+)", thdr, re.M) == ['"maskrcnn_hip.h"']
 
 
 def test_c_host_builds_and_fails_loudly_without_gpu(tmp_path):

@@ -294,6 +294,9 @@ HALO_SHAPES = [  # B, H, W, Cin, Cout — every geometry class of the tile's inp
     (1, 32, 32, 320, 64),       # 64 output columns (narrowest tile), 20 slabs
     (4, 48, 40, 128, 192),      # Npad 256, ragged last M tile (7680 = 60 tiles exactly) — and 40-wide rows
     (1, 33, 47, 192, 128),      # M = 1551: ragged last tile, odd sizes
+    (2, 8, 192, 64, 256),       # round 4: W = 192 (the P3 level of 1536² inputs) — eligible through the two-row tiles only; 3 column blocks per row
+    (1, 6, 256, 64, 256),       # two-row tiles, 4 column blocks: the left / right image border inside the row of tiles
+    (3, 10, 128, 128, 512),     # two-row tiles with 512 columns (the fused-head layers' shape), three images
 ]
 
 
@@ -335,3 +338,65 @@ def test_halo_kernel_results_do_not_depend_on_the_batch(shape, dtype):
         np.testing.assert_array_equal(conv(x[b:b + 1], w, 3, 1, None, shift, None, 1, dtype)[0], y[b], err_msg=f"image {b}")
     if B >= 4:
         np.testing.assert_array_equal(conv(x[1:4], w, 3, 1, None, shift, None, 1, dtype), y[1:4])
+
+
+@pytest.mark.parametrize("dtype", ["f32x3", "f32s"])
+@pytest.mark.parametrize("shape", [(2, 128, 128, 64, 256), (1, 256, 256, 64, 512), (3, 64, 64, 256, 256), (20, 14, 14, 256, 256), (5, 16, 16, 64, 512),
+                                   (2, 72, 56, 96, 300), (1, 32, 32, 320, 64), (9, 14, 14, 256, 256), (1, 64, 64, 256, 256), (1, 6, 256, 64, 256)])
+def test_halo_tile_geometries_are_bit_identical(shape, dtype):
+    """Round 4 changed WHICH output pixels a halo tile owns (two rows x 64 columns instead of one row x 128 where W >= 128:
+    4 x 66 = 264 staged pixels per slab instead of 3 x 130 = 390), how many staging pieces a thread moves (2 / 3 / 5, by region
+    size) and the LDS pitch of multi-row regions (conflict-free fragment reads) — none of which may change a single output bit:
+    every tile sums its K in the same (slab, tap, part) order.  mrcnn_debug_set("halo_geo", 0) runs the round-3 geometries."""
+    B, H, W, Ci, Co = shape
+    rng = np.random.default_rng(sum(shape) + 29)
+    x = (rng.standard_normal((B, H, W, Ci)) * 3).astype(np.float32)
+    w = (rng.standard_normal((Co, 3, 3, Ci)) * np.sqrt(2.0 / (9 * Ci))).astype(np.float32)
+    scale = (0.5 + rng.random(Co)).astype(np.float32)
+    shift = (rng.standard_normal(Co) * 0.1).astype(np.float32)
+    y = conv(x, w, 3, 1, scale, shift, None, 1, dtype)
+    try:
+        L.check(L.lib().mrcnn_debug_set(b"halo_geo", 0))
+        y3 = conv(x, w, 3, 1, scale, shift, None, 1, dtype)
+    finally:
+        L.check(L.lib().mrcnn_debug_set(b"halo_geo", 1))
+    np.testing.assert_array_equal(y, y3)
+
+
+ALIAS_SHAPES = [  # B, H, W, Cin, Cout, k — one per epilogue form a residual layer can take (the mode x tile class decides which)
+    (2, 64, 64, 256, 1024, 1),     # C4 branch2c: 128-column tiles (split: wave-private fp32 epilogue; f16: wave_h; f32: wave)
+    (1, 32, 32, 512, 2048, 1),     # C5 branch2c: narrowed N tile on an under-filled grid
+    (2, 40, 40, 64, 256, 1),       # C2 branch2c: two K steps
+    (1, 33, 47, 192, 300, 3),      # ragged everything: Cout 300 (Npad 384), M = 1551: the block-staged general epilogue
+    (8, 64, 64, 256, 256, 3),      # 256-row ping-pong kernel in fp16 (direct epilogue, residual inside the store loop)
+]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "f32s", "f32x3"])
+@pytest.mark.parametrize("shape", ALIAS_SHAPES)
+def test_every_epilogue_is_safe_in_place_over_its_residual(shape, dtype):
+    """The engine writes every bottleneck block's output IN PLACE over its shortcut (engine.hip: `to = sc`, res == out).  That
+    rests on a contract of every epilogue form — a residual element is loaded by the thread that stores the output element at the
+    same address, before the store (ConvDesc::res) — which nothing pinned (ADVICE r3): here each form runs with the output aliased
+    onto the residual (mrcnn_debug_set("conv2d_alias_res", 1)) and must give the bits of the separate-buffer run, for every
+    conv_direct policy (block-staged / direct / wave-private)."""
+    B, H, W, Ci, Co, k = shape
+    if dtype == "f16" and Ci % 64:
+        pytest.skip("the fp16 kernels step K by 64 channels")
+    rng = np.random.default_rng(sum(shape) + 31)
+    x = rng.standard_normal((B, H, W, Ci), np.float32)
+    w = (rng.standard_normal((Co, k, k, Ci), np.float32) * np.float32(1.0 / np.sqrt(k * k * Ci)))
+    scale = (0.5 + rng.random(Co)).astype(np.float32)
+    shift = rng.standard_normal(Co).astype(np.float32) * np.float32(0.1)
+    res = rng.standard_normal((B, H, W, Co), np.float32)
+    lib = L.lib()
+    for direct in (0, 1, 2, 3):
+        try:
+            L.check(lib.mrcnn_debug_set(b"conv_direct", direct))
+            y = conv(x, w, k, 1, scale, shift, res, 1, dtype)
+            L.check(lib.mrcnn_debug_set(b"conv2d_alias_res", 1))
+            y_inplace = conv(x, w, k, 1, scale, shift, res, 1, dtype)
+        finally:
+            L.check(lib.mrcnn_debug_set(b"conv2d_alias_res", 0))
+            L.check(lib.mrcnn_debug_set(b"conv_direct", 3))
+        np.testing.assert_array_equal(y_inplace, y, err_msg=f"conv_direct {direct}")

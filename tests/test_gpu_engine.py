@@ -597,3 +597,31 @@ def test_predict_scalefit_equals_letterbox_then_predict(pkg, small_model, mode):
     with pytest.raises(L.MrcnnError):
         m.predict(rng.integers(0, 256, (1, 64, 64, 3), dtype=np.uint8))      # the exact-size entry still refuses other sizes
     pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None
+
+
+@pytest.mark.parametrize("dtype", ["f32x3", "f32s"])
+def test_halo_tile_geometry_leaves_predict_bit_identical(pkg, weights_mod, tmp_path_factory, dtype):
+    """Round 4: the halo kernel's tiles at P2 / P3 of a 512² input are two rows x 64 columns (round 3: one row x 128), incl. the
+    instantiation that carries the fused RPN heads; which pixels a tile owns must not change one bit of a predict
+    (mrcnn_debug_set("halo_geo", 0) = the round-3 geometries)."""
+    import importlib
+    L = importlib.import_module("mask-rcnn-coreml_amd._lib")
+    models = importlib.import_module("mask-rcnn-coreml_amd.models")
+    d, cfg = make_model_dir(tmp_path_factory, pkg, weights_mod, "geo512", architecture="resnet50", input_image_shape=(512, 512, 3),
+                            num_classes=21, pre_nms_max_proposals=1000, max_proposals=128, max_detections=32)
+    B = 2
+    m = models.load_maskrcnn(d, max_batch=B, compute_dtype=dtype)
+    images = rand_images(B, 512, 512, seed=5)
+    det, mask = m.predict(images)
+    taps = {n: [m.read_tensor(n, b).copy() for b in range(B)] for n in ("rpn_probs", "rpn_deltas", "P2", "P3", "P4", "P5")}
+    try:
+        L.check(L.lib().mrcnn_debug_set(b"halo_geo", 0))
+        det3, mask3 = m.predict(images)
+        for n, want in taps.items():
+            for b in range(B):
+                np.testing.assert_array_equal(m.read_tensor(n, b), want[b], err_msg=f"{n} image {b}")
+    finally:
+        L.check(L.lib().mrcnn_debug_set(b"halo_geo", 1))
+    np.testing.assert_array_equal(det, det3)
+    np.testing.assert_array_equal(mask, mask3)
+    assert (det[..., 5] > 0).sum() > 0

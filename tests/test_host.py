@@ -106,13 +106,18 @@ def test_c_abi_exports_every_declared_symbol(pkg):
     lib_mod = importlib.import_module("mask-rcnn-coreml_amd._lib")
     if not os.path.exists(lib_mod.SO_PATH):
         pytest.skip("libmaskrcnn_hip.so not built (run python __graft_entry__.py)")
-    hdr = open(os.path.join(ROOT, "include", "maskrcnn_hip.h")).read()
-    declared = sorted(set(re.findall(r"MRCNN_API\s+[\w\s\*]+?\b(mrcnn_\w+)\s*\(", hdr)))
-    assert len(declared) >= 25
     L = lib_mod.lib()
-    missing = [s for s in declared if not hasattr(L, s)]
-    assert not missing, missing
-    assert sorted(lib_mod.EXPORTED_SYMBOLS) == declared
+    for header, names, floor in (("maskrcnn_hip.h", lib_mod.EXPORTED_SYMBOLS, 25), ("maskrcnn_hip_test.h", lib_mod.TEST_SYMBOLS, 5)):
+        hdr = open(os.path.join(ROOT, "include", header)).read()
+        declared = sorted(set(re.findall(r"MRCNN_API\s+[\w\s\*]+?\b(mrcnn_\w+)\s*\(", hdr)))
+        assert len(declared) >= floor
+        missing = [s for s in declared if not hasattr(L, s)]
+        assert not missing, (header, missing)
+        assert sorted(names) == declared, header
+    # the drop-in header carries no test / measurement knob
+    prod = open(os.path.join(ROOT, "include", "maskrcnn_hip.h")).read()
+    for knob in ("mrcnn_debug_set", "mrcnn_bench_conv", "mrcnn_conv2d_nhwc", "mrcnn_model_conv_profile"):
+        assert knob + "(" not in prod.replace(" (", "("), knob
     assert L.mrcnn_version().startswith(b"maskrcnn_hip")
 
 
@@ -287,6 +292,18 @@ def test_unletterbox_boxes_follow_the_norm_boxes_convention(pkg):
     # boxes in the black borders clip to the frame
     border = np.array([[0.0, 0.0, 50 / (H - 1), 1.0, 1, 0.9]])
     assert ev.unletterbox_boxes(border, h, w, H, W)[0, 2] == 0.0
+    # zero-padded rows (the detections array always has maxDetections rows) stay all-zero, in the mirror and in the C entry:
+    # for a down-scaled source an all-zero box would otherwise come back with a non-zero far edge
+    padded = np.zeros((4, 6), np.float32)
+    padded[0] = [0.3, 0.3, 0.6, 0.6, 2, 0.9]
+    back = ev.unletterbox_boxes(padded, 2000, 3000, 1024, 1024)
+    assert np.all(back[1:] == 0.0) and np.any(back[0, :4] != padded[0, :4])
+    lib_mod = __import__("importlib").import_module("mask-rcnn-coreml_amd._lib")
+    if os.path.exists(lib_mod.SO_PATH):
+        c = padded.copy()
+        lib_mod.check(lib_mod.lib().mrcnn_unletterbox_boxes(c.ctypes.data, 4, 6, 2000, 3000, 1024, 1024))
+        assert np.all(c[1:] == 0.0)
+        np.testing.assert_allclose(c[0, :4], back[0, :4].astype(np.float32), atol=1e-7)
 
 
 def test_detection_agreement_counts(pkg):
