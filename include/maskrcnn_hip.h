@@ -159,9 +159,15 @@ typedef struct mrcnn_model mrcnn_model;
  * engine); a smaller one is carried to 2^-25 ABSOLUTE, rounded to nearest (the third part reaches the fp16 subnormal
  * step; this also relies on the MFMA not flushing fp16 subnormals, which gfx950 does not), i.e. about 14 significant bits
  * at |a| = 1e-3.  An output is therefore off by at most 2^-25 * sum|w| beyond fp32 summation noise: invisible while a layer's
- * activations are O(1) or larger (every tensor of a BatchNorm-folded trunk), but unlike fp32 the mode is NOT scale-invariant —
- * a model whose activations are uniformly tiny should be loaded with MRCNN_F32 (tests/test_gpu_conv_kernels.py,
- * profiles/r03_split_scale_curve.txt).
+ * activations are O(1) or larger (every tensor of a BatchNorm-folded trunk), but unlike fp32 the RAW split is not scale-invariant
+ * (tests/test_gpu_conv_kernels.py, profiles/r03_split_scale_curve.txt).  mrcnn_model_calibrate_split (below) removes the caveat:
+ * a power-of-two exponent per tensor group, folded into the layers at no run-time cost, keeps every tensor's maximum in
+ * [2^11, 2^12) — the mode is then fp32-grade for a checkpoint at ANY activation scale (tests/test_gpu_split_scale.py) and a
+ * checkpoint whose raw activations would leave the fp16 range runs instead of tripping the watchdog.
+ * End-to-end tolerance of MRCNN_F16 (BASELINE configs[3]; tests/test_gpu_fullsize.py::test_fp16_mode_end_to_end_bar, full size,
+ * batch 8, against the fp32 CPU oracle): >= 95 % of the detections have a partner with the same class id and a box within 2e-3
+ * (normalized coordinates), matched scores within 5e-4, matched masks within 3e-2; the fp32 modes' bars are 1e-4 / 1e-5 / 2e-4
+ * with >= 99.9 % matched.
  * In MRCNN_F16 and MRCNN_F32S every convolution watches its outputs: if one leaves the fp16 range (|v| >= 65504,
  * which the next layer could not read), the synchronous predict fails with MRCNN_ERR_UNSUPPORTED instead of
  * returning saturated results (mrcnn_model_get_int key "range_overflows" counts such calls). */
@@ -195,6 +201,18 @@ MRCNN_API int mrcnn_maskrcnn_predict(mrcnn_model* model, const uint8_t* rgb, int
 MRCNN_API int mrcnn_maskrcnn_predict_scalefit(mrcnn_model* model, const uint8_t* rgb, int batch, int height, int width, int memspace,
                                               float* detections, float* masks);
 MRCNN_API int mrcnn_unletterbox_boxes(float* detections, int64_t n, int64_t stride, int src_h, int src_w, int model_h, int model_w);
+/* Pipelined host entry — the evaluate loop of EvaluateCommand.swift:167-179 (images handed over one call after the other, the
+ * hand-over inside the per-image time) with the hand-over of batch i + 1 OVERLAPPED with the computation of batch i:
+ *   mrcnn_maskrcnn_submit   copies a batch of host images (pinned memory makes the copy asynchronous) on the handle's copy
+ *                           stream into one of two staging buffers and enqueues its predict behind the copy; returns at once.
+ *                           At most two submissions may be in flight.
+ *   mrcnn_maskrcnn_collect  waits for the OLDEST submission and copies its records to the host buffers (*batch = its size);
+ *                           reports that batch's range-watchdog status like the synchronous predict.
+ * The loop:  submit(b0); for i: submit(b[i+1]); collect(results of b[i]).   Results are bit-identical to
+ * mrcnn_maskrcnn_predict's (the same launches on the same stream); do not interleave it with the synchronous entry while a
+ * submission is in flight.  examples/maskrcnn_predict_stream.c is this loop as a plain-C host. */
+MRCNN_API int mrcnn_maskrcnn_submit(mrcnn_model* model, const uint8_t* rgb_host, int batch, int height, int width);
+MRCNN_API int mrcnn_maskrcnn_collect(mrcnn_model* model, float* detections_host, float* masks_host, int* batch);
 /* Same, but only enqueues on the model's stream (no synchronisation); device buffers only. */
 MRCNN_API int mrcnn_maskrcnn_predict_async(mrcnn_model* model, const uint8_t* rgb, int batch, int height,
                                            int width, float* detections, float* masks);

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "mrcnn_config_get_classifier_path", "mrcnn_config_get_mask_path", "mrcnn_layer_create",
     "mrcnn_layer_set_weight_data", "mrcnn_layer_output_shapes", "mrcnn_layer_evaluate", "mrcnn_layer_destroy",
     "mrcnn_iou", "mrcnn_model_load", "mrcnn_model_destroy", "mrcnn_model_set_stream", "mrcnn_maskrcnn_predict",
-    "mrcnn_maskrcnn_predict_async", "mrcnn_classifier_predict", "mrcnn_mask_predict", "mrcnn_model_get_int",
+    "mrcnn_maskrcnn_predict_async", "mrcnn_maskrcnn_submit", "mrcnn_maskrcnn_collect", "mrcnn_classifier_predict", "mrcnn_mask_predict", "mrcnn_model_get_int",
     "mrcnn_model_read_tensor", "mrcnn_model_enable_timing", "mrcnn_model_stage_ms", "mrcnn_model_enable_graph",
     "mrcnn_detections_decode", "mrcnn_mask_to_u8", "mrcnn_paste_masks", "mrcnn_generate_anchors",
     "mrcnn_letterbox_geometry", "mrcnn_letterbox_rgb", "mrcnn_model_check_range", "mrcnn_model_calibrate_split", "mrcnn_model_split_group_stat",
@@ -120,6 +120,8 @@ def lib():
     L.mrcnn_maskrcnn_predict_scalefit.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     L.mrcnn_unletterbox_boxes.argtypes = [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
     L.mrcnn_maskrcnn_predict_async.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.mrcnn_maskrcnn_submit.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
+    L.mrcnn_maskrcnn_collect.argtypes = [vp, vp, vp, C.POINTER(C.c_int)]
     L.mrcnn_classifier_predict.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
     L.mrcnn_mask_predict.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     L.mrcnn_model_get_int.argtypes = [vp, cp, i64p]

@@ -566,6 +566,20 @@ extern "C" int mrcnn_unletterbox_boxes(float* detections, int64_t n, int64_t str
         }
     });
 }
+extern "C" int mrcnn_maskrcnn_submit(mrcnn_model* model, const uint8_t* rgb_host, int batch, int height, int width)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model, MRCNN_ERR_INVALID, "null model");
+        model->m.submit(rgb_host, batch, height, width);
+    });
+}
+extern "C" int mrcnn_maskrcnn_collect(mrcnn_model* model, float* detections, float* masks, int* batch)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model, MRCNN_ERR_INVALID, "null model");
+        model->m.collect(detections, masks, batch);
+    });
+}
 extern "C" int mrcnn_maskrcnn_predict_async(mrcnn_model* model, const uint8_t* rgb, int batch, int height, int width,
                                             float* detections, float* masks)
 {

@@ -222,6 +222,21 @@ struct Model {
     hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;
     double gpu_busy_ms = 0;
     long predict_calls = 0;
+    // ---- pipelined host entry (mrcnn_maskrcnn_submit / _collect): two batches in flight -----------------------------------
+    // The uint8 images of batch i + 1 cross PCIe on a copy stream while batch i computes; the records of a finished batch wait
+    // in their own device slot until the host collects them (EvaluateCommand.swift:167-179 hands images over one by one: the
+    // hand-over is part of its per-image time).
+    struct PipeSlot {
+        DevBuf rgb, det, mask, flag;
+        hipEvent_t ev_in = nullptr, ev_done = nullptr;
+        int batch = 0;
+        bool busy = false;
+    };
+    PipeSlot pipe[2];
+    hipStream_t pipe_in = nullptr, pipe_out = nullptr;     // H2D of the images / D2H of the records
+    long pipe_submitted = 0, pipe_collected = 0;
+    void submit(const uint8_t* rgb_host, int batch, int h, int w);
+    void collect(float* det_host, float* masks_host, int* batch_out);
     // Held by the stand-alone TimeDistributed*Layer plugins around stage → forward → unstage: every layer instance
     // shares the cached sub-model's head scratch (stage_in, h1/h2, cls6, feat, full) but launches on its own stream.
     std::mutex eval_mu;

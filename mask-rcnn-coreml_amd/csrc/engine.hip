@@ -598,6 +598,12 @@ void Model::drop_graphs()
 Model::~Model()
 {
     drop_graphs();
+    for (auto& sl : pipe) {
+        if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
+        if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+    }
+    if (pipe_in) (void)hipStreamDestroy(pipe_in);
+    if (pipe_out) (void)hipStreamDestroy(pipe_out);
     if (ev_p0) (void)hipEventDestroy(ev_p0);
     if (ev_p1) (void)hipEventDestroy(ev_p1);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -1202,6 +1208,68 @@ void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, f
                      "not valid; load the model with MRCNN_F32", mode == MRCNN_F16 ? "MRCNN_F16" : (mode == MRCNN_F32S ? "MRCNN_F32S" : "MRCNN_F32X3"));
             }
         }
+    }
+}
+
+// ---- pipelined host entry ------------------------------------------------------------------------------------------------
+void Model::submit(const uint8_t* rgb_host, int batch, int h, int w)
+{
+    MRCNN_REQUIRE(kind == MRCNN_MODEL_MASKRCNN, MRCNN_ERR_INVALID, "submit called on a non-MaskRCNN model");
+    MRCNN_REQUIRE(rgb_host, MRCNN_ERR_INVALID, "null buffer");
+    MRCNN_REQUIRE(h == H && w == W, MRCNN_ERR_SHAPE, "image is %dx%d, the model expects %dx%d", h, w, H, W);
+    MRCNN_REQUIRE(batch >= 1 && batch <= max_batch, MRCNN_ERR_SHAPE, "batch %d outside 1..%d", batch, max_batch);
+    MRCNN_REQUIRE(pipe_submitted - pipe_collected < 2, MRCNN_ERR_INVALID, "two batches are in flight already: call mrcnn_maskrcnn_collect first");
+    PipeSlot& sl = pipe[pipe_submitted & 1];
+    const int HW = 4 * mask_pool * mask_pool;
+    if (!pipe_in) {
+        HIP_CHECK(hipStreamCreateWithFlags(&pipe_in, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&pipe_out, hipStreamNonBlocking));
+    }
+    if (!sl.ev_in) {
+        HIP_CHECK(hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
+        sl.rgb.alloc((size_t)max_batch * H * W * 3);
+        sl.det.alloc((size_t)max_batch * max_det * 6 * 4);
+        sl.mask.alloc((size_t)max_batch * max_det * HW * 4);
+        sl.flag.alloc(sizeof(int));
+    }
+    hipStream_t s = stream;
+    // the images cross PCIe on the copy stream (under whatever the compute stream is doing: the previous batch's predict) ...
+    HIP_CHECK(hipMemcpyAsync(sl.rgb.p, rgb_host, (size_t)batch * H * W * 3, hipMemcpyHostToDevice, pipe_in));
+    HIP_CHECK(hipEventRecord(sl.ev_in, pipe_in));
+    // ... and the compute stream picks them up when they have arrived
+    HIP_CHECK(hipStreamWaitEvent(s, sl.ev_in, 0));
+    HIP_CHECK(hipMemcpyAsync(d_rgb, sl.rgb.p, (size_t)batch * H * W * 3, hipMemcpyDeviceToDevice, s));
+    enqueue_pipeline(s, batch);
+    HIP_CHECK(hipMemcpyAsync(sl.det.p, detections, (size_t)batch * max_det * 6 * 4, hipMemcpyDeviceToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(sl.mask.p, mask_out, (size_t)batch * max_det * HW * 4, hipMemcpyDeviceToDevice, s));
+    if (mode != MRCNN_F32) HIP_CHECK(hipMemcpyAsync(sl.flag.p, range_flag.p, sizeof(int), hipMemcpyDeviceToDevice, s));
+    HIP_CHECK(hipEventRecord(sl.ev_done, s));
+    sl.batch = batch;
+    sl.busy = true;
+    ++pipe_submitted;
+}
+
+void Model::collect(float* det_host, float* masks_host, int* batch_out)
+{
+    MRCNN_REQUIRE(det_host && masks_host, MRCNN_ERR_INVALID, "null buffer");
+    MRCNN_REQUIRE(pipe_submitted > pipe_collected, MRCNN_ERR_INVALID, "nothing was submitted");
+    PipeSlot& sl = pipe[pipe_collected & 1];
+    const int HW = 4 * mask_pool * mask_pool;
+    int tripped = 0;
+    HIP_CHECK(hipStreamWaitEvent(pipe_out, sl.ev_done, 0));
+    HIP_CHECK(hipMemcpyAsync(det_host, sl.det.p, (size_t)sl.batch * max_det * 6 * 4, hipMemcpyDeviceToHost, pipe_out));
+    HIP_CHECK(hipMemcpyAsync(masks_host, sl.mask.p, (size_t)sl.batch * max_det * HW * 4, hipMemcpyDeviceToHost, pipe_out));
+    if (mode != MRCNN_F32) HIP_CHECK(hipMemcpyAsync(&tripped, sl.flag.p, sizeof(int), hipMemcpyDeviceToHost, pipe_out));
+    HIP_CHECK(hipStreamSynchronize(pipe_out));
+    if (batch_out) *batch_out = sl.batch;
+    sl.busy = false;
+    ++pipe_collected;
+    ++predict_calls;
+    if (tripped) {
+        ++range_overflows;
+        fail(MRCNN_ERR_UNSUPPORTED, "an activation left the fp16 range (|v| >= 65504) in a split / fp16 compute mode: the results of this batch are "
+             "not valid; calibrate the split (mrcnn_model_calibrate_split) or load the model with MRCNN_F32");
     }
 }
 

@@ -471,17 +471,10 @@ bool conv_debug_set(const char* key, int value)
     return true;
 }
 
-void conv_forward(hipStream_t s, const ConvDesc& d)
+// The launch arguments every kernel of the family shares (geometry, strides, epilogue fields) from a layer description.
+static void conv_fill_args(const ConvDesc& d, ConvArgs& a)
 {
     const bool half = d.dtype == MRCNN_F16;
-    const int wdtype = d.wdtype < 0 ? d.dtype : d.wdtype;
-    // fp32 activations, fp16 filters: two-pass (wdtype F16) or exact three-pass (wdtype F32X3, a filter-side tag) fp16 MFMA
-    const bool split = d.dtype == MRCNN_F32 && (wdtype == MRCNN_F16 || wdtype == MRCNN_F32X3);
-    MRCNN_REQUIRE(d.dtype == MRCNN_F32 || half, MRCNN_ERR_UNSUPPORTED, "conv: dtype %d", d.dtype);
-    MRCNN_REQUIRE(wdtype == d.dtype || split, MRCNN_ERR_UNSUPPORTED, "conv: activation dtype %d with filter dtype %d", d.dtype, wdtype);
-    const int bk = half ? 64 : 32;
-    MRCNN_REQUIRE(d.Cin % bk == 0, MRCNN_ERR_SHAPE, "conv: Cin %d not a multiple of %d", d.Cin, bk);
-    ConvArgs a;
     a.in = d.in; a.wgt = d.wgt; a.scale = d.scale; a.shift = d.shift; a.res = d.res; a.out = d.out; a.out2 = d.out2;
     a.in_sB = d.in_sB; a.in_sH = d.in_sH; a.in_sW = d.in_sW;
     a.res_sB = d.res_sB; a.res_sH = d.res_sH; a.res_sW = d.res_sW;
@@ -499,6 +492,32 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     a.range_flag = g_range_flag;
     a.dbg = pp_policy().dbg;
     a.sel_w = d.sel_w; a.sel_cid = d.sel_cid; a.sel_partial = d.sel_partial;
+}
+
+// May the epilogue use 16-B vector stores / residual loads for this layer?
+static int conv_vec_ok(const ConvDesc& d, const ConvArgs& a)
+{
+    const bool half = d.dtype == MRCNN_F16;
+    auto al = [](const void* p, size_t n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
+    const int cpt = half ? 8 : 4;        // columns per epilogue thread: 16 B of the activation type
+    return a.ncols % cpt == 0 && d.out2 == nullptr && d.out_sP % cpt == 0 && d.out_sB % cpt == 0 && al(d.out, 16) &&
+               (!d.scale || al(d.scale, 16)) && (!d.shift || al(d.shift, 16)) &&
+               (!d.res || (d.res_sW % cpt == 0 && d.res_sH % cpt == 0 && d.res_sB % cpt == 0 && al(d.res, 16))) &&
+               (!d.deconv2 || (d.Cout % cpt == 0 && d.out_sH % cpt == 0 && d.out_sW % cpt == 0));
+}
+
+void conv_forward(hipStream_t s, const ConvDesc& d)
+{
+    const bool half = d.dtype == MRCNN_F16;
+    const int wdtype = d.wdtype < 0 ? d.dtype : d.wdtype;
+    // fp32 activations, fp16 filters: two-pass (wdtype F16) or exact three-pass (wdtype F32X3, a filter-side tag) fp16 MFMA
+    const bool split = d.dtype == MRCNN_F32 && (wdtype == MRCNN_F16 || wdtype == MRCNN_F32X3);
+    MRCNN_REQUIRE(d.dtype == MRCNN_F32 || half, MRCNN_ERR_UNSUPPORTED, "conv: dtype %d", d.dtype);
+    MRCNN_REQUIRE(wdtype == d.dtype || split, MRCNN_ERR_UNSUPPORTED, "conv: activation dtype %d with filter dtype %d", d.dtype, wdtype);
+    const int bk = half ? 64 : 32;
+    MRCNN_REQUIRE(d.Cin % bk == 0, MRCNN_ERR_SHAPE, "conv: Cin %d not a multiple of %d", d.Cin, bk);
+    ConvArgs a;
+    conv_fill_args(d, a);
     MRCNN_REQUIRE(!d.sel_partial || (d.deconv2 && d.sel_w && d.sel_cid && d.Cout % 128 == 0 && d.Npad == 4 * d.Cout && !d.out2),
                   MRCNN_ERR_INVALID, "conv: the selected-class mode needs a 2x2 transposed convolution with Cout a multiple of 128");
     // Tile choice: the widest N tile the packed weights allow, narrowed while the grid would leave
@@ -508,12 +527,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     a.tiles_m = (a.M + BM_DEFAULT - 1) / BM_DEFAULT;
     int bn = bn_max;
     while (bn > 32 && !d.sel_partial && (long)a.tiles_m * (d.Npad / bn) < g_min_blocks) bn >>= 1;     // (selected-class mode: fixed 128-channel parts)
-    auto al = [](const void* p, size_t n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
-    const int cpt = half ? 8 : 4;        // columns per epilogue thread: 16 B of the activation type
-    a.vec_ok = a.ncols % cpt == 0 && d.out2 == nullptr && d.out_sP % cpt == 0 && d.out_sB % cpt == 0 && al(d.out, 16) &&
-               (!d.scale || al(d.scale, 16)) && (!d.shift || al(d.shift, 16)) &&
-               (!d.res || (d.res_sW % cpt == 0 && d.res_sH % cpt == 0 && d.res_sB % cpt == 0 && al(d.res, 16))) &&
-               (!d.deconv2 || (d.Cout % cpt == 0 && d.out_sH % cpt == 0 && d.out_sW % cpt == 0));
+    a.vec_ok = conv_vec_ok(d, a);
     a.tiles_n = d.Npad / bn;
     MRCNN_REQUIRE(!d.sel_partial || (bn == 128 && a.vec_ok), MRCNN_ERR_INVALID, "conv: the selected-class mode needs the 128-wide vector epilogue");
     // Epilogue without block barriers wherever the layer allows: fp32 tensors through wave-private LDS tiles (conv_epilogue_wave:

@@ -105,6 +105,73 @@ def detection_agreement(det_a: np.ndarray, det_b: np.ndarray, box_tol: float = 1
             "max_mask_diff_behind_presence_mismatch": max(after, default=0.0), "masks_behind_presence_mismatch": len(after)}
 
 
+def mask_flip_causes(det_a: np.ndarray, det_b: np.ndarray, pooled_a: np.ndarray, pooled_b: np.ndarray, masks_a, masks_b,
+                     box_tol: float = 1e-4, coord_tol: float = 1e-6) -> dict:
+    """Why the masks of two engines differ in PRESENCE for one image — the reference's removeZeros cliff, proven from the taps.
+
+    The mask layer skips a detection whose pooled 14x14x256 row holds an exactly-zero sample (TimeDistributedClassifierLayer.swift:
+    116-127 via TimeDistributedMaskLayer.swift:52).  A sample is exactly zero when the sampler lands outside the map (a box clipped
+    to the frame whose last sample position sits an ulp beyond the edge: a whole line of zeros) or when the bilinear interpolation
+    of a sign change cancels exactly (chance: ~1e-7 per sample, 5 million samples per image).  Two evaluations that differ in the
+    last bits can therefore disagree on whether a row is kept, and — since the kept rows are written COMPACTED and the class is
+    looked up at the compact index (TimeDistributedMaskLayer.swift:58-89, :71) — every later mask of that image then sits one row
+    further up on one side, under a class that may differ.
+
+    det_* (n,6), pooled_* = the engines' own pooled_mask taps (n rows), masks_* (n,S,S).  Checked:
+      * write set, per side: with n_kept = the rows whose pooled row has no exact zero, a row holds a mask iff it is kept AND its
+        index is below n_kept (:83 writes the kept rows at their original index, :87-89 then zero rows [n_kept, D)) — the
+        reference's rule applied to the side's OWN samples, so every presence difference between the sides follows from
+        zero-sample differences, nothing else;
+      * every matched pair (same class id, box within box_tol) whose zero predicate differs — a FLIP — is explained iff the two
+        boxes agree within coord_tol per coordinate (last bits; they may be identical, the pyramids differ in the last bits too)
+        and the zero side's row is not zero altogether.
+    Returns {"flips", "explained", "unexplained": [...], "write_set_ok", "presence_mismatch", "masks_behind_flip"} —
+    masks_behind_flip = matched pairs behind the first flip: their rows / class lookups are shifted on one side, compared by nobody."""
+    a = np.asarray(det_a, np.float32); b = np.asarray(det_b, np.float32)
+    pa = np.asarray(pooled_a, np.float32).reshape(a.shape[0], -1); pb = np.asarray(pooled_b, np.float32).reshape(b.shape[0], -1)
+    ka = np.asarray(masks_a, np.float32).reshape(a.shape[0], -1); kb = np.asarray(masks_b, np.float32).reshape(b.shape[0], -1)
+    ia = np.flatnonzero(a[:, 5] > 0); ib = np.flatnonzero(b[:, 5] > 0)
+    zero_a = np.array([bool(np.any(pa[i] == 0.0)) for i in range(a.shape[0])]); zero_b = np.array([bool(np.any(pb[j] == 0.0)) for j in range(b.shape[0])])
+
+    def write_set_ok(zero, k):
+        # TimeDistributedMaskLayer.swift:58-89: the i-th KEPT row's mask goes to its original row (:83), then rows [n_kept, D) are
+        # zeroed (:87-89) — which also wipes a kept row whose original index is >= n_kept
+        kept = int(np.sum(~zero))
+        has = np.any(k != 0, axis=1)
+        want = (~zero) & (np.arange(zero.size) < kept)
+        return bool(np.array_equal(has, want))
+    ws_ok = write_set_ok(zero_a, ka) and write_set_ok(zero_b, kb)
+    used = np.zeros(len(ib), dtype=bool)
+    flips, explained, unexplained, first, presence = 0, 0, [], None, 0
+    pairs = []
+    for i in ia:
+        ok = (~used) & (b[ib, 4] == a[i, 4]) & (np.abs(b[ib, :4] - a[i, :4]).max(axis=1) <= box_tol)
+        js = np.flatnonzero(ok)
+        if js.size == 0:
+            continue
+        jj = js[np.argmin(np.abs(b[ib[js], 5] - a[i, 5]))]
+        used[jj] = True
+        j = int(ib[jj])
+        pairs.append((int(i), j))
+        presence += int(bool(np.any(ka[i] != 0)) != bool(np.any(kb[j] != 0)))
+        if zero_a[i] == zero_b[j]:
+            continue
+        flips += 1
+        first = min(i, j) if first is None else min(first, i, j)
+        dbox = np.abs(a[i, :4].astype(np.float64) - b[j, :4].astype(np.float64))
+        zrow = pa[i] if zero_a[i] else pb[j]
+        why = {"row_a": int(i), "row_b": j, "zero_sample_a": bool(zero_a[i]), "zero_sample_b": bool(zero_b[j]),
+               "zeros_in_row": int(np.sum(zrow == 0.0)), "row_len": int(zrow.size),
+               "box_a": a[i, :4].tolist(), "box_b": b[j, :4].tolist(), "max_coord_diff": float(dbox.max())}
+        if dbox.max() <= coord_tol and why["zeros_in_row"] < why["row_len"]:
+            explained += 1
+        else:
+            unexplained.append(why)
+    behind = sum(1 for i, j in pairs if first is not None and max(i, j) > first)
+    return {"flips": flips, "explained": explained, "unexplained": unexplained, "write_set_ok": ws_ok, "presence_mismatch": int(presence),
+            "masks_behind_flip": int(behind)}
+
+
 def evaluate(model: MaskRCNN, images: Iterable[Tuple[int, np.ndarray]], dataset_id: str = "coco",
              limit: Optional[int] = 5, verbose: bool = True):
     """images: (image_id, HxWx3 uint8).  Returns (results.proto bytes, [seconds per image], [PBResult])."""

@@ -126,6 +126,18 @@ class MaskRCNN(_Model):
         B, H, W, _ = images.shape
         _lib.check(_lib.lib().mrcnn_maskrcnn_predict(self._h, images.ctypes.data, B, H, W, _lib.HOST, det.ctypes.data, mask.ctypes.data))
 
+    def submit(self, images: np.ndarray):
+        """Pipelined host entry (mrcnn_maskrcnn_submit): the H2D copy of this batch overlaps the predict of the previous one.
+        `images` must stay alive (and unchanged) until the matching collect()."""
+        B, H, W, _ = images.shape
+        _lib.check(_lib.lib().mrcnn_maskrcnn_submit(self._h, images.ctypes.data, B, H, W))
+
+    def collect(self, det: np.ndarray, mask: np.ndarray) -> int:
+        """Results of the OLDEST submission into the given host buffers; returns its batch size."""
+        n = C.c_int(0)
+        _lib.check(_lib.lib().mrcnn_maskrcnn_collect(self._h, det.ctypes.data, mask.ctypes.data, C.byref(n)))
+        return int(n.value)
+
     def check_range(self) -> bool:
         """After predict_into(sync=False): synchronises the model's stream and reports whether the last predict left
         the fp16 range (its results are then not valid) — the async counterpart of the error predict() raises."""

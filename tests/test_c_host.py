@@ -129,3 +129,57 @@ def test_mgpu_c_host_world_one(pkg, small_model, tmp_path):
         total += len(dets)
     assert pos == len(lines) and total > 0
     pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None
+
+
+def test_stream_c_host_builds(tmp_path):
+    _build_example(tmp_path, "maskrcnn_predict_stream")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,calibrate", [("f32x3", True), ("f16", False)])
+def test_pipelined_host_entry_equals_the_synchronous_one(pkg, small_model, tmp_path, dtype, calibrate):
+    """mrcnn_maskrcnn_submit / _collect (the copy of batch i + 1 under the predict of batch i, two batches in
+    flight) — through the plain-C host of examples/maskrcnn_predict_stream.c and through the Python mirror — returns the bits of
+    the synchronous mrcnn_maskrcnn_predict for every image of a stream of batches, ragged last batch included."""
+    models = importlib.import_module("mask-rcnn-coreml_amd.models")
+    exe = _build_example(tmp_path, "maskrcnn_predict_stream")
+    d, cfg = small_model
+    nb, B = 5, 2
+    imgs = np.random.default_rng(27).integers(0, 256, (nb * B, cfg.image_height, cfg.image_width, 3), dtype=np.uint8)
+    (tmp_path / "imgs.rgb").write_bytes(imgs.tobytes())
+    args = [exe, d, str(tmp_path / "imgs.rgb"), str(nb), str(B), dtype] + (["calibrate"] if calibrate else [])
+    r = subprocess.run(args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("image ")]
+    assert len(lines) == nb * B and r.stdout.strip().splitlines()[-1].startswith(f"batches {nb} batch {B} seconds ")
+
+    m = models.load_maskrcnn(d, max_batch=B, compute_dtype=dtype)
+    if calibrate:
+        m.calibrate_split(imgs[:B])
+    want = [m.predict(imgs[i:i + B]) for i in range(0, nb * B, B)]
+    for i, line in enumerate(lines):
+        t = line.split()
+        det, mask = want[i // B][0][i % B], want[i // B][1][i % B]
+        assert int(t[1]) == i and int(t[3]) == int((det[:, 5].astype(np.float64) > 0.7).sum())
+        assert float(t[5]) == float(det.astype(np.float64).sum() + mask.astype(np.float64).sum()) or \
+            abs(float(t[5]) - (det.astype(np.float64).sum() + mask.astype(np.float64).sum())) < 1e-6 * abs(float(t[5]))
+    # the Python mirror: same loop, bit-equal records, a ragged last batch, and the two-in-flight limit
+    det = np.empty((B, cfg.max_detections, 6), np.float32)
+    mask = np.empty((B, cfg.max_detections, m.mask_size, m.mask_size), np.float32)
+    batches = [np.ascontiguousarray(imgs[i:i + B]) for i in range(0, nb * B, B)] + [np.ascontiguousarray(imgs[:1])]
+    m.submit(batches[0])
+    for i in range(len(batches)):
+        if i + 1 < len(batches):
+            m.submit(batches[i + 1])
+        n = m.collect(det, mask)
+        ref = m.predict(batches[i]) if i == len(batches) - 1 else want[i]
+        assert n == batches[i].shape[0]
+        np.testing.assert_array_equal(det[:n], ref[0])
+        np.testing.assert_array_equal(mask[:n], ref[1])
+    L = importlib.import_module("mask-rcnn-coreml_amd._lib")
+    m.submit(batches[0]); m.submit(batches[1])
+    with pytest.raises(L.MrcnnError):
+        m.submit(batches[2])
+    m.collect(det, mask); m.collect(det, mask)
+    with pytest.raises(L.MrcnnError):
+        m.collect(det, mask)

@@ -42,6 +42,8 @@ def test_headline_batch8_full_size(pkg, orc, full_model, full_images, full_oracl
     d, cfg = full_model
     om, trunk = full_oracle
     m = models.load_maskrcnn(d, max_batch=8, compute_dtype=mode)
+    if mode in ("f32x3", "f32s"):
+        m.calibrate_split(full_images[:2])             # the split modes as bench.py runs them: calibrated exponents (round 4)
     det, mask = m.predict(full_images)
     f16 = mode == "f16"
     for b, tb in ((0, 0), (7, 1)):
@@ -82,30 +84,119 @@ def test_config5_1536_batch2(pkg, orc, tmp_path_factory, weights_mod, mode):
     pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None
 
 
-def test_headline_end_to_end_agreement_with_the_oracle(pkg, full_model):
-    """The end-to-end figure bench.py prints as parity_e2e, as a test: HIP predict in the headline
-    mode (f32x3) vs the CPU oracle's predict on 8 full-size images of the headline workload — EVERY detection of every
-    image must have a partner with the same class id and a box within 1e-4 (order-insensitive: scores that differ in the
-    last bits may swap neighbours), scores within 1e-5, masks (present on both sides) within 2e-4."""
-    import importlib
+N_E2E = 16          # oracle images of the end-to-end tests (~5 s of host time each; bench.py / profiles/ carry 64 and 256)
+
+
+@pytest.fixture(scope="module")
+def e2e_oracle(full_model):
+    """The CPU oracle's predict (with its pooled_mask taps) on N_E2E full-size images, shared by the end-to-end tests."""
     from oracle.network import load_oracle_model
+    d, cfg = full_model
+    images = rand_images(N_E2E, 1024, 1024, seed=31)
+    om = load_oracle_model(d)
+    dets, masks, pooled = [], [], []
+    for i in range(0, N_E2E, 4):                              # four images per trunk call: bounded host memory
+        dd, kk, taps = om.predict(images[i:i + 4], taps=True)
+        dets.append(dd); masks.append(kk)
+        pooled += [t["pooled_mask"] for t in taps["per_image"]]
+    return images, np.concatenate(dets), np.concatenate(masks), pooled
+
+
+def _hip_predict_with_taps(m, images, B=8):
+    dets, masks, pooled = [], [], []
+    for i in range(0, len(images), B):
+        d_, k_ = m.predict(images[i:i + B])
+        dets.append(d_); masks.append(k_)
+        for b in range(d_.shape[0]):
+            pooled.append(m.read_tensor("pooled_mask", b).reshape(d_.shape[1], -1))
+    return np.concatenate(dets), np.concatenate(masks), pooled
+
+
+def test_headline_end_to_end_agreement_with_the_oracle(pkg, full_model, e2e_oracle):
+    """The end-to-end figure bench.py prints as parity_e2e, as a test: HIP predict in the headline mode (f32x3, calibrated split)
+    vs the CPU oracle's predict on 16 full-size images of the headline workload.  Two fp32 evaluations that sum in different
+    orders can swap a near-tie — profiles/r03_parity_e2e_256.json: 25 593 / 25 600 detections, 249 / 256 images fully matched —
+    so the bar is a FRACTION (>= 0.999 of the detections: at most one of 1 600), not equality at one seed; matched
+    pairs agree in score within 1e-5 and in mask (where both sides have one, in front of any removeZeros flip) within 2e-4.
+    VERDICT r3 item 4: every mask that is present on one side only must be the reference's removeZeros cliff, PROVEN from the
+    taps (evaluate.mask_flip_causes) — each side's masks are exactly the compacted rows its OWN pooled samples keep (no exact 0.0
+    in the row), and where the two sides' predicates differ the boxes agree to the last bits; anything else fails."""
+    import importlib
     models = importlib.import_module("mask-rcnn-coreml_amd.models")
     ev = importlib.import_module("mask-rcnn-coreml_amd.evaluate")
     d, cfg = full_model
-    images = rand_images(8, 1024, 1024, seed=31)
+    images, od, ok, opool = e2e_oracle
     m = models.load_maskrcnn(d, max_batch=8, compute_dtype="f32x3")
-    hd, hk = m.predict(images)
-    om = load_oracle_model(d)
-    tot = matched = presence = 0
-    for b in range(8):
-        od, ok = om.predict(images[b:b + 1])
-        a = ev.detection_agreement(hd[b], od[0], 1e-4, hk[b], ok[0])
+    m.calibrate_split(images[:2])
+    hd, hk, hpool = _hip_predict_with_taps(m, images)
+    tot = matched = flips = behind = 0
+    for b in range(N_E2E):
+        a = ev.detection_agreement(hd[b], od[b], 1e-4, hk[b], ok[b])
         assert a["n_a"] == a["n_b"] == cfg.max_detections, (b, a)
-        assert a["matched"] == a["n_a"], f"image {b}: {a}"
         assert a["max_score_diff"] < 1e-5 and a["max_mask_diff"] < 2e-4, (b, a)
-        tot += a["n_a"]; matched += a["matched"]; presence += a["mask_presence_mismatch"]
-    assert matched == tot == 8 * cfg.max_detections            # fraction == 1.0
-    assert presence <= 2                                        # the reference's removeZeros cliff (an exact-zero sample): rare
+        tot += a["n_a"]; matched += a["matched"]
+        why = ev.mask_flip_causes(hd[b], od[b], hpool[b], opool[b], hk[b], ok[b])
+        assert why["write_set_ok"], f"image {b}: a side's masks are not the compacted rows its own zero-sample predicate keeps"
+        assert not why["unexplained"], f"image {b}: a kept / dropped difference that is NOT the removeZeros cliff: {why['unexplained']}"
+        flips += why["flips"]; behind += why["masks_behind_flip"]
+    assert matched >= 0.999 * tot, (matched, tot)
+    print(f"e2e f32x3 vs oracle: {matched}/{tot} detections, {flips} removeZeros flips (all explained), {behind} masks behind a flip")
+    pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None
+
+
+def test_fp16_mode_end_to_end_bar(pkg, full_model, e2e_oracle):
+    """BASELINE configs[3] (fp16 tensors + fp16 MFMA) has an end-to-end bar of its own, the one
+    include/maskrcnn_hip.h states for MRCNN_F16: at full size, batch 8, against the fp32 CPU oracle at least 95 % of the
+    detections have a partner with the same class id and a box within 2e-3 (normalized), matched scores agree within 5e-4 and
+    matched masks (in front of any removeZeros flip) within 3e-2; every image yields its full 100 detections."""
+    import importlib
+    models = importlib.import_module("mask-rcnn-coreml_amd.models")
+    ev = importlib.import_module("mask-rcnn-coreml_amd.evaluate")
+    d, cfg = full_model
+    images, od, ok, _ = e2e_oracle
+    m = models.load_maskrcnn(d, max_batch=8, compute_dtype="f16")
+    hd, hk, _ = _hip_predict_with_taps(m, images)
+    tot = matched = 0
+    worst_score = worst_mask = 0.0
+    for b in range(N_E2E):
+        a = ev.detection_agreement(hd[b], od[b], 2e-3, hk[b], ok[b])
+        assert a["n_a"] == a["n_b"] == cfg.max_detections, (b, a)
+        tot += a["n_a"]; matched += a["matched"]
+        worst_score = max(worst_score, a["max_score_diff"]); worst_mask = max(worst_mask, a["max_mask_diff"])
+    print(f"e2e f16 vs oracle: {matched}/{tot} detections within 2e-3, score diff {worst_score:.2e}, mask diff {worst_mask:.2e}")
+    assert matched >= 0.95 * tot, (matched, tot)             # measured: 1584 / 1600
+    assert worst_score < 5e-4 and worst_mask < 3e-2, (worst_score, worst_mask)     # measured: 1.6e-4, 1.3e-2
+    pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None
+
+
+def test_removezeros_flips_between_two_engines_are_all_the_cliff(pkg, full_model):
+    """The same proof on MORE images than the CPU oracle affords in a test: 64 full-size images, the headline mode (f32x3) against
+    the exact-fp32 MFMA engine — two independent summation orders, both with taps.  Detection agreement >= 0.999, and every
+    kept / dropped difference is an exact-zero sample on one side between boxes that agree to the last bits (the reference's
+    semantics: TimeDistributedMaskLayer.swift:52-89, TimeDistributedClassifierLayer.swift:116-127); "masks behind a flip" — rows whose
+    class lookup the compact-index rule shifts on one side — are counted, not compared."""
+    import importlib
+    models = importlib.import_module("mask-rcnn-coreml_amd.models")
+    ev = importlib.import_module("mask-rcnn-coreml_amd.evaluate")
+    d, cfg = full_model
+    images = rand_images(64, 1024, 1024, seed=47)
+    m3 = models.load_maskrcnn(d, max_batch=8, compute_dtype="f32x3")
+    m3.calibrate_split(images[:2])
+    d3, k3, p3 = _hip_predict_with_taps(m3, images)
+    del m3
+    m1 = models.load_maskrcnn(d, max_batch=8, compute_dtype="f32")
+    d1, k1, p1 = _hip_predict_with_taps(m1, images)
+    tot = matched = flips = behind = 0
+    for b in range(64):
+        a = ev.detection_agreement(d3[b], d1[b], 1e-4, k3[b], k1[b])
+        tot += max(a["n_a"], a["n_b"]); matched += a["matched"]
+        assert a["max_score_diff"] < 1e-5 and a["max_mask_diff"] < 2e-4, (b, a)
+        why = ev.mask_flip_causes(d3[b], d1[b], p3[b], p1[b], k3[b], k1[b])
+        assert why["write_set_ok"], f"image {b}: a side's masks are not the compacted rows its own zero-sample predicate keeps"
+        assert not why["unexplained"], f"image {b}: {why['unexplained']}"
+        flips += why["flips"]; behind += why["masks_behind_flip"]
+    print(f"f32x3 vs f32 engine, 64 images: {matched}/{tot} detections, {flips} removeZeros flips (all explained), {behind} masks behind a flip")
+    assert matched >= 0.999 * tot, (matched, tot)
     pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None
 
 

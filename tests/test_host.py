@@ -505,3 +505,24 @@ def test_bench_gpus_n_fails_loudly_without_n_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode != 0 and not r.stdout.strip() and "WORLD_SIZE" in r.stderr
+
+
+def test_native_dist_binds_the_rccl_copy_the_process_already_holds(pkg):
+    """VERDICT r3 item 8 — one RCCL per process: dist.hip takes the copy the host has already mapped (PyTorch ships one under the
+    soname librccl.so.1) before it loads its own.  Two fresh interpreters: with torch imported first the library reports the
+    shared copy (1), without torch its own dlopen (0); MRCNN_RCCL_PRIVATE=1 forces the private load.  No GPU needed."""
+    import subprocess
+    import sys
+    lib_mod = importlib.import_module("mask-rcnn-coreml_amd._lib")
+    if not os.path.exists(lib_mod.SO_PATH):
+        pytest.skip("libmaskrcnn_hip.so not built")
+    probe = ("import ctypes, sys; {pre}; L = ctypes.CDLL({so!r}); L.mrcnn_dist_rccl_shared.restype = ctypes.c_int; "
+             "print('shared', L.mrcnn_dist_rccl_shared())")
+    def run(pre, env=None):
+        r = subprocess.run([sys.executable, "-c", probe.format(pre=pre, so=lib_mod.SO_PATH)], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, **(env or {})))
+        assert r.returncode == 0, r.stderr
+        return int(r.stdout.strip().split()[-1])
+    assert run("import torch") == 1
+    assert run("pass") == 0
+    assert run("import torch", {"MRCNN_RCCL_PRIVATE": "1"}) == 0
