@@ -18,7 +18,8 @@ extern "C" {
 /* Live per-kernel profile of the convolution family during predict (bench.py roofline leg): when
  * enabled every conv launch is bracketed by HIP events on the model's stream.  tile: 0 = the
  * 128x128 kernel, 1 = 128x64, 2 = 128x32, 3 = 128x128 run by four waves of 32x128 (split modes, K >= 2048), 4 = 256x256 ping-pong,
- * 5 = the persistent halo tiles of the 3x3 layers of the split modes (kernels_conv_halo.hip).  enable(1) opens a measurement window (totals reset);
+ * 5 = the persistent halo tiles of the 3x3 layers of the split modes (kernels_conv_halo.hip), 6 = halo tiles with the fused
+ * bottleneck tail (a 3x3 `branch2b` and the 1x1 `branch2c` behind it in one launch; flops of both layers).  enable(1) opens a measurement window (totals reset);
  * enable(0) closes it and the totals stay readable — the events cost ~2 % (fp32) / ~13 % (fp16) of a step,
  * so bench.py opens the window for the first steps of its timed region only.
  * total_flops is ALGORITHMIC work (2*M*N*K of the convolution, padding excluded). */
@@ -56,7 +57,8 @@ MRCNN_API int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout,
  * deconvolution + selected-class 1x1 as two launches over a materialised tensor | fused — results within fp32 summation noise): every choice must give
  * bit-identical results — the tile shape depends on the batch size and per-image results must not.  Further knobs: "conv_halo" 0|1 the
  * persistent halo kernel of the 3x3 layers of the split modes (its K order is its own: results differ from "0" by summation noise);
- * "halo_geo" 0|1: its round-3 tile geometries | two-row tiles, region-sized staging, conflict-free LDS pitch (bit-identical).
+ * "halo_geo" 0|1: its round-3 tile geometries | two-row tiles, region-sized staging, conflict-free LDS pitch (bit-identical);
+ * "conv_tail" 0|1: bottleneck tails as two launches | one fused launch where the grid fills the chip (bit-identical).
  * The switches are PROCESS-WIDE test / measurement knobs: not thread-safe; a choice captured in a hipGraph stays captured. */
 MRCNN_API int mrcnn_conv2d_nhwc(const float* in, int batch, int h, int w, int cin, const float* filters, int cout,
                                 int ksize, int stride, const float* scale, const float* shift, const float* residual,

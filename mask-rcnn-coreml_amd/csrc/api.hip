@@ -833,7 +833,7 @@ extern "C" int mrcnn_model_conv_profile_enable(mrcnn_model* model, int on)
 extern "C" int mrcnn_model_conv_profile_get(mrcnn_model* model, int tile, int64_t* launches, double* total_ms, double* total_flops)
 {
     return guarded([&] {
-        MRCNN_REQUIRE(model && launches && total_ms && total_flops && tile >= 0 && tile < 6, MRCNN_ERR_INVALID, "bad argument");
+        MRCNN_REQUIRE(model && launches && total_ms && total_flops && tile >= 0 && tile < 7, MRCNN_ERR_INVALID, "bad argument");
         HIP_CHECK(hipStreamSynchronize(model->m.stream));
         model->m.conv_profile.collect();
         const auto& sl = model->m.conv_profile.by_tile[tile];

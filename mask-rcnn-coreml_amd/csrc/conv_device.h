@@ -386,7 +386,12 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x16 (
 //   piece); tab: scale[BN] | shift[BN] of the block's columns.  A wave's LDS writes and reads execute in order, so no wait
 //   is needed between the transposing write and the row-wise read-back.
 // ----------------------------------------------------------------------------------------------------------------
-template <int BN, int TMS, int TNS>
+// RES_FIRST: request the residual of ALL the wave's 32 x 32 pieces before the first piece is staged and stored (the loads of a piece
+// otherwise queue behind the previous piece's stores — `res` may alias `out` — one memory round trip per piece).  Legal under the
+// in-place contract: a wave loads exactly the elements it will overwrite, all of them before its first store.  Neutral for the
+// 128-row kernels (two co-resident blocks cover the latency); used by the fused bottleneck tail, whose
+// CU holds two waves per SIMD.
+template <int BN, int TMS, int TNS, bool RES_FIRST = false>
 __device__ __forceinline__ void conv_epilogue_wave(const ConvArgs& a, f32x16 (&acc)[TMS][TNS], float* stage, const float* tab, int row0, int n0,
                                                    int colrel0, int lane)
 {
@@ -400,6 +405,33 @@ __device__ __forceinline__ void conv_epilogue_wave(const ConvArgs& a, f32x16 (&a
     const bool relu = a.act == ACT_RELU;
     const int rrow = lane >> 3, c4 = (lane & 7) * 4;     // read-back: eight lanes per row, four passes of eight rows
     bool out_of_range = false;
+    float4 rv_all[RES_FIRST ? TMS : 1][RES_FIRST ? TNS : 1][4];
+    if constexpr (RES_FIRST) {
+        if (res) {
+#pragma unroll
+            for (int i = 0; i < TMS; ++i)
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int m = row0 + i * 32 + 8 * ps + rrow;
+                    const bool okr = m < a.M;
+                    long rr = (long)m * a.res_sW;
+                    if (!dense_res) {
+                        const int mm = okr ? m : 0;
+                        const int b = mm / ohw, pix = mm - b * ohw;
+                        if (a.res_shift) {
+                            const int oh = pix / a.OW, ow = pix - oh * a.OW;
+                            rr = (long)b * a.res_sB + (long)(oh >> a.res_shift) * a.res_sH + (long)(ow >> a.res_shift) * a.res_sW;
+                        } else rr = (long)b * a.res_sB + (long)pix * a.res_sW;
+                    }
+#pragma unroll
+                    for (int j = 0; j < TNS; ++j) {
+                        const int n = n0 + colrel0 + j * 32 + c4;
+                        rv_all[i][j][ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (okr && n < a.ncols) rv_all[i][j][ps] = *reinterpret_cast<const float4*>(res + rr + n);
+                    }
+                }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TMS; ++i) {
         // rows of this 32-row slab the lane handles in the read-back: row = 8 * pass + rrow
@@ -432,8 +464,11 @@ __device__ __forceinline__ void conv_epilogue_wave(const ConvArgs& a, f32x16 (&a
             if (res) {
 #pragma unroll
                 for (int ps = 0; ps < 4; ++ps) {
-                    rv[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (ok[ps] && col_ok) rv[ps] = *reinterpret_cast<const float4*>(res + r_row[ps] + n);
+                    if constexpr (RES_FIRST) rv[ps] = rv_all[i][j][ps];
+                    else {
+                        rv[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (ok[ps] && col_ok) rv[ps] = *reinterpret_cast<const float4*>(res + r_row[ps] + n);
+                    }
                 }
             }
 #pragma unroll

@@ -290,6 +290,9 @@ PackedConv pack_conv_oihw(const MrcwFile& f, const std::string& conv, const std:
     if (pc.wdtype != pc.dtype && conv_halo_packable(KH, KW, I, pc.Npad)) {
         conv_halo_pack(nullptr, pc.wgt.p, pc.Npad, I, pc.wgt_halo);           // split modes: also in the halo kernel's tiling
         HIP_CHECK(hipStreamSynchronize(nullptr));
+    } else if (pc.wdtype != pc.dtype && conv_halo_tail_packable(KH, KW, I, pc.Npad) && O == pc.Npad) {
+        conv_halo_pack(nullptr, pc.wgt.p, pc.Npad, I, pc.wgt_halo, 1);        // ... the 256 -> 1024 1x1 layers for the fused bottleneck tail
+        HIP_CHECK(hipStreamSynchronize(nullptr));
     }
     std::vector<float> sc, sh;
     fold_bn(f, conv, bn, O, pc.Npad, sc, sh);
@@ -748,8 +751,8 @@ void Model::build_maskrcnn()
         // split groups (engine.h: SplitGroup): g_in / g_out of every convolution; a residual rides in the output's group
         const int g_img = new_split_group("image", true);        // pixel - mean: written by the pre-processing kernel, exponent 0
         const int g_zero = new_split_group("outputs", true);      // logits, box deltas, probabilities: consumed by fp32 arithmetic
-        auto conv_op = [&](const std::string& name, const Tensor4& in, const Tensor4& out, int stride, int pad, int act,
-                           const Tensor4* res, int res_shift, int g_in, int g_out) {
+        auto make_desc = [&](const std::string& name, const Tensor4& in, const Tensor4& out, int stride, int pad, int act,
+                             const Tensor4* res, int res_shift, int g_in, int g_out) {
             const PackedConv* pc = &convs.at(name);
             ScaledOp* const so = real ? new_scaled_op(pc, g_in, g_out) : nullptr;
             ConvDesc d;
@@ -764,10 +767,32 @@ void Model::build_maskrcnn()
             d.out = out.p; d.out_sP = out.C; d.out_sB = out.sB();
             d.act = act;
             if (res) { d.res = res->p; d.res_sB = res->sB(); d.res_sH = (long)res->W * res->C; d.res_sW = res->C; d.res_shift = res_shift; }
+            return d;
+        };
+        auto conv_op = [&](const std::string& name, const Tensor4& in, const Tensor4& out, int stride, int pad, int act,
+                           const Tensor4* res, int res_shift, int g_in, int g_out) {
+            const ConvDesc d = make_desc(name, in, out, stride, pad, act, res, res_shift, g_in, g_out);
             const size_t per_image = (size_t)out.sB();
             add([d, self, g_out, per_image](hipStream_t s, int batch) {
                 ConvDesc x = d; x.B = batch; conv_forward(s, x);
                 if (self->calib_phase) self->observe_split(s, g_out, d.out, per_image * batch);
+            });
+        };
+        // a bottleneck's tail: branch2b (3x3) and the branch2c (1x1 + shortcut) behind it — one fused launch where the pair
+        // qualifies and the grid fills the chip (conv_forward_tail: bit-identical to the two launches), two launches otherwise
+        // and while a calibration pass needs the tensor between them
+        auto tail_op = [&](const std::string& n3, const std::string& n1, const Tensor4& in3, const Tensor4& mid, const Tensor4& out, const Tensor4& res,
+                           int g_in, int g_mid, int g_out) {
+            const ConvDesc d3 = make_desc(n3, in3, mid, 1, 1, ACT_RELU, nullptr, 0, g_in, g_mid);
+            const ConvDesc d1 = make_desc(n1, mid, out, 1, 0, ACT_RELU, &res, 0, g_mid, g_out);
+            const size_t pm = (size_t)mid.sB(), po = (size_t)out.sB();
+            add([d3, d1, self, g_mid, g_out, pm, po](hipStream_t s, int batch) {
+                ConvDesc x3 = d3, x1 = d1;
+                x3.B = x1.B = batch;
+                if (self->calib_phase) {
+                    conv_forward(s, x3); self->observe_split(s, g_mid, d3.out, pm * batch);
+                    conv_forward(s, x1); self->observe_split(s, g_out, d1.out, po * batch);
+                } else conv_forward_tail(s, x3, x1);
             });
         };
 
@@ -829,7 +854,6 @@ void Model::build_maskrcnn()
                 Tensor4 ta = stage_ta;
                 conv_op("res" + p + "_branch2a", x, ta, stride, 0, ACT_RELU, nullptr, 0, g_x, g_a);
                 Tensor4 tb = stage_tb;
-                conv_op("res" + p + "_branch2b", ta, tb, 1, 1, ACT_RELU, nullptr, 0, g_a, g_b);
                 Tensor4 sc = x;
                 if (first) {
                     sc = T(oh, ow, f3s[st]);
@@ -840,7 +864,7 @@ void Model::build_maskrcnn()
                 // through x + two branch tensors — 200 MB for C4 at batch 8, inside the 256 MB Infinity Cache — instead of
                 // streaming a fresh 134 MB tensor per block through HBM.
                 Tensor4 to = sc;
-                conv_op("res" + p + "_branch2c", tb, to, 1, 0, ACT_RELU, &sc, 0, g_b, g_stage);
+                tail_op("res" + p + "_branch2b", "res" + p + "_branch2c", ta, tb, to, sc, g_a, g_b, g_stage);
                 x = to;
                 g_x = g_stage;
             }

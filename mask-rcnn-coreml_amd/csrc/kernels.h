@@ -152,8 +152,8 @@ struct ConvDesc {
 // has been synchronised) folds the elapsed times into per-tile-shape totals.
 struct ConvProfile {
     struct Slot { long launches = 0; double ms = 0, flops = 0; };
-    Slot by_tile[6];                 // 0: 128x128, 1: 128x64, 2: 128x32, 3: 128x128 run by 4 waves of 32x128 (split modes, long K), 4: 256x256 ping-pong,
-                                     // 5: persistent halo tiles (3x3 stride 1, split modes)
+    Slot by_tile[7];                 // 0: 128x128, 1: 128x64, 2: 128x32, 3: 128x128 run by 4 waves of 32x128 (split modes, long K), 4: 256x256 ping-pong,
+                                     // 5: persistent halo tiles (3x3 stride 1, split modes), 6: halo tiles with the fused bottleneck tail (3x3 + 1x1)
     std::vector<hipEvent_t> pool;
     struct Shape { int M, N, K, tile; bool operator<(const Shape& o) const { return std::tie(M, N, K, tile) < std::tie(o.M, o.N, o.K, o.tile); } };
     std::map<Shape, Slot> by_shape;  // per GEMM shape (M = images·OH·OW, N = output columns, K = taps·Cin)
@@ -181,14 +181,22 @@ bool conv_debug_set(const char* key, int value);
 // filters (device) into its granule layout; conv_halo_eligible says whether a layer can run on it (a property of the layer's
 // geometry and mode only — never of the batch: the K order of the kernel differs from the 128-row kernel's).
 struct ConvArgs;
-void conv_halo_pack(hipStream_t s, const void* wgt_std, int Npad, int Cin, DevBuf& out);
+void conv_halo_pack(hipStream_t s, const void* wgt_std, int Npad, int Cin, DevBuf& out, int taps = 9);
 void conv_halo_pack_head(hipStream_t s, const void* wgt_std, int Npad, int Cin, DevBuf& out);
 bool conv_halo_eligible(const ConvDesc& d);
 bool conv_halo_head_eligible(const ConvDesc& d);
 bool conv_halo_enabled();                   // the run-time switch mrcnn_debug_set("conv_halo") / MRCNN_HALO
 bool conv_halo_debug_set(const char* key, int value);     // "halo_geo" 0 = the round-3 tile geometries (A/B, bit-identity tests) | 1
 bool conv_halo_packable(int KH, int KW, int Cin, int Npad);   // the filter shapes conv_halo_eligible can accept (re-tile only those)
-int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, int n_cus);
+int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, int n_cus, const ConvArgs* tail = nullptr, const void* tail_w = nullptr);
+bool conv_halo_tail_packable(int KH, int KW, int Cin, int Npad);       // the 1x1 filters the fused bottleneck tail accepts (re-tiled with one tap)
+bool conv_halo_tail_geometry_ok(int H, int W);                          // ... and the 3x3 tile geometries it is instantiated for
+// A ResNet bottleneck's tail — d3: the 3x3 `branch2b` (halo-eligible, 256 output columns, ReLU), d1: the 1x1 `branch2c` that reads
+// d3's output (256 -> 1024, + shortcut, ReLU; d1.wgt_halo = its filters re-tiled with one tap) — as ONE persistent launch in which the
+// 256-column tensor between them never exists (kernels_conv_halo.hip: TAIL).  Bit-identical to conv_forward(d3); conv_forward(d1),
+// which is what runs when the pair does not qualify, the grid would not fill the chip, or mrcnn_debug_set("conv_tail", 0).
+bool conv_tail_fusable(const ConvDesc& d3, const ConvDesc& d1);
+void conv_forward_tail(hipStream_t s, const ConvDesc& d3, const ConvDesc& d1);
 
 // uint8 RGB (B,H,W,3) → fp32 (B, H+2*pad, W+2*pad, 4) minus mean, zero border, channel 3 = 0.
 void preprocess_forward(hipStream_t s, const uint8_t* rgb, int B, int H, int W, int pad, const float mean[3],

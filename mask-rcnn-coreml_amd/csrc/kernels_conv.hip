@@ -407,6 +407,12 @@ static int g_min_blocks = 448;   // narrow the N tile while the grid has fewer b
 static int g_direct = env_int("MRCNN_DIRECT", 3);   // 0: every layer through the block-staged epilogue; 1: fp16 tensors straight from the accumulators;
                                  // 2: also fp32 tensors through wave-private LDS tiles (conv_epilogue_wave); 3: also the fp16 tensors of the
                                  // 128-column kernel (conv_epilogue_wave_h: full-line residual loads and stores; +3.6 % end to end in fp16 mode)
+static int g_tail_dbg = env_int("MRCNN_TAIL_DBG", 0);        // measurement only: ablation bits of the fused tail's 1x1 phase (1 no epilogue, 2 no K loop)
+// Bottleneck tails (3x3 + 1x1) as one persistent launch when the grid fills the chip: bit-identical to the two launches, and
+// measured SLOWER (C4, batch 8: 180 us against 88 + 75; ablations: 3x3 loop 91 + barriers / prologues 7 + staging and parking 21 +
+// 1x1 K loop 21 + epilogue 37, strictly additive — profiles/r04_tail_ablate_f32x3.txt), so OFF by default;
+// MRCNN_TAIL=1 / mrcnn_debug_set("conv_tail", 1) switch it on (tests keep it bit-identical)
+static int g_tail = env_int("MRCNN_TAIL", 0);
 static int g_halo = env_int("MRCNN_HALO", 1);        // 3x3 stride-1 layers of the split modes on the halo kernel (kernels_conv_halo.hip) when the filters come re-tiled
 static int g_tn4 = -1;       // split modes, 128x128 tile as 4 waves of 32x128: -1 by policy (conv_forward), 0 never, 1 always (tests)
 template <typename T, typename TW, int PARTS = 2>
@@ -467,6 +473,8 @@ bool conv_debug_set(const char* key, int value)
     else if (k == "conv_halo") g_halo = value;
     else if (k == "conv_direct") g_direct = value;
     else if (k == "conv_min_blocks") g_min_blocks = value;
+    else if (k == "conv_tail") g_tail = value;
+    else if (k == "conv_tail_dbg") g_tail_dbg = value;
     else return conv_halo_debug_set(key, value);
     return true;
 }
@@ -574,6 +582,56 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
         const double k = d.algo_k > 0 ? d.algo_k : a.Ktot;
         const int tile = halo ? 5 : pp_bn == 256 ? 4 : (wide_waves ? 3 : (bn == 128 ? 0 : (bn == 64 ? 1 : 2)));
         prof->pending.push_back({tile, 2.0 * (double)a.M * (double)a.ncols * k, e0, e1, {a.M, a.ncols, a.Ktot, tile}});
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused bottleneck tail (kernels.h: conv_forward_tail)
+// ------------------------------------------------------------------------------------------------
+bool conv_tail_fusable(const ConvDesc& d3, const ConvDesc& d1)
+{
+    const int w3 = d3.wdtype < 0 ? d3.dtype : d3.wdtype, w1 = d1.wdtype < 0 ? d1.dtype : d1.wdtype;
+    if (d3.dtype != MRCNN_F32 || d1.dtype != MRCNN_F32 || w3 != w1 || !(w3 == MRCNN_F16 || w3 == MRCNN_F32X3)) return false;      // split modes only
+    if (!d3.wgt_halo || !d1.wgt_halo || !conv_halo_eligible(d3) || d3.head_w || !conv_halo_tail_geometry_ok(d3.H, d3.W)) return false;
+    if (d3.Cout != 256 || d3.Npad != 256 || d3.act != ACT_RELU) return false;
+    if (!conv_halo_tail_packable(d1.KH, d1.KW, d1.Cin, d1.Npad) || d1.Cout != 1024 || d1.stride != 1 || d1.padH != 0 || d1.padW != 0) return false;
+    if (d1.deconv2 || d1.out2 || d1.sel_partial || d1.act == ACT_SIGMOID || d1.res_shift || d1.head_w) return false;
+    // the 1x1 reads exactly what the 3x3 writes: a dense NHWC tensor of 256 channels
+    if (d1.in != d3.out || d1.B != d3.B || d1.H != d3.OH || d1.W != d3.OW || d1.OH != d3.OH || d1.OW != d3.OW) return false;
+    if (d3.out_sP != 256 || d3.out_sB != (long)d3.OH * d3.OW * 256 || d1.in_sW != 256 || d1.in_sH != (long)d3.OW * 256 || d1.in_sB != d3.out_sB) return false;
+    return true;
+}
+
+void conv_forward_tail(hipStream_t s, const ConvDesc& d3, const ConvDesc& d1)
+{
+    static int n_cus = [] { int dev = 0; hipDeviceProp_t p; (void)hipGetDevice(&dev); return hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }();
+    const long tiles = ((long)d3.B * d3.OH * d3.OW + 127) / 128;
+    ConvArgs a3, a1;
+    bool fuse = g_tail && g_halo && conv_tail_fusable(d3, d1) && tiles * 8 >= (long)n_cus * 7;       // a grid that fills the chip: one 128 x 256 tile per block
+    if (fuse) {
+        conv_fill_args(d3, a3);
+        conv_fill_args(d1, a1);
+        a3.vec_ok = conv_vec_ok(d3, a3);
+        a1.vec_ok = conv_vec_ok(d1, a1);
+        a3.tiles_m = a1.tiles_m = 0; a3.tiles_n = a1.tiles_n = 0; a3.direct = a1.direct = 1;
+        a1.dbg = g_tail_dbg;
+        fuse = a3.vec_ok && a1.vec_ok && a3.dbg == 0;
+    }
+    if (!fuse) {
+        conv_forward(s, d3);
+        conv_forward(s, d1);
+        return;
+    }
+    ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
+    const int e0 = prof ? prof_event(prof, s) : 0;
+    const int w3 = d3.wdtype < 0 ? d3.dtype : d3.wdtype;
+    (void)conv_halo_forward(s, a3, d3, w3 == MRCNN_F32X3 ? 3 : 2, n_cus, &a1, d1.wgt_halo);
+    if (prof) {
+        const int e1 = prof_event(prof, s);
+        // one launch, two layers: algorithmic flops of both; the shape key is the 3x3 layer's M and K with the 1x1's N (tile class 6)
+        const double fl = 2.0 * (double)a3.M * ((double)a3.ncols * a3.Ktot + (double)a1.ncols * a1.Ktot);
+        prof->pending.push_back({6, fl, e0, e1, {a3.M, a1.ncols, a3.Ktot + a1.Ktot, 6}});
     }
     HIP_CHECK(hipGetLastError());
 }

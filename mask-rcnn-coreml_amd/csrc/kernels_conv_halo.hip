@@ -34,6 +34,8 @@
 #include "conv_device.h"
 
 #include <stdlib.h>
+#include <map>
+#include <mutex>
 #include <string>
 
 namespace mrcnn {
@@ -70,6 +72,11 @@ struct HaloArgs {
     long head_out_sB, head_out_sP, head_out2_sB, head_out2_sP;
     int head_split, head_cols;
     float head_mul;              // head sums * head_mul + bias (ConvDesc::head_mul)
+    // fused bottleneck tail (TAIL): the 1x1 layer that consumes this 3x3 layer's 256 ReLU'd output columns — its launch arguments
+    // (epilogue fields, residual, output) and its filters in granule order (conv_halo_pack with one tap)
+    ConvArgs t;
+    const void* t_w;
+    void* t_park;                // grid x 64 KB: where the waves of a tile's rows 64..127 park their activated 3x3 outputs during the first half's 1x1
 };
 
 // 4 fp32 → PARTS × 4 fp16 (the same round-to-nearest chain as split_hi_mid_lo / split_hi_lo of conv_device.h)
@@ -99,11 +106,21 @@ __device__ __forceinline__ void split4(const u32x4 v, u32x2 (&out)[PARTS])
 // Every thread loads, splits and parks MAXPC pieces per slab whether the region needs them or not, so the launcher picks the
 // smallest that fits: 2 (<= 256 pixels: the mask head, C5, the top pyramid levels), 3 (<= 384: the 4 x 66 regions of C4 and of
 // the two-row tiles — rounds 1-3 staged 5 pieces for all of them), 5 (anything up to 640).
-template <int PARTS, int TN, bool HEAD = false, bool DBG = false, int TM = 2, int MAXPC = 5>       // TM = 1: 64-row tiles for grids that would not fill the chip
+//
+// TAIL (round 4): the bottleneck block's 1x1 `branch2c` (256 -> 1024 + shortcut + ReLU, Conversion/task.py:69-92) is
+// computed by the block that has just produced the 128 x 256 tile of `branch2b` — those 256 columns ARE the full K of the 1x1.
+// The ReLU'd tile never goes to memory: per 64-row half it is split ONCE into hi / mid / lo planes in LDS (96 KB, the 3x3 planes
+// are dead by then), and every wave multiplies 64 rows x 64 output columns against filter fragments straight from memory
+// (16 K groups x 12 MFMAs, fragment reads as in the 3x3 loop), twice per half; the epilogue is conv_epilogue_wave with the
+// 1x1 layer's arguments.  K order = 16-channel groups ascending, parts hi / mid / lo per group, one running accumulator: the
+// order of the 128-row kernel's 1x1 — the fused launch is BIT-IDENTICAL to the two launches it replaces, so whether a call
+// fuses is a launch-time choice (grid fill), like a tile shape.
+template <int PARTS, int TN, bool HEAD = false, bool DBG = false, int TM = 2, int MAXPC = 5, bool TAIL = false>       // TM = 1: 64-row tiles for grids that would not fill the chip
 __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
 {
     const ConvArgs& a = ha.a;
     static_assert(!HEAD || TM == 2, "the fused head reduces over 128-row tiles");
+    static_assert(!TAIL || (TM == 2 && TN == 2 && !HEAD), "the fused tail needs the whole 128 x 256 tile in one block");
     static_assert(MAXPC >= 2 && MAXPC <= 5, "staging pieces per thread");
     constexpr int BM = 2 * TM * 32, WN = 4, BN = WN * TN * 32;
     constexpr int PLANE = (HALO_MAX_SLOT + 1) * 32;       // bytes of one part of one slab (+ one dump slot: pieces beyond the region write there, unconditionally)
@@ -112,11 +129,17 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
     constexpr int HPART = 4 * 128 * 32 * 4;               // HEAD: the four wave columns' partial head sums of a tile (they live in the planes)
     constexpr int HRUN = HEAD ? 128 * 32 * 4 : 0;         // HEAD: running head sum of the M tile over its N tiles
     constexpr int PLANES_ = 2 * PBUF > PBUF + STAGE ? 2 * PBUF : PBUF + STAGE;
-    constexpr int PLANES = HEAD && HPART > PLANES_ ? HPART : PLANES_;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[PLANES + 2 * 2 * BN * 4 + HRUN];
+    constexpr int TAILPL = 16 * 64 * 32;                  // TAIL: one part of the 64-row half: [16 K groups][64 rows] x 32 B
+    constexpr int TAILN = 1024;                           // TAIL: output columns of the 1x1 layer
+    constexpr int TPLANES = TAIL ? PARTS * TAILPL + STAGE : 0;            // ... all parts + the wave-private epilogue tiles
+    constexpr int PLANES__ = HEAD && HPART > PLANES_ ? HPART : PLANES_;
+    constexpr int PLANES = TPLANES > PLANES__ ? TPLANES : PLANES__;
+    constexpr int TAB1 = TAIL ? 2 * TAILN * 4 : 0;        // TAIL: scale | shift of the 1x1 layer
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PLANES + 2 * 2 * BN * 4 + HRUN + TAB1];
     unsigned char* const planes = smem;
     float* const s_tab0 = reinterpret_cast<float*>(smem + PLANES);         // scale | shift of the tile's columns, by tile parity
     float* const h_run = reinterpret_cast<float*>(smem + PLANES + 2 * 2 * BN * 4);
+    float* const tab1 = reinterpret_cast<float*>(smem + PLANES + 2 * 2 * BN * 4 + HRUN);
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -153,6 +176,21 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
         srdB[3] = 0x00020000u;
     }
     const unsigned vlane16 = (unsigned)lane * 16u;
+    srd_t srdT;                     // TAIL: the 1x1 layer's filters (granule order)
+    {
+        const unsigned long long ta_ = (unsigned long long)(uintptr_t)(TAIL ? ha.t_w : ha.wgt_halo);
+        srdT[0] = __builtin_amdgcn_readfirstlane((unsigned)ta_);
+        srdT[1] = __builtin_amdgcn_readfirstlane((unsigned)(ta_ >> 32) & 0xffffu);
+        srdT[2] = 0xffffffffu;
+        srdT[3] = 0x00020000u;
+    }
+    if constexpr (TAIL) {           // the 1x1 layer's scale | shift, once per block (first read behind the tile's barriers)
+        const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < TAILN / 4) {
+            *reinterpret_cast<float4*>(&tab1[4 * t]) = ha.t.scale ? *reinterpret_cast<const float4*>(ha.t.scale + 4 * t) : one;
+            *reinterpret_cast<float4*>(&tab1[TAILN + 4 * t]) = ha.t.shift ? *reinterpret_cast<const float4*>(ha.t.shift + 4 * t) : zero;
+        }
+    }
     // measurement-only ablations (ha.a.dbg = 0 in production; mrcnn_debug_set("conv_pp_dbg")): 1 no filter loads in the main
     // loop, 2 no barriers, 4 no activation-fragment reads, 8 no MFMAs, 16 no slab staging
     // (compiled in only in the DBG instantiation, which the launcher picks when a.dbg != 0: the production loop carries no switch)
@@ -376,7 +414,136 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
         // Epilogue through a wave-private 32 x 36-float tile inside plane buffer 1 (free since the last slab's barrier; the next
         // tile's prologue only writes plane buffer 0 and the other s_tab, and its first write to buffer 1 comes after its own
         // prologue barrier, i.e. after every wave has left this epilogue): full-line stores, no block barrier.
-        if constexpr (!HEAD) {
+        if constexpr (TAIL) {
+            const ConvArgs& t1 = ha.t;
+            unsigned char* const tpl = smem;                               // [part][K group][row] x 32 B, halves swapped when bit 3 of the row is set
+            float* const tstage = reinterpret_cast<float*>(smem + PARTS * TAILPL) + wave * (32 * 36);
+            const bool relu3 = a.act == ACT_RELU;
+            bool oor = false;
+            // y = act(acc * scale + shift) — the 3x3 layer's own epilogue arithmetic.  lane (pixel l31, kk), accumulator slot 4q + r
+            // <-> channel 32 j + 8 q + 4 kk + r of this wave's 64 columns.  The waves of rows 0..63 (wm = 0) split their y into the
+            // LDS planes at once; the waves of rows 64..127 park theirs (fp32, 16 KB per wave, one coalesced KB per store) in the
+            // block's slice of a global scratch and fetch it back for the second half: carrying the 64 accumulator registers through
+            // the first half's 1x1 left the compiler no room to keep loads in flight (every fragment read and filter load was
+            // waited for on the spot: 179 us against 163 for the two launches, gpurun_out/r4f).
+            if (t1.dbg & 4) { if (acc[0][0][0] == 123.456f) tab1[1] = acc[1][1][3]; continue; }      // measurement only: the 3x3 loop alone
+            float4* const park = static_cast<float4*>(ha.t_park) + ((size_t)blockIdx.x * 4 + wn) * 16 * 64 + lane;
+            auto stage_piece = [&](const float (&x)[4], int i, int j, int q) {
+                u32x4 v = {__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
+                u32x2 parts[PARTS];
+                split4<PARTS>(v, parts);
+                const int row = i * 32 + l31, g = wn * 4 + j * 2 + (q >> 1);
+                const unsigned addr = (unsigned)((g * 64 + row) * 32 + ((((q & 1) ^ (row >> 3)) & 1) << 4) + 8 * kk);
+#pragma unroll
+                for (int p = 0; p < PARTS; ++p) *reinterpret_cast<u32x2*>(tpl + p * TAILPL + addr) = parts[p];
+            };
+            __syncthreads();          // every wave has left the 3x3 loop: its planes may be overwritten
+            if (!(t1.dbg & 8))        // measurement only: 8 = no staging / parking of the activated tile
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int cl = wn * 64 + j * 32 + 8 * q + 4 * kk;
+                        const float4 sc = *reinterpret_cast<const float4*>(s_tab + cl), sh = *reinterpret_cast<const float4*>(s_tab + BN + cl);
+                        float x[4] = {acc[i][j][4 * q + 0] * sc.x + sh.x, acc[i][j][4 * q + 1] * sc.y + sh.y,
+                                      acc[i][j][4 * q + 2] * sc.z + sh.z, acc[i][j][4 * q + 3] * sc.w + sh.w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (relu3) x[r] = fmaxf(x[r], 0.f);
+                            oor = oor || !(fabsf(x[r]) < 65504.0f);
+                        }
+                        if (wm == 0) stage_piece(x, i, j, q);
+                        else park[((i * 2 + j) * 4 + q) * 64] = make_float4(x[0], x[1], x[2], x[3]);
+                    }
+            if (a.range_flag && oor) atomicOr(a.range_flag, 1);
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                if (h == 1 && wm == 1 && !(t1.dbg & 8)) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float4 y = park[((i * 2 + j) * 4 + q) * 64];
+                                const float x[4] = {y.x, y.y, y.z, y.w};
+                                stage_piece(x, i, j, q);
+                            }
+                }
+                __syncthreads();
+                const int half_row0 = ha.geo == HALO_GEO_2ROWS ? m0 + h * a.OW : m0 + h * 64;
+#pragma unroll 1
+                for (int it = 0; it < 2; ++it) {
+                    const int n1 = it * 512 + wave * 64;                   // this wave's 64 output columns of the 1x1
+                    f32x16 acc1[2][2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) acc1[i][j][e] = 0.0f;
+                    // filter fragments straight from memory, two steps ahead (three register sets): granule (n1 / 32 + j), K group s,
+                    // one coalesced KB per load.  The loads and their waits are inline asm like the 3x3 loop's: left to the compiler,
+                    // every load was sunk to its use and waited for on the spot (gpurun_out/r4f: the fused launch 10 % SLOWER than the
+                    // two it replaces).  vmcnt: at the end of step s the fragments of step s + 1 must have landed; behind them only the
+                    // two loads of step s + 2 may be outstanding (stores of the previous epilogue retire independently: loads return in
+                    // order, so "at most 2 outstanding" still means every load but the two newest is home).  All drained by step 14:
+                    // the epilogue's own loads and stores are counted by the compiler.
+                    const unsigned wofs = (unsigned)((n1 / 32) * 16 * 1024);
+                    u32x4 bw[3][2];
+#define TAIL_BLOAD(SET, S_)                                                                                      \
+    {                                                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
+            const unsigned so_ = wofs + (unsigned)((j * 16 + (S_)) * 1024);                                      \
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(bw[SET][j]) : "v"(vlane16), "s"(srdT), "s"(so_) : "memory"); \
+        }                                                                                                        \
+    }
+#define TAIL_BPIN() { _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) _Pragma("unroll") for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(bw[q_][j])); }
+                    TAIL_BLOAD(0, 0)
+                    TAIL_BLOAD(1, 1)
+                    const unsigned a_off = (unsigned)(l31 * 32 + ((kk ^ ((l31 >> 3) & 1)) << 4));
+                    uint4 fa[2][PARTS];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int p = 0; p < PARTS; ++p) fa[i][p] = *reinterpret_cast<const uint4*>(tpl + p * TAILPL + (i * 32) * 32 + a_off);
+                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    TAIL_BPIN()
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) {
+                        if (t1.dbg & 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break; }       // measurement only (mrcnn_debug_set("conv_tail_dbg")): no 1x1 K loop
+                        if (s + 2 < 16) TAIL_BLOAD((s + 2) % 3, s + 2)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int p = 0; p < PARTS; ++p)
+#pragma unroll
+                                for (int j = 0; j < 2; ++j)
+                                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bw[s % 3][j]), __builtin_bit_cast(f16x8, fa[i][p]),
+                                                                                        acc1[i][j], 0, 0, 0);
+                        // the fragments of the next K group replace the ones just multiplied (the SIMD's other wave owns the matrix pipe meanwhile)
+                        if (s + 1 < 16) {
+#pragma unroll
+                            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                                for (int p = 0; p < PARTS; ++p)
+                                    fa[i][p] = *reinterpret_cast<const uint4*>(tpl + p * TAILPL + ((s + 1) * 64 + i * 32) * 32 + a_off);
+                        }
+                        if (s + 2 < 16) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        TAIL_BPIN()
+                    }
+#undef TAIL_BPIN
+#undef TAIL_BLOAD
+                    if (!(t1.dbg & 1))          // measurement only: 1 = no 1x1 epilogue (residual loads, stores)
+                        conv_epilogue_wave<TAILN, 2, 2, true>(t1, acc1, tstage, tab1, half_row0, 0, n1, lane);
+                    else if (acc1[0][0][0] == 123.456f) tab1[0] = acc1[1][1][3];       // (keeps the accumulators alive)
+                }
+                __syncthreads();          // the planes are rewritten by the other half / the next tile's prologue
+            }
+        } else if constexpr (!HEAD) {
             conv_epilogue_wave<BN, TM, TN>(a, acc, reinterpret_cast<float*>(planes + PBUF) + wave * (32 * 36), s_tab, wave_row0, n0,
                                            wn * TN * 32, lane);
         } else {
@@ -464,19 +631,19 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
 // filter re-tiling: [Npad][9][Cin] fp16 (the family's packing) → granules [Npad/32][Cin/16][9][1 KB] in MFMA-fragment order:
 // the 16 B of lane (l31, kk) — filter row 32 g + l31, channels 16 h + 8 kk .. + 8 — at byte 16 · (32 kk + l31)
 // ----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_halo_pack(const uint4* __restrict__ src, int Npad, int Cin, uint4* __restrict__ dst)
+__global__ __launch_bounds__(256) void k_halo_pack(const uint4* __restrict__ src, int Npad, int Cin, int taps, uint4* __restrict__ dst)
 {
     const int NH = Cin / 16;
-    const long total = (long)(Npad / 32) * NH * 9 * 64;         // 16-B pieces
+    const long total = (long)(Npad / 32) * NH * taps * 64;      // 16-B pieces
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const int piece = (int)(e & 63);
         const long gs = e >> 6;                                   // (granule, step)
-        const int step = (int)(gs % (NH * 9));
-        const int g = (int)(gs / (NH * 9));
-        const int h = step / 9, tap = step - h * 9;
+        const int step = (int)(gs % (NH * taps));
+        const int g = (int)(gs / (NH * taps));
+        const int h = step / taps, tap = step - h * taps;
         const int r = piece & 31, half = piece >> 5;             // piece = lane of the wave that will load it
         const int n = g * 32 + r;
-        dst[e] = src[(((long)n * 9 + tap) * Cin + 16 * h + 8 * half) / 8];
+        dst[e] = src[(((long)n * taps + tap) * Cin + 16 * h + 8 * half) / 8];
     }
 }
 
@@ -501,14 +668,14 @@ void conv_halo_pack_head(hipStream_t s, const void* wgt_std, int Npad, int Cin, 
     HIP_CHECK(hipGetLastError());
 }
 
-void conv_halo_pack(hipStream_t s, const void* wgt_std, int Npad, int Cin, DevBuf& out)
+void conv_halo_pack(hipStream_t s, const void* wgt_std, int Npad, int Cin, DevBuf& out, int taps)
 {
-    MRCNN_REQUIRE(Npad % 32 == 0 && Cin % 16 == 0, MRCNN_ERR_SHAPE, "halo packing: Npad %d / Cin %d", Npad, Cin);
-    const size_t bytes = (size_t)Npad * 9 * Cin * 2;
+    MRCNN_REQUIRE(Npad % 32 == 0 && Cin % 16 == 0 && (taps == 9 || taps == 1), MRCNN_ERR_SHAPE, "halo packing: Npad %d / Cin %d / taps %d", Npad, Cin, taps);
+    const size_t bytes = (size_t)Npad * taps * Cin * 2;
     out.alloc(bytes);
     const long total = (long)bytes / 16;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(k_halo_pack, dim3(grid), dim3(256), 0, s, static_cast<const uint4*>(wgt_std), Npad, Cin, static_cast<uint4*>(out.p));
+    hipLaunchKernelGGL(k_halo_pack, dim3(grid), dim3(256), 0, s, static_cast<const uint4*>(wgt_std), Npad, Cin, taps, static_cast<uint4*>(out.p));
     HIP_CHECK(hipGetLastError());
 }
 
@@ -628,17 +795,27 @@ bool conv_halo_head_eligible(const ConvDesc& d)
            d.head_cols >= 1 && d.head_cols <= 32 && d.head_split >= 0 && d.head_split <= d.head_cols;
 }
 
+// the 1x1 filter shapes the fused tail accepts (re-tiled at load with one tap): 256 -> 1024
+bool conv_halo_tail_packable(int KH, int KW, int Cin, int Npad) { return KH == 1 && KW == 1 && Cin == 256 && Npad == 1024; }
+// ... and the 3x3 geometries: the tail is instantiated for the three-piece staging only (regions of <= 384 pixels: C4 at 1024²)
+bool conv_halo_tail_geometry_ok(int H, int W) { const HaloGeo g = halo_geometry(H, W, 128); return g.ok && g.maxpc <= 3; }
+
 // a: filled by conv_forward (M, strides, epilogue fields, vec_ok checked by the caller); returns the N tile used
-int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, int n_cus)
+// t1 / t_w != nullptr: the fused bottleneck tail (conv_forward_tail has checked the pair)
+int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, int n_cus, const ConvArgs* t1, const void* t_w)
 {
     HaloArgs ha;
+    ha.t_w = t_w;
+    ha.t_park = nullptr;
+    if (t1) ha.t = *t1;
     // tile shape: the largest whose tiles occupy the chip (the K order, hence the result, does not depend on it): 128 x 256,
     // then 128 x 128, then — small grids: batch 1, the top pyramid levels — 64 x 128
     int bm = 128, bn = d.Npad % 256 == 0 ? 256 : 128;
-    if (!d.head_w) {
+    if (!d.head_w && !t1) {
         if (bn > 128 && (long)((a.M + 127) / 128) * (d.Npad / bn) < n_cus) bn = 128;
         if (bn == 128 && (long)((a.M + 127) / 128) * (d.Npad / bn) * 4 < (long)n_cus * 3) bm = 64;
     }
+    MRCNN_REQUIRE(!t1 || (bn == 256 && d.Npad == 256), MRCNN_ERR_INVALID, "fused tail: the 3x3 layer must have exactly 256 output columns");
     const int tiles_m = (a.M + bm - 1) / bm;
     a.tiles_m = tiles_m;
     a.tiles_n = d.Npad / bn;
@@ -656,6 +833,24 @@ int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, i
     const int units = d.head_w ? a.tiles_m : ha.n_tiles;
     int grid = units < n_cus ? units : n_cus;
     if (grid >= 8) grid &= ~7;                  // a multiple of 8: every XCD runs the same number of blocks
+    if (t1) {
+        ha.t.direct = 1;
+        // the parking scratch: 64 KB per block, one buffer per stream (launches on one stream are ordered; two models on two
+        // streams must not share it), grown on demand and never freed (a static destructor would run after the HIP runtime's)
+        static std::mutex park_mu;
+        static std::map<hipStream_t, DevBuf*> parks;
+        {
+            std::lock_guard<std::mutex> lk(park_mu);
+            DevBuf*& pk = parks[s];
+            if (!pk) pk = new DevBuf;
+            if (pk->bytes < (size_t)grid * 65536) { HIP_CHECK(hipStreamSynchronize(s)); pk->alloc((size_t)grid * 65536); }
+            ha.t_park = pk->p;
+        }
+        MRCNN_REQUIRE(g.maxpc <= 3, MRCNN_ERR_INVALID, "fused tail: the tile's input region needs more than three staging pieces (conv_halo_tail_geometry_ok)");
+        if (parts == 3) hipLaunchKernelGGL((k_conv_halo<3, 2, false, false, 2, 3, true>), dim3(grid), dim3(512), 0, s, ha);
+        else hipLaunchKernelGGL((k_conv_halo<2, 2, false, false, 2, 3, true>), dim3(grid), dim3(512), 0, s, ha);
+        return bn;
+    }
     if (parts == 3) halo_launch<3>(s, ha, bm, bn, g.maxpc, grid);
     else halo_launch<2>(s, ha, bm, bn, g.maxpc, grid);
     return bn;

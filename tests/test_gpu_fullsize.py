@@ -60,6 +60,21 @@ def test_headline_batch8_full_size(pkg, orc, full_model, full_images, full_oracl
     det4, mask4 = m.predict(full_images[2:6])
     np.testing.assert_array_equal(det4, det[2:6])
     np.testing.assert_array_equal(mask4, mask[2:6])
+    if mode in ("f32x3", "f32s"):
+        # the fused bottleneck tail (C4's 3x3 + 1x1 + shortcut in one persistent launch; opt-in: measured slower)
+        # sums in the order of the two launches it replaces: bit-identical, all 23 blocks of C4, at the batch that fills the chip
+        L = __import__("importlib").import_module("mask-rcnn-coreml_amd._lib")
+        try:
+            L.check(L.lib().mrcnn_debug_set(b"conv_tail", 1))
+            det_t, mask_t = m.predict(full_images)
+            p5 = [m.read_tensor("P5", b) for b in (0, 7)]
+        finally:
+            L.check(L.lib().mrcnn_debug_set(b"conv_tail", 0))
+        np.testing.assert_array_equal(det_t, det)
+        np.testing.assert_array_equal(mask_t, mask)
+        m.predict(full_images)
+        for k, b in enumerate((0, 7)):
+            np.testing.assert_array_equal(m.read_tensor("P5", b), p5[k])
     pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None
 
 

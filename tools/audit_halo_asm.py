@@ -40,18 +40,23 @@ def audit(lines):
         scratch = [k for k, l in enumerate(body) if "scratch_" in l]
         mfma = [k for k, l in enumerate(body) if "v_mfma" in l]
         labels = {l.split(":")[0]: k for k, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)}
-        best = None
+        # every backward branch spanning >= 72 MFMAs is a candidate; the hand-counted loop is the 36-step loop of the 3x3 phase — the
+        # innermost candidate with the MOST MFMAs (the fused-tail instantiations also hold the 16-step 1x1 loop, whose loads the
+        # compiler counts itself: spills there cost time, not correctness, and are reported separately)
+        cands = []
         for k, l in enumerate(body):
             m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
             if not m or labels.get(m.group(1), k) >= k:
                 continue
             t = labels[m.group(1)]
             nm = sum(1 for x in mfma if t <= x <= k)
-            if nm >= 2 * 36 and (best is None or k - t < best[1] - best[0]):
-                best = (t, k, nm)
-        if best is None:   # no loop found: report it as a violation rather than pass silently
+            if nm >= 2 * 36:
+                cands.append((t, k, nm))
+        inner = [c for c in cands if not any(o is not c and c[0] <= o[0] and o[1] <= c[1] for o in cands)]
+        if not inner:   # no loop found: report it as a violation rather than pass silently
             rows.append((name, len(scratch), 0, -1))
             continue
+        best = max(inner, key=lambda c: c[2])
         inside = sum(1 for x in scratch if best[0] <= x <= best[1])
         rows.append((name, len(scratch), best[2], inside))
     return rows
