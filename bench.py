@@ -292,6 +292,7 @@ def main():
                 tail = {"f32": "2,2", "f16": "2,2", "f32s": "3,2", "f32x3": "3,3"}[args.dtype]
                 kname = {"128x128": f"k_conv_mfma_glds<{ktypes},128,1,2,4,2,{tail}>", "128x64": f"k_conv_mfma_glds<{ktypes},64,1,1,4,2,...>",
                          "128x32": f"k_conv_mfma_glds<{ktypes},32,1,1,4,1,...>", "128x128w4": f"k_conv_mfma_glds<{ktypes},128,1,4,4,1,{tail}>",
+                         "128x256tail": f"k_conv_halo<{parts},2,false,false,2,3,TAIL> (3x3 + 1x1 + shortcut of a bottleneck block in one launch; opt-in)",
                          "256x256pp": "k_conv_pp<0>", "128xNhalo": f"k_conv_halo<{parts},TN,HEAD> (persistent 128 x 128*TN halo tiles; instantiations <{parts},2,false>, <{parts},2,true> = fused RPN heads, <{parts},1,false>)"}[dom]
                 out["roofline"] = {
                     "kernel": kname, "bound": "mfma",
@@ -404,9 +405,8 @@ def sustained_peak(dtype, parts, achieved):
     """What the matrix cores of this board sustain for seconds with NO data movement (tools/probes/mfma_probe.hip under
     tools/mfma_power.sh, committed under profiles/): the fp16 MFMA on operands that change every instruction, the fp32 MFMA
     on constants.  Informational — `peak` / `frac` above stay the nominal figures of MI355X_MICROARCH.md."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_mfma_power.txt")
-    if not os.path.exists(path):
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_mfma_power.txt")
+    path = next((p for p in (os.path.join(ROOT, "profiles", f"{r}_mfma_power.txt") for r in ("r04", "r03", "r02")) if os.path.exists(p)),
+                os.path.join(ROOT, "profiles", "r02_mfma_power.txt"))
     try:
         want = "v_mfma_f32_32x32x2_f32" if dtype == "f32" else "random data"
         for line in open(path):
@@ -419,7 +419,7 @@ def sustained_peak(dtype, parts, achieved):
     return None
 
 
-CLASS_KERNELS = {"128xNhalo": ("k_conv_halo<",), "256x256pp": ("k_conv_pp<",), "128x128": (", 128, 1, 2, 4, 2,",), "128x64": (", 64, 1, 1, 4, 2,",),
+CLASS_KERNELS = {"128xNhalo": ("k_conv_halo<",), "128x256tail": ("k_conv_halo<",), "256x256pp": ("k_conv_pp<",), "128x128": (", 128, 1, 2, 4, 2,",), "128x64": (", 64, 1, 1, 4, 2,",),
                  "128x32": (", 32, 1, 1, 4, 1,",), "128x128w4": (", 128, 1, 4, 4, 1,",)}
 
 
@@ -429,7 +429,7 @@ def pmc_traffic(dtype, tile_class=None):
     command in this compute mode (profiles/rNN_pmc_kernels_<dtype>.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE
     doubled per MI355X_MICROARCH.md §HBM).  PMC collection cannot run inside the timed process, hence a committed value."""
     if tile_class in CLASS_KERNELS:
-        for rnd in ("r03",):
+        for rnd in ("r04", "r03"):
             try:
                 with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_kernels_{dtype}.json")) as f:
                     ks = json.load(f)["kernels"]
@@ -439,7 +439,7 @@ def pmc_traffic(dtype, tile_class=None):
                     return round(sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in sel) / n)
             except Exception:
                 pass
-    for name in (f"r03_pmc_traffic_{dtype}.json", f"r02_pmc_traffic_{dtype}.json", "r01_pmc_traffic.json" if dtype == "f32" else None):
+    for name in (f"r04_pmc_traffic_{dtype}.json", f"r03_pmc_traffic_{dtype}.json", f"r02_pmc_traffic_{dtype}.json", "r01_pmc_traffic.json" if dtype == "f32" else None):
         if not name:
             continue
         try:
@@ -451,7 +451,7 @@ def pmc_traffic(dtype, tile_class=None):
 
 
 def pmc_traffic_source(dtype):
-    for name in (f"r03_pmc_kernels_{dtype}.json", f"r03_pmc_traffic_{dtype}.json", f"r02_pmc_traffic_{dtype}.json", "r01_pmc_traffic.json" if dtype == "f32" else None):
+    for name in (f"r04_pmc_kernels_{dtype}.json", f"r03_pmc_kernels_{dtype}.json", f"r03_pmc_traffic_{dtype}.json", f"r02_pmc_traffic_{dtype}.json", "r01_pmc_traffic.json" if dtype == "f32" else None):
         if name and os.path.exists(os.path.join(ROOT, "profiles", name)):
             return "profiles/" + name
     return None

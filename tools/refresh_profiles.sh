@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerates everything under profiles/ for round $1 (default r02) on a GPU box:
-#   gpurun --timeout 3000 -- 'bash tools/refresh_profiles.sh r03'
+#   gpurun --timeout 3300 -- 'bash tools/refresh_profiles.sh r04'
 # Outputs land in gpurun_out/profiles_<round>/ (merged back by gpurun); copy them into profiles/ and commit.
 # Counter passes follow MI355X_MICROARCH.md: --pmc in its own run with --kernel-trace only, FETCH_SIZE and WRITE_SIZE separately.
 set -u
-RND=${1:-r03}
+RND=${1:-r04}
 MODES=${2:-"f32x3 f16 f32s f32"}
 R=$(pwd)
 OUT=$R/gpurun_out/profiles_$RND
@@ -48,6 +48,12 @@ fi
 timeout 300 python tools/conv_ab.py 3 10 1 f16 > $OUT/${RND}_conv_ab_f16.txt 2>/dev/null
 for dt in f32x3 f32s; do timeout 300 python tools/halo_ab.py 3 10 $dt 2>/dev/null | grep -v amdgpu > $OUT/${RND}_halo_ab_$dt.txt; done
 timeout 200 python tools/halo_ablate.py f32x3 2>/dev/null | grep -v amdgpu > $OUT/${RND}_halo_ablate_f32x3.txt
+# round 4: the halo kernel's tile geometries (MRCNN_HALO_GEO=0 = round 3's one-row tiles, five staging pieces, pitch W + 2) — timing and LDS conflicts per layer
+for g in 0 1; do MRCNN_HALO_GEO=$g timeout 300 python tools/halo_ab.py 3 10 f32x3 2>/dev/null | grep -v amdgpu > $OUT/${RND}_halo_ab_geo${g}_f32x3.txt; done
+timeout 600 bash tools/pmc_halo_geo_probe.sh f32x3 "8 256 256 256 512 3 1" "8 256 256 256 256 3 1" "800 14 14 256 256 3 1" "8 64 64 256 256 3 1" "8 32 32 512 512 3 1" "8 32 32 256 256 3 1" > $OUT/${RND}_pmc_halo_geo_f32x3.txt 2>&1
+python tools/lds_bank_model.py > $OUT/${RND}_lds_bank_model.txt 2>&1
+# the split modes' calibration report on the headline model (per tensor group: max |a|, exponent, counters)
+timeout 300 python tools/split_report.py > $OUT/${RND}_split_report_f32x3.txt 2>/dev/null
 bash tools/pmc_halo_probe.sh f32x3 "8 256 256 256 512 3 1" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD" "FETCH_SIZE" "WRITE_SIZE" > $OUT/${RND}_pmc_probe_rpn3x3_f32x3.txt 2>&1
 [ -x tools/probes/vmem_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/probes/vmem_probe tools/probes/vmem_probe.hip 2>/dev/null
 [ -x tools/probes/vmem_probe ] && timeout 120 ./tools/probes/vmem_probe 2048 > $OUT/${RND}_vmem_probe.txt 2>&1
