@@ -77,6 +77,31 @@ public final class MaskRCNN {
         return (det, msk)
     }
 
+    /// Scale-aware split (`.f32x3` / `.f32s` only): one calibration predict on a representative image picks a power-of-two exponent per
+    /// tensor group (folded into the layers at no run-time cost) so that the mode carries activations like fp32 whatever the
+    /// checkpoint's scale; returns the number of inputs the split still cannot carry exactly.  `apply: false` only diagnoses.
+    @discardableResult
+    public func calibrateSplit(image rgb: UnsafePointer<UInt8>, apply: Bool = true) throws -> Int64 {
+        try check(mrcnn_model_calibrate_split(handle, rgb, 1, height, width, Int32(MRCNN_HOST.rawValue), apply ? 1 : 0))
+        var n: Int64 = 0
+        try check(mrcnn_model_get_int(handle, "split_inexact_inputs", &n))
+        return n
+    }
+
+    /// The evaluate loop with the hand-over of the NEXT image overlapped (EvaluateCommand.swift:167-179): `submit` copies an image on the
+    /// handle's copy stream and enqueues its predict, `collect` returns the OLDEST submission's outputs.  At most two in flight; the
+    /// buffer passed to `submit` must stay alive until the matching `collect`.
+    public func submit(image rgb: UnsafePointer<UInt8>) throws {
+        try check(mrcnn_maskrcnn_submit(handle, rgb, 1, height, width))
+    }
+    public func collect() throws -> (detections: [Float], mask: [Float]) {
+        var det = [Float](repeating: 0, count: maxDetections * 6)
+        var msk = [Float](repeating: 0, count: maxDetections * maskSide * maskSide)
+        var n: Int32 = 0
+        try check(mrcnn_maskrcnn_collect(handle, &det, &msk, &n))
+        return (det, msk)
+    }
+
     /// `image`: RGB8 of ANY size — what `VNCoreMLRequest` with `.scaleFit` does for the reference (EvaluateCommand.swift:152-157,
     /// ViewController.swift:45): the letterbox runs inside the engine's pre-processing kernel.  Boxes are normalized in the
     /// letterboxed frame, like the reference's; `unletterboxed` maps them back to the source image.
