@@ -599,7 +599,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4*>(&part[((wn * 128) + wm * (TM * 32) + i * 32 + l31) * 32 + 8 * q + 4 * kk]) =
+                    // (16-B chunk c = 2q + kk of row r sits at chunk c ^ (r & 7): eight consecutive rows — one ds_write_b128 lane group —
+                    // would otherwise hit ONE bank, 128 B apart: the 0.09 conflict rate of this instantiation in round 3 / VERDICT r3)
+                    *reinterpret_cast<float4*>(&part[((wn * 128) + wm * (TM * 32) + i * 32 + l31) * 32 + (((2 * q + kk) ^ (l31 & 7)) << 2)]) =
                         make_float4(hp[i][4 * q], hp[i][4 * q + 1], hp[i][4 * q + 2], hp[i][4 * q + 3]);
             __syncthreads();
             const bool last = inner == n_inner - 1;
@@ -607,10 +609,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
             for (int k = 0; k < 8; ++k) {
                 const int o = t + 512 * k, row = o >> 5, col = o & 31;
                 float sum = inner == 0 ? 0.0f : h_run[o];
-                sum += part[(0 * 128 + row) * 32 + col];
-                sum += part[(1 * 128 + row) * 32 + col];
-                sum += part[(2 * 128 + row) * 32 + col];
-                sum += part[(3 * 128 + row) * 32 + col];
+                const int pc = ((((col >> 2) ^ (row & 7)) << 2) | (col & 3));          // the swizzled position of column col in row `row`
+                sum += part[(0 * 128 + row) * 32 + pc];
+                sum += part[(1 * 128 + row) * 32 + pc];
+                sum += part[(2 * 128 + row) * 32 + pc];
+                sum += part[(3 * 128 + row) * 32 + pc];
                 if (!last) h_run[o] = sum;
                 else {
                     const int m = ha.geo == HALO_GEO_2ROWS ? m0 + (row >> 6) * a.OW + (row & 63) : m0 + row;
@@ -740,7 +743,8 @@ bool conv_halo_eligible(const ConvDesc& d)
     const bool split = d.dtype == MRCNN_F32 && (wdtype == MRCNN_F16 || wdtype == MRCNN_F32X3);
     if (!split || d.KH != 3 || d.KW != 3 || d.stride != 1 || d.padH != 1 || d.padW != 1) return false;
     // slabs in fours (the main loop is unrolled by four slabs); 256 output columns or more: with 128 the wave tile is 64 x 32 and the activation-fragment reads per
-    // MFMA double — measured slower than the 128-row kernel (C3's 128 -> 128 layers: x0.92)
+    // MFMA double — round 3 measured x0.92 against the 128-row kernel on C3's 128 -> 128 layers; with round 4's cheaper staging x1.08
+    // (110 -> 102 us, gpurun_out/r4i): 0.2 % of a step, not worth a second K order for those layers — left on the 128-row kernel
     if (d.OH != d.H || d.OW != d.W || d.Cin % 64 != 0 || d.Npad % 256 != 0 || d.Cout % 4 != 0) return false;
     if (d.deconv2 || d.out2 || d.sel_partial || d.act == ACT_SIGMOID || d.res) return false;
     if (d.H >= 32760 || d.W >= 32760 || (double)d.in_sB * 8.0 >= 2.0e9) return false;
