@@ -119,15 +119,15 @@ template <int PARTS, int TN, bool HEAD = false, bool DBG = false, int TM = 2, in
 __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
 {
     const ConvArgs& a = ha.a;
-    static_assert(!HEAD || TM == 2, "the fused head reduces over 128-row tiles");
+    static_assert(!HEAD || TN == 2, "the fused head walks the K groups of 256-column tiles");
     static_assert(!TAIL || (TM == 2 && TN == 2 && !HEAD), "the fused tail needs the whole 128 x 256 tile in one block");
     static_assert(MAXPC >= 2 && MAXPC <= 5, "staging pieces per thread");
     constexpr int BM = 2 * TM * 32, WN = 4, BN = WN * TN * 32;
     constexpr int PLANE = (HALO_MAX_SLOT + 1) * 32;       // bytes of one part of one slab (+ one dump slot: pieces beyond the region write there, unconditionally)
     constexpr int PBUF = PARTS * PLANE;                   // one plane buffer (all parts)
     constexpr int STAGE = 8 * 32 * 36 * 4;                // the epilogue's wave-private tiles: they live in plane buffer 1
-    constexpr int HPART = 4 * 128 * 32 * 4;               // HEAD: the four wave columns' partial head sums of a tile (they live in the planes)
-    constexpr int HRUN = HEAD ? 128 * 32 * 4 : 0;         // HEAD: running head sum of the M tile over its N tiles
+    constexpr int HPART = 4 * BM * 32 * 4;                // HEAD: the four wave columns' partial head sums of a tile (they live in the planes)
+    constexpr int HRUN = HEAD ? BM * 32 * 4 : 0;          // HEAD: running head sum of the M tile over its N tiles
     constexpr int PLANES_ = 2 * PBUF > PBUF + STAGE ? 2 * PBUF : PBUF + STAGE;
     constexpr int TAILPL = 16 * 64 * 32;                  // TAIL: one part of the 64-row half: [16 K groups][64 rows] x 32 B
     constexpr int TAILN = 1024;                           // TAIL: output columns of the 1x1 layer
@@ -601,19 +601,19 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
                 for (int q = 0; q < 4; ++q)
                     // (16-B chunk c = 2q + kk of row r sits at chunk c ^ (r & 7): eight consecutive rows — one ds_write_b128 lane group —
                     // would otherwise hit ONE bank, 128 B apart: the 0.09 conflict rate of this instantiation in round 3 / VERDICT r3)
-                    *reinterpret_cast<float4*>(&part[((wn * 128) + wm * (TM * 32) + i * 32 + l31) * 32 + (((2 * q + kk) ^ (l31 & 7)) << 2)]) =
+                    *reinterpret_cast<float4*>(&part[((wn * BM) + wm * (TM * 32) + i * 32 + l31) * 32 + (((2 * q + kk) ^ (l31 & 7)) << 2)]) =
                         make_float4(hp[i][4 * q], hp[i][4 * q + 1], hp[i][4 * q + 2], hp[i][4 * q + 3]);
             __syncthreads();
             const bool last = inner == n_inner - 1;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < BM / 16; ++k) {               // BM rows x 32 head columns, 512 threads
                 const int o = t + 512 * k, row = o >> 5, col = o & 31;
                 float sum = inner == 0 ? 0.0f : h_run[o];
                 const int pc = ((((col >> 2) ^ (row & 7)) << 2) | (col & 3));          // the swizzled position of column col in row `row`
-                sum += part[(0 * 128 + row) * 32 + pc];
-                sum += part[(1 * 128 + row) * 32 + pc];
-                sum += part[(2 * 128 + row) * 32 + pc];
-                sum += part[(3 * 128 + row) * 32 + pc];
+                sum += part[(0 * BM + row) * 32 + pc];
+                sum += part[(1 * BM + row) * 32 + pc];
+                sum += part[(2 * BM + row) * 32 + pc];
+                sum += part[(3 * BM + row) * 32 + pc];
                 if (!last) h_run[o] = sum;
                 else {
                     const int m = ha.geo == HALO_GEO_2ROWS ? m0 + (row >> 6) * a.OW + (row & 63) : m0 + row;
@@ -776,7 +776,8 @@ static void halo_launch(hipStream_t s, const HaloArgs& ha, int bm, int bn, int m
         else hipLaunchKernelGGL((k_conv_halo<3, 2, false, true, 2, 5>), dim3(grid), dim3(512), 0, s, ha);
         return;
     }
-    if (ha.head_w) halo_launch_pc<PARTS, 2, true, 2>(s, ha, maxpc, grid);
+    if (ha.head_w && bm == 64) hipLaunchKernelGGL((k_conv_halo<PARTS, 2, true, false, 1, 3>), dim3(grid), dim3(512), 0, s, ha);      // small batches: 64-row tiles (regions of <= 198 pixels)
+    else if (ha.head_w) halo_launch_pc<PARTS, 2, true, 2>(s, ha, maxpc, grid);
     else if (bn == 256) halo_launch_pc<PARTS, 2, false, 2>(s, ha, maxpc, grid);
     else if (bm == 128) halo_launch_pc<PARTS, 1, false, 2>(s, ha, maxpc, grid);
     else halo_launch_pc<PARTS, 1, false, 1>(s, ha, maxpc, grid);
@@ -819,6 +820,10 @@ int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, i
         if (bn > 128 && (long)((a.M + 127) / 128) * (d.Npad / bn) < n_cus) bn = 128;
         if (bn == 128 && (long)((a.M + 127) / 128) * (d.Npad / bn) * 4 < (long)n_cus * 3) bm = 64;
     }
+    // a fused head owns whole M tiles (its N tiles run back to back on one block): when the 128-row M tiles alone would leave a
+    // quarter of the chip idle — single images at P3 / P4 — 64-row tiles double the blocks (same per-pixel summation order:
+    // bit-identical, tests/test_gpu_fullsize.py batch 8 vs batch 1); levels whose rows are not a multiple of 64 wide keep 128
+    if (d.head_w && (long)((a.M + 127) / 128) * 4 < (long)n_cus * 3 && d.W % 64 == 0) bm = 64;
     MRCNN_REQUIRE(!t1 || (bn == 256 && d.Npad == 256), MRCNN_ERR_INVALID, "fused tail: the 3x3 layer must have exactly 256 output columns");
     const int tiles_m = (a.M + bm - 1) / bm;
     a.tiles_m = tiles_m;

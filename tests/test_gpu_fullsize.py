@@ -99,6 +99,29 @@ def test_config5_1536_batch2(pkg, orc, tmp_path_factory, weights_mod, mode):
     pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None
 
 
+@pytest.mark.parametrize("mode", ["f32x3", "f16"])
+@pytest.mark.parametrize("name,kw", [("resnet50", dict(architecture="resnet50")),
+                                     ("c5_1536", dict(architecture="resnet101", input_image_shape=(1536, 1536, 3), num_classes=2, pre_nms_max_proposals=12000))])
+def test_other_configs_batch8_equals_eight_batch1_calls(pkg, tmp_path_factory, weights_mod, name, kw, mode):
+    """the bench numbers of BASELINE configs[2] (ResNet-50) and configs[4] (1536², 2 classes, pre_nms 12000) are
+    batch-8 numbers, while their parity tests ran at batch 1 / 2.  Per-image results must not depend on the batch THERE either (the
+    tile shapes, the halo kernel's tile widths and the fused-head policy all change with M): batch 8 bit-equal to eight batch-1 calls,
+    in the headline mode (calibrated split) and in fp16; every image yields its full load of proposals."""
+    models = __import__("importlib").import_module("mask-rcnn-coreml_amd.models")
+    d, cfg = make_model_dir(tmp_path_factory, pkg, weights_mod, "b8" + name + mode, **kw)
+    m = models.load_maskrcnn(d, max_batch=8, compute_dtype=mode)
+    images = rand_images(8, cfg.image_height, cfg.image_width, seed=53)
+    if mode == "f32x3":
+        m.calibrate_split(images[:1])
+    det, mask = m.predict(images)
+    assert int(m.read_tensor("keep_count", 0)[0]) == cfg.max_proposals and int((det[7, :, 5] > 0).sum()) > 0
+    for b in range(8):
+        d1, m1 = m.predict(images[b:b + 1])
+        np.testing.assert_array_equal(d1[0], det[b], err_msg=f"{name} {mode} image {b}: batch-8 result differs from its batch-1 result")
+        np.testing.assert_array_equal(m1[0], mask[b])
+    pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None
+
+
 N_E2E = 16          # oracle images of the end-to-end tests (~5 s of host time each; bench.py / profiles/ carry 64 and 256)
 
 
