@@ -1286,6 +1286,10 @@ void Model::collect(float* det_host, float* masks_host, int* batch_out)
     HIP_CHECK(hipMemcpyAsync(masks_host, sl.mask.p, (size_t)sl.batch * max_det * HW * 4, hipMemcpyDeviceToHost, pipe_out));
     if (mode != MRCNN_F32) HIP_CHECK(hipMemcpyAsync(&tripped, sl.flag.p, sizeof(int), hipMemcpyDeviceToHost, pipe_out));
     HIP_CHECK(hipStreamSynchronize(pipe_out));
+    if (pipe_submitted == pipe_collected + 1) {      // nothing newer has been enqueued: the stage timer / conv profile hold THIS batch's events
+        timer.finish();
+        if (conv_profile.active) conv_profile.collect();
+    }
     if (batch_out) *batch_out = sl.batch;
     sl.busy = false;
     ++pipe_collected;

@@ -173,12 +173,16 @@ def mask_flip_causes(det_a: np.ndarray, det_b: np.ndarray, pooled_a: np.ndarray,
 
 
 def evaluate(model: MaskRCNN, images: Iterable[Tuple[int, np.ndarray]], dataset_id: str = "coco",
-             limit: Optional[int] = 5, verbose: bool = True):
-    """images: (image_id, HxWx3 uint8).  Returns (results.proto bytes, [seconds per image], [PBResult])."""
+             limit: Optional[int] = 5, verbose: bool = True, calibrate: bool = False):
+    """images: (image_id, HxWx3 uint8).  Returns (results.proto bytes, [seconds per image], [PBResult]).
+    calibrate: split modes only — one calibration predict on the first image before the timed loop (model set-up, like the load
+    the reference keeps outside its timing, EvaluateCommand.swift:146-156): mrcnn_model_calibrate_split."""
     items = sorted(images, key=lambda it: it[0])           # sortById:true
     if limit is not None:
         items = items[:limit]
     H, W = model.image_height, model.image_width
+    if calibrate and items and model.compute_dtype in ("f32x3", "f32s"):
+        model.calibrate_split(letterbox(items[0][1], H, W)[None])
     out: List[PBResult] = []
     secs: List[float] = []
     for image_id, img in items:

@@ -429,6 +429,13 @@ def test_evaluate_harness(pkg, small_model):
     lb = E.letterbox(dict(images)[3], cfg.image_height, cfg.image_width)
     want = rp.detections_to_pb(m.prediction(lb)["detections"])
     assert results[2].detections == want and (results[2].width, results[2].height) == (160 - 21, 120)
+    # the headline mode with the scale-aware split calibrated on the first image, outside the timed loop (round 4)
+    m3 = models.load_maskrcnn(d, max_batch=1, compute_dtype="f32x3")
+    data3, secs3, results3 = E.evaluate(m3, images, dataset_id="synthetic", limit=5, verbose=False, calibrate=True)
+    assert m3.get_int("split_calibrated") == 1 and len(secs3) == 5
+    assert [r.id for r in results3] == ["1", "2", "3", "5", "7"]
+    # (the 0.7 score filter of the record may move a borderline detection between two fp32-grade modes)
+    assert all(abs(len(a.detections) - len(b.detections)) <= 1 for a, b in zip(results3, results))
 
 
 def test_layers_with_strided_and_device_arrays(pkg, orc):
