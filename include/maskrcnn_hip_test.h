@@ -58,7 +58,8 @@ MRCNN_API int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout,
  * bit-identical results — the tile shape depends on the batch size and per-image results must not.  Further knobs: "conv_halo" 0|1 the
  * persistent halo kernel of the 3x3 layers of the split modes (its K order is its own: results differ from "0" by summation noise);
  * "halo_geo" 0|1: its round-3 tile geometries | two-row tiles, region-sized staging, conflict-free LDS pitch (bit-identical);
- * "conv_tail" 0|1: bottleneck tails as two launches | one fused launch where the grid fills the chip (bit-identical).
+ * "conv_tail" 0|1: bottleneck tails as two launches | one fused launch where the grid fills the chip (bit-identical; default 0: measured slower);
+ * "conv_stem" 0|1: split modes, conv1 and the max-pool as two launches | one fused launch (bit-identical; default 1).
  * The switches are PROCESS-WIDE test / measurement knobs: not thread-safe; a choice captured in a hipGraph stays captured. */
 MRCNN_API int mrcnn_conv2d_nhwc(const float* in, int batch, int h, int w, int cin, const float* filters, int cout,
                                 int ksize, int stride, const float* scale, const float* shift, const float* residual,

@@ -810,6 +810,7 @@ void Model::build_maskrcnn()
             add([=](hipStream_t s, int batch) { preprocess_forward(s, src, batch, h, w, 3, m3, x0, dt); });
         }
         Tensor4 c1 = T(H / 2, W / 2, 64);
+        Tensor4 x_after_stem;
         const int g_c1 = new_split_group("C1");                  // conv1's output and its max-pooled version (max-pool commutes with the scaling)
         {
             const PackedConv* pc = &convs.at("conv1");
@@ -824,18 +825,26 @@ void Model::build_maskrcnn()
             d.OH = c1.H; d.OW = c1.W; d.Cout = pc->Cout; d.Npad = pc->Npad;
             d.out = c1.p; d.out_sP = c1.C; d.out_sB = c1.sB(); d.act = ACT_RELU;
             d.algo_k = 147;   // 7*7*3 real taps (the packed row is padded to 7*32)
+            // split modes: conv1 and the max-pool behind it as ONE persistent launch (kernels_conv_stem.hip) — c1 is then neither
+            // written nor read; bit-identical to the two launches, which remain for the other modes and behind "conv_stem" 0
             const size_t per_image = (size_t)c1.sB();
             const int g = g_c1;
-            add([d, self, g, per_image](hipStream_t s, int batch) {
-                ConvDesc x = d; x.B = batch; conv_forward(s, x);
+            Tensor4 xo = T(H / 4, W / 4, 64);
+            const bool stem = conv_stem_eligible(d);
+            add([d, self, g, per_image, stem, xo, c1, dt](hipStream_t s, int batch) {
+                ConvDesc x = d; x.B = batch;
+                if (stem && conv_stem_enabled()) {
+                    conv_stem_forward(s, x, xo.p, xo.H, xo.W);
+                    if (self->calib_phase) self->observe_split(s, g, xo.p, (size_t)xo.sB() * batch);     // (max over the pooled tensor = max over c1: every element of c1 lies in a window)
+                    return;
+                }
+                conv_forward(s, x);
                 if (self->calib_phase) self->observe_split(s, g, d.out, per_image * batch);
+                maxpool3x3s2_forward(s, c1.p, batch, c1.H, c1.W, c1.C, xo.p, xo.H, xo.W, dt);
             });
+            x_after_stem = xo;
         }
-        Tensor4 x = T(H / 4, W / 4, 64);
-        {
-            const Tensor4 i = c1, o = x;
-            add([i, o, dt](hipStream_t s, int batch) { maxpool3x3s2_forward(s, i.p, batch, i.H, i.W, i.C, o.p, o.H, o.W, dt); });
-        }
+        Tensor4 x = x_after_stem;
         Tensor4 Cf[6];
         const int f1s[6] = {0, 0, 64, 128, 256, 512}, f3s[6] = {0, 0, 256, 512, 1024, 2048};
         int g_x = g_c1;                                           // group of the running tensor x

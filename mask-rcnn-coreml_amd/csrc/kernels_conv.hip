@@ -407,6 +407,7 @@ static int g_min_blocks = 448;   // narrow the N tile while the grid has fewer b
 static int g_direct = env_int("MRCNN_DIRECT", 3);   // 0: every layer through the block-staged epilogue; 1: fp16 tensors straight from the accumulators;
                                  // 2: also fp32 tensors through wave-private LDS tiles (conv_epilogue_wave); 3: also the fp16 tensors of the
                                  // 128-column kernel (conv_epilogue_wave_h: full-line residual loads and stores; +3.6 % end to end in fp16 mode)
+static int g_stem = env_int("MRCNN_STEM", 1);        // split modes: conv1 + max-pool as one persistent launch (kernels_conv_stem.hip; bit-identical to the two launches)
 static int g_tail_dbg = env_int("MRCNN_TAIL_DBG", 0);        // measurement only: ablation bits of the fused tail's 1x1 phase (1 no epilogue, 2 no K loop)
 // Bottleneck tails (3x3 + 1x1) as one persistent launch when the grid fills the chip: bit-identical to the two launches, and
 // measured SLOWER (C4, batch 8: 180 us against 88 + 75; ablations: 3x3 loop 91 + barriers / prologues 7 + staging and parking 21 +
@@ -474,6 +475,7 @@ bool conv_debug_set(const char* key, int value)
     else if (k == "conv_direct") g_direct = value;
     else if (k == "conv_min_blocks") g_min_blocks = value;
     else if (k == "conv_tail") g_tail = value;
+    else if (k == "conv_stem") g_stem = value;
     else if (k == "conv_tail_dbg") g_tail_dbg = value;
     else return conv_halo_debug_set(key, value);
     return true;
@@ -584,6 +586,37 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
         prof->pending.push_back({tile, 2.0 * (double)a.M * (double)a.ncols * k, e0, e1, {a.M, a.ncols, a.Ktot, tile}});
     }
     HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused stem (kernels.h: conv_stem_forward)
+// ------------------------------------------------------------------------------------------------
+bool conv_stem_enabled() { return g_stem != 0; }
+bool conv_stem_eligible(const ConvDesc& d)
+{
+    const int wdtype = d.wdtype < 0 ? d.dtype : d.wdtype;
+    const bool split = d.dtype == MRCNN_F32 && (wdtype == MRCNN_F16 || wdtype == MRCNN_F32X3);
+    return split && d.KH == 7 && d.KW == 1 && d.Cin == 32 && d.stride == 2 && d.padH == 0 && d.padW == 0 && d.Cout == 64 && d.Npad == 64 &&
+           d.act == ACT_RELU && !d.res && !d.out2 && !d.deconv2 && d.in_sW == 4 && d.in_sH == (long)d.W * 4 && d.in_sB == (long)d.H * d.W * 4 &&
+           d.OH == (d.H - 7) / 2 + 1 && d.OW == (d.W - 7) / 2 + 1;
+}
+
+void conv_stem_forward(hipStream_t s, const ConvDesc& d, void* pooled, int PH, int PW)
+{
+    MRCNN_REQUIRE(conv_stem_eligible(d) && pooled && PH == (d.OH + 1) / 2 && PW == (d.OW + 1) / 2, MRCNN_ERR_INVALID, "conv_stem_forward: not the stem layer");
+    static int n_cus = [] { int dev = 0; hipDeviceProp_t p; (void)hipGetDevice(&dev); return hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }();
+    ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
+    const int e0 = prof ? prof_event(prof, s) : 0;
+    const int wdtype = d.wdtype < 0 ? d.dtype : d.wdtype;
+    conv_stem_launch(s, static_cast<const float*>(d.in), d.B, d.H, d.W, d.wgt, d.scale, d.shift, d.OH, d.OW, static_cast<float*>(pooled), PH, PW,
+                     wdtype == MRCNN_F32X3 ? 3 : 2, g_range_flag, n_cus);
+    if (prof) {
+        const int e1 = prof_event(prof, s);
+        const long M = (long)d.B * d.OH * d.OW;
+        const double k = d.algo_k > 0 ? d.algo_k : d.KH * d.KW * d.Cin;
+        // (the 64-column class of the table: the layer it replaces ran there; the pool rides in the same launch)
+        prof->pending.push_back({1, 2.0 * (double)M * 64.0 * k, e0, e1, {(int)M, 64, d.KH * d.KW * d.Cin, 1}});
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

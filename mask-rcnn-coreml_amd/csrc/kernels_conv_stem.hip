@@ -1,0 +1,211 @@
+// kernels_conv_stem.hip — the stem of the trunk in the split modes: conv1 (7x7 stride 2, 3 -> 64, BatchNorm, ReLU) and the 3x3 stride-2
+// max-pool behind it as ONE persistent kernel (round 4).
+//
+// Why: as an implicit GEMM on the 128-row kernel, conv1 stages one kernel row (8 pixels x 4 channels = 128 B) per output pixel and
+// K step — neighbouring output pixels overlap by three quarters, so 1.9 GB cross L2 -> LDS for a 136 MB input (batch 8), every
+// wave column splits the same values again, and the 537 MB fp32 output is written only to be read back by the pool: 335 + 144 us
+// on neither roofline.  Here a block owns a patch of 3 x 16 POOLED outputs: the 19 x 71 input pixels it
+// needs are loaded once, split once into fp16 planes in LDS (8 B per pixel and part), the 7 x 33 conv outputs behind the patch are
+// computed from shifted windows of those planes, activated, parked in LDS and max-pooled there; conv1's output never exists.
+//
+// Arithmetic: EXACTLY the 128-row kernel's for this layer — K order = kernel rows ascending, within a row the two 16-wide groups
+// (4 pixels x 4 channels each), parts hi / mid / lo per group, one running fp32 accumulator, y = max(acc * scale + shift, 0) —
+// so the fused stem is bit-identical to conv1 + max-pool (tests), at every batch.  The 1.2x recomputation of conv outputs shared by
+// neighbouring patches changes no value.
+//
+// Per tile: 8 waves, wave w owns conv outputs 32 w .. 32 w + 31 of the patch (row-major over 7 x 33 = 231, padded to 256) x all 64
+// channels: 14 groups x PARTS x 2 MFMAs; the filter fragments of all 14 groups stay in registers for the life of the block (112
+// VGPRs); the next tile's input patch is loaded one tile ahead.  LDS: planes 3 x 11 KB + conv tile 64 KB.
+#include "conv_device.h"
+
+namespace mrcnn {
+
+namespace {
+constexpr int PR = 3, PC = 16;                  // pooled rows / columns of a tile
+constexpr int CR = 2 * PR + 1, CC = 2 * PC + 1; // conv outputs behind it: 7 x 33
+constexpr int IR = 2 * CR + 5, IC = 72;         // input rows 19, columns 2 * 33 + 5 = 71 (pitch 72)
+constexpr int NQ = 256;                         // conv outputs per tile, padded to 8 MFMA row blocks
+static_assert(CR * CC <= NQ, "tile shape");
+
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+}  // namespace
+
+struct StemArgs {
+    const float* in;              // zero-padded NHWC4 fp32 (B, Hp, Wp, 4): pixel - mean, channel 3 = 0 (k_preprocess)
+    const _Float16* wgt;          // [64][7][32] fp16: k = kw * 4 + ci inside a kernel row (pack_conv1)
+    const float* scale; const float* shift;
+    float* out;                   // pooled NHWC (B, PH, PW, 64)
+    int B, Hp, Wp, CH, CW, PH, PW;
+    int tiles_r, tiles_c, n_tiles;
+    int* range_flag;
+};
+
+// 4 fp32 -> PARTS x 4 fp16: the round-to-nearest chain of split_hi_mid_lo / split_hi_lo (conv_device.h)
+template <int PARTS>
+__device__ __forceinline__ void stem_split4(const u32x4_t v, u32x2_t (&part)[3])
+{
+    const float f[4] = {__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2) {
+        const uint32_t h2 = cvt_pk_rne(f[2 * p2], f[2 * p2 + 1]);
+        float e0, e1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(e0) : "v"(h2), "v"(f[2 * p2]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(e1) : "v"(h2), "v"(f[2 * p2 + 1]));
+        const uint32_t m2 = cvt_pk_rne(e0, e1);
+        part[0][p2] = h2;
+        part[1][p2] = m2;
+        if constexpr (PARTS == 3) {
+            float g0, g1;
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(g0) : "v"(m2), "v"(e0));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(g1) : "v"(m2), "v"(e1));
+            part[2][p2] = cvt_pk_rne(g0, g1);
+        }
+    }
+}
+
+template <int PARTS>
+__global__ __launch_bounds__(512, 2) void k_conv_stem(const StemArgs a)
+{
+    constexpr int PLANE = IR * IC * 8;                // one part of the input patch
+    constexpr int CT = NQ * 64 * 4;                   // activated conv outputs [q][64], 16-B chunk c of row q at c ^ (q & 7)
+    constexpr int NPX = (IR * IC + 511) / 512;        // input pixels a thread stages per tile (3)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PARTS * PLANE + CT + 2 * 64 * 4];
+    unsigned char* const planes = smem;
+    float* const ct = reinterpret_cast<float*>(smem + PARTS * PLANE);
+    float* const tab = reinterpret_cast<float*>(smem + PARTS * PLANE + CT);        // scale[64] | shift[64]
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, kk = lane >> 5;
+
+    // ---- filter fragments stay in REGISTERS for the life of the block (every wave multiplies all 14 groups x 2 column blocks once
+    // per tile: through LDS they were 40 % of the fragment reads): group g = 2 kh + G, column block j: lane (n, kk) holds
+    // W[32 j + n][kh][16 G + 8 kk .. + 8] ------------------------------------------------------------------------------------------
+    uint4 bw[14][2];
+#pragma unroll
+    for (int g = 0; g < 14; ++g)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            bw[g][j] = *reinterpret_cast<const uint4*>(a.wgt + ((size_t)(j * 32 + l31) * 7 + (g >> 1)) * 32 + 16 * (g & 1) + 8 * kk);
+    if (t < 64) { tab[t] = a.scale ? a.scale[t] : 1.0f; tab[64 + t] = a.shift ? a.shift[t] : 0.0f; }
+    // this lane's conv output inside the tile and the plane offset of its tap (0, 0) input pixel pair
+    const int q = wave * 32 + l31;
+    const bool q_real = q < CR * CC;                    // rows 231..255 of the eighth block are padding: they multiply conv output 0's window and are never read
+    const int qa = q_real ? q : 0;
+    const int qr = qa / CC, qc = qa - qr * CC;
+    const unsigned a_base = (unsigned)(((2 * qr) * IC + 2 * qc + 2 * kk) * 8);
+    bool oor = false;
+    const int per_img = a.tiles_r * a.tiles_c;
+
+    // the input patch of a tile: NPX pixels per thread, loaded one tile AHEAD into registers (the loads fly under the MFMAs of the
+    // current tile) and split into the planes once every wave has left the current tile's MFMAs
+    u32x4_t px[NPX];
+    auto load_patch = [&](int tile) {
+        const int b = tile / per_img, rem = tile - b * per_img, tr = rem / a.tiles_c, tc = rem - tr * a.tiles_c;
+        const float* const img = a.in + (size_t)b * a.Hp * a.Wp * 4;
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            const int e = t + 512 * i;
+            const int pr_ = e / IC, pc_ = e - pr_ * IC;
+            const int y = 4 * tr * PR + pr_, x = 4 * tc * PC + pc_;
+            px[i] = u32x4_t{0u, 0u, 0u, 0u};
+            if (tile < a.n_tiles && e < IR * IC && y < a.Hp && x < a.Wp) px[i] = *reinterpret_cast<const u32x4_t*>(img + ((size_t)y * a.Wp + x) * 4);
+        }
+    };
+    auto park_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            const int e = t + 512 * i;
+            if (e < IR * IC) {
+                u32x2_t part[3];
+                stem_split4<PARTS>(px[i], part);
+#pragma unroll
+                for (int p = 0; p < PARTS; ++p) *reinterpret_cast<u32x2_t*>(planes + p * PLANE + e * 8) = part[p];
+            }
+        }
+    };
+    load_patch(blockIdx.x);
+    park_patch();
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int b = tile / per_img, rem = tile - b * per_img, tr = rem / a.tiles_c, tc = rem - tr * a.tiles_c;
+        const int pr0 = tr * PR, pc0 = tc * PC;
+        const int r0 = 2 * pr0, c0 = 2 * pc0;                       // first conv output of the patch
+        load_patch(tile + gridDim.x);
+        // ---- 7 kernel rows x 2 groups x PARTS x 2 column blocks ----------------------------------------------------------
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 14; ++g) {
+            uint4 fa[PARTS];
+#pragma unroll
+            for (int p = 0; p < PARTS; ++p) fa[p] = *reinterpret_cast<const uint4*>(planes + p * PLANE + a_base + ((g >> 1) * IC + 4 * (g & 1)) * 8);
+#pragma unroll
+            for (int p = 0; p < PARTS; ++p)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bw[g][j]), __builtin_bit_cast(f16x8, fa[p]), acc[j], 0, 0, 0);
+        }
+        // ---- activate, park: lane (q, kk), slot 4 g4 + r  <->  channel 32 j + 8 g4 + 4 kk + r ---------------------------------
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int c = j * 32 + 8 * g4 + 4 * kk;
+                const float4 sc = *reinterpret_cast<const float4*>(tab + c), sh = *reinterpret_cast<const float4*>(tab + 64 + c);
+                float4 y;
+                y.x = fmaxf(acc[j][4 * g4 + 0] * sc.x + sh.x, 0.f);
+                y.y = fmaxf(acc[j][4 * g4 + 1] * sc.y + sh.y, 0.f);
+                y.z = fmaxf(acc[j][4 * g4 + 2] * sc.z + sh.z, 0.f);
+                y.w = fmaxf(acc[j][4 * g4 + 3] * sc.w + sh.w, 0.f);
+                oor = oor || (q_real && (!(y.x < 65504.0f) || !(y.y < 65504.0f) || !(y.z < 65504.0f) || !(y.w < 65504.0f)));
+                const int chunk = j * 8 + 2 * g4 + kk;
+                *reinterpret_cast<float4*>(&ct[q * 64 + ((chunk ^ (q & 7)) << 2)]) = y;
+            }
+        __syncthreads();          // every wave has left the MFMAs (the planes are free) and the conv tile is complete
+        park_patch();             // the next tile's input, split into the planes — beside the pooling of this one
+        // ---- 3x3 stride-2 max-pool, Keras 'same': the window is clipped at the bottom / right edge of the conv output ------------
+        for (int e = t; e < PR * PC * 16; e += 512) {
+            const int ch4 = e & 15, pc = (e >> 4) & 15, pr = e >> 8;
+            if (pr0 + pr >= a.PH || pc0 + pc >= a.PW) continue;
+            float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                if (r0 + 2 * pr + dy >= a.CH) break;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    if (c0 + 2 * pc + dx >= a.CW) break;
+                    const int qq = (2 * pr + dy) * CC + 2 * pc + dx;
+                    const float4 v = *reinterpret_cast<const float4*>(&ct[qq * 64 + ((ch4 ^ (qq & 7)) << 2)]);
+                    m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                }
+            }
+            *reinterpret_cast<float4*>(a.out + (((size_t)b * a.PH + pr0 + pr) * a.PW + pc0 + pc) * 64 + ch4 * 4) = m;
+        }
+        __syncthreads();          // the planes hold the next tile; the conv tile may be overwritten
+    }
+    if (a.range_flag && oor) atomicOr(a.range_flag, 1);
+}
+
+// in: padded NHWC4 (B, Hp, Wp, 4); out: pooled (B, PH, PW, 64).  parts = 2 | 3.
+void conv_stem_launch(hipStream_t s, const float* in, int B, int Hp, int Wp, const void* wgt, const float* scale, const float* shift, int CH, int CW,
+                      float* out, int PH, int PW, int parts, int* range_flag, int n_cus)
+{
+    StemArgs a;
+    a.in = in; a.wgt = static_cast<const _Float16*>(wgt); a.scale = scale; a.shift = shift; a.out = out;
+    a.B = B; a.Hp = Hp; a.Wp = Wp; a.CH = CH; a.CW = CW; a.PH = PH; a.PW = PW;
+    a.tiles_r = (PH + PR - 1) / PR; a.tiles_c = (PW + PC - 1) / PC;
+    a.n_tiles = B * a.tiles_r * a.tiles_c;
+    a.range_flag = range_flag;
+    const int grid = a.n_tiles < n_cus ? a.n_tiles : n_cus;
+    if (parts == 3) hipLaunchKernelGGL(k_conv_stem<3>, dim3(grid), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(k_conv_stem<2>, dim3(grid), dim3(512), 0, s, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace mrcnn

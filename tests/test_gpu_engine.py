@@ -625,3 +625,35 @@ def test_halo_tile_geometry_leaves_predict_bit_identical(pkg, weights_mod, tmp_p
     np.testing.assert_array_equal(det, det3)
     np.testing.assert_array_equal(mask, mask3)
     assert (det[..., 5] > 0).sum() > 0
+
+
+@pytest.mark.parametrize("dtype", ["f32x3", "f32s"])
+def test_fused_stem_is_bit_identical_to_conv1_plus_maxpool(pkg, weights_mod, tmp_path_factory, dtype):
+    """Round 4: in the split modes conv1 (7x7 / 2 + BatchNorm + ReLU) and the 3x3 / 2 max-pool run as ONE persistent launch
+    (kernels_conv_stem.hip: the input patch of a 3 x 16 block of pooled outputs is loaded and split once; conv1's output never
+    exists) with the 128-row kernel's arithmetic in its K order: a predict must not change by one bit against the two launches
+    (mrcnn_debug_set("conv_stem", 0)) — odd image sizes in tiles (a 320 x 448 input: ragged last tile row, right / bottom pool
+    clipping), several images, and per-image results independent of the batch."""
+    import importlib
+    L = importlib.import_module("mask-rcnn-coreml_amd._lib")
+    models = importlib.import_module("mask-rcnn-coreml_amd.models")
+    d, cfg = make_model_dir(tmp_path_factory, pkg, weights_mod, "stem" + dtype, architecture="resnet50", input_image_shape=(320, 448, 3),
+                            num_classes=21, pre_nms_max_proposals=1000, max_proposals=128, max_detections=32)
+    B = 3
+    m = models.load_maskrcnn(d, max_batch=B, compute_dtype=dtype)
+    images = rand_images(B, 320, 448, seed=9)
+    det, mask = m.predict(images)
+    taps = {n: [m.read_tensor(n, b).copy() for b in range(B)] for n in ("rpn_probs", "rpn_deltas", "P2", "P5")}
+    try:
+        L.check(L.lib().mrcnn_debug_set(b"conv_stem", 0))
+        det2, mask2 = m.predict(images)
+        for n, want in taps.items():
+            for b in range(B):
+                np.testing.assert_array_equal(m.read_tensor(n, b), want[b], err_msg=f"{n} image {b}")
+    finally:
+        L.check(L.lib().mrcnn_debug_set(b"conv_stem", 1))
+    np.testing.assert_array_equal(det, det2)
+    np.testing.assert_array_equal(mask, mask2)
+    d1, m1 = m.predict(images[2:3])
+    np.testing.assert_array_equal(d1[0], det[2])
+    assert (det[..., 5] > 0).sum() > 0
