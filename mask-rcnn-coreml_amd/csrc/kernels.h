@@ -198,16 +198,16 @@ bool conv_halo_tail_geometry_ok(int H, int W);                          // ... a
 bool conv_tail_fusable(const ConvDesc& d3, const ConvDesc& d1);
 void conv_forward_tail(hipStream_t s, const ConvDesc& d3, const ConvDesc& d1);
 
-// The stem in the split modes (kernels_conv_stem.hip): conv1 — described by d exactly as for conv_forward (7 row taps of 32 "channels"
+// The stem in the split modes and the fp16 mode (kernels_conv_stem.hip): conv1 — described by d exactly as for conv_forward (7 row taps of 32 "channels"
 // on the zero-padded NHWC4 input, 64 output columns, ReLU) — and the 3x3 stride-2 'same' max-pool behind it in ONE persistent launch;
 // conv1's output tensor is neither written nor read.  pooled: (B, PH, PW, 64) fp32.  Bit-identical to conv_forward(d) +
-// maxpool3x3s2_forward.  conv_stem_eligible: whether d is that layer in a split mode (a property of the layer, not of the batch);
+// maxpool3x3s2_forward.  conv_stem_eligible: whether d is that layer in a split mode or the fp16 mode (a property of the layer, not of the batch);
 // mrcnn_debug_set("conv_stem", 0) sends callers back to the two launches.
 bool conv_stem_eligible(const ConvDesc& d);
 bool conv_stem_enabled();
 void conv_stem_forward(hipStream_t s, const ConvDesc& d, void* pooled, int PH, int PW);
-void conv_stem_launch(hipStream_t s, const float* in, int B, int Hp, int Wp, const void* wgt, const float* scale, const float* shift, int CH, int CW,
-                      float* out, int PH, int PW, int parts, int* range_flag, int n_cus);
+void conv_stem_launch(hipStream_t s, const void* in, int B, int Hp, int Wp, const void* wgt, const float* scale, const float* shift, int CH, int CW,
+                      void* out, int PH, int PW, int parts, int* range_flag, int n_cus);
 
 // uint8 RGB (B,H,W,3) → fp32 (B, H+2*pad, W+2*pad, 4) minus mean, zero border, channel 3 = 0.
 void preprocess_forward(hipStream_t s, const uint8_t* rgb, int B, int H, int W, int pad, const float mean[3],

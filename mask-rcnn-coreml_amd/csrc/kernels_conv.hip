@@ -596,8 +596,10 @@ bool conv_stem_eligible(const ConvDesc& d)
 {
     const int wdtype = d.wdtype < 0 ? d.dtype : d.wdtype;
     const bool split = d.dtype == MRCNN_F32 && (wdtype == MRCNN_F16 || wdtype == MRCNN_F32X3);
-    return split && d.KH == 7 && d.KW == 1 && d.Cin == 32 && d.stride == 2 && d.padH == 0 && d.padW == 0 && d.Cout == 64 && d.Npad == 64 &&
-           d.act == ACT_RELU && !d.res && !d.out2 && !d.deconv2 && d.in_sW == 4 && d.in_sH == (long)d.W * 4 && d.in_sB == (long)d.H * d.W * 4 &&
+    const bool half = d.dtype == MRCNN_F16 && wdtype == MRCNN_F16 && !d.out_f32;
+    const int pxc = half ? 8 : 4;          // channels of a staged pixel: 16 B either way
+    return (split || half) && d.KH == 7 && d.KW == 1 && d.Cin == 8 * pxc && d.stride == 2 && d.padH == 0 && d.padW == 0 && d.Cout == 64 && d.Npad == 64 &&
+           d.act == ACT_RELU && !d.res && !d.out2 && !d.deconv2 && d.in_sW == pxc && d.in_sH == (long)d.W * pxc && d.in_sB == (long)d.H * d.W * pxc &&
            d.OH == (d.H - 7) / 2 + 1 && d.OW == (d.W - 7) / 2 + 1;
 }
 
@@ -608,8 +610,8 @@ void conv_stem_forward(hipStream_t s, const ConvDesc& d, void* pooled, int PH, i
     ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
     const int e0 = prof ? prof_event(prof, s) : 0;
     const int wdtype = d.wdtype < 0 ? d.dtype : d.wdtype;
-    conv_stem_launch(s, static_cast<const float*>(d.in), d.B, d.H, d.W, d.wgt, d.scale, d.shift, d.OH, d.OW, static_cast<float*>(pooled), PH, PW,
-                     wdtype == MRCNN_F32X3 ? 3 : 2, g_range_flag, n_cus);
+    conv_stem_launch(s, d.in, d.B, d.H, d.W, d.wgt, d.scale, d.shift, d.OH, d.OW, pooled, PH, PW,
+                     d.dtype == MRCNN_F16 ? 1 : (wdtype == MRCNN_F32X3 ? 3 : 2), g_range_flag, n_cus);
     if (prof) {
         const int e1 = prof_event(prof, s);
         const long M = (long)d.B * d.OH * d.OW;

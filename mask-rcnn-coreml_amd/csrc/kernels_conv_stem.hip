@@ -32,10 +32,10 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 }  // namespace
 
 struct StemArgs {
-    const float* in;              // zero-padded NHWC4 fp32 (B, Hp, Wp, 4): pixel - mean, channel 3 = 0 (k_preprocess)
-    const _Float16* wgt;          // [64][7][32] fp16: k = kw * 4 + ci inside a kernel row (pack_conv1)
+    const void* in;               // zero-padded input (B, Hp, Wp) x 16 B per pixel: NHWC4 fp32 (split modes) or NHWC8 fp16 — pixel - mean, spare channels 0 (k_preprocess)
+    const _Float16* wgt;          // [64][7][32 | 64] fp16: k = kw * 4 + ci (split modes) / kw * 8 + ci (fp16) inside a kernel row (pack_conv1)
     const float* scale; const float* shift;
-    float* out;                   // pooled NHWC (B, PH, PW, 64)
+    void* out;                    // pooled NHWC (B, PH, PW, 64), fp32 / fp16
     int B, Hp, Wp, CH, CW, PH, PW;
     int tiles_r, tiles_c, n_tiles;
     int* range_flag;
@@ -64,16 +64,24 @@ __device__ __forceinline__ void stem_split4(const u32x4_t v, u32x2_t (&part)[3])
     }
 }
 
+// PARTS = 2 | 3: the split modes (fp32 tensors, 4 channels per pixel, two 16-wide K groups per kernel row = 4 pixels each);
+// PARTS = 1: the fp16 mode (fp16 tensors, 8 channels per pixel, four K groups per row = 2 pixels each; no split, filters through LDS).
 template <int PARTS>
 __global__ __launch_bounds__(512, 2) void k_conv_stem(const StemArgs a)
 {
-    constexpr int PLANE = IR * IC * 8;                // one part of the input patch
+    constexpr bool F16 = PARTS == 1;
+    constexpr int PXB = F16 ? 16 : 8;                 // bytes of a pixel in a plane
+    constexpr int NG = F16 ? 4 : 2;                   // K groups per kernel row
+    constexpr int NGR = 7 * NG;                       // ... per output
+    constexpr int PLANE = IR * IC * PXB;              // one part of the input patch
+    constexpr int WF = F16 ? NGR * 2 * 1024 : 0;      // fp16: the filter fragments live in LDS (28 groups x 2 would be 224 registers)
     constexpr int CT = NQ * 64 * 4;                   // activated conv outputs [q][64], 16-B chunk c of row q at c ^ (q & 7)
     constexpr int NPX = (IR * IC + 511) / 512;        // input pixels a thread stages per tile (3)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[PARTS * PLANE + CT + 2 * 64 * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PARTS * PLANE + CT + 2 * 64 * 4 + WF];
     unsigned char* const planes = smem;
     float* const ct = reinterpret_cast<float*>(smem + PARTS * PLANE);
     float* const tab = reinterpret_cast<float*>(smem + PARTS * PLANE + CT);        // scale[64] | shift[64]
+    unsigned char* const wf = smem + PARTS * PLANE + CT + 2 * 64 * 4;
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -82,19 +90,28 @@ __global__ __launch_bounds__(512, 2) void k_conv_stem(const StemArgs a)
     // ---- filter fragments stay in REGISTERS for the life of the block (every wave multiplies all 14 groups x 2 column blocks once
     // per tile: through LDS they were 40 % of the fragment reads): group g = 2 kh + G, column block j: lane (n, kk) holds
     // W[32 j + n][kh][16 G + 8 kk .. + 8] ------------------------------------------------------------------------------------------
-    uint4 bw[14][2];
+    uint4 bw[F16 ? 1 : NGR][2];
+    if constexpr (!F16) {
 #pragma unroll
-    for (int g = 0; g < 14; ++g)
+        for (int g = 0; g < NGR; ++g)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            bw[g][j] = *reinterpret_cast<const uint4*>(a.wgt + ((size_t)(j * 32 + l31) * 7 + (g >> 1)) * 32 + 16 * (g & 1) + 8 * kk);
+            for (int j = 0; j < 2; ++j)
+                bw[g][j] = *reinterpret_cast<const uint4*>(a.wgt + ((size_t)(j * 32 + l31) * 7 + g / NG) * (16 * NG) + 16 * (g % NG) + 8 * kk);
+    } else {
+        for (int e = t; e < NGR * 2 * 64; e += 512) {
+            const int ln = e & 63, j = (e >> 6) & 1, g = e >> 7;
+            *reinterpret_cast<uint4*>(wf + (size_t)e * 16) =
+                *reinterpret_cast<const uint4*>(a.wgt + ((size_t)(j * 32 + (ln & 31)) * 7 + g / NG) * (16 * NG) + 16 * (g % NG) + 8 * (ln >> 5));
+        }
+    }
     if (t < 64) { tab[t] = a.scale ? a.scale[t] : 1.0f; tab[64 + t] = a.shift ? a.shift[t] : 0.0f; }
     // this lane's conv output inside the tile and the plane offset of its tap (0, 0) input pixel pair
     const int q = wave * 32 + l31;
     const bool q_real = q < CR * CC;                    // rows 231..255 of the eighth block are padding: they multiply conv output 0's window and are never read
     const int qa = q_real ? q : 0;
     const int qr = qa / CC, qc = qa - qr * CC;
-    const unsigned a_base = (unsigned)(((2 * qr) * IC + 2 * qc + 2 * kk) * 8);
+    // split modes: a lane's fragment of a group = 2 neighbouring pixels (8 B each); fp16: one pixel (16 B)
+    const unsigned a_base = F16 ? (unsigned)(((2 * qr) * IC + 2 * qc + kk) * 16) : (unsigned)(((2 * qr) * IC + 2 * qc + 2 * kk) * 8);
     bool oor = false;
     const int per_img = a.tiles_r * a.tiles_c;
 
@@ -103,14 +120,14 @@ __global__ __launch_bounds__(512, 2) void k_conv_stem(const StemArgs a)
     u32x4_t px[NPX];
     auto load_patch = [&](int tile) {
         const int b = tile / per_img, rem = tile - b * per_img, tr = rem / a.tiles_c, tc = rem - tr * a.tiles_c;
-        const float* const img = a.in + (size_t)b * a.Hp * a.Wp * 4;
+        const u32x4_t* const img = static_cast<const u32x4_t*>(a.in) + (size_t)b * a.Hp * a.Wp;
 #pragma unroll
         for (int i = 0; i < NPX; ++i) {
             const int e = t + 512 * i;
             const int pr_ = e / IC, pc_ = e - pr_ * IC;
             const int y = 4 * tr * PR + pr_, x = 4 * tc * PC + pc_;
             px[i] = u32x4_t{0u, 0u, 0u, 0u};
-            if (tile < a.n_tiles && e < IR * IC && y < a.Hp && x < a.Wp) px[i] = *reinterpret_cast<const u32x4_t*>(img + ((size_t)y * a.Wp + x) * 4);
+            if (tile < a.n_tiles && e < IR * IC && y < a.Hp && x < a.Wp) px[i] = img[(size_t)y * a.Wp + x];
         }
     };
     auto park_patch = [&]() {
@@ -118,10 +135,13 @@ __global__ __launch_bounds__(512, 2) void k_conv_stem(const StemArgs a)
         for (int i = 0; i < NPX; ++i) {
             const int e = t + 512 * i;
             if (e < IR * IC) {
-                u32x2_t part[3];
-                stem_split4<PARTS>(px[i], part);
+                if constexpr (F16) *reinterpret_cast<u32x4_t*>(planes + e * 16) = px[i];
+                else {
+                    u32x2_t part[3];
+                    stem_split4<PARTS>(px[i], part);
 #pragma unroll
-                for (int p = 0; p < PARTS; ++p) *reinterpret_cast<u32x2_t*>(planes + p * PLANE + e * 8) = part[p];
+                    for (int p = 0; p < PARTS; ++p) *reinterpret_cast<u32x2_t*>(planes + p * PLANE + e * 8) = part[p];
+                }
             }
         }
     };
@@ -141,15 +161,18 @@ __global__ __launch_bounds__(512, 2) void k_conv_stem(const StemArgs a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
 #pragma unroll
-        for (int g = 0; g < 14; ++g) {
-            uint4 fa[PARTS];
+        for (int g = 0; g < NGR; ++g) {
+            uint4 fa[PARTS], fb[2];
 #pragma unroll
-            for (int p = 0; p < PARTS; ++p) fa[p] = *reinterpret_cast<const uint4*>(planes + p * PLANE + a_base + ((g >> 1) * IC + 4 * (g & 1)) * 8);
+            for (int p = 0; p < PARTS; ++p)
+                fa[p] = *reinterpret_cast<const uint4*>(planes + p * PLANE + a_base + ((g / NG) * IC + (F16 ? 2 : 4) * (g % NG)) * PXB);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = F16 ? *reinterpret_cast<const uint4*>(wf + ((g * 2 + j) * 64 + lane) * 16) : bw[F16 ? 0 : g][j];
 #pragma unroll
             for (int p = 0; p < PARTS; ++p)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bw[g][j]), __builtin_bit_cast(f16x8, fa[p]), acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j]), __builtin_bit_cast(f16x8, fa[p]), acc[j], 0, 0, 0);
         }
         // ---- activate, park: lane (q, kk), slot 4 g4 + r  <->  channel 32 j + 8 g4 + 4 kk + r ---------------------------------
 #pragma unroll
@@ -185,16 +208,18 @@ __global__ __launch_bounds__(512, 2) void k_conv_stem(const StemArgs a)
                     m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
                 }
             }
-            *reinterpret_cast<float4*>(a.out + (((size_t)b * a.PH + pr0 + pr) * a.PW + pc0 + pc) * 64 + ch4 * 4) = m;
+            const size_t o = (((size_t)b * a.PH + pr0 + pr) * a.PW + pc0 + pc) * 64 + ch4 * 4;
+            if constexpr (F16) store4<_Float16>(static_cast<_Float16*>(a.out) + o, m);         // (max commutes with the monotone rounding: one rounding, like the two launches)
+            else *reinterpret_cast<float4*>(static_cast<float*>(a.out) + o) = m;
         }
         __syncthreads();          // the planes hold the next tile; the conv tile may be overwritten
     }
     if (a.range_flag && oor) atomicOr(a.range_flag, 1);
 }
 
-// in: padded NHWC4 (B, Hp, Wp, 4); out: pooled (B, PH, PW, 64).  parts = 2 | 3.
-void conv_stem_launch(hipStream_t s, const float* in, int B, int Hp, int Wp, const void* wgt, const float* scale, const float* shift, int CH, int CW,
-                      float* out, int PH, int PW, int parts, int* range_flag, int n_cus)
+// in: padded (B, Hp, Wp) x 16 B; out: pooled (B, PH, PW, 64).  parts = 2 | 3 (split modes, fp32 tensors) | 1 (fp16 tensors).
+void conv_stem_launch(hipStream_t s, const void* in, int B, int Hp, int Wp, const void* wgt, const float* scale, const float* shift, int CH, int CW,
+                      void* out, int PH, int PW, int parts, int* range_flag, int n_cus)
 {
     StemArgs a;
     a.in = in; a.wgt = static_cast<const _Float16*>(wgt); a.scale = scale; a.shift = shift; a.out = out;
@@ -204,7 +229,8 @@ void conv_stem_launch(hipStream_t s, const float* in, int B, int Hp, int Wp, con
     a.range_flag = range_flag;
     const int grid = a.n_tiles < n_cus ? a.n_tiles : n_cus;
     if (parts == 3) hipLaunchKernelGGL(k_conv_stem<3>, dim3(grid), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(k_conv_stem<2>, dim3(grid), dim3(512), 0, s, a);
+    else if (parts == 2) hipLaunchKernelGGL(k_conv_stem<2>, dim3(grid), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(k_conv_stem<1>, dim3(grid), dim3(512), 0, s, a);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -627,9 +627,9 @@ def test_halo_tile_geometry_leaves_predict_bit_identical(pkg, weights_mod, tmp_p
     assert (det[..., 5] > 0).sum() > 0
 
 
-@pytest.mark.parametrize("dtype", ["f32x3", "f32s"])
+@pytest.mark.parametrize("dtype", ["f32x3", "f32s", "f16"])
 def test_fused_stem_is_bit_identical_to_conv1_plus_maxpool(pkg, weights_mod, tmp_path_factory, dtype):
-    """Round 4: in the split modes conv1 (7x7 / 2 + BatchNorm + ReLU) and the 3x3 / 2 max-pool run as ONE persistent launch
+    """Round 4: in the split modes and in fp16 mode conv1 (7x7 / 2 + BatchNorm + ReLU) and the 3x3 / 2 max-pool run as ONE persistent launch
     (kernels_conv_stem.hip: the input patch of a 3 x 16 block of pooled outputs is loaded and split once; conv1's output never
     exists) with the 128-row kernel's arithmetic in its K order: a predict must not change by one bit against the two launches
     (mrcnn_debug_set("conv_stem", 0)) — odd image sizes in tiles (a 320 x 448 input: ragged last tile row, right / bottom pool
