@@ -140,15 +140,7 @@ def main():
         # (mrcnn_dist_*); the torch process group only carries the 128-byte rendezvous id, the model directory's path, the
         # barriers and the max-over-ranks of the elapsed time — host-side work, so it runs over gloo and holds no communicator
         # on the GPU.  (mrcnn_dist_* binds the RCCL copy the process has already mapped — torch's — before loading its own.)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if "MASTER_PORT" not in os.environ:                 # --force-dist outside torchrun: a free port, not a fixed one
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
-        if world > 1:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("gloo", rank=0, world_size=1)
+        host_group_init(rank, world)
 
     pkg = importlib.import_module("mask-rcnn-coreml_amd")
     models = importlib.import_module("mask-rcnn-coreml_amd.models")
@@ -158,14 +150,7 @@ def main():
     cfg = pkg.ModelConfig(architecture=args.arch, input_image_shape=(args.size, args.size, 3), num_classes=args.num_classes,
                           pre_nms_max_proposals=args.pre_nms)
     # rank 0 writes the 250 MB synthetic model directory ONCE; the other ranks of the node load the same files
-    box = [tempfile.mkdtemp(prefix="mrcnn_bench_") if rank == 0 else None]
-    if use_dist:
-        dist.broadcast_object_list(box, src=0)
-    model_dir = box[0]
-    if rank == 0:
-        weights.save_synthetic_models(model_dir, cfg, seed=0, forced_load=True)
-    if use_dist:
-        dist.barrier()
+    model_dir = shared_model_dir(rank, use_dist, lambda d: weights.save_synthetic_models(d, cfg, seed=0, forced_load=True))
     m = models.load_maskrcnn(model_dir, max_batch=args.batch, compute_dtype=args.dtype)
     B = args.batch
     # Scale-aware split (include/maskrcnn_hip.h: mrcnn_model_calibrate_split): the split modes run with a power-of-two pre-scale
@@ -185,11 +170,7 @@ def main():
     # shipped multi-GPU path; torch.distributed only carries the 128-byte rendezvous id, the barriers and the timing reduce.
     gather = None
     if use_dist:
-        idt = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(dmod.NativeDist.unique_id()), dtype=torch.uint8))
-        dist.broadcast(idt, src=0)
-        gather = dmod.NativeDist(rank, world, bytes(idt.numpy().tobytes()))
+        gather = dmod.NativeDist(rank, world, broadcast_id(rank, dmod.NativeDist.unique_id if rank == 0 else None))
         all_det = torch.empty((world * B, m.max_detections, 6), dtype=torch.float32, device=dev)
         all_mask = torch.empty((world * B, m.max_detections, m.mask_size, m.mask_size), dtype=torch.float32, device=dev)
 
@@ -231,13 +212,9 @@ def main():
     elapsed = time.perf_counter() - t0
     busy_s = (m.get_int("gpu_busy_us") - busy0) * 1e-6
     busy_calls = m.get_int("predict_calls") - calls0
-    per_rank_ms = [1e3 * elapsed / args.steps]
-    if use_dist:
-        mine = torch.tensor([elapsed], dtype=torch.float64)
-        every = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(every, mine)
-        per_rank_ms = [1e3 * float(e.item()) / args.steps for e in every]
-        elapsed = max(float(e.item()) for e in every)          # the job is as slow as its slowest rank
+    every = gather_elapsed(elapsed, world) if use_dist else [elapsed]
+    per_rank_ms = [1e3 * e / args.steps for e in every]
+    elapsed = max(every)                                        # the job is as slow as its slowest rank
 
     prof = m.conv_profile() if not args.no_kernel_events else None
     stages = m.stage_ms()
@@ -399,6 +376,54 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# ---- the host-side group of an N > 1 run (gloo: rendezvous, barriers, the max-over-ranks of a float — never a GPU communicator) ----
+# tests/test_host.py drives exactly these functions at world size 2 on CPU.
+def host_group_init(rank, world):
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:                     # --force-dist outside torchrun: a free port, not a fixed one
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+    if world > 1:
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+
+
+def shared_model_dir(rank, use_dist, write):
+    """Rank 0 creates the model directory, writes it ONCE (write(dir)) and tells the others its path; they wait until it is complete."""
+    import torch.distributed as dist
+    box = [tempfile.mkdtemp(prefix="mrcnn_bench_") if rank == 0 else None]
+    if use_dist:
+        dist.broadcast_object_list(box, src=0)
+    if rank == 0:
+        write(box[0])
+    if use_dist:
+        dist.barrier()
+    return box[0]
+
+
+def broadcast_id(rank, make_id):
+    """The 128-byte communicator id of the native exchange from rank 0 (make_id() -> bytes) to every rank."""
+    import torch
+    import torch.distributed as dist
+    idt = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        idt.copy_(torch.frombuffer(bytearray(make_id()), dtype=torch.uint8))
+    dist.broadcast(idt, src=0)
+    return bytes(idt.numpy().tobytes())
+
+
+def gather_elapsed(elapsed, world):
+    """Every rank's elapsed seconds, on every rank."""
+    import torch
+    import torch.distributed as dist
+    every = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(every, torch.tensor([elapsed], dtype=torch.float64))
+    return [float(e.item()) for e in every]
 
 
 def sustained_peak(dtype, parts, achieved):

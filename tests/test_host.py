@@ -526,3 +526,41 @@ def test_native_dist_binds_the_rccl_copy_the_process_already_holds(pkg):
     assert run("import torch") == 1
     assert run("pass") == 0
     assert run("import torch", {"MRCNN_RCCL_PRIVATE": "1"}) == 0
+
+
+def _bench_host_group_rank(rank, world, port, q):
+    """One rank of bench.py's host-side group, environment as torchrun sets it."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    bench = importlib.import_module("bench")
+    bench.host_group_init(rank, world)
+    wrote = []
+    d = bench.shared_model_dir(rank, True, lambda path: (open(os.path.join(path, "model.bin"), "wb").write(b"x" * 1000), wrote.append(path)))
+    ident = bench.broadcast_id(rank, (lambda: bytes(range(128))) if rank == 0 else None)
+    every = bench.gather_elapsed(1.0 + rank, world)
+    q.put((rank, d, os.path.getsize(os.path.join(d, "model.bin")), len(wrote), ident, every))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_host_group_at_world_two_on_gloo():
+    """the N > 1 control flow of bench.py that never ran anywhere — its torch process group is gloo (host-side
+    only: ONE RCCL user per process, the native exchange), rank 0 writes the model directory ONCE and every rank reads the complete
+    files, the 128-byte communicator id reaches every rank, every rank learns every rank's time (the job is as slow as its slowest
+    rank).  The same functions bench.py calls, two processes, no GPU."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_host_group_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, d0, sz0, w0, id0, e0), (r1, d1, sz1, w1, id1, e1) = res
+    assert d0 == d1 and sz0 == sz1 == 1000 and (w0, w1) == (1, 0)          # one writer, both see the finished file
+    assert id0 == id1 == bytes(range(128))
+    assert e0 == e1 == [1.0, 2.0]
