@@ -28,6 +28,11 @@ struct ConvArgs {
     int dbg;
     int direct;              // the layer's epilogue can go straight from the accumulators (conv_epilogue_direct)
     const float* sel_w; const int32_t* sel_cid; float* sel_partial;      // deconv2: selected-class dot instead of the store (ConvDesc)                 // ablation switches of the ping-pong kernels (measurement only; 0 in production)
+    // canonical K chunks (kernels_conv.hip: conv_k_chunks): the layer's sum is ((0 + P0) + P1) + ... over kchunks equal runs of K
+    // steps, each Pc a running accumulator from zero — by one block (ksplit == 1: two accumulator sets) or by kchunks blocks per
+    // tile (ksplit == kchunks: partial sums through ks_scratch, the last block to arrive folds them in that order)
+    int kchunks, ksplit;
+    float* ks_scratch; unsigned* ks_count;
 };
 
 static constexpr int BM_DEFAULT = 128;   // rows of the block tile = WM*TM*32

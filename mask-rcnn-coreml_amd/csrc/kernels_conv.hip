@@ -21,6 +21,7 @@
 //     outputs (RPN class + bbox from one GEMM) or 2×2 scatter (transposed conv);
 //   * XCD-aware block→tile map: the 8 XCDs get contiguous runs of tiles, N-tiles of one M-tile
 //     adjacent, so an A tile is fetched into one XCD's L2 once.
+#include <map>
 #include <mutex>
 
 #include "conv_device.h"
@@ -87,11 +88,17 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
     }
 #endif
 
-    const int nblocks = a.tiles_m * a.tiles_n;
+    // KCH: the kernel carries the canonical K chunks of long-K 1x1 layers (ConvArgs::kchunks; conv_k_chunks below).  The 8-wave
+    // 128-column instantiation has no room for the second accumulator set (112 of the 128 VGPRs that four waves per SIMD
+    // allow): chunked layers take the 4-wave 128-column form instead (conv_forward; same speed on them, gpurun_out/r4v)
+    constexpr bool KCH = SPLIT && !(BN == 128 && WM * WN >= 8);
+    const int ksplit = KCH ? a.ksplit : 1;
+    const int nblocks = a.tiles_m * a.tiles_n * ksplit;
     const int bid = blockIdx.x;
     const int q = nblocks >> 3, r8 = nblocks & 7;
     const int xcd = bid & 7, local = bid >> 3;
-    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + local;
+    const int unit = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + local;
+    const int tile = unit / ksplit, chunk = unit - tile * ksplit;          // the blocks of a tile are neighbours in the walk (mostly one XCD)
     const int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
     const int m0 = mt * BM, n0 = nt * BN;
 
@@ -137,7 +144,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
         a_ob[p] = (unsigned)(((long)(b - b0) * a.in_sB + (long)ih0[p] * a.in_sH + (long)iw0[p] * a.in_sW + kq * EPV) * (long)sizeof(T));
     }
     const int cin_tiles = a.Cin / BK;
-    const int KT = a.KH * a.KW * cin_tiles;
+    const int KT_all = a.KH * a.KW * cin_tiles;
+    const int KT = KT_all / ksplit;                       // K steps of THIS block: one chunk when the tile is shared
+    const int kbeg = chunk * KT;
     // wave-uniform LDS destinations: this wave's 8 rows of each staging pass
     const int wrow = __builtin_amdgcn_readfirstlane(wave) * 8;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(
@@ -195,6 +204,12 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
         }                                                                                                      \
     }
     MRCNN_SET_TAP(0) MRCNN_SET_TAP(1) MRCNN_SET_TAP(2) MRCNN_SET_TAP(3)
+    if constexpr (KCH) {
+        if (kbeg) {                                       // (1x1 layers only: a K step is a channel step)
+            oa0 += kbeg * sa0; oa1 += kbeg * sa1; oa2 += kbeg * sa2; oa3 += kbeg * sa3;
+            sob += (unsigned)kbeg * BK * (unsigned)sizeof(TW);
+        }
+    }
 
     const int wm = wave / WN, wn = wave - wm * WN;
     const int l31 = lane & 31, kk = lane >> 5;
@@ -207,6 +222,22 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    // canonical K chunks, one block per tile: `tot` folds the finished chunks, `acc` restarts from zero at every boundary
+    f32x16 tot[KCH ? TM : 1][KCH ? TN : 1];
+    const int klen = KCH ? KT_all / a.kchunks : 0;
+    int kb = (KCH && a.kchunks > 1 && ksplit == 1) ? klen : 0x7fffffff;
+    if constexpr (KCH) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) tot[i][j][e] = 0.0f;
+    }
+#define MRCNN_KFOLD                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                             \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                         \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) { tot[i][j][e] += acc[i][j][e]; acc[i][j][e] = 0.0f; }
 
     // Ring of STAGES operand buffers, STAGES-1 tiles in flight: tile k+STAGES-1 is issued at the top of
     // step k, and only tile k+1 has to have landed at the end of it — counted vmcnt lets the
@@ -296,6 +327,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
     {                                                                                                          \
         const bool more = (KTV) + STAGES - 1 < KT MRCNN_ABL_NODMA;                                             \
         if (more) MRCNN_DMA_TILE((KTV) + STAGES - 1, NBUF)                                                     \
+        if constexpr (KCH) { if ((KTV) == kb) { MRCNN_KFOLD kb += klen; } }                                    \
         uint4 av[4][TM], bv[4][TN];                                                                            \
         if constexpr (SPLIT) {                                                                                 \
             MRCNN_KLOAD_SPLIT(0, BUF, ca0, ca1, cb0) MRCNN_KLOAD_SPLIT(1, BUF, ca2, ca3, cb1)                  \
@@ -317,6 +349,71 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
         if constexpr (STAGES > 2) { if (kt + 2 < KT) MRCNN_STEP(2, 1, kt + 2) }
         if constexpr (STAGES > 3) { if (kt + 3 < KT) MRCNN_STEP(3, 2, kt + 3) }
     }
+    if constexpr (KCH) {
+        if (ksplit > 1) {
+            // this block's chunk goes to the scratch (16-B piece q of thread t at [tile][chunk][q][t]: full lines); the block that
+            // arrives last — whichever it is — folds the chunks in THE canonical order and runs the epilogue.  The blocks of a tile
+            // may sit on different XCDs (one L2 each): the partial sums are stored and loaded at DEVICE scope (sc1: written through /
+            // fetched past the non-coherent L2 lines), the stores have completed (vmcnt) before the block counts itself in, and the
+            // counter is a device-scope atomic — no cache-wide write-back or invalidate, which is what a __threadfence() costs here
+            // (measured: 18.6 -> 86 us on C4's branch2a at batch 1, gpurun_out/r4w).  The counter is left at zero for the next launch.
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            constexpr int NP = TM * TN * 4;                        // 16-B pieces of a thread's accumulators
+            constexpr int SC1 = 16;                                // cache policy of the buffer builtins: device scope
+            float* const tbase = a.ks_scratch + (size_t)tile * ksplit * NP * NT * 4;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tbase, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        typedef float f32x4 __attribute__((ext_vector_type(4)));
+                        const f32x4 v = {acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, ((chunk * NP + (i * TN + j) * 4 + qd) * NT + t) * 16, 0, SC1);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __shared__ unsigned s_arrived;
+            __syncthreads();                                       // every thread's stores have completed
+            if (t == 0) s_arrived = __hip_atomic_fetch_add(a.ks_count + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (s_arrived != (unsigned)(ksplit - 1)) return;
+            if (t == 0) __hip_atomic_store(a.ks_count + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+            u32x4 cur[NP], nxt[NP];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) cur[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (u * NT + t) * 16, 0, SC1);
+            for (int c = 0; c < ksplit; ++c) {
+                if (c + 1 < ksplit) {
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) nxt[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (((c + 1) * NP + u) * NT + t) * 16, 0, SC1);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[i][j][4 * qd + e] += __uint_as_float(cur[(i * TN + j) * 4 + qd][e]);
+#pragma unroll
+                for (int u = 0; u < NP; ++u) cur[u] = nxt[u];
+            }
+        } else if (a.kchunks > 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = tot[i][j][e] + acc[i][j][e];
+        }
+    }
+#undef MRCNN_KFOLD
 #undef MRCNN_STEP
 #undef MRCNN_KMATH_SPLIT
 #undef MRCNN_KMATH
@@ -414,13 +511,23 @@ static int g_tail_dbg = env_int("MRCNN_TAIL_DBG", 0);        // measurement only
 // 1x1 K loop 21 + epilogue 37, strictly additive — profiles/r04_tail_ablate_f32x3.txt), so OFF by default;
 // MRCNN_TAIL=1 / mrcnn_debug_set("conv_tail", 1) switch it on (tests keep it bit-identical)
 static int g_tail = env_int("MRCNN_TAIL", 0);
+// Canonical K chunks (round 4): the long-K 1x1 layers of the split modes — K >= 2048: C5's `branch2a`, the P5
+// lateral, the box head's first inner product (K = 12 544) — sum their K steps as ((0 + P0) + P1) + ..., 4 / 8 equal chunks by the
+// layer's shape alone, at EVERY batch.  A grid that fills the chip runs the chunks in one block (a second accumulator set, folded at
+// the chunk boundaries); a grid that does not — single images: 32 tiles at C5, 64 in the box head — gives every chunk its own block
+// and the last one to finish folds the partial sums in the same order: bit-identical, and the dependent chain of K steps is 4 - 8 x
+// shorter (single image: 171 -> 85, 29 -> 18, 28 -> 15 us; batch 8 unchanged).
+// MRCNN_KCHUNK=0 / "conv_kchunk" 0: one running sum as in rounds 1-3 (other bits); "conv_ksplit" 0: never share a tile (same bits).
+static int g_kchunk = env_int("MRCNN_KCHUNK", 1);
+static int g_ksplit = env_int("MRCNN_KSPLIT", 1);
+static int g_ksplit_below = env_int("MRCNN_KSPLIT_BELOW", 256);       // share tiles when the widest-tile grid has fewer blocks than this
 static int g_halo = env_int("MRCNN_HALO", 1);        // 3x3 stride-1 layers of the split modes on the halo kernel (kernels_conv_halo.hip) when the filters come re-tiled
 static int g_tn4 = -1;       // split modes, 128x128 tile as 4 waves of 32x128: -1 by policy (conv_forward), 0 never, 1 always (tests)
 template <typename T, typename TW, int PARTS = 2>
 static void conv_launch(hipStream_t s, const ConvArgs& a, int bn, bool wide_waves = false)
 {
     // 8 waves as 4 (M) × 2 (N): 128×128 block tile, 32×64 per wave; narrower N tiles keep 128 rows.
-    const dim3 grid(a.tiles_m * a.tiles_n);
+    const dim3 grid(a.tiles_m * a.tiles_n * a.ksplit);
 #ifndef MRCNN_RING64
 #define MRCNN_RING64 3
 #endif
@@ -437,6 +544,7 @@ static void conv_launch(hipStream_t s, const ConvArgs& a, int bn, bool wide_wave
         // the 3x3 layers, bit-identical (same products, same order per accumulator); short-K layers lose to its 4-wave epilogue.
         if (bn == 128 && wide_waves) { hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 128, 1, 4, 4, 1, R128, PARTS>), grid, dim3(256), 0, s, a); return; }
     }
+    MRCNN_REQUIRE(a.kchunks == 1 || (sizeof(T) == 4 && sizeof(TW) == 2 && bn != 128), MRCNN_ERR_INVALID, "conv: K chunks on a kernel that does not carry them");
     if (bn == 128) hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 128, 1, 2, 4, 2, R128, PARTS>), grid, dim3(512), 0, s, a);
     else if (bn == 64) hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 64, 1, 1, 4, 2, MRCNN_RING64, PARTS>), grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 32, 1, 1, 4, 1, MRCNN_RING32, PARTS>), grid, dim3(256), 0, s, a);
@@ -474,6 +582,9 @@ bool conv_debug_set(const char* key, int value)
     else if (k == "conv_halo") g_halo = value;
     else if (k == "conv_direct") g_direct = value;
     else if (k == "conv_min_blocks") g_min_blocks = value;
+    else if (k == "conv_kchunk") g_kchunk = value;
+    else if (k == "conv_ksplit") g_ksplit = value;
+    else if (k == "conv_ksplit_below") g_ksplit_below = value;
     else if (k == "conv_tail") g_tail = value;
     else if (k == "conv_stem") g_stem = value;
     else if (k == "conv_tail_dbg") g_tail_dbg = value;
@@ -502,6 +613,42 @@ static void conv_fill_args(const ConvDesc& d, ConvArgs& a)
     a.range_flag = g_range_flag;
     a.dbg = pp_policy().dbg;
     a.sel_w = d.sel_w; a.sel_cid = d.sel_cid; a.sel_partial = d.sel_partial;
+    a.kchunks = 1; a.ksplit = 1; a.ks_scratch = nullptr; a.ks_count = nullptr;
+}
+
+// Canonical K chunks of a layer (1 = one running sum): by its shape and mode alone — never by the batch or the grid
+int conv_k_chunks(const ConvDesc& d)
+{
+    const int wdtype = d.wdtype < 0 ? d.dtype : d.wdtype;
+    const bool split = d.dtype == MRCNN_F32 && (wdtype == MRCNN_F16 || wdtype == MRCNN_F32X3);
+    // (K = 1024 — C4's branch2a, the box head's second inner product — is left as one sum: two chunks gain 1.2 us per launch on a
+    //  single image and cost 1.5 us at batch 8 for the second accumulator set, gpurun_out/r4w)
+    if (!g_kchunk || !split || d.KH != 1 || d.KW != 1 || d.Cin < 2048 || d.Cin % 32 != 0 || d.head_w) return 1;
+    int n = d.Cin >= 8192 ? 8 : 4;
+    while ((d.Cin / 32) % n) n >>= 1;
+    return n;
+}
+
+// Partial sums of shared tiles: 64 MB + 8192 counters per stream, allocated at the stream's first shared launch and kept (a
+// captured graph holds the pointers; the engine's first predict at a batch size runs eagerly, so the allocation never falls
+// inside a capture).  Launches on one stream are ordered, and a launch leaves its counters at zero.
+static constexpr size_t KS_BYTES = 64u << 20;
+static constexpr int KS_TILES = 8192;
+static void ks_scratch(hipStream_t s, float** scratch, unsigned** count)
+{
+    struct Ks { DevBuf buf, cnt; };
+    static std::mutex mu;
+    static std::map<hipStream_t, Ks*> all;
+    std::lock_guard<std::mutex> lk(mu);
+    Ks*& k = all[s];
+    if (!k) {
+        k = new Ks;
+        k->buf.alloc(KS_BYTES);
+        k->cnt.alloc(KS_TILES * sizeof(unsigned));
+        HIP_CHECK(hipMemsetAsync(k->cnt.p, 0, KS_TILES * sizeof(unsigned), s));
+    }
+    *scratch = static_cast<float*>(k->buf.p);
+    *count = static_cast<unsigned*>(k->cnt.p);
 }
 
 // May the epilogue use 16-B vector stores / residual loads for this layer?
@@ -537,6 +684,18 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     a.tiles_m = (a.M + BM_DEFAULT - 1) / BM_DEFAULT;
     int bn = bn_max;
     while (bn > 32 && !d.sel_partial && (long)a.tiles_m * (d.Npad / bn) < g_min_blocks) bn >>= 1;     // (selected-class mode: fixed 128-channel parts)
+    a.kchunks = d.sel_partial ? 1 : conv_k_chunks(d);
+    if (a.kchunks > 1 && g_ksplit && (long)a.tiles_m * (d.Npad / bn_max) < g_ksplit_below) {
+        // an under-filled grid: one block per (tile, chunk), the N tile as wide as the shared grid allows
+        int bs = bn_max;
+        while (bs > 32 && (long)a.tiles_m * (d.Npad / bs) * a.kchunks < g_min_blocks) bs >>= 1;
+        const long tiles = (long)a.tiles_m * (d.Npad / bs);
+        if (tiles <= KS_TILES && (size_t)tiles * a.kchunks * BM_DEFAULT * bs * 4 <= KS_BYTES) {
+            bn = bs;
+            a.ksplit = a.kchunks;
+            ks_scratch(s, &a.ks_scratch, &a.ks_count);
+        }
+    }
     a.vec_ok = conv_vec_ok(d, a);
     a.tiles_n = d.Npad / bn;
     MRCNN_REQUIRE(!d.sel_partial || (bn == 128 && a.vec_ok), MRCNN_ERR_INVALID, "conv: the selected-class mode needs the 128-wide vector epilogue");
@@ -558,11 +717,12 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
         const bool fills = tiles >= pol.min_tiles && tiles * 100 >= rounds * 256 * pol.min_fill_pct;
         const int bk_pp = half ? 64 : 32;
         if (pol.on && (half || (split && pol.split)) && d.Cin % bk_pp == 0 && a.Ktot / bk_pp >= pol.min_kt && d.Npad % 256 == 0 && fills &&
-            a.vec_ok && (!half || !a.out_f32) && !d.deconv2 && !d.out2 && d.act != ACT_SIGMOID && d.H < 32760 && d.W < 32760)
+            a.kchunks == 1 && a.vec_ok && (!half || !a.out_f32) && !d.deconv2 && !d.out2 && d.act != ACT_SIGMOID && d.H < 32760 && d.W < 32760)
             pp_bn = 256;                    // ... and the epilogue / address forms pp_store_tile and PP_SRC_A cover
     }
     if (pp_bn) { a.tiles_m = (a.M + 255) / 256; a.tiles_n = d.Npad / pp_bn; }
-    const bool wide_waves = split && bn == 128 && (g_tn4 < 0 ? a.Ktot / bk >= 64 : g_tn4 != 0);      // K >= 2048: the 3x3 layers
+    // K >= 2048: the 3x3 layers; and every chunked layer (the 8-wave form has no registers for the second accumulator set)
+    const bool wide_waves = split && bn == 128 && (a.kchunks > 1 || (g_tn4 < 0 ? a.Ktot / bk >= 64 : g_tn4 != 0));
     ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
     const int e0 = prof ? prof_event(prof, s) : 0;
     // 3x3 stride-1 layers of the split modes: the persistent halo kernel, whenever the layer qualifies — by its geometry and

@@ -742,10 +742,11 @@ bool conv_halo_eligible(const ConvDesc& d)
     const int wdtype = d.wdtype < 0 ? d.dtype : d.wdtype;
     const bool split = d.dtype == MRCNN_F32 && (wdtype == MRCNN_F16 || wdtype == MRCNN_F32X3);
     if (!split || d.KH != 3 || d.KW != 3 || d.stride != 1 || d.padH != 1 || d.padW != 1) return false;
-    // slabs in fours (the main loop is unrolled by four slabs); 256 output columns or more: with 128 the wave tile is 64 x 32 and the activation-fragment reads per
-    // MFMA double — round 3 measured x0.92 against the 128-row kernel on C3's 128 -> 128 layers; with round 4's cheaper staging x1.08
-    // (110 -> 102 us, gpurun_out/r4i): 0.2 % of a step, not worth a second K order for those layers — left on the 128-row kernel
-    if (d.OH != d.H || d.OW != d.W || d.Cin % 64 != 0 || d.Npad % 256 != 0 || d.Cout % 4 != 0) return false;
+    // slabs in fours (the main loop is unrolled by four slabs); 128 output columns or more.  With exactly 128 the wave tile is 64 x 32 and
+    // the activation-fragment reads per MFMA double: round 3 measured x0.92 against the 128-row kernel on C3's 128 -> 128 layers and kept
+    // them there; with round 4's cheaper staging it is x1.08 (110 -> 102 us, gpurun_out/r4i) and they run here (their K order changes with
+    // the kernel, once, for every batch)
+    if (d.OH != d.H || d.OW != d.W || d.Cin % 64 != 0 || d.Npad % 128 != 0 || d.Cout % 4 != 0) return false;
     if (d.deconv2 || d.out2 || d.sel_partial || d.act == ACT_SIGMOID || d.res) return false;
     if (d.H >= 32760 || d.W >= 32760 || (double)d.in_sB * 8.0 >= 2.0e9) return false;
     // A property of the layer, never of the batch: both tile heights the launcher may pick must have a geometry that fits.
@@ -784,7 +785,7 @@ static void halo_launch(hipStream_t s, const HaloArgs& ha, int bm, int bn, int m
 }
 
 // the filter shapes conv_halo_eligible can accept: only those are re-tiled at load (engine.hip: pack_conv_oihw)
-bool conv_halo_packable(int KH, int KW, int Cin, int Npad) { return KH == 3 && KW == 3 && Cin % 64 == 0 && Npad % 256 == 0; }
+bool conv_halo_packable(int KH, int KW, int Cin, int Npad) { return KH == 3 && KW == 3 && Cin % 64 == 0 && Npad % 128 == 0; }
 
 bool conv_halo_debug_set(const char* key, int value)
 {

@@ -363,6 +363,73 @@ def test_halo_tile_geometries_are_bit_identical(shape, dtype):
     np.testing.assert_array_equal(y, y3)
 
 
+KCHUNK_SHAPES = [  # B, H, W, Cin, Cout, stride, residual — long-K 1x1 layers: 4 / 8 canonical chunks (conv_k_chunks)
+    (1, 32, 32, 2048, 512, 1, False),      # C5 branch2a, single image: 8 M tiles -> four blocks per tile
+    (2, 32, 32, 2048, 256, 1, True),       # the P5 lateral with a residual
+    (1, 64, 64, 2048, 512, 2, False),      # stride-2 1x1
+    (1, 31, 33, 2048, 300, 1, False),      # ragged M and N
+    (600, 1, 1, 12544, 1024, 1, False),    # the box head's first inner product: eight chunks of 49 K steps
+    (3, 7, 9, 2080, 64, 1, True),          # 65 K steps: the chunk count falls back to 1 (odd), 64-column tiles
+    (2, 16, 16, 2112, 96, 1, False),       # 66 K steps: two chunks of 33, narrow tiles
+    (1, 64, 64, 1024, 256, 1, False),      # K = 1024 stays one sum (C4 branch2a)
+]
+
+
+def _kchunk_operands(shape):
+    B, H, W, Ci, Co, stride, with_res = shape
+    rng = np.random.default_rng(sum(shape) + 41)
+    x = rng.standard_normal((B, H, W, Ci), np.float32)
+    w = (rng.standard_normal((Co, 1, 1, Ci), np.float32) * np.float32(1.0 / np.sqrt(Ci)))
+    scale = (0.5 + rng.random(Co)).astype(np.float32)
+    shift = rng.standard_normal(Co).astype(np.float32) * np.float32(0.1)
+    oh, ow = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = rng.standard_normal((B, oh, ow, Co), np.float32) if with_res else None
+    return x, w, scale, shift, res
+
+
+@pytest.mark.parametrize("dtype", ["f32x3", "f32s"])
+@pytest.mark.parametrize("shape", KCHUNK_SHAPES)
+def test_shared_tiles_fold_the_k_chunks_in_the_canonical_order(shape, dtype):
+    """the long-K 1x1 layers of the split modes sum ((0 + P0) + P1) + ... over canonical K chunks.  An
+    under-filled grid gives every chunk its own block (partials through a scratch, the last block to arrive folds them); a
+    full grid runs the chunks in one block.  Same bits either way, repeatably (the arrival order varies from launch to
+    launch), and close to fp64."""
+    x, w, scale, shift, res = _kchunk_operands(shape)
+    stride = shape[5]
+    lib = L.lib()
+    try:
+        L.check(lib.mrcnn_debug_set(b"conv_ksplit", 0))
+        y0 = conv(x, w, 1, stride, scale, shift, res, 1, dtype)
+        L.check(lib.mrcnn_debug_set(b"conv_ksplit", 1))
+        L.check(lib.mrcnn_debug_set(b"conv_ksplit_below", 1 << 30))          # share whatever the grid
+        ys = [conv(x, w, 1, stride, scale, shift, res, 1, dtype) for _ in range(4)]
+        L.check(lib.mrcnn_debug_set(b"conv_min_blocks", 1))                   # ... and on the widest tiles
+        ys.append(conv(x, w, 1, stride, scale, shift, res, 1, dtype))
+    finally:
+        L.check(lib.mrcnn_debug_set(b"conv_min_blocks", 448))
+        L.check(lib.mrcnn_debug_set(b"conv_ksplit_below", 256))
+        L.check(lib.mrcnn_debug_set(b"conv_ksplit", 1))
+    for y in ys:
+        np.testing.assert_array_equal(y, y0)
+    ref = torch_ref(x, w, 1, stride, scale, shift, res, 1, dtype)
+    assert np.abs(y0 - ref).max() <= (4e-6 if dtype == "f32x3" else 2e-5) * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("dtype", ["f32x3", "f32s"])
+def test_chunked_layers_do_not_depend_on_the_batch(dtype):
+    """The sharding contract on the chunked layers: batch 8 fills the chip (one block per tile), a single image does not
+    (a block per chunk) — the same bits per image."""
+    rng = np.random.default_rng(77)
+    for (B, H, Ci, Co) in [(8, 32, 2048, 512), (8, 32, 2048, 256), (24, 32, 2048, 512)]:
+        x = rng.standard_normal((B, H, H, Ci), np.float32)
+        w = (rng.standard_normal((Co, 1, 1, Ci), np.float32) * np.float32(1.0 / np.sqrt(Ci)))
+        shift = (rng.standard_normal(Co) * 0.1).astype(np.float32)
+        y = conv(x, w, 1, 1, None, shift, None, 1, dtype)
+        for b in (0, B - 1):
+            np.testing.assert_array_equal(conv(x[b:b + 1], w, 1, 1, None, shift, None, 1, dtype)[0], y[b], err_msg=f"{(B, H, Ci, Co)} image {b}")
+        np.testing.assert_array_equal(conv(x[1:3], w, 1, 1, None, shift, None, 1, dtype), y[1:3])
+
+
 ALIAS_SHAPES = [  # B, H, W, Cin, Cout, k — one per epilogue form a residual layer can take (the mode x tile class decides which)
     (2, 64, 64, 256, 1024, 1),     # C4 branch2c: 128-column tiles (split: wave-private fp32 epilogue; f16: wave_h; f32: wave)
     (1, 32, 32, 512, 2048, 1),     # C5 branch2c: narrowed N tile on an under-filled grid

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Where a predict's wall time goes between kernels: from a rocprofv3 --kernel-trace CSV, the kernels of the LAST predict
 (a run of launches delimited by k_preprocess), their summed duration, the idle gaps between consecutive kernels and the
-distribution of kernel durations.  usage: trace_gaps.py <dir with *kernel_trace.csv>"""
+distribution of kernel durations.  usage: trace_gaps.py <dir with *kernel_trace.csv> [--list]      --list: every kernel of that predict in launch order"""
 import csv
 import glob
 import sys
@@ -20,3 +20,8 @@ print(f"kernels {len(ks)}  wall {wall / 1e3:.1f} us  sum of kernel durations {bu
 print("kernel durations (us): min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f" % tuple(dur[int(q * (len(dur) - 1))] / 1e3 for q in (0, 0.1, 0.5, 0.9, 1)))
 short = [d for d in dur if d < 20000]
 print(f"kernels shorter than 20 us: {len(short)} ({sum(short) / 1e3:.1f} us together)")
+if "--list" in sys.argv:
+    import re
+    t0 = ks[0][0]
+    for s_, e_, n_ in ks:
+        print(f"{(s_ - t0) / 1e3:9.1f} {(e_ - s_) / 1e3:8.1f} us  {re.sub(r'^void |mrcnn::', '', n_)[:100]}")
