@@ -630,6 +630,247 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// k_conv_halo_lat — the same layer, the same K order (slab, tap, part), for grids that leave half the chip idle (round 4;
+// single images — C4's 24 3x3 layers are 128 tiles of 64 x 128 on 256 CUs, each SIMD multiplying for two waves).
+// 64 x 64 tiles, FOUR waves as 2 x 2 (one 32 x 32 accumulator each): twice the tiles, the same filter bytes per tile row as the
+// 64 x 128 form (every tile of the big form reads its 128 columns once; here two tiles read 64 each).  A SIMD holds ONE wave, so
+// nothing hides behind a partner — the schedule itself has to:
+//   * filter fragments (one coalesced KB per step and wave) are requested ELEVEN steps ahead into twelve register sets: a step is
+//     three MFMAs (~100 clk); three steps ahead, the big kernel's distance, is less than an L2 round trip;
+//   * the activation fragments of step s + 1 are read from LDS BEFORE the MFMAs of step s issue (two register sets);
+//   * the slab loads run TWO slabs ahead (two register sets): issued in tap 0 of slab h for slab h + 2, split and written in taps
+//     4..7 of slab h + 1 — waiting for them never drains the filter queue.
+// vmcnt of a wave, in issue order: one filter load per step; MAXPC slab loads behind the filter load of tap 0.  Before step s + 1
+// multiplies, the filter load issued in step s - 10 must be home: behind it come the ten filter loads of steps s - 9 .. s, the slab
+// loads of this slab's tap 0 and — in taps 0 and 1 — those of the previous slab's tap 0 (issued nine steps earlier, behind that
+// step's filter load).  The slab loads consumed in tap 4 of slab h were issued in tap 0 of slab h - 1: twelve filter loads and the
+// next slab loads lie behind them by the end of tap 3, more than any wait allows outstanding.
+// Bit-identical to k_conv_halo (tests/test_gpu_conv_kernels.py: knob "halo_lat" 0 / 1; the full-size batch-8 vs batch-1 identity).
+// ------------------------------------------------------------------------------------------------------------------------------
+static constexpr int HALO_LAT_MAX_SLOT = 320;
+template <int PARTS, int MAXPC>
+__global__ __launch_bounds__(256, 2) void k_conv_halo_lat(const HaloArgs ha)
+{
+    const ConvArgs& a = ha.a;
+    static_assert(MAXPC >= 3 && MAXPC <= 5, "staging pieces per thread");
+    constexpr int BM = 64, BN = 64, NT = 256, D = 11, NSET = 12;
+    constexpr int PLANE = (HALO_LAT_MAX_SLOT + 1) * 32;
+    constexpr int PBUF = PARTS * PLANE;
+    static_assert(PBUF >= 4 * 32 * 32 * 4, "the four wave-private epilogue tiles live in plane buffer 1");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PBUF + 2 * 2 * BN * 4];
+    unsigned char* const planes = smem;
+    float* const s_tab0 = reinterpret_cast<float*>(smem + 2 * PBUF);
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int ohw = a.OH * a.OW;
+    const int NH = ha.NH, NS = NH * 9;
+
+    const int T = ha.n_tiles;
+    const int nb = gridDim.x;
+    const int bid = blockIdx.x;
+    int t_first, t_end, t_step;
+    {
+        const int q = T >> 3, r8 = T & 7;
+        const int xcd = bid & 7, j = bid >> 3;
+        const int lo = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
+        const int cnt = q + (xcd < r8 ? 1 : 0);
+        const int per = nb >> 3;
+        t_first = lo + j; t_end = lo + cnt; t_step = per;
+        if (nb < 8) { t_first = bid; t_end = T; t_step = nb; }
+    }
+    typedef unsigned srd_t __attribute__((ext_vector_type(4)));
+    srd_t srdB;
+    {
+        const unsigned long long wa = (unsigned long long)(uintptr_t)ha.wgt_halo;
+        srdB[0] = __builtin_amdgcn_readfirstlane((unsigned)wa);
+        srdB[1] = __builtin_amdgcn_readfirstlane((unsigned)(wa >> 32) & 0xffffu);
+        srdB[2] = 0xffffffffu;
+        srdB[3] = 0x00020000u;
+    }
+    const unsigned vlane16 = (unsigned)lane * 16u;
+
+    int tile_par = 0;
+    for (int unit = t_first; unit < t_end; unit += t_step, tile_par ^= 1) {
+        const int mt = unit / a.tiles_n, nt = unit - mt * a.tiles_n;
+        const int n0 = nt * BN;
+        float* const s_tab = s_tab0 + tile_par * 2 * BN;
+        // ---- geometry of the tile's input region (HALO_GEO_LINEAR / HALO_GEO_ROW, as k_conv_halo) -----------------------
+        const int Hp = a.H + 2;
+        const int pitch = ha.pitch, ecols = ha.ecols;
+        const int m0 = mt * BM;
+        const int m_last = (m0 + BM - 1 < a.M ? m0 + BM - 1 : a.M - 1);
+        const int b0 = m0 / ohw;
+        const int rem0 = m0 - b0 * ohw, oh0 = rem0 / a.OW, ow0 = rem0 - oh0 * a.OW;
+        const int b1 = m_last / ohw, rem1 = m_last - b1 * ohw, oh1 = rem1 / a.OW;
+        const int gy_first = b0 * Hp + oh0 + 1;
+        const int gy_last = b1 * Hp + oh1 + 1;
+        const int col0 = ha.geo == HALO_GEO_ROW ? ow0 - 1 : -1;
+        const int rows = gy_last - gy_first + 3;
+        const int npx = rows * ecols;                     // <= MAXPC * 64 pixels, rows * pitch (+ skew) <= HALO_LAT_MAX_SLOT: host-checked
+        srd_t srdA;
+        {
+            const unsigned long long ia = (unsigned long long)(uintptr_t)(static_cast<const float*>(a.in) + (long)b0 * a.in_sB);
+            const unsigned long long rest = (unsigned long long)(a.B - b0) * (unsigned long long)a.in_sB * 4ull;
+            srdA[0] = __builtin_amdgcn_readfirstlane((unsigned)ia);
+            srdA[1] = __builtin_amdgcn_readfirstlane((unsigned)(ia >> 32) & 0xffffu);
+            srdA[2] = __builtin_amdgcn_readfirstlane((unsigned)(rest < 0x80000000ull ? rest : 0x80000000ull));
+            srdA[3] = 0x00020000u;
+        }
+        unsigned p_off[MAXPC], p_lds[MAXPC];
+#pragma unroll
+        for (int i = 0; i < MAXPC; ++i) {
+            const int j = t + NT * i;
+            const int px = j >> 2, qt = j & 3;
+            const int r = px / ecols, c = px - r * ecols;
+            const int gy = gy_first - 1 + r;
+            const int b = gy / Hp, y = gy - b * Hp - 1;
+            const int x = col0 + c;
+            const bool ok = px < npx && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W && b < a.B;
+            p_off[i] = ok ? (unsigned)(((long)(b - b0) * a.in_sB + (long)y * a.in_sH + (long)x * a.in_sW + qt * 4) * 4) : HALO_OOB;
+            const int slot = r * pitch + c + (b - b0) * ha.img_skew;
+            p_lds[i] = px < npx ? (unsigned)(slot * 32 + (((qt >> 1) ^ ((slot >> 3) & 1)) << 4) + (qt & 1) * 8) : (unsigned)(HALO_LAT_MAX_SLOT * 32 + qt * 8);
+        }
+        const int wave_row0 = m0 + wm * 32;
+        int base_idx;
+        {
+            const int m = wave_row0 + l31;
+            const int mm = m < a.M ? m : a.M - 1;
+            const int b = mm / ohw, rem = mm - b * ohw, oh = rem / a.OW, ow = rem - oh * a.OW;
+            base_idx = ha.geo == HALO_GEO_ROW ? (ow - ow0) : (b * Hp + oh + 1 - gy_first) * pitch + ow + (b - b0) * ha.img_skew;
+        }
+        const unsigned sob = (unsigned)(((size_t)(n0 / 32 + wn) * NS) * 1024u);
+        if (t < BN / 2) {
+            const int c = (t < BN / 4 ? t : t - BN / 4) * 4;
+            const float* src = t < BN / 4 ? a.scale : a.shift;
+            const float fill = t < BN / 4 ? 1.0f : 0.0f;
+            *reinterpret_cast<float4*>(&s_tab[(t < BN / 4 ? 0 : BN) + c]) =
+                src ? *reinterpret_cast<const float4*>(src + n0 + c) : make_float4(fill, fill, fill, fill);
+        }
+
+#define LAT_LOAD(S, I) if constexpr ((I) < MAXPC) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(st[S][(I) < MAXPC ? (I) : 0]) : "v"(p_off[(I) < MAXPC ? (I) : 0]), "s"(srdA) : "memory");
+#define LAT_LOADS(S) { LAT_LOAD(S, 0) LAT_LOAD(S, 1) LAT_LOAD(S, 2) LAT_LOAD(S, 3) LAT_LOAD(S, 4) }
+#define LAT_ADVANCE() { _Pragma("unroll") for (int i = 0; i < MAXPC; ++i) p_off[i] += (p_off[i] < HALO_OOB ? 64u : 0u); }
+#define LAT_PIN1(S, I) if constexpr ((I) < MAXPC) asm volatile("" : "+v"(st[S][(I) < MAXPC ? (I) : 0]));
+#define LAT_PIN(S) { LAT_PIN1(S, 0) LAT_PIN1(S, 1) LAT_PIN1(S, 2) LAT_PIN1(S, 3) LAT_PIN1(S, 4) }
+#define LAT_WRITE1(S, BUF, I_)                                                                                   \
+    if constexpr ((I_) < MAXPC) {                                                                                \
+        constexpr int I = (I_) < MAXPC ? (I_) : 0;                                                               \
+        u32x2 parts[PARTS];                                                                                      \
+        split4<PARTS>(st[S][I], parts);                                                                          \
+        _Pragma("unroll") for (int p = 0; p < PARTS; ++p)                                                        \
+            *reinterpret_cast<u32x2*>(planes + (BUF) * PBUF + p * PLANE + p_lds[I]) = parts[p];                  \
+    }
+#define LAT_BLOAD(SET, SO_) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(bv[SET]) : "v"(vlane16), "s"(srdB), "s"(SO_) : "memory");
+#define LAT_BPIN() { _Pragma("unroll") for (int q_ = 0; q_ < NSET; ++q_) asm volatile("" : "+v"(bv[q_])); }
+#define LAT_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define LAT_AFRAGS(AV, PB_, TAP_)                                                                                \
+    {                                                                                                            \
+        const int idx_ = base_idx + ((TAP_) / 3) * pitch + ((TAP_) % 3);                                         \
+        const unsigned a_addr_ = (unsigned)(idx_ << 5) + (unsigned)(((kk << 4) ^ ((idx_ << 1) & 16)));           \
+        _Pragma("unroll") for (int p = 0; p < PARTS; ++p) AV[p] = *reinterpret_cast<const uint4*>(planes + (PB_) * PBUF + p * PLANE + a_addr_); \
+    }
+#ifdef MRCNN_CONV_ABLATE      /* measurement build (make ablate; a.dbg = "conv_pp_dbg"): 1 no filter loads in the loop, 2 no MFMAs, 4 no fragment reads, 8 no slab staging, 16 no epilogue, 32 no loop */
+#define LAT_ABL(BIT) (!(a.dbg & (BIT)))
+#else
+#define LAT_ABL(BIT) true
+#endif
+        u32x4 st[2][MAXPC];
+        u32x4 bv[NSET];
+        // ---- prologue: slabs 0 and 1 requested, then the filter fragments of steps 0..10; slab 0 into plane buffer 0 -----
+        LAT_LOADS(0)
+        LAT_ADVANCE()
+        const bool two = NH > 1;
+        if (two) { LAT_LOADS(1) LAT_ADVANCE() }
+        const unsigned so_last = sob + (unsigned)(NS - 1) * 1024u;
+        unsigned so_next = sob;                           // byte offset of the newest fragment request (past the last step: the last one again)
+#pragma unroll
+        for (int q_ = 0; q_ < D; ++q_) {
+            if (q_) so_next = so_next + 1024u < so_last ? so_next + 1024u : so_last;
+            LAT_BLOAD(q_, so_next)
+        }
+        if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D + MAXPC) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");
+        LAT_PIN(0)
+        LAT_WRITE1(0, 0, 0) LAT_WRITE1(0, 0, 1) LAT_WRITE1(0, 0, 2) LAT_WRITE1(0, 0, 3) LAT_WRITE1(0, 0, 4)
+        LAT_BARRIER();
+
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+        uint4 av[2][PARTS];
+        LAT_AFRAGS(av[0], 0, 0)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 1) : "memory");        // the fragments of step 0 (the slab-1 loads, if any, are older)
+        LAT_BPIN()
+// One step = one (slab, tap): the requests first (the filter fragments of step + 11; tap 0: the slab two slabs ahead; the activation
+// fragments of step + 1), then the step's dependent MFMAs BACK TO BACK — hi, mid, lo on one accumulator: any instruction between two
+// of them costs a 43-clk cliff (MI355X_MICROARCH.md; placing the fillers in the MFMA shadows was tried: C4 23.3 -> 25.3 us,
+// gpurun_out/r4y) — then the tap's share of the next slab's staging under the last MFMA, and the wait that makes step + 1's filter
+// fragments valid.  taps 4..7 split and write pieces 0..3 of slab h + 1 (tap 3: piece 4).
+#define LAT_PIECE(TAP) ((TAP) >= 4 && (TAP) <= 7 ? (TAP) - 4 : ((TAP) == 3 ? 4 : 99))
+#define LAT_MFMA(K, P) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bv[(K) % NSET]), __builtin_bit_cast(f16x8, av[(K) & 1][P]), acc, 0, 0, 0);
+#define LAT_STEP(K, TAP, PB, HP)                                                                                 \
+    {                                                                                                            \
+        constexpr int PI = LAT_PIECE(TAP) < MAXPC ? LAT_PIECE(TAP) : 0;                                          \
+        constexpr bool HASP = LAT_PIECE(TAP) < MAXPC;                                                            \
+        if (LAT_ABL(1)) { so_next = so_next + 1024u < so_last ? so_next + 1024u : so_last; LAT_BLOAD(((K) + D) % NSET, so_next) } \
+        if ((TAP) == 0 && stage_now) { LAT_LOADS(HP) LAT_ADVANCE() }                                             \
+        if (LAT_ABL(4)) {                                                                                        \
+            if ((TAP) == 8) LAT_AFRAGS(av[((K) + 1) & 1], (PB) ^ 1, 0)                                           \
+            else LAT_AFRAGS(av[((K) + 1) & 1], PB, ((TAP) + 1) % 9)                                              \
+        }                                                                                                        \
+        if (LAT_ABL(2)) { _Pragma("unroll") for (int p = 0; p < PARTS; ++p) LAT_MFMA(K, p) }                     \
+        if (HASP && write_next && LAT_ABL(8)) { LAT_PIN1((HP) ^ 1, PI) LAT_WRITE1((HP) ^ 1, (PB) ^ 1, PI) }      \
+        if (stage_now) {                                                                                         \
+            if ((TAP) <= 1 && stage_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 1 + 2 * MAXPC) : "memory"); \
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 1 + MAXPC) : "memory");                            \
+        } else {                                                                                                 \
+            if ((TAP) <= 1 && stage_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 1 + MAXPC) : "memory");   \
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 1) : "memory");                                    \
+        }                                                                                                        \
+        LAT_BPIN()                                                                                               \
+        if ((TAP) == 7) LAT_BARRIER();                                                                           \
+    }
+#define LAT_SLAB(K0, PB, HP)                                                                                     \
+    LAT_STEP((K0) + 0, 0, PB, HP) LAT_STEP((K0) + 1, 1, PB, HP) LAT_STEP((K0) + 2, 2, PB, HP) LAT_STEP((K0) + 3, 3, PB, HP) LAT_STEP((K0) + 4, 4, PB, HP) \
+    LAT_STEP((K0) + 5, 5, PB, HP) LAT_STEP((K0) + 6, 6, PB, HP) LAT_STEP((K0) + 7, 7, PB, HP) LAT_STEP((K0) + 8, 8, PB, HP)
+        for (int h = 0; h < NH; h += 4) {          // four slabs per iteration: 36 steps, the twelve filter sets and the two fragment sets rotate statically
+            if (!LAT_ABL(32)) break;
+            { const bool stage_now = h + 2 < NH && LAT_ABL(8), write_next = h + 1 < NH && LAT_ABL(8), stage_prev = h >= 1 && h + 1 < NH && LAT_ABL(8); LAT_SLAB(0, 0, 0) }
+            { const bool stage_now = h + 3 < NH && LAT_ABL(8), write_next = h + 2 < NH && LAT_ABL(8), stage_prev = h + 2 < NH && LAT_ABL(8);           LAT_SLAB(9, 1, 1) }
+            { const bool stage_now = h + 4 < NH && LAT_ABL(8), write_next = h + 3 < NH && LAT_ABL(8), stage_prev = h + 3 < NH && LAT_ABL(8);           LAT_SLAB(18, 0, 0) }
+            { const bool stage_now = h + 5 < NH && LAT_ABL(8), write_next = h + 4 < NH && LAT_ABL(8), stage_prev = h + 4 < NH && LAT_ABL(8);           LAT_SLAB(27, 1, 1) }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the last steps requested fragments nobody multiplies
+        LAT_BPIN()
+#undef LAT_SLAB
+#undef LAT_STEP
+#undef LAT_MFMA
+#undef LAT_PIECE
+#undef LAT_AFRAGS
+#undef LAT_BARRIER
+#undef LAT_BPIN
+#undef LAT_BLOAD
+#undef LAT_WRITE1
+#undef LAT_PIN
+#undef LAT_PIN1
+#undef LAT_ADVANCE
+#undef LAT_LOADS
+#undef LAT_LOAD
+        // epilogue through wave-private tiles in plane buffer 1 (the last slab read it, and its barrier is behind every wave; the next
+        // tile's prologue writes buffer 0 and the other s_tab, and its first write to buffer 1 comes after its own prologue barrier)
+        f32x16 accs[1][1];
+        accs[0][0] = acc;
+        if (!LAT_ABL(16)) { if (acc[0] == 123.456f) s_tab[0] = acc[3]; continue; }
+        conv_epilogue_wave<BN, 1, 1>(a, accs, reinterpret_cast<float*>(planes + PBUF) + wave * (32 * 32), s_tab, wave_row0, n0, wn * 32, lane);
+#undef LAT_ABL
+    }
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // filter re-tiling: [Npad][9][Cin] fp16 (the family's packing) → granules [Npad/32][Cin/16][9][1 KB] in MFMA-fragment order:
 // the 16 B of lane (l31, kk) — filter row 32 g + l31, channels 16 h + 8 kk .. + 8 — at byte 16 · (32 kk + l31)
@@ -693,9 +934,10 @@ static int halo_linear_rows(int H, int W, int bm)
     return rows_touched + 2 * boundaries + 2;
 }
 
+static int g_halo_lat = env_int_halo("MRCNN_HALO_LAT", 1);     // grids under 3/4 of the chip even at 64 x 128: 64 x 64 tiles in the latency form (k_conv_halo_lat; bit-identical)
 static int g_halo_geo = env_int_halo("MRCNN_HALO_GEO", 1);     // 0: the round-3 geometries (one-row 3 x 130 regions, five staging pieces, pitch W + 2) — A/B and bit-identity tests
 
-struct HaloGeo { int geo, ecols, pitch, img_skew, tiles_row, tiles_img, rows, maxpc; bool ok; };
+struct HaloGeo { int geo, ecols, pitch, img_skew, tiles_row, tiles_img, rows, maxpc, slots; bool ok; };
 
 // Geometry of the tiles of a layer for block tiles of bm rows.  Which geometry is used never changes a result: every tile sums
 // its K in the same (slab, tap, part) order.
@@ -733,7 +975,8 @@ static HaloGeo halo_geometry(int H, int W, int bm)
     }
     const int px = g.rows * g.ecols;
     g.maxpc = px <= 256 ? 2 : px <= 384 ? 3 : 5;
-    g.ok = px <= 640 && g.rows * g.pitch + slots_extra <= HALO_MAX_SLOT;
+    g.slots = g.rows * g.pitch + slots_extra;
+    g.ok = px <= 640 && g.slots <= HALO_MAX_SLOT;
     return g;
 }
 
@@ -790,6 +1033,7 @@ bool conv_halo_packable(int KH, int KW, int Cin, int Npad) { return KH == 3 && K
 bool conv_halo_debug_set(const char* key, int value)
 {
     if (std::string(key) == "halo_geo") { g_halo_geo = value; return true; }
+    if (std::string(key) == "halo_lat") { g_halo_lat = value; return true; }
     return false;
 }
 
@@ -826,6 +1070,17 @@ int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, i
     // bit-identical, tests/test_gpu_fullsize.py batch 8 vs batch 1); levels whose rows are not a multiple of 64 wide keep 128
     if (d.head_w && (long)((a.M + 127) / 128) * 4 < (long)n_cus * 3 && d.W % 64 == 0) bm = 64;
     MRCNN_REQUIRE(!t1 || (bn == 256 && d.Npad == 256), MRCNN_ERR_INVALID, "fused tail: the 3x3 layer must have exactly 256 output columns");
+    // grids that cover less than 3/8 of the chip even with 64 x 128 tiles — single images at C5 / P5: 64 x 64 tiles in the latency
+    // form (four waves per block, deep prefetch: k_conv_halo_lat), when the 64-row region fits its smaller planes.  At one 32 x 32
+    // accumulator per wave both forms are bound by the activation-fragment reads (3 KB of LDS per wave and step against three MFMAs:
+    // the LDS port is busy 96 of the chain's 96 clk), so C4's 128 tiles gain nothing from becoming 256 (23.3 -> 23.3 us) and stay
+    // on the eight-wave form; C5's 64 tiles do (42 -> 34 us).  ("halo_lat" 2: also grids under 3/4 — the A/B of that statement)
+    int lat_pc = 0;
+    if (!d.head_w && !t1 && g_halo_lat && g_halo_geo && bm == 64 && bn == 128 && (long)((a.M + 63) / 64) * (d.Npad / 128) * 8 < (long)n_cus * 3 * g_halo_lat) {
+        const HaloGeo g64 = halo_geometry(d.H, d.W, 64);
+        const int px = g64.rows * g64.ecols;
+        if (g64.ok && g64.geo != HALO_GEO_2ROWS && px <= 320 && g64.slots <= HALO_LAT_MAX_SLOT) { lat_pc = px <= 192 ? 3 : px <= 256 ? 4 : 5; bn = 64; }
+    }
     const int tiles_m = (a.M + bm - 1) / bm;
     a.tiles_m = tiles_m;
     a.tiles_n = d.Npad / bn;
@@ -859,6 +1114,15 @@ int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, i
         MRCNN_REQUIRE(g.maxpc <= 3, MRCNN_ERR_INVALID, "fused tail: the tile's input region needs more than three staging pieces (conv_halo_tail_geometry_ok)");
         if (parts == 3) hipLaunchKernelGGL((k_conv_halo<3, 2, false, false, 2, 3, true>), dim3(grid), dim3(512), 0, s, ha);
         else hipLaunchKernelGGL((k_conv_halo<2, 2, false, false, 2, 3, true>), dim3(grid), dim3(512), 0, s, ha);
+        return bn;
+    }
+    if (lat_pc) {
+        grid = units < 2 * n_cus ? units : 2 * n_cus;       // 63 KB of LDS per block: two fit a CU
+        if (grid >= 8) grid &= ~7;
+#define MRCNN_LAT(P, PC) hipLaunchKernelGGL((k_conv_halo_lat<P, PC>), dim3(grid), dim3(256), 0, s, ha)
+        if (parts == 3) { if (lat_pc == 3) MRCNN_LAT(3, 3); else if (lat_pc == 4) MRCNN_LAT(3, 4); else MRCNN_LAT(3, 5); }
+        else { if (lat_pc == 3) MRCNN_LAT(2, 3); else if (lat_pc == 4) MRCNN_LAT(2, 4); else MRCNN_LAT(2, 5); }
+#undef MRCNN_LAT
         return bn;
     }
     if (parts == 3) halo_launch<3>(s, ha, bm, bn, g.maxpc, grid);

@@ -363,6 +363,44 @@ def test_halo_tile_geometries_are_bit_identical(shape, dtype):
     np.testing.assert_array_equal(y, y3)
 
 
+LAT_SHAPES = [  # B, H, W, Cin, Cout — grids under 3/4 of the chip with 64 x 128 tiles: the 64 x 64 latency form (k_conv_halo_lat)
+    (1, 64, 64, 256, 256),      # C4 at a single image: one-row regions of 3 x 66 pixels, four staging pieces
+    (1, 32, 32, 512, 512),      # C5: two image rows per tile (4 x 34 pixels, three pieces), 32 slabs
+    (1, 32, 32, 256, 256),      # P5
+    (2, 16, 16, 64, 128),       # four rows per tile, pitch W + 16; a tile never straddles (256 % 64 == 0)
+    (1, 33, 47, 192, 128),      # ragged rows: 5 x 49 pixels, pitch 63 (315 of the 320 slots), M % 64 != 0
+    (3, 14, 14, 256, 256),      # tiles straddle images (two zero rows + the image skew inside the region)
+    (1, 64, 64, 64, 320),       # four slabs only (the prologue's eleven fragment requests run past the end), ragged N
+]
+
+
+@pytest.mark.parametrize("dtype", ["f32x3", "f32s"])
+@pytest.mark.parametrize("shape", LAT_SHAPES)
+def test_latency_form_of_the_halo_kernel_is_bit_identical(shape, dtype):
+    """single-image grids run 64 x 64 tiles on four waves with deep prefetch (k_conv_halo_lat) — the same
+    (slab, tap, part) order as the persistent 128 / 64-row kernel, hence the same bits; and repeatably (hand-counted vmcnt)."""
+    B, H, W, Ci, Co = shape
+    rng = np.random.default_rng(sum(shape) + 5)
+    x = (rng.standard_normal((B, H, W, Ci)) * 2).astype(np.float32)
+    w = (rng.standard_normal((Co, 3, 3, Ci)) * np.sqrt(2.0 / (9 * Ci))).astype(np.float32)
+    scale = (0.5 + rng.random(Co)).astype(np.float32)
+    shift = (rng.standard_normal(Co) * 0.1).astype(np.float32)
+    lib = L.lib()
+    try:
+        L.check(lib.mrcnn_debug_set(b"halo_lat", 0))
+        y0 = conv(x, w, 3, 1, scale, shift, None, 1, dtype)
+        L.check(lib.mrcnn_debug_set(b"halo_lat", 2))          # every grid under 3/4 of the chip (the policy, 1: under 3/8)
+        ys = [conv(x, w, 3, 1, scale, shift, None, 1, dtype) for _ in range(3)]
+        L.check(lib.mrcnn_debug_set(b"halo_lat", 1))
+        ys.append(conv(x, w, 3, 1, scale, shift, None, 1, dtype))
+    finally:
+        L.check(lib.mrcnn_debug_set(b"halo_lat", 1))
+    for y in ys:
+        np.testing.assert_array_equal(y, y0)
+    ref = torch_ref(x, w, 3, 1, scale, shift, None, 1, dtype)
+    assert np.abs(y0 - ref).max() <= (4e-6 if dtype == "f32x3" else 2e-5) * max(1.0, np.abs(ref).max())
+
+
 KCHUNK_SHAPES = [  # B, H, W, Cin, Cout, stride, residual — long-K 1x1 layers: 4 / 8 canonical chunks (conv_k_chunks)
     (1, 32, 32, 2048, 512, 1, False),      # C5 branch2a, single image: 8 M tiles -> four blocks per tile
     (2, 32, 32, 2048, 256, 1, True),       # the P5 lateral with a residual
