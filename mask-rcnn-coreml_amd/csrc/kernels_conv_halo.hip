@@ -1074,7 +1074,10 @@ int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, i
     // form (four waves per block, deep prefetch: k_conv_halo_lat), when the 64-row region fits its smaller planes.  At one 32 x 32
     // accumulator per wave both forms are bound by the activation-fragment reads (3 KB of LDS per wave and step against three MFMAs:
     // the LDS port is busy 96 of the chain's 96 clk), so C4's 128 tiles gain nothing from becoming 256 (23.3 -> 23.3 us) and stay
-    // on the eight-wave form; C5's 64 tiles do (42 -> 34 us).  ("halo_lat" 2: also grids under 3/4 — the A/B of that statement)
+    // on the eight-wave form; C5's 64 tiles do (42 -> 34 us).  ("halo_lat" 2: also grids under 3/4 — the A/B of that statement.)
+    // A four-wave form with 64 x 128 tiles and two accumulators per wave (half the fragment reads per MFMA) was built and measured as
+    // well: C4 23.3 -> 28.7 us, C5 42 -> 45 — with one wave per SIMD the alternating accumulators wait for each other's write-back
+    // (a dependent MFMA one instruction behind its producer does not get the back-to-back forwarding); gpurun_out/r4z/lat2.txt.
     int lat_pc = 0;
     if (!d.head_w && !t1 && g_halo_lat && g_halo_geo && bm == 64 && bn == 128 && (long)((a.M + 63) / 64) * (d.Npad / 128) * 8 < (long)n_cus * 3 * g_halo_lat) {
         const HaloGeo g64 = halo_geometry(d.H, d.W, 64);
