@@ -63,6 +63,12 @@ python tools/split_scale_curve.py 2>/dev/null | grep -v amdgpu > $OUT/${RND}_spl
 timeout 200 bash tools/power_probe.sh > $OUT/${RND}_power_probe.txt 2>&1
 timeout 200 bash tools/mfma_power.sh > $OUT/${RND}_mfma_power.txt 2>&1
 timeout 400 python tools/fp64_trunk_parity.py --out $OUT/${RND}_fp64_trunk_parity.json > $OUT/fp64.log 2>&1
+# round 4 (late): canonical K chunks and the halo kernel's latency form — knob A/Bs on single layers; where a single image's time goes
+{ for kv in "conv_ksplit 0 1" "conv_kchunk 0 1" "halo_lat 0 1" "halo_lat 0 2"; do timeout 200 python tools/knob_ab.py $kv f32x3 3 20 all 2>/dev/null | grep -v amdgpu; done; } > $OUT/${RND}_knob_ab_f32x3.txt
+( cd /tmp && export TMPDIR=/tmp
+  for b in 1 8; do rm -rf /tmp/tr$b; timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr$b -o t -- python $R/bench.py --batch $b --steps 5 --warmup 2 --no-cpu-baseline --e2e-images 0 --no-other-modes --no-kernel-events > /dev/null 2>&1; done
+  { echo "# batch 1"; python $R/tools/trace_gaps.py /tmp/tr1; echo "# batch 8"; python $R/tools/trace_gaps.py /tmp/tr8; } > $OUT/${RND}_trace_gaps_f32x3.txt
+  python $R/tools/trace_gaps.py /tmp/tr1 --list > $OUT/${RND}_trace_b1_kernels_f32x3.txt )
 # per-GPU slices of the other BASELINE configs (configs[2]: ResNet50; configs[3]: fp16; configs[4]: 1536², 2 classes, pre_nms 12000) and the batch sweep
 python bench.py --steps 10 --warmup 3 --arch resnet50 --no-cpu-baseline --no-other-modes > $OUT/${RND}_bench_n1_resnet50.json 2>/dev/null
 python bench.py --steps 10 --warmup 3 --arch resnet50 --dtype f16 --no-cpu-baseline --no-other-modes > $OUT/${RND}_bench_n1_resnet50_f16.json 2>/dev/null
