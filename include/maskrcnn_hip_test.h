@@ -59,7 +59,13 @@ MRCNN_API int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout,
  * persistent halo kernel of the 3x3 layers of the split modes (its K order is its own: results differ from "0" by summation noise);
  * "halo_geo" 0|1: its round-3 tile geometries | two-row tiles, region-sized staging, conflict-free LDS pitch (bit-identical);
  * "conv_tail" 0|1: bottleneck tails as two launches | one fused launch where the grid fills the chip (bit-identical; default 0: measured slower);
- * "conv_stem" 0|1: split modes, conv1 and the max-pool as two launches | one fused launch (bit-identical; default 1).
+ * "conv_stem" 0|1: split modes, conv1 and the max-pool as two launches | one fused launch (bit-identical; default 1);
+ * "halo_lat" 0|1|2: 3x3 layers on grids under 3/8 of the chip (single images at C5 / P5): the eight-wave 64 x 128 tiles | 64 x 64 tiles on
+ * four waves with deep prefetch (default) | that form for every grid under 3/4 (bit-identical);
+ * "conv_kchunk" 0|1: the long-K (>= 2048) 1x1 layers of the split modes as one running sum | as 4 / 8 canonical K chunks folded in order
+ * (default 1; the two differ by summation noise — the chunk count is a property of the layer, never of the batch);
+ * "conv_ksplit" 0|1 and "conv_ksplit_below" n: chunked layers whose widest-tile grid has fewer than n (256) blocks give every chunk its
+ * own block, the last one to finish folds the partial sums | never (bit-identical to each other).
  * The switches are PROCESS-WIDE test / measurement knobs: not thread-safe; a choice captured in a hipGraph stays captured. */
 MRCNN_API int mrcnn_conv2d_nhwc(const float* in, int batch, int h, int w, int cin, const float* filters, int cout,
                                 int ksize, int stride, const float* scale, const float* shift, const float* residual,
