@@ -246,11 +246,6 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
     // tiles run on under-filled grids with short steps and use deeper rings.
     // direct epilogue (conv_device.h): its scale / shift table goes to LDS before the first barrier
     const bool direct = DIRECT_OK && a.direct;
-    MRCNN_DMA_TILE(0, 0)
-    if (STAGES > 2 && KT > 1) MRCNN_DMA_TILE(1, 1)
-    if (STAGES > 3 && KT > 2) MRCNN_DMA_TILE(2, 2)
-    // (behind the first tiles' requests, not in front of them: the table's own round trip then overlaps theirs — a launch on a single
-    //  image is a handful of dependent round trips)
     if (direct && t < BN / 2) {
         const int c = (t < BN / 4 ? t : t - BN / 4) * 4;
         const float* src = t < BN / 4 ? a.scale : a.shift;
@@ -258,6 +253,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
         *reinterpret_cast<float4*>(&s_tab[(t < BN / 4 ? 0 : BN) + c]) =
             src ? *reinterpret_cast<const float4*>(src + n0 + c) : make_float4(fill, fill, fill, fill);
     }
+    MRCNN_DMA_TILE(0, 0)
+    if (STAGES > 2 && KT > 1) MRCNN_DMA_TILE(1, 1)
+    if (STAGES > 3 && KT > 2) MRCNN_DMA_TILE(2, 2)
     if (KT - 1 >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS * (STAGES - 2)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();          // tile 0 is in LDS

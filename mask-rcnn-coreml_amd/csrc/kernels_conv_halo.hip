@@ -276,6 +276,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
 #pragma unroll
         for (int j = 0; j < TN; ++j) sob[j] = (unsigned)(((size_t)(n0 / 32 + wn * TN + j) * NS) * 1024u);
 
+        // scale / shift of the tile's columns for the epilogue (double-buffered by tile parity: read after the main loop's barriers)
+        if (t < BN / 2) {
+            const int c = (t < BN / 4 ? t : t - BN / 4) * 4;
+            const float* src = t < BN / 4 ? a.scale : a.shift;
+            const float fill = t < BN / 4 ? 1.0f : 0.0f;
+            *reinterpret_cast<float4*>(&s_tab[(t < BN / 4 ? 0 : BN) + c]) =
+                src ? *reinterpret_cast<const float4*>(src + n0 + c) : make_float4(fill, fill, fill, fill);
+        }
+
 #define HALO_LOAD(I) if constexpr ((I) < MAXPC) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(st[(I) < MAXPC ? (I) : 0]) : "v"(p_off[(I) < MAXPC ? (I) : 0]), "s"(srdA) : "memory");
 #define HALO_LOADS()  { HALO_LOAD(0) HALO_LOAD(1) HALO_LOAD(2) HALO_LOAD(3) HALO_LOAD(4) }
 #define HALO_ADVANCE() { _Pragma("unroll") for (int i = 0; i < MAXPC; ++i) p_off[i] += (p_off[i] < HALO_OOB ? 64u : 0u); }
@@ -312,15 +321,6 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
         HALO_BLOAD(bv0, 0)
         HALO_BLOAD(bv1, 1)
         HALO_BLOAD(bv2, 2)
-        // scale / shift of the tile's columns for the epilogue (double-buffered by tile parity: read after the main loop's barriers) — requested
-        // behind the prologue's loads so that its round trip overlaps theirs (the compiler waits for it with vmcnt(0), as the prologue does)
-        if (t < BN / 2) {
-            const int c = (t < BN / 4 ? t : t - BN / 4) * 4;
-            const float* src = t < BN / 4 ? a.scale : a.shift;
-            const float fill = t < BN / 4 ? 1.0f : 0.0f;
-            *reinterpret_cast<float4*>(&s_tab[(t < BN / 4 ? 0 : BN) + c]) =
-                src ? *reinterpret_cast<const float4*>(src + n0 + c) : make_float4(fill, fill, fill, fill);
-        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         HALO_PIN()
         HALO_BPIN(bv0)
@@ -744,6 +744,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_halo_lat(const HaloArgs ha)
             base_idx = ha.geo == HALO_GEO_ROW ? (ow - ow0) : (b * Hp + oh + 1 - gy_first) * pitch + ow + (b - b0) * ha.img_skew;
         }
         const unsigned sob = (unsigned)(((size_t)(n0 / 32 + wn) * NS) * 1024u);
+        if (t < BN / 2) {
+            const int c = (t < BN / 4 ? t : t - BN / 4) * 4;
+            const float* src = t < BN / 4 ? a.scale : a.shift;
+            const float fill = t < BN / 4 ? 1.0f : 0.0f;
+            *reinterpret_cast<float4*>(&s_tab[(t < BN / 4 ? 0 : BN) + c]) =
+                src ? *reinterpret_cast<const float4*>(src + n0 + c) : make_float4(fill, fill, fill, fill);
+        }
+
 #define LAT_LOAD(S, I) if constexpr ((I) < MAXPC) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(st[S][(I) < MAXPC ? (I) : 0]) : "v"(p_off[(I) < MAXPC ? (I) : 0]), "s"(srdA) : "memory");
 #define LAT_LOADS(S) { LAT_LOAD(S, 0) LAT_LOAD(S, 1) LAT_LOAD(S, 2) LAT_LOAD(S, 3) LAT_LOAD(S, 4) }
 #define LAT_ADVANCE() { _Pragma("unroll") for (int i = 0; i < MAXPC; ++i) p_off[i] += (p_off[i] < HALO_OOB ? 64u : 0u); }
@@ -785,19 +793,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_halo_lat(const HaloArgs ha)
             if (q_) so_next = so_next + 1024u < so_last ? so_next + 1024u : so_last;
             LAT_BLOAD(q_, so_next)
         }
-        // scale / shift of the tile's columns: requested behind the prologue's loads (its round trip overlaps theirs), parked in LDS
-        // after slab 0 (the compiler's own wait for it is a vmcnt(0): by then only filter fragments are outstanding)
-        float4 tab_v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < BN / 2) {
-            const float* src = t < BN / 4 ? a.scale : a.shift;
-            const float fill = t < BN / 4 ? 1.0f : 0.0f;
-            tab_v = src ? *reinterpret_cast<const float4*>(src + n0 + (t < BN / 4 ? t : t - BN / 4) * 4) : make_float4(fill, fill, fill, fill);
-        }
-        if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D + MAXPC) : "memory");          // (the table's load is wave 0's only: not counted — one load stricter there)
+        if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D + MAXPC) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");
         LAT_PIN(0)
         LAT_WRITE1(0, 0, 0) LAT_WRITE1(0, 0, 1) LAT_WRITE1(0, 0, 2) LAT_WRITE1(0, 0, 3) LAT_WRITE1(0, 0, 4)
-        if (t < BN / 2) *reinterpret_cast<float4*>(&s_tab[(t < BN / 4 ? 0 : BN) + (t < BN / 4 ? t : t - BN / 4) * 4]) = tab_v;
         LAT_BARRIER();
 
         f32x16 acc;
