@@ -115,14 +115,17 @@ __device__ __forceinline__ void split4(const u32x4 v, u32x2 (&out)[PARTS])
 // 1x1 layer's arguments.  K order = 16-channel groups ascending, parts hi / mid / lo per group, one running accumulator: the
 // order of the 128-row kernel's 1x1 — the fused launch is BIT-IDENTICAL to the two launches it replaces, so whether a call
 // fuses is a launch-time choice (grid fill), like a tile shape.
-template <int PARTS, int TN, bool HEAD = false, bool DBG = false, int TM = 2, int MAXPC = 5, bool TAIL = false>       // TM = 1: 64-row tiles for grids that would not fill the chip
+// WN = 2 (round 4, late): the eight waves as 4 x 2 — 128 x 64 tiles for the 64-column layers (C2's 3x3 64 -> 64), one 32 x 32 accumulator per wave
+template <int PARTS, int TN, bool HEAD = false, bool DBG = false, int TM = 2, int MAXPC = 5, bool TAIL = false, int WN = 4>       // TM = 1: 64-row tiles for grids that would not fill the chip
 __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
 {
     const ConvArgs& a = ha.a;
+    static_assert(WN == 4 || (WN == 2 && TM == 1 && TN == 1 && !HEAD && !TAIL), "wave arrangement 2 x 4, or 4 x 2 with one accumulator per wave");
     static_assert(!HEAD || TN == 2, "the fused head walks the K groups of 256-column tiles");
     static_assert(!TAIL || (TM == 2 && TN == 2 && !HEAD), "the fused tail needs the whole 128 x 256 tile in one block");
     static_assert(MAXPC >= 2 && MAXPC <= 5, "staging pieces per thread");
-    constexpr int BM = 2 * TM * 32, WN = 4, BN = WN * TN * 32;
+    constexpr int WMR = 8 / WN;                           // wave rows
+    constexpr int BM = WMR * TM * 32, BN = WN * TN * 32;
     constexpr int PLANE = (HALO_MAX_SLOT + 1) * 32;       // bytes of one part of one slab (+ one dump slot: pieces beyond the region write there, unconditionally)
     constexpr int PBUF = PARTS * PLANE;                   // one plane buffer (all parts)
     constexpr int STAGE = 8 * 32 * 36 * 4;                // the epilogue's wave-private tiles: they live in plane buffer 1
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = WN == 4 ? wave >> 2 : wave >> 1, wn = WN == 4 ? wave & 3 : wave & 1;
     const int l31 = lane & 31, kk = lane >> 5;
     const int ohw = a.OH * a.OW;
     const int NH = ha.NH, NS = NH * 9;
@@ -257,9 +260,14 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
         int base_idx[TM];
         int wave_row0;                                    // linear M index of the wave's first output pixel (its TM * 32 pixels are consecutive)
         if (ha.geo == HALO_GEO_2ROWS) {
-            wave_row0 = m0 + wm * a.OW;
+            if constexpr (WN == 4) {
+                wave_row0 = m0 + wm * a.OW;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) base_idx[i] = wm * pitch + i * 32 + l31;
+                for (int i = 0; i < TM; ++i) base_idx[i] = wm * pitch + i * 32 + l31;
+            } else {                                      // four wave rows of 32 pixels: (tile row wm >> 1, column half wm & 1)
+                wave_row0 = m0 + (wm >> 1) * a.OW + (wm & 1) * 32;
+                base_idx[0] = (wm >> 1) * pitch + (wm & 1) * 32 + l31;
+            }
         } else {
             wave_row0 = m0 + wm * (TM * 32);
             const int ow0 = col0 + 1;                     // HALO_GEO_ROW: the tile's first column
@@ -935,6 +943,7 @@ static int halo_linear_rows(int H, int W, int bm)
 }
 
 static int g_halo_lat = env_int_halo("MRCNN_HALO_LAT", 1);     // grids under 3/4 of the chip even at 64 x 128: 64 x 64 tiles in the latency form (k_conv_halo_lat; bit-identical)
+static int g_halo_n64 = env_int_halo("MRCNN_HALO_N64", 1);     // 64-column 3x3 layers on the halo kernel (128 x 64 tiles)
 static int g_halo_geo = env_int_halo("MRCNN_HALO_GEO", 1);     // 0: the round-3 geometries (one-row 3 x 130 regions, five staging pieces, pitch W + 2) — A/B and bit-identity tests
 
 struct HaloGeo { int geo, ecols, pitch, img_skew, tiles_row, tiles_img, rows, maxpc, slots; bool ok; };
@@ -989,7 +998,9 @@ bool conv_halo_eligible(const ConvDesc& d)
     // the activation-fragment reads per MFMA double: round 3 measured x0.92 against the 128-row kernel on C3's 128 -> 128 layers and kept
     // them there; with round 4's cheaper staging it is x1.08 (110 -> 102 us, gpurun_out/r4i) and they run here (their K order changes with
     // the kernel, once, for every batch)
-    if (d.OH != d.H || d.OW != d.W || d.Cin % 64 != 0 || d.Npad % 128 != 0 || d.Cout % 4 != 0) return false;
+    // (late round 4) exactly 64 columns — C2's 64 -> 64 layers, 9 taps re-staged and re-split per tap on the 64-column 128-row kernel
+    // (169 us, 2.8 x their HBM floor): 128 x 64 tiles on the same eight waves as 4 x 2 (g_halo_n64)
+    if (d.OH != d.H || d.OW != d.W || d.Cin % 64 != 0 || (d.Npad % 128 != 0 && !(d.Npad == 64 && g_halo_n64)) || d.Cout % 4 != 0) return false;
     if (d.deconv2 || d.out2 || d.sel_partial || d.act == ACT_SIGMOID || d.res) return false;
     if (d.H >= 32760 || d.W >= 32760 || (double)d.in_sB * 8.0 >= 2.0e9) return false;
     // A property of the layer, never of the batch: both tile heights the launcher may pick must have a geometry that fits.
@@ -1020,6 +1031,12 @@ static void halo_launch(hipStream_t s, const HaloArgs& ha, int bm, int bn, int m
         else hipLaunchKernelGGL((k_conv_halo<3, 2, false, true, 2, 5>), dim3(grid), dim3(512), 0, s, ha);
         return;
     }
+    if (bn == 64) {                     // 128 x 64 tiles, the eight waves as 4 x 2
+        if (maxpc == 2) hipLaunchKernelGGL((k_conv_halo<PARTS, 1, false, false, 1, 2, false, 2>), dim3(grid), dim3(512), 0, s, ha);
+        else if (maxpc == 3) hipLaunchKernelGGL((k_conv_halo<PARTS, 1, false, false, 1, 3, false, 2>), dim3(grid), dim3(512), 0, s, ha);
+        else hipLaunchKernelGGL((k_conv_halo<PARTS, 1, false, false, 1, 5, false, 2>), dim3(grid), dim3(512), 0, s, ha);
+        return;
+    }
     if (ha.head_w && bm == 64) hipLaunchKernelGGL((k_conv_halo<PARTS, 2, true, false, 1, 3>), dim3(grid), dim3(512), 0, s, ha);      // small batches: 64-row tiles (regions of <= 198 pixels)
     else if (ha.head_w) halo_launch_pc<PARTS, 2, true, 2>(s, ha, maxpc, grid);
     else if (bn == 256) halo_launch_pc<PARTS, 2, false, 2>(s, ha, maxpc, grid);
@@ -1028,12 +1045,13 @@ static void halo_launch(hipStream_t s, const HaloArgs& ha, int bm, int bn, int m
 }
 
 // the filter shapes conv_halo_eligible can accept: only those are re-tiled at load (engine.hip: pack_conv_oihw)
-bool conv_halo_packable(int KH, int KW, int Cin, int Npad) { return KH == 3 && KW == 3 && Cin % 64 == 0 && Npad % 128 == 0; }
+bool conv_halo_packable(int KH, int KW, int Cin, int Npad) { return KH == 3 && KW == 3 && Cin % 64 == 0 && (Npad % 128 == 0 || Npad == 64); }
 
 bool conv_halo_debug_set(const char* key, int value)
 {
     if (std::string(key) == "halo_geo") { g_halo_geo = value; return true; }
     if (std::string(key) == "halo_lat") { g_halo_lat = value; return true; }
+    if (std::string(key) == "halo_n64") { g_halo_n64 = value; return true; }
     return false;
 }
 
@@ -1060,8 +1078,8 @@ int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, i
     if (t1) ha.t = *t1;
     // tile shape: the largest whose tiles occupy the chip (the K order, hence the result, does not depend on it): 128 x 256,
     // then 128 x 128, then — small grids: batch 1, the top pyramid levels — 64 x 128
-    int bm = 128, bn = d.Npad % 256 == 0 ? 256 : 128;
-    if (!d.head_w && !t1) {
+    int bm = 128, bn = d.Npad % 256 == 0 ? 256 : (d.Npad % 128 == 0 ? 128 : 64);
+    if (!d.head_w && !t1 && bn != 64) {
         if (bn > 128 && (long)((a.M + 127) / 128) * (d.Npad / bn) < n_cus) bn = 128;
         if (bn == 128 && (long)((a.M + 127) / 128) * (d.Npad / bn) * 4 < (long)n_cus * 3) bm = 64;
     }

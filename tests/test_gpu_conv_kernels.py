@@ -297,6 +297,11 @@ HALO_SHAPES = [  # B, H, W, Cin, Cout — every geometry class of the tile's inp
     (2, 8, 192, 64, 256),       # round 4: W = 192 (the P3 level of 1536² inputs) — eligible through the two-row tiles only; 3 column blocks per row
     (1, 6, 256, 64, 256),       # two-row tiles, 4 column blocks: the left / right image border inside the row of tiles
     (3, 10, 128, 128, 512),     # two-row tiles with 512 columns (the fused-head layers' shape), three images
+    (1, 256, 256, 64, 64),      # late round 4: 64 columns on the halo kernel (128 x 64 tiles, the waves as 4 x 2) — C2's layers: two-row tiles, four slabs
+    (2, 64, 64, 64, 64),        # ... two image rows per tile (linear geometry)
+    (3, 40, 40, 128, 64),       # ... ragged rows, tiles straddle images
+    (9, 14, 14, 64, 64),        # ... nine rows per tile, pitch W + 16 and the image skew
+    (2, 8, 192, 64, 64),        # ... two-row tiles, three column blocks per row
 ]
 
 
@@ -324,7 +329,7 @@ def test_halo_kernel_against_fp64_and_the_128row_kernel(shape, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f32x3", "f32s"])
-@pytest.mark.parametrize("shape", [(6, 64, 64, 256, 256), (9, 14, 14, 256, 256), (4, 128, 128, 64, 512), (3, 72, 56, 96, 300)])
+@pytest.mark.parametrize("shape", [(6, 64, 64, 256, 256), (9, 14, 14, 256, 256), (4, 128, 128, 64, 512), (3, 72, 56, 96, 300), (4, 128, 128, 64, 64), (5, 24, 40, 64, 64)])
 def test_halo_kernel_results_do_not_depend_on_the_batch(shape, dtype):
     """The sharding contract: an image's result is the same bits whatever batch it rides in — the batch changes the number
     of tiles, hence the tile WIDTH the launcher picks (256 / 128 / 64 columns) and which tiles straddle two images."""
@@ -342,7 +347,8 @@ def test_halo_kernel_results_do_not_depend_on_the_batch(shape, dtype):
 
 @pytest.mark.parametrize("dtype", ["f32x3", "f32s"])
 @pytest.mark.parametrize("shape", [(2, 128, 128, 64, 256), (1, 256, 256, 64, 512), (3, 64, 64, 256, 256), (20, 14, 14, 256, 256), (5, 16, 16, 64, 512),
-                                   (2, 72, 56, 96, 300), (1, 32, 32, 320, 64), (9, 14, 14, 256, 256), (1, 64, 64, 256, 256), (1, 6, 256, 64, 256)])
+                                   (2, 72, 56, 96, 300), (1, 32, 32, 320, 64), (9, 14, 14, 256, 256), (1, 64, 64, 256, 256), (1, 6, 256, 64, 256),
+                                   (2, 128, 128, 64, 64), (1, 256, 256, 64, 64)])
 def test_halo_tile_geometries_are_bit_identical(shape, dtype):
     """Round 4 changed WHICH output pixels a halo tile owns (two rows x 64 columns instead of one row x 128 where W >= 128:
     4 x 66 = 264 staged pixels per slab instead of 3 x 130 = 390), how many staging pieces a thread moves (2 / 3 / 5, by region

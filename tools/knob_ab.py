@@ -32,6 +32,8 @@ ALL = PW + [
     ("C4 3x3 256->256 @64 b8", 8, 64, 64, 256, 256, 3, 1),
     ("C4 3x3 256->256 @64 b1", 1, 64, 64, 256, 256, 3, 1),
     ("C5 3x3 512->512 @32 b1", 1, 32, 32, 512, 512, 3, 1),
+    ("C2 3x3 64->64 @256 b8", 8, 256, 256, 64, 64, 3, 1),
+    ("C2 3x3 64->64 @256 b1", 1, 256, 256, 64, 64, 3, 1),
 ]
 knob, v0, v1 = sys.argv[1].encode(), int(sys.argv[2]), int(sys.argv[3])
 DT = {"f32": L.F32, "f16": L.F16, "f32s": L.F32S, "f32x3": L.F32X3}[sys.argv[4]]
