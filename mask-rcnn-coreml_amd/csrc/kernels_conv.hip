@@ -537,7 +537,10 @@ static void conv_launch(hipStream_t s, const ConvArgs& a, int bn, bool wide_wave
 #ifndef MRCNN_RING128S
 #define MRCNN_RING128S 3    /* split mode: a step is 8 MFMAs per wave, two tiles in flight (+2 %) */
 #endif
-    constexpr int R128 = (sizeof(T) == 4 && sizeof(TW) == 2) ? MRCNN_RING128S : 2;
+#ifndef MRCNN_RING128H
+#define MRCNN_RING128H 2    /* fp16 tensors: a third stage (96 KB) leaves one block per CU — measured, see DESIGN.md §6 */
+#endif
+    constexpr int R128 = (sizeof(T) == 4 && sizeof(TW) == 2) ? MRCNN_RING128S : (sizeof(T) == 2 ? MRCNN_RING128H : 2);
     if constexpr (sizeof(T) == 4 && sizeof(TW) == 2) {
         // Split modes, long K: the same 128x128 tile as 4 waves of 32x128 — one register split of an activation fragment feeds
         // four column tiles instead of two (half the split VALU and half the activation-fragment LDS reads per MFMA): +2-4 % on
