@@ -47,7 +47,8 @@ static constexpr unsigned HALO_OOB = 0xC0000000u;
 // Tile geometries (HaloArgs::geo) — which 64 / 128 output pixels a tile owns.  The K order, hence every output bit, is the same in all.
 enum { HALO_GEO_LINEAR = 0,      // BM consecutive output pixels (any W; tiles may span rows and straddle images)
        HALO_GEO_ROW = 1,         // BM consecutive pixels inside ONE image row (OW % BM == 0): region 3 x (BM + 2)
-       HALO_GEO_2ROWS = 2 };     // 2 rows x 64 columns (BM = 128, OW % 64 == 0, OH % 2 == 0): region 4 x 66 = 264 pixels instead of 3 x 130 = 390
+       HALO_GEO_2ROWS = 2,       // 2 rows x 64 columns (BM = 128, OW % 64 == 0, OH % 2 == 0): region 4 x 66 = 264 pixels instead of 3 x 130 = 390
+       HALO_GEO_4ROWS = 3 };     // 4 rows x 64 columns (BM = 256: the 64-column layers' 256 x 64 tiles; OH % 4 == 0): region 6 x 66 = 396 pixels
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -120,7 +121,8 @@ template <int PARTS, int TN, bool HEAD = false, bool DBG = false, int TM = 2, in
 __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
 {
     const ConvArgs& a = ha.a;
-    static_assert(WN == 4 || (WN == 2 && TM == 1 && TN == 1 && !HEAD && !TAIL), "wave arrangement 2 x 4, or 4 x 2 with one accumulator per wave");
+    static_assert(WN == 4 || (WN == 2 && TM == 1 && TN == 1 && !HEAD && !TAIL) || (WN == 1 && TM == 1 && TN == 2 && !HEAD && !TAIL),
+                  "wave arrangement 2 x 4; 4 x 2 with one accumulator per wave; 8 x 1 with two (256 x 64 tiles)");
     static_assert(!HEAD || TN == 2, "the fused head walks the K groups of 256-column tiles");
     static_assert(!TAIL || (TM == 2 && TN == 2 && !HEAD), "the fused tail needs the whole 128 x 256 tile in one block");
     static_assert(MAXPC >= 2 && MAXPC <= 5, "staging pieces per thread");
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = WN == 4 ? wave >> 2 : wave >> 1, wn = WN == 4 ? wave & 3 : wave & 1;
+    const int wm = WN == 4 ? wave >> 2 : (WN == 2 ? wave >> 1 : wave), wn = WN == 4 ? wave & 3 : (WN == 2 ? wave & 1 : 0);
     const int l31 = lane & 31, kk = lane >> 5;
     const int ohw = a.OH * a.OW;
     const int NH = ha.NH, NS = NH * 9;
@@ -211,13 +213,14 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
         const int Hp = a.H + 2;
         const int pitch = ha.pitch, ecols = ha.ecols;
         int m0, b0, gy_first, col0, rows;                 // m0: first output pixel (linear M index) of the tile — of its first row in HALO_GEO_2ROWS
-        if (ha.geo == HALO_GEO_2ROWS) {
+        if (ha.geo == HALO_GEO_2ROWS || ha.geo == HALO_GEO_4ROWS) {
+            const int trows = ha.geo == HALO_GEO_2ROWS ? 2 : 4;
             b0 = mt / ha.tiles_img;
             const int r = mt - b0 * ha.tiles_img, rp = r / ha.tiles_row, cb = r - rp * ha.tiles_row;
-            m0 = b0 * ohw + 2 * rp * a.OW + 64 * cb;
-            gy_first = b0 * Hp + 2 * rp + 1;
+            m0 = b0 * ohw + trows * rp * a.OW + 64 * cb;
+            gy_first = b0 * Hp + trows * rp + 1;
             col0 = 64 * cb - 1;
-            rows = 4;
+            rows = trows + 2;
         } else {
             m0 = mt * BM;
             const int m_last = (m0 + BM - 1 < a.M ? m0 + BM - 1 : a.M - 1);
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_halo(const HaloArgs ha)
         // ---- this lane's output pixels → slot of their tap (0,0) input pixel in the region; the wave's first output row -----
         int base_idx[TM];
         int wave_row0;                                    // linear M index of the wave's first output pixel (its TM * 32 pixels are consecutive)
-        if (ha.geo == HALO_GEO_2ROWS) {
+        if (ha.geo == HALO_GEO_2ROWS || ha.geo == HALO_GEO_4ROWS) {
             if constexpr (WN == 4) {
                 wave_row0 = m0 + wm * a.OW;
 #pragma unroll
@@ -943,7 +946,7 @@ static int halo_linear_rows(int H, int W, int bm)
 }
 
 static int g_halo_lat = env_int_halo("MRCNN_HALO_LAT", 1);     // grids under 3/4 of the chip even at 64 x 128: 64 x 64 tiles in the latency form (k_conv_halo_lat; bit-identical)
-static int g_halo_n64 = env_int_halo("MRCNN_HALO_N64", 1);     // 64-column 3x3 layers on the halo kernel (128 x 64 tiles)
+static int g_halo_n64 = env_int_halo("MRCNN_HALO_N64", 2);     // 64-column 3x3 layers on the halo kernel: 1 as 128 x 64 tiles, 2 also 256 x 64 where the level allows
 static int g_halo_geo = env_int_halo("MRCNN_HALO_GEO", 1);     // 0: the round-3 geometries (one-row 3 x 130 regions, five staging pieces, pitch W + 2) — A/B and bit-identity tests
 
 struct HaloGeo { int geo, ecols, pitch, img_skew, tiles_row, tiles_img, rows, maxpc, slots; bool ok; };
@@ -963,7 +966,11 @@ static HaloGeo halo_geometry(int H, int W, int bm)
         g.ok = g.rows * g.ecols <= 528;
         return g;
     }
-    if (bm == 128 && W % 64 == 0 && W >= 128 && H % 2 == 0) {
+    if (bm == 256) {                    // (the 64-column layers' 256 x 64 tiles only: conv_halo_forward asks for it where it exists)
+        if (W % 64 != 0 || H % 4 != 0) return g;
+        g.geo = HALO_GEO_4ROWS; g.ecols = g.pitch = 66; g.rows = 6;
+        g.tiles_row = W / 64; g.tiles_img = (H / 4) * g.tiles_row;
+    } else if (bm == 128 && W % 64 == 0 && W >= 128 && H % 2 == 0) {
         g.geo = HALO_GEO_2ROWS; g.ecols = g.pitch = 66; g.rows = 4;
         g.tiles_row = W / 64; g.tiles_img = (H / 2) * g.tiles_row;
     } else if (W % bm == 0) {
@@ -1031,6 +1038,10 @@ static void halo_launch(hipStream_t s, const HaloArgs& ha, int bm, int bn, int m
         else hipLaunchKernelGGL((k_conv_halo<3, 2, false, true, 2, 5>), dim3(grid), dim3(512), 0, s, ha);
         return;
     }
+    if (bn == 64 && bm == 256) {        // 256 x 64 tiles, the eight waves as 8 x 1 (396-pixel regions: five staging pieces)
+        hipLaunchKernelGGL((k_conv_halo<PARTS, 2, false, false, 1, 5, false, 1>), dim3(grid), dim3(512), 0, s, ha);
+        return;
+    }
     if (bn == 64) {                     // 128 x 64 tiles, the eight waves as 4 x 2
         if (maxpc == 2) hipLaunchKernelGGL((k_conv_halo<PARTS, 1, false, false, 1, 2, false, 2>), dim3(grid), dim3(512), 0, s, ha);
         else if (maxpc == 3) hipLaunchKernelGGL((k_conv_halo<PARTS, 1, false, false, 1, 3, false, 2>), dim3(grid), dim3(512), 0, s, ha);
@@ -1040,6 +1051,8 @@ static void halo_launch(hipStream_t s, const HaloArgs& ha, int bm, int bn, int m
     if (ha.head_w && bm == 64) hipLaunchKernelGGL((k_conv_halo<PARTS, 2, true, false, 1, 3>), dim3(grid), dim3(512), 0, s, ha);      // small batches: 64-row tiles (regions of <= 198 pixels)
     else if (ha.head_w) halo_launch_pc<PARTS, 2, true, 2>(s, ha, maxpc, grid);
     else if (bn == 256) halo_launch_pc<PARTS, 2, false, 2>(s, ha, maxpc, grid);
+    // (128 x 128 with the waves as 4 x 2 and two accumulators each — one activation fragment per two MFMAs, twice the filter requests —
+    //  was measured against this 2 x 4 arrangement on C3's layers: 107.6 -> 104.8 us, bit-identical; not worth six instantiations)
     else if (bm == 128) halo_launch_pc<PARTS, 1, false, 2>(s, ha, maxpc, grid);
     else halo_launch_pc<PARTS, 1, false, 1>(s, ha, maxpc, grid);
 }
@@ -1079,6 +1092,9 @@ int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, i
     // tile shape: the largest whose tiles occupy the chip (the K order, hence the result, does not depend on it): 128 x 256,
     // then 128 x 128, then — small grids: batch 1, the top pyramid levels — 64 x 128
     int bm = 128, bn = d.Npad % 256 == 0 ? 256 : (d.Npad % 128 == 0 ? 128 : 64);
+    // 64 columns: 256 x 64 tiles (the waves as 8 x 1, two accumulators each: half the activation-fragment reads per MFMA of the 128 x 64
+    // arrangement) where four image rows x 64 columns tile the level and the grid still fills the chip
+    if (bn == 64 && g_halo_n64 >= 2 && g_halo_geo && halo_geometry(d.H, d.W, 256).ok && (long)(a.M / 256) >= (long)n_cus * 2) bm = 256;
     if (!d.head_w && !t1 && bn != 64) {
         if (bn > 128 && (long)((a.M + 127) / 128) * (d.Npad / bn) < n_cus) bn = 128;
         if (bn == 128 && (long)((a.M + 127) / 128) * (d.Npad / bn) * 4 < (long)n_cus * 3) bm = 64;

@@ -369,6 +369,36 @@ def test_halo_tile_geometries_are_bit_identical(shape, dtype):
     np.testing.assert_array_equal(y, y3)
 
 
+@pytest.mark.parametrize("dtype", ["f32x3", "f32s"])
+@pytest.mark.parametrize("shape", [(2, 256, 256, 64, 64), (8, 128, 128, 64, 64), (16, 64, 128, 64, 64), (34, 60, 64, 64, 64)])
+def test_64_column_layers_256_row_arrangement_is_bit_identical(shape, dtype):
+    """C2's 64 -> 64 layers: 256 x 64 tiles (four image rows x 64 columns, the eight waves as 8 x 1 with two accumulators each) on
+    grids that fill the chip, 128 x 64 tiles (4 x 2 waves) otherwise — "halo_n64" 2 / 1; same (slab, tap, part) order, same bits,
+    and a single image of the batch (which takes the 128-row arrangement) agrees too."""
+    B, H, W, Ci, Co = shape
+    rng = np.random.default_rng(sum(shape) + 3)
+    x = (rng.standard_normal((B, H, W, Ci)) * 2).astype(np.float32)
+    w = (rng.standard_normal((Co, 3, 3, Ci)) * np.sqrt(2.0 / (9 * Ci))).astype(np.float32)
+    scale = (0.5 + rng.random(Co)).astype(np.float32)
+    shift = (rng.standard_normal(Co) * 0.1).astype(np.float32)
+    lib = L.lib()
+    try:
+        L.check(lib.mrcnn_debug_set(b"halo_n64", 1))
+        y1 = conv(x, w, 3, 1, scale, shift, None, 1, dtype)
+        L.check(lib.mrcnn_debug_set(b"halo_n64", 2))
+        y2 = conv(x, w, 3, 1, scale, shift, None, 1, dtype)
+        y2b = conv(x, w, 3, 1, scale, shift, None, 1, dtype)
+        yb = conv(x[B - 1:], w, 3, 1, scale, shift, None, 1, dtype)
+    finally:
+        L.check(lib.mrcnn_debug_set(b"halo_n64", 2))
+    np.testing.assert_array_equal(y2, y1)
+    np.testing.assert_array_equal(y2b, y2)
+    np.testing.assert_array_equal(yb[0], y2[B - 1])
+    xs, ys = x[:1], y2[:1]
+    ref = torch_ref(xs, w, 3, 1, scale, shift, None, 1, dtype)
+    assert np.abs(ys - ref).max() <= (1e-5 if dtype == "f32x3" else 2e-5) * max(1.0, np.abs(ref).max())
+
+
 LAT_SHAPES = [  # B, H, W, Cin, Cout — grids under 3/4 of the chip with 64 x 128 tiles: the 64 x 64 latency form (k_conv_halo_lat)
     (1, 64, 64, 256, 256),      # C4 at a single image: one-row regions of 3 x 66 pixels, four staging pieces
     (1, 32, 32, 512, 512),      # C5: two image rows per tile (4 x 34 pixels, three pieces), 32 slabs
