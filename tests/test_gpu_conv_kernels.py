@@ -510,6 +510,8 @@ ALIAS_SHAPES = [  # B, H, W, Cin, Cout, k — one per epilogue form a residual l
     (2, 40, 40, 64, 256, 1),       # C2 branch2c: two K steps
     (1, 33, 47, 192, 300, 3),      # ragged everything: Cout 300 (Npad 384), M = 1551: the block-staged general epilogue
     (8, 64, 64, 256, 256, 3),      # 256-row ping-pong kernel in fp16 (direct epilogue, residual inside the store loop)
+    (1, 32, 32, 2048, 256, 1),     # a chunked layer on an under-filled grid (split modes): the block that arrives last runs the epilogue of a shared tile
+    (16, 32, 32, 2048, 256, 1),    # ... and on a full grid: one block folds the chunks (the four-wave 128-column form)
 ]
 
 
