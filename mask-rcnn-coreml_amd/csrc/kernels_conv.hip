@@ -22,6 +22,7 @@
 //   * XCD-aware block→tile map: the 8 XCDs get contiguous runs of tiles, N-tiles of one M-tile
 //     adjacent, so an A tile is fetched into one XCD's L2 once.
 #include <map>
+#include <utility>
 #include <mutex>
 
 #include "conv_device.h"
@@ -641,9 +642,11 @@ static void ks_scratch(hipStream_t s, float** scratch, unsigned** count)
 {
     struct Ks { DevBuf buf, cnt; };
     static std::mutex mu;
-    static std::map<hipStream_t, Ks*> all;
+    static std::map<std::pair<int, hipStream_t>, Ks*> all;          // (device, stream): the null stream exists on every device
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
-    Ks*& k = all[s];
+    Ks*& k = all[std::make_pair(dev, s)];
     if (!k) {
         k = new Ks;
         k->buf.alloc(KS_BYTES);

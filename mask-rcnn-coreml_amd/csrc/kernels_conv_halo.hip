@@ -37,6 +37,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <utility>
 
 namespace mrcnn {
 
@@ -1140,10 +1141,12 @@ int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, i
         // the parking scratch: 64 KB per block, one buffer per stream (launches on one stream are ordered; two models on two
         // streams must not share it), grown on demand and never freed (a static destructor would run after the HIP runtime's)
         static std::mutex park_mu;
-        static std::map<hipStream_t, DevBuf*> parks;
+        static std::map<std::pair<int, hipStream_t>, DevBuf*> parks;          // (device, stream)
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
         {
             std::lock_guard<std::mutex> lk(park_mu);
-            DevBuf*& pk = parks[s];
+            DevBuf*& pk = parks[std::make_pair(dev, s)];
             if (!pk) pk = new DevBuf;
             if (pk->bytes < (size_t)grid * 65536) { HIP_CHECK(hipStreamSynchronize(s)); pk->alloc((size_t)grid * 65536); }
             ha.t_park = pk->p;
