@@ -270,7 +270,7 @@ def main():
                 kname = {"128x128": f"k_conv_mfma_glds<{ktypes},128,1,2,4,2,{tail}>", "128x64": f"k_conv_mfma_glds<{ktypes},64,1,1,4,2,...>",
                          "128x32": f"k_conv_mfma_glds<{ktypes},32,1,1,4,1,...>", "128x128w4": f"k_conv_mfma_glds<{ktypes},128,1,4,4,1,{tail}>",
                          "128x256tail": f"k_conv_halo<{parts},2,false,false,2,3,TAIL> (3x3 + 1x1 + shortcut of a bottleneck block in one launch; opt-in)",
-                         "256x256pp": "k_conv_pp<0>", "128xNhalo": f"k_conv_halo<{parts},TN,HEAD> (persistent 128 x 128*TN halo tiles; instantiations <{parts},2,false>, <{parts},2,true> = fused RPN heads, <{parts},1,false>)"}[dom]
+                         "256x256pp": "k_conv_pp<0>", "128xNhalo": f"k_conv_halo<{parts},TN,HEAD,.,TM,MAXPC,.,WN> (persistent halo tiles: 128 x 256 / 128 x 128 / 64 x 128, 256 x 64 / 128 x 64 for 64 columns; instantiations <{parts},2,false>, <{parts},2,true> = fused RPN heads, <{parts},1,false>, <{parts},2,false,.,1,5,.,1> = C2; k_conv_halo_lat on under-filled grids)"}[dom]
                 out["roofline"] = {
                     "kernel": kname, "bound": "mfma",
                     "achieved": round(achieved, 2),
