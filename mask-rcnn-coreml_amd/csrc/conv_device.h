@@ -33,6 +33,11 @@ struct ConvArgs {
     // tile (ksplit == kchunks: partial sums through ks_scratch, the last block to arrive folds them in that order)
     int kchunks, ksplit;
     float* ks_scratch; unsigned* ks_count;
+    // fused shortcut (kernels_conv.hip: conv_forward's `sc`): the 1x1 convolution whose output this layer would have read as its residual —
+    // its input tensor (same batch, sampled with sc_stride), filters and folded BatchNorm; the residual fields above are then unused
+    const void* sc_in; const void* sc_wgt; const float* sc_scale; const float* sc_shift;
+    long sc_in_sB, sc_in_sH, sc_in_sW;
+    int sc_H, sc_W, sc_Cin, sc_stride;
 };
 
 static constexpr int BM_DEFAULT = 128;   // rows of the block tile = WM*TM*32
@@ -396,9 +401,11 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x16 (
 // in-place contract: a wave loads exactly the elements it will overwrite, all of them before its first store.  Neutral for the
 // 128-row kernels (two co-resident blocks cover the latency); used by the fused bottleneck tail, whose
 // CU holds two waves per SIMD.
+// res_acc / tab2 (fused shortcut): the residual of a piece is not loaded but formed from a second accumulator set, y = res_acc * scale2 + shift2 —
+// the arithmetic of the shortcut convolution's own (activation-less) epilogue — through the same wave-private transpose.
 template <int BN, int TMS, int TNS, bool RES_FIRST = false>
 __device__ __forceinline__ void conv_epilogue_wave(const ConvArgs& a, f32x16 (&acc)[TMS][TNS], float* stage, const float* tab, int row0, int n0,
-                                                   int colrel0, int lane)
+                                                   int colrel0, int lane, const f32x16 (*res_acc)[TNS] = nullptr, const float* tab2 = nullptr)
 {
     constexpr int SW = 32;                               // floats per staged row (unpadded: XOR-swizzled 16-B chunks)
     const int l31 = lane & 31, kk = lane >> 5;
@@ -466,6 +473,20 @@ __device__ __forceinline__ void conv_epilogue_wave(const ConvArgs& a, f32x16 (&a
             const bool col_ok = n < a.ncols;
             // the residual of the 32 × 32 piece is requested before the LDS round trip (its latency overlaps it)
             float4 rv[4];
+            if (res_acc) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(&stage[l31 * SW + (((2 * q + kk) ^ (l31 & 7)) << 2)]) =
+                        make_float4(res_acc[i][j][4 * q], res_acc[i][j][4 * q + 1], res_acc[i][j][4 * q + 2], res_acc[i][j][4 * q + 3]);
+                const float4 sc2 = *reinterpret_cast<const float4*>(tab2 + cl), sh2 = *reinterpret_cast<const float4*>(tab2 + BN + cl);
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    float4 y = *reinterpret_cast<const float4*>(&stage[(8 * ps + rrow) * SW + (((lane & 7) ^ rrow) << 2)]);
+                    y.x = y.x * sc2.x + sh2.x; y.y = y.y * sc2.y + sh2.y; y.z = y.z * sc2.z + sh2.z; y.w = y.w * sc2.w + sh2.w;
+                    out_of_range = out_of_range || !(fabsf(y.x) < 65504.0f) || !(fabsf(y.y) < 65504.0f) || !(fabsf(y.z) < 65504.0f) || !(fabsf(y.w) < 65504.0f);
+                    rv[ps] = y;
+                }
+            } else
             if (res) {
 #pragma unroll
                 for (int ps = 0; ps < 4; ++ps) {
@@ -485,7 +506,7 @@ __device__ __forceinline__ void conv_epilogue_wave(const ConvArgs& a, f32x16 (&a
             for (int ps = 0; ps < 4; ++ps) {
                 float4 x = *reinterpret_cast<const float4*>(&stage[(8 * ps + rrow) * SW + (((lane & 7) ^ rrow) << 2)]);
                 x.x = x.x * sc.x + sh.x; x.y = x.y * sc.y + sh.y; x.z = x.z * sc.z + sh.z; x.w = x.w * sc.w + sh.w;
-                if (res) { x.x += rv[ps].x; x.y += rv[ps].y; x.z += rv[ps].z; x.w += rv[ps].w; }
+                if (res || res_acc) { x.x += rv[ps].x; x.y += rv[ps].y; x.z += rv[ps].z; x.w += rv[ps].w; }
                 if (relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
                 if (ok[ps] && col_ok) {
                     out_of_range = out_of_range || !(fabsf(x.x) < 65504.0f) || !(fabsf(x.y) < 65504.0f) || !(fabsf(x.z) < 65504.0f) || !(fabsf(x.w) < 65504.0f);

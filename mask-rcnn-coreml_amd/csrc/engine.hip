@@ -781,18 +781,23 @@ void Model::build_maskrcnn()
         // a bottleneck's tail: branch2b (3x3) and the branch2c (1x1 + shortcut) behind it — one fused launch where the pair
         // qualifies and the grid fills the chip (conv_forward_tail: bit-identical to the two launches), two launches otherwise
         // and while a calibration pass needs the tensor between them
+        // dsc: the stage's shortcut convolution (first block) — computed inside branch2c's launch where the pair qualifies (conv_forward),
+        // so that its tensor is neither written nor read back; its own launch in a calibration pass (which observes its output)
         auto tail_op = [&](const std::string& n3, const std::string& n1, const Tensor4& in3, const Tensor4& mid, const Tensor4& out, const Tensor4& res,
-                           int g_in, int g_mid, int g_out) {
+                           int g_in, int g_mid, int g_out, const ConvDesc* dsc) {
             const ConvDesc d3 = make_desc(n3, in3, mid, 1, 1, ACT_RELU, nullptr, 0, g_in, g_mid);
             const ConvDesc d1 = make_desc(n1, mid, out, 1, 0, ACT_RELU, &res, 0, g_mid, g_out);
             const size_t pm = (size_t)mid.sB(), po = (size_t)out.sB();
-            add([d3, d1, self, g_mid, g_out, pm, po](hipStream_t s, int batch) {
-                ConvDesc x3 = d3, x1 = d1;
-                x3.B = x1.B = batch;
+            const bool has_sc = dsc != nullptr;
+            const ConvDesc dS = has_sc ? *dsc : ConvDesc();
+            add([d3, d1, dS, has_sc, self, g_mid, g_out, pm, po](hipStream_t s, int batch) {
+                ConvDesc x3 = d3, x1 = d1, xs = dS;
+                x3.B = x1.B = xs.B = batch;
                 if (self->calib_phase) {
+                    if (has_sc) { conv_forward(s, xs); self->observe_split(s, g_out, dS.out, po * batch); }
                     conv_forward(s, x3); self->observe_split(s, g_mid, d3.out, pm * batch);
                     conv_forward(s, x1); self->observe_split(s, g_out, d1.out, po * batch);
-                } else conv_forward_tail(s, x3, x1);
+                } else conv_forward_tail(s, x3, x1, has_sc ? &xs : nullptr);
             });
         };
 
@@ -864,16 +869,17 @@ void Model::build_maskrcnn()
                 conv_op("res" + p + "_branch2a", x, ta, stride, 0, ACT_RELU, nullptr, 0, g_x, g_a);
                 Tensor4 tb = stage_tb;
                 Tensor4 sc = x;
+                ConvDesc dsc;
                 if (first) {
                     sc = T(oh, ow, f3s[st]);
-                    conv_op("res" + p + "_branch1", x, sc, stride, 0, ACT_NONE, nullptr, 0, g_x, g_stage);
+                    dsc = make_desc("res" + p + "_branch1", x, sc, stride, 0, ACT_NONE, nullptr, 0, g_x, g_stage);
                 }
                 // The block's output overwrites its shortcut IN PLACE (branch2c reads a residual element and writes the output
                 // element at the same address, from the same thread; nothing reads the shortcut afterwards): a stage then cycles
                 // through x + two branch tensors — 200 MB for C4 at batch 8, inside the 256 MB Infinity Cache — instead of
                 // streaming a fresh 134 MB tensor per block through HBM.
                 Tensor4 to = sc;
-                tail_op("res" + p + "_branch2b", "res" + p + "_branch2c", ta, tb, to, sc, g_a, g_b, g_stage);
+                tail_op("res" + p + "_branch2b", "res" + p + "_branch2c", ta, tb, to, sc, g_a, g_b, g_stage, first ? &dsc : nullptr);
                 x = to;
                 g_x = g_stage;
             }

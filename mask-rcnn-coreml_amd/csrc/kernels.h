@@ -173,7 +173,9 @@ void boxes_one_time_init();
 void conv_set_range_flag(int* device_flag);
 // Picks the tile shape from Cout; returns the N tile it will use so that callers can pad weights.
 int conv_n_tile(int Cout);
-void conv_forward(hipStream_t s, const ConvDesc& d);
+// sc != nullptr: `sc` is the 1x1 convolution whose output is d's residual (a ResNet stage's shortcut): computed inside d's launch where the pair
+// qualifies (bit-identical to the two launches; the shortcut tensor is then not written), as its own launch before d otherwise
+void conv_forward(hipStream_t s, const ConvDesc& d, const ConvDesc* sc = nullptr);
 // Test / measurement switches of the kernel choice ("conv_pp" 0|1, "conv_pp_split" 0|1, "conv_pp_min_tiles", "conv_pp_min_kt",
 // "conv_pp_min_fill" percent, "conv_pp_dbg" ablation bits); false = unknown key.
 bool conv_debug_set(const char* key, int value);
@@ -196,7 +198,7 @@ bool conv_halo_tail_geometry_ok(int H, int W);                          // ... a
 // 256-column tensor between them never exists (kernels_conv_halo.hip: TAIL).  Bit-identical to conv_forward(d3); conv_forward(d1),
 // which is what runs when the pair does not qualify, the grid would not fill the chip, or mrcnn_debug_set("conv_tail", 0).
 bool conv_tail_fusable(const ConvDesc& d3, const ConvDesc& d1);
-void conv_forward_tail(hipStream_t s, const ConvDesc& d3, const ConvDesc& d1);
+void conv_forward_tail(hipStream_t s, const ConvDesc& d3, const ConvDesc& d1, const ConvDesc* sc = nullptr);      // sc: d1's shortcut convolution (conv_forward)
 
 // The stem in the split modes and the fp16 mode (kernels_conv_stem.hip): conv1 — described by d exactly as for conv_forward (7 row taps of 32 "channels"
 // on the zero-padded NHWC4 input, 64 output columns, ReLU) — and the 3x3 stride-2 'same' max-pool behind it in ONE persistent launch;

@@ -130,7 +130,13 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
         srdB[2] = 0xffffffffu;
         srdB[3] = 0x00020000u;
     }
+    // SC (fused shortcut, round 4): behind the layer's own K steps the SAME loop runs the K steps of the block's shortcut convolution — a
+    // second 1x1 over the block's input (other tensor, strides, filters, K).  The DMA stream switches source when the layer's channels are
+    // exhausted (the ring never drains: no second pipeline fill), the accumulators change hands at that step (`tot` keeps the layer's sums,
+    // `acc` restarts for the shortcut's), and the epilogue forms the residual y_sc = acc * scale2 + shift2 where it would have loaded it.
+    const bool sc_fused = KCH && DIRECT_OK && a.sc_in != nullptr;
     unsigned a_ob[AP];          // byte offset of tap (0, 0) of the staged row from the resource base (mod 2^32: it may lie before it)
+    unsigned a_ob2[KCH ? AP : 1];                         // ... of the shortcut's input row
     int ih0[AP], iw0[AP];
     bool a_ok[AP];
 #pragma unroll
@@ -143,9 +149,24 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
         ih0[p] = oh * a.stride - a.padH;
         iw0[p] = ow * a.stride - a.padW;
         a_ob[p] = (unsigned)(((long)(b - b0) * a.in_sB + (long)ih0[p] * a.in_sH + (long)iw0[p] * a.in_sW + kq * EPV) * (long)sizeof(T));
+        if constexpr (KCH)
+            a_ob2[p] = (unsigned)(((long)(b - b0) * a.sc_in_sB + (long)(oh * a.sc_stride) * a.sc_in_sH + (long)(ow * a.sc_stride) * a.sc_in_sW + kq * EPV) * (long)sizeof(T));
     }
-    const int cin_tiles = a.Cin / BK;
-    const int KT_all = a.KH * a.KW * cin_tiles;
+    srd_t srdA2 = srdA, srdB2 = srdB;
+    if constexpr (KCH) {
+        if (sc_fused) {
+            const unsigned long long ia = (unsigned long long)(uintptr_t)(static_cast<const T*>(a.sc_in) + (long)b0 * a.sc_in_sB), wa = (unsigned long long)(uintptr_t)a.sc_wgt;
+            const unsigned long long rest = (unsigned long long)(a.M / ohw - b0) * (unsigned long long)a.sc_in_sB * sizeof(T);
+            srdA2[0] = __builtin_amdgcn_readfirstlane((unsigned)ia);
+            srdA2[1] = __builtin_amdgcn_readfirstlane((unsigned)(ia >> 32) & 0xffffu);
+            srdA2[2] = __builtin_amdgcn_readfirstlane((unsigned)(rest < OOB ? rest : OOB));
+            srdB2[0] = __builtin_amdgcn_readfirstlane((unsigned)wa);
+            srdB2[1] = __builtin_amdgcn_readfirstlane((unsigned)(wa >> 32) & 0xffffu);
+        }
+    }
+    int cin_tiles = a.Cin / BK;
+    const int KT_main = a.KH * a.KW * cin_tiles;
+    const int KT_all = KT_main + (sc_fused ? a.sc_Cin / BK : 0);
     const int KT = KT_all / ksplit;                       // K steps of THIS block: one chunk when the tile is shared
     const int kbeg = chunk * KT;
     // wave-uniform LDS destinations: this wave's 8 rows of each staging pass
@@ -168,9 +189,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
     // SPLIT: thread t stages 16 B (8 fp16 channels) of filter row t>>2; chunk c of row r sits at position c ^ ((r>>2)&3)
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const bool wave_has_b = !SPLIT || BN * 4 >= NT || wave_u < BN / 16;
-    const unsigned vb0 = SPLIT ? (unsigned)(((size_t)(t >> 2) * a.Ktot + (((t & 3) ^ ((t >> 4) & 3)) << 3)) * sizeof(TW))
+    unsigned vb0 = SPLIT ? (unsigned)(((size_t)(t >> 2) * a.Ktot + (((t & 3) ^ ((t >> 4) & 3)) << 3)) * sizeof(TW))
                                : (unsigned)(((size_t)r0 * a.Ktot + kq * EPV) * sizeof(T));
-    const unsigned vb1 = SPLIT ? vb0 + (unsigned)((size_t)(NT / 4) * a.Ktot * sizeof(TW))
+    unsigned vb1 = SPLIT ? vb0 + (unsigned)((size_t)(NT / 4) * a.Ktot * sizeof(TW))
                                : (unsigned)(((size_t)(r0 + RPT) * a.Ktot + kq * EPV) * sizeof(T));
     const unsigned vb2 = (unsigned)(((size_t)(r0 + 2 * RPT) * a.Ktot + kq * EPV) * sizeof(T));
     const unsigned vb3 = (unsigned)(((size_t)(r0 + 3 * RPT) * a.Ktot + kq * EPV) * sizeof(T));
@@ -182,6 +203,21 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
         const bool ok = a_ok[P] && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;               \
         oa##P = ok ? a_ob[P] + (unsigned)(((long)kh * a.in_sH + (long)kw * a.in_sW) * (long)sizeof(T)) : OOB;  \
         sa##P = ok ? BK * (unsigned)sizeof(T) : 0u;                                                            \
+    }
+    bool sc_pending = sc_fused;
+    /* the layer's channels are exhausted: the stream continues with the shortcut's input and filters (1x1, no padding: every staged row in range) */
+#define MRCNN_SC_ROW(P) if constexpr (AP > P) { oa##P = a_ok[P] ? a_ob2[P] : OOB; sa##P = a_ok[P] ? BK * (unsigned)sizeof(T) : 0u; }
+#define MRCNN_SC_SWITCH()                                                                                      \
+    {                                                                                                          \
+        if constexpr (KCH) {                                                                                   \
+            sc_pending = false;                                                                                \
+            MRCNN_SC_ROW(0) MRCNN_SC_ROW(1) MRCNN_SC_ROW(2) MRCNN_SC_ROW(3)                                    \
+            srdA = srdA2; srdB = srdB2;                                                                        \
+            cin_tiles = a.sc_Cin / BK;                                                                         \
+            vb0 = (unsigned)(((size_t)(t >> 2) * a.sc_Cin + (((t & 3) ^ ((t >> 4) & 3)) << 3)) * sizeof(TW));   \
+            vb1 = vb0 + (unsigned)((size_t)(NT / 4) * a.sc_Cin * sizeof(TW));                                  \
+            sob = (unsigned)((size_t)n0 * a.sc_Cin * sizeof(TW));                                              \
+        }                                                                                                      \
     }
 #define MRCNN_GLDS_V(VOFF, DST)                                                                                \
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(VOFF), "s"(srdA), "s"(DST) : "memory", "m0");
@@ -200,8 +236,11 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
         sob += BK * (unsigned)sizeof(TW);                                                                      \
         if (++ct == cin_tiles) {                                                                               \
             ct = 0;                                                                                            \
-            if (++kw == a.KW) { kw = 0; ++kh; }                                                                \
-            MRCNN_SET_TAP(0) MRCNN_SET_TAP(1) MRCNN_SET_TAP(2) MRCNN_SET_TAP(3)                                \
+            if (KCH && sc_pending) { MRCNN_SC_SWITCH() }                                                       \
+            else {                                                                                             \
+                if (++kw == a.KW) { kw = 0; ++kh; }                                                            \
+                MRCNN_SET_TAP(0) MRCNN_SET_TAP(1) MRCNN_SET_TAP(2) MRCNN_SET_TAP(3)                            \
+            }                                                                                                  \
         }                                                                                                      \
     }
     MRCNN_SET_TAP(0) MRCNN_SET_TAP(1) MRCNN_SET_TAP(2) MRCNN_SET_TAP(3)
@@ -226,7 +265,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
     // canonical K chunks, one block per tile: `tot` folds the finished chunks, `acc` restarts from zero at every boundary
     f32x16 tot[KCH ? TM : 1][KCH ? TN : 1];
     const int klen = KCH ? KT_all / a.kchunks : 0;
-    int kb = (KCH && a.kchunks > 1 && ksplit == 1) ? klen : 0x7fffffff;
+    int kb = (KCH && a.kchunks > 1 && ksplit == 1) ? klen : (sc_fused ? KT_main : 0x7fffffff);        // (fused shortcut: the accumulators change hands behind the layer's own steps)
     if constexpr (KCH) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -253,6 +292,16 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
         const float fill = t < BN / 4 ? 1.0f : 0.0f;
         *reinterpret_cast<float4*>(&s_tab[(t < BN / 4 ? 0 : BN) + c]) =
             src ? *reinterpret_cast<const float4*>(src + n0 + c) : make_float4(fill, fill, fill, fill);
+    }
+    __shared__ __attribute__((aligned(16))) float s_tab2[KCH && DIRECT_OK ? 2 * BN : 4];       // scale | shift of the shortcut convolution's columns
+    if constexpr (KCH && DIRECT_OK) {
+        if (sc_fused && t < BN / 2) {
+            const int c = (t < BN / 4 ? t : t - BN / 4) * 4;
+            const float* src = t < BN / 4 ? a.sc_scale : a.sc_shift;
+            const float fill = t < BN / 4 ? 1.0f : 0.0f;
+            *reinterpret_cast<float4*>(&s_tab2[(t < BN / 4 ? 0 : BN) + c]) =
+                src ? *reinterpret_cast<const float4*>(src + n0 + c) : make_float4(fill, fill, fill, fill);
+        }
     }
     MRCNN_DMA_TILE(0, 0)
     if (STAGES > 2 && KT > 1) MRCNN_DMA_TILE(1, 1)
@@ -422,6 +471,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
 #undef MRCNN_KLOAD
 #undef MRCNN_DMA_TILE
 #undef MRCNN_DMA_A
+#undef MRCNN_SC_SWITCH
+#undef MRCNN_SC_ROW
 #undef MRCNN_GLDS_V
 #undef MRCNN_GLDS_S
 #undef MRCNN_SET_TAP
@@ -434,6 +485,12 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
                 // fp32 tensors (a.direct == 2): through a wave-private 32 x 36-float LDS tile (the operand ring is free: the K loop
                 // ended in a barrier) — full-line stores without the two block barriers of the staged epilogue
                 static_assert(WM * WN * 32 * 36 * 4 <= SMEM, "wave-private epilogue tiles fit in the operand ring");
+                if constexpr (KCH) {
+                    if (sc_fused) {           // the layer's sums wait in `tot`, the shortcut's are in `acc`
+                        conv_epilogue_wave<BN, TM, TN>(a, tot, reinterpret_cast<float*>(smem) + wave * (32 * 36), s_tab, m0 + wm * TM * 32, n0, wn * TN * 32, lane, acc, s_tab2);
+                        return;
+                    }
+                }
                 conv_epilogue_wave<BN, TM, TN>(a, acc, reinterpret_cast<float*>(smem) + wave * (32 * 36), s_tab, m0 + wm * TM * 32, n0, wn * TN * 32, lane);
             } else {
                 if constexpr (WAVE_H) {
@@ -519,6 +576,12 @@ static int g_tail = env_int("MRCNN_TAIL", 0);
 // and the last one to finish folds the partial sums in the same order: bit-identical, and the dependent chain of K steps is 4 - 8 x
 // shorter (single image: 171 -> 85, 29 -> 18, 28 -> 15 us; batch 8 unchanged).
 // MRCNN_KCHUNK=0 / "conv_kchunk" 0: one running sum as in rounds 1-3 (other bits); "conv_ksplit" 0: never share a tile (same bits).
+// Fused shortcut (round 4, late): the first block of a ResNet stage convolves the block's input twice — `branch1` (1x1, the shortcut) and,
+// three layers later, `branch2c` adds that tensor as its residual.  conv_forward(s, branch2c, &branch1) computes both in ONE launch: the
+// shortcut's K loop first (its sums wait in the second accumulator set), then branch2c's, and the epilogue forms the residual from the waiting
+// sums with the shortcut's own scale / shift — the same fp32 operations, bit for bit (tests/test_gpu_engine.py), and the 4 x-wide shortcut
+// tensor is neither written nor read back (C2: 537 MB each way at batch 8).  "conv_scfuse" 0 / MRCNN_SCFUSE=0: the two launches.
+static int g_scfuse = env_int("MRCNN_SCFUSE", 1);
 static int g_kchunk = env_int("MRCNN_KCHUNK", 1);
 static int g_ksplit = env_int("MRCNN_KSPLIT", 1);
 static int g_ksplit_below = env_int("MRCNN_KSPLIT_BELOW", 256);       // share tiles when the widest-tile grid has fewer blocks than this
@@ -548,7 +611,7 @@ static void conv_launch(hipStream_t s, const ConvArgs& a, int bn, bool wide_wave
         // the 3x3 layers, bit-identical (same products, same order per accumulator); short-K layers lose to its 4-wave epilogue.
         if (bn == 128 && wide_waves) { hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 128, 1, 4, 4, 1, R128, PARTS>), grid, dim3(256), 0, s, a); return; }
     }
-    MRCNN_REQUIRE(a.kchunks == 1 || (sizeof(T) == 4 && sizeof(TW) == 2 && bn != 128), MRCNN_ERR_INVALID, "conv: K chunks on a kernel that does not carry them");
+    MRCNN_REQUIRE((a.kchunks == 1 && !a.sc_in) || (sizeof(T) == 4 && sizeof(TW) == 2 && bn != 128), MRCNN_ERR_INVALID, "conv: K chunks / a fused shortcut on a kernel that does not carry them");
     if (bn == 128) hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 128, 1, 2, 4, 2, R128, PARTS>), grid, dim3(512), 0, s, a);
     else if (bn == 64) hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 64, 1, 1, 4, 2, MRCNN_RING64, PARTS>), grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL((k_conv_mfma_glds<T, TW, 32, 1, 1, 4, 1, MRCNN_RING32, PARTS>), grid, dim3(256), 0, s, a);
@@ -586,6 +649,7 @@ bool conv_debug_set(const char* key, int value)
     else if (k == "conv_halo") g_halo = value;
     else if (k == "conv_direct") g_direct = value;
     else if (k == "conv_min_blocks") g_min_blocks = value;
+    else if (k == "conv_scfuse") g_scfuse = value;
     else if (k == "conv_kchunk") g_kchunk = value;
     else if (k == "conv_ksplit") g_ksplit = value;
     else if (k == "conv_ksplit_below") g_ksplit_below = value;
@@ -618,6 +682,8 @@ static void conv_fill_args(const ConvDesc& d, ConvArgs& a)
     a.dbg = pp_policy().dbg;
     a.sel_w = d.sel_w; a.sel_cid = d.sel_cid; a.sel_partial = d.sel_partial;
     a.kchunks = 1; a.ksplit = 1; a.ks_scratch = nullptr; a.ks_count = nullptr;
+    a.sc_in = nullptr; a.sc_wgt = nullptr; a.sc_scale = nullptr; a.sc_shift = nullptr;
+    a.sc_in_sB = a.sc_in_sH = a.sc_in_sW = 0; a.sc_H = a.sc_W = a.sc_Cin = 0; a.sc_stride = 1;
 }
 
 // Canonical K chunks of a layer (1 = one running sum): by its shape and mode alone — never by the batch or the grid
@@ -669,8 +735,39 @@ static int conv_vec_ok(const ConvDesc& d, const ConvArgs& a)
                (!d.deconv2 || (d.Cout % cpt == 0 && d.out_sH % cpt == 0 && d.out_sW % cpt == 0));
 }
 
-void conv_forward(hipStream_t s, const ConvDesc& d)
+// May `main` (a 1x1 layer whose residual is exactly the output of the 1x1 layer `sc`) absorb `sc`?  (conv_forward checks the tile and the epilogue form.)
+static bool conv_shortcut_fusable(const ConvDesc& m, const ConvDesc& sc)
 {
+    const int wm = m.wdtype < 0 ? m.dtype : m.wdtype, ws = sc.wdtype < 0 ? sc.dtype : sc.wdtype;
+    if (m.dtype != MRCNN_F32 || sc.dtype != MRCNN_F32 || wm != ws || !(wm == MRCNN_F16 || wm == MRCNN_F32X3)) return false;          // split modes
+    if (m.KH != 1 || m.KW != 1 || sc.KH != 1 || sc.KW != 1 || m.padH || m.padW || sc.padH || sc.padW || m.stride != 1) return false;
+    if (m.B != sc.B || m.OH != sc.OH || m.OW != sc.OW || m.Cout != sc.Cout || m.Npad != sc.Npad || sc.Cin % 32 != 0) return false;
+    if (sc.act != ACT_NONE || sc.res || sc.out2 || sc.deconv2 || sc.sel_partial || sc.head_w || m.out2 || m.deconv2 || m.sel_partial || m.head_w || m.act == ACT_SIGMOID) return false;
+    // the residual IS the shortcut's output, element for element
+    if (m.res != sc.out || m.res_shift != 0 || m.res_sW != sc.out_sP || m.res_sB != sc.out_sB || m.res_sH != (long)m.OW * m.res_sW) return false;
+    if (sc.out_sB != (long)sc.OH * sc.OW * sc.out_sP) return false;
+    return true;
+}
+
+void conv_forward(hipStream_t s, const ConvDesc& d_in, const ConvDesc* sc)
+{
+    // a shortcut that cannot ride in this launch runs first, as its own (its output is this layer's residual)
+    bool fuse = sc && g_scfuse && conv_shortcut_fusable(d_in, *sc) && conv_k_chunks(d_in) == 1 && conv_k_chunks(*sc) == 1;
+    if (fuse) {
+        // the fused form needs the direct fp32 epilogue (tiles of 64 columns or more)
+        const int bn_max = conv_n_tile(d_in.Cout);
+        int bn = bn_max;
+        const long tiles_m = ((long)d_in.B * d_in.OH * d_in.OW + BM_DEFAULT - 1) / BM_DEFAULT;
+        while (bn > 32 && tiles_m * (d_in.Npad / bn) < g_min_blocks) bn >>= 1;
+        ConvDesc probe = d_in;
+        probe.res = nullptr;
+        ConvArgs pa;
+        conv_fill_args(probe, pa);
+        if (bn < 64 || g_direct < 2 || !conv_vec_ok(probe, pa) || pp_policy().dbg) fuse = false;
+    }
+    if (sc && !fuse) conv_forward(s, *sc, nullptr);
+    ConvDesc d = d_in;
+    if (fuse) { d.res = nullptr; d.res_sB = d.res_sH = d.res_sW = 0; }
     const bool half = d.dtype == MRCNN_F16;
     const int wdtype = d.wdtype < 0 ? d.dtype : d.wdtype;
     // fp32 activations, fp16 filters: two-pass (wdtype F16) or exact three-pass (wdtype F32X3, a filter-side tag) fp16 MFMA
@@ -690,6 +787,14 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     a.tiles_m = (a.M + BM_DEFAULT - 1) / BM_DEFAULT;
     int bn = bn_max;
     while (bn > 32 && !d.sel_partial && (long)a.tiles_m * (d.Npad / bn) < g_min_blocks) bn >>= 1;     // (selected-class mode: fixed 128-channel parts)
+    if (fuse) {
+        a.sc_in = sc->in; a.sc_wgt = sc->wgt; a.sc_scale = sc->scale; a.sc_shift = sc->shift;
+        a.sc_in_sB = sc->in_sB; a.sc_in_sH = sc->in_sH; a.sc_in_sW = sc->in_sW;
+        a.sc_H = sc->H; a.sc_W = sc->W; a.sc_Cin = sc->Cin; a.sc_stride = sc->stride;
+    }
+    // (a fused shortcut needs the second accumulator set: the eight-wave 128-column form has no registers for it; of the two forms that do,
+    //  the four-wave 128-column one measured C2 / C3 / C4 / C5 321 / 247 / 171 / 150 us against 355 / 282 / 221 / 193 for the eight-wave
+    //  64-column one, and 430 / 288 / 180 / 159 for the two launches each replaces: gpurun_out/r5g)
     a.kchunks = d.sel_partial ? 1 : conv_k_chunks(d);
     if (a.kchunks > 1 && g_ksplit && (long)a.tiles_m * (d.Npad / bn_max) < g_ksplit_below) {
         // an under-filled grid: one block per (tile, chunk), the N tile as wide as the shared grid allows
@@ -712,6 +817,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     // +3.6 % end to end in fp16 mode over the form below, tools/e2e_ab.py f16 conv_direct 2 3), the narrower fp16 tiles straight
     // from the accumulators (conv_epilogue_direct: 32-B pieces per pixel and store, +0.9 % over the block-staged form).
     a.direct = (g_direct && (half || g_direct > 1) && a.vec_ok && !d.out2 && !d.deconv2 && d.act != ACT_SIGMOID && (!half || !a.out_f32)) ? 1 : 0;
+    MRCNN_REQUIRE(!fuse || (a.direct && bn >= 64), MRCNN_ERR_INVALID, "conv: fused shortcut without the direct epilogue (conv_forward's own check should have said so)");
     if (a.direct && half && g_direct > 2) a.direct = 2;      // fp16 tensors through wave-private tiles where the wave tile is 32 x 64 (the 128-column kernel)
     // Layers with a large GEMM: the 256×256 persistent ping-pong kernel (kernels_conv_pp.hip), one block per CU — when the
     // tiles fill whole rounds of the chip well enough (a static walk: the last round costs as much as a full one).
@@ -723,12 +829,12 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
         const bool fills = tiles >= pol.min_tiles && tiles * 100 >= rounds * 256 * pol.min_fill_pct;
         const int bk_pp = half ? 64 : 32;
         if (pol.on && (half || (split && pol.split)) && d.Cin % bk_pp == 0 && a.Ktot / bk_pp >= pol.min_kt && d.Npad % 256 == 0 && fills &&
-            a.kchunks == 1 && a.vec_ok && (!half || !a.out_f32) && !d.deconv2 && !d.out2 && d.act != ACT_SIGMOID && d.H < 32760 && d.W < 32760)
+            a.kchunks == 1 && !fuse && a.vec_ok && (!half || !a.out_f32) && !d.deconv2 && !d.out2 && d.act != ACT_SIGMOID && d.H < 32760 && d.W < 32760)
             pp_bn = 256;                    // ... and the epilogue / address forms pp_store_tile and PP_SRC_A cover
     }
     if (pp_bn) { a.tiles_m = (a.M + 255) / 256; a.tiles_n = d.Npad / pp_bn; }
     // K >= 2048: the 3x3 layers; and every chunked layer (the 8-wave form has no registers for the second accumulator set)
-    const bool wide_waves = split && bn == 128 && (a.kchunks > 1 || (g_tn4 < 0 ? a.Ktot / bk >= 64 : g_tn4 != 0));
+    const bool wide_waves = split && bn == 128 && (a.kchunks > 1 || fuse || (g_tn4 < 0 ? a.Ktot / bk >= 64 : g_tn4 != 0));
     ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
     const int e0 = prof ? prof_event(prof, s) : 0;
     // 3x3 stride-1 layers of the split modes: the persistent halo kernel, whenever the layer qualifies — by its geometry and
@@ -747,7 +853,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d)
     else conv_launch<float, float>(s, a, bn);
     if (prof) {
         const int e1 = prof_event(prof, s);
-        const double k = d.algo_k > 0 ? d.algo_k : a.Ktot;
+        const double k = (d.algo_k > 0 ? d.algo_k : a.Ktot) + (fuse ? sc->Cin : 0);          // (a fused shortcut: both K loops)
         const int tile = halo ? 5 : pp_bn == 256 ? 4 : (wide_waves ? 3 : (bn == 128 ? 0 : (bn == 64 ? 1 : 2)));
         prof->pending.push_back({tile, 2.0 * (double)a.M * (double)a.ncols * k, e0, e1, {a.M, a.ncols, a.Ktot, tile}});
     }
@@ -804,12 +910,13 @@ bool conv_tail_fusable(const ConvDesc& d3, const ConvDesc& d1)
     return true;
 }
 
-void conv_forward_tail(hipStream_t s, const ConvDesc& d3, const ConvDesc& d1)
+void conv_forward_tail(hipStream_t s, const ConvDesc& d3, const ConvDesc& d1, const ConvDesc* sc)
 {
     static int n_cus = [] { int dev = 0; hipDeviceProp_t p; (void)hipGetDevice(&dev); return hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }();
     const long tiles = ((long)d3.B * d3.OH * d3.OW + 127) / 128;
     ConvArgs a3, a1;
     bool fuse = g_tail && g_halo && conv_tail_fusable(d3, d1) && tiles * 8 >= (long)n_cus * 7;       // a grid that fills the chip: one 128 x 256 tile per block
+    if (sc && fuse) { conv_forward(s, *sc); sc = nullptr; }          // (the fused tail reads its residual from memory: the shortcut runs as its own launch)
     if (fuse) {
         conv_fill_args(d3, a3);
         conv_fill_args(d1, a1);
@@ -821,7 +928,7 @@ void conv_forward_tail(hipStream_t s, const ConvDesc& d3, const ConvDesc& d1)
     }
     if (!fuse) {
         conv_forward(s, d3);
-        conv_forward(s, d1);
+        conv_forward(s, d1, sc);
         return;
     }
     ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;

@@ -657,3 +657,37 @@ def test_fused_stem_is_bit_identical_to_conv1_plus_maxpool(pkg, weights_mod, tmp
     d1, m1 = m.predict(images[2:3])
     np.testing.assert_array_equal(d1[0], det[2])
     assert (det[..., 5] > 0).sum() > 0
+
+
+@pytest.mark.parametrize("dtype", ["f32x3", "f32s"])
+def test_fused_shortcut_is_bit_identical_to_the_two_launches(pkg, weights_mod, tmp_path_factory, dtype):
+    """Round 4 (late): at the entry of a ResNet stage `branch1` (the shortcut, a 1x1 over the block's input) rides inside the launch of
+    `branch2c`, which would have read its output as the residual: the shortcut's K loop first, its sums waiting in the second
+    accumulator set, the residual formed in the epilogue with the shortcut's own scale / shift — the shortcut tensor is never written.
+    Same fp32 operations: a predict must not change by one bit against mrcnn_debug_set("conv_scfuse", 0) — stride-2 shortcuts (C3..C5),
+    ragged tiles (a 320 x 448 input), several images, calibrated exponents, and per-image results independent of the batch."""
+    import importlib
+    L = importlib.import_module("mask-rcnn-coreml_amd._lib")
+    models = importlib.import_module("mask-rcnn-coreml_amd.models")
+    d, cfg = make_model_dir(tmp_path_factory, pkg, weights_mod, "scfuse" + dtype, architecture="resnet50", input_image_shape=(320, 448, 3),
+                            num_classes=21, pre_nms_max_proposals=1000, max_proposals=128, max_detections=32)
+    B = 3
+    m = models.load_maskrcnn(d, max_batch=B, compute_dtype=dtype)
+    images = rand_images(B, 320, 448, seed=11)
+    m.calibrate_split(images[:2])
+    det, mask = m.predict(images)
+    names = ("P2", "P3", "P4", "P5", "rpn_probs", "rpn_deltas")         # every stage's output feeds one of them
+    taps = {n: [m.read_tensor(n, b).copy() for b in range(B)] for n in names}
+    try:
+        L.check(L.lib().mrcnn_debug_set(b"conv_scfuse", 0))
+        det2, mask2 = m.predict(images)
+        for n, want in taps.items():
+            for b in range(B):
+                np.testing.assert_array_equal(m.read_tensor(n, b), want[b], err_msg=f"{n} image {b}")
+    finally:
+        L.check(L.lib().mrcnn_debug_set(b"conv_scfuse", 1))
+    np.testing.assert_array_equal(det, det2)
+    np.testing.assert_array_equal(mask, mask2)
+    d1, m1 = m.predict(images[2:3])
+    np.testing.assert_array_equal(d1[0], det[2])
+    assert (det[..., 5] > 0).sum() > 0

@@ -64,12 +64,16 @@ def test_headline_batch8_full_size(pkg, orc, full_model, full_images, full_oracl
         # the fused bottleneck tail (C4's 3x3 + 1x1 + shortcut in one persistent launch; opt-in: measured slower)
         # sums in the order of the two launches it replaces: bit-identical, all 23 blocks of C4, at the batch that fills the chip
         L = __import__("importlib").import_module("mask-rcnn-coreml_amd._lib")
+        # ... and in the same predict the stage-entry shortcuts run as their own launches ("conv_scfuse" 0) instead of inside branch2c's
+        # (late round 4): one comparison pins both fusions at the full-size grids
         try:
             L.check(L.lib().mrcnn_debug_set(b"conv_tail", 1))
+            L.check(L.lib().mrcnn_debug_set(b"conv_scfuse", 0))
             det_t, mask_t = m.predict(full_images)
             p5 = [m.read_tensor("P5", b) for b in (0, 7)]
         finally:
             L.check(L.lib().mrcnn_debug_set(b"conv_tail", 0))
+            L.check(L.lib().mrcnn_debug_set(b"conv_scfuse", 1))
         np.testing.assert_array_equal(det_t, det)
         np.testing.assert_array_equal(mask_t, mask)
         m.predict(full_images)
