@@ -763,7 +763,10 @@ void conv_forward(hipStream_t s, const ConvDesc& d_in, const ConvDesc* sc)
         probe.res = nullptr;
         ConvArgs pa;
         conv_fill_args(probe, pa);
-        if (bn < 64 || g_direct < 2 || !conv_vec_ok(probe, pa) || pp_policy().dbg) fuse = false;
+        if (bn < 64 || g_direct < 2 || !conv_vec_ok(probe, pa)) fuse = false;
+#ifndef MRCNN_CONV_ABLATE
+        if (pp_policy().dbg) fuse = false;          // (the measurement build ablates the fused launch too)
+#endif
     }
     if (sc && !fuse) conv_forward(s, *sc, nullptr);
     ConvDesc d = d_in;
