@@ -947,6 +947,7 @@ static int halo_linear_rows(int H, int W, int bm)
 }
 
 static int g_halo_lat = env_int_halo("MRCNN_HALO_LAT", 1);     // grids under 3/4 of the chip even at 64 x 128: 64 x 64 tiles in the latency form (k_conv_halo_lat; bit-identical)
+static int g_halo_rounds = env_int_halo("MRCNN_HALO_ROUNDS", 1);     // 64-row tiles where they shorten the last round of a 128 x 128 grid
 static int g_halo_n64 = env_int_halo("MRCNN_HALO_N64", 2);     // 64-column 3x3 layers on the halo kernel: 1 as 128 x 64 tiles, 2 also 256 x 64 where the level allows
 static int g_halo_geo = env_int_halo("MRCNN_HALO_GEO", 1);     // 0: the round-3 geometries (one-row 3 x 130 regions, five staging pieces, pitch W + 2) — A/B and bit-identity tests
 
@@ -1066,6 +1067,7 @@ bool conv_halo_debug_set(const char* key, int value)
     if (std::string(key) == "halo_geo") { g_halo_geo = value; return true; }
     if (std::string(key) == "halo_lat") { g_halo_lat = value; return true; }
     if (std::string(key) == "halo_n64") { g_halo_n64 = value; return true; }
+    if (std::string(key) == "halo_rounds") { g_halo_rounds = value; return true; }
     return false;
 }
 
@@ -1099,6 +1101,13 @@ int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, i
     if (!d.head_w && !t1 && bn != 64) {
         if (bn > 128 && (long)((a.M + 127) / 128) * (d.Npad / bn) < n_cus) bn = 128;
         if (bn == 128 && (long)((a.M + 127) / 128) * (d.Npad / bn) * 4 < (long)n_cus * 3) bm = 64;
+        // ... and where the 128 x 128 grid's last round would run nearly empty (the mask head of a single image: 308 tiles = 2 rounds of
+        // 256 blocks, the second 20 % full): 64 x 128 tiles when their rounds, at ~0.575 of a 128-row tile each, come out shorter
+        if (bn == 128 && bm == 128 && g_halo_rounds) {
+            const long t128 = (long)((a.M + 127) / 128) * (d.Npad / bn), t64 = (long)((a.M + 63) / 64) * (d.Npad / bn);
+            const long r128 = (t128 + n_cus - 1) / n_cus, r64 = (t64 + n_cus - 1) / n_cus;
+            if (r64 * 575 < r128 * 1000 && halo_geometry(d.H, d.W, 64).ok) bm = 64;
+        }
     }
     // a fused head owns whole M tiles (its N tiles run back to back on one block): when the 128-row M tiles alone would leave a
     // quarter of the chip idle — single images at P3 / P4 — 64-row tiles double the blocks (same per-pixel summation order:

@@ -437,6 +437,26 @@ def test_latency_form_of_the_halo_kernel_is_bit_identical(shape, dtype):
     assert np.abs(y0 - ref).max() <= (4e-6 if dtype == "f32x3" else 2e-5) * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("dtype", ["f32x3", "f32s"])
+def test_round_aware_tile_height_is_bit_identical(dtype):
+    """The mask head of a single image is 308 tiles of 128 x 128 — two rounds of the 256 persistent blocks, the second a fifth full: the launcher
+    takes 64 x 128 tiles where their rounds come out shorter ("halo_rounds" 1).  A tile shape, not a summation order: same bits."""
+    B, H, W, Ci, Co = 100, 14, 14, 256, 256
+    rng = np.random.default_rng(123)
+    x = (rng.standard_normal((B, H, W, Ci)) * 2).astype(np.float32)
+    w = (rng.standard_normal((Co, 3, 3, Ci)) * np.sqrt(2.0 / (9 * Ci))).astype(np.float32)
+    shift = (rng.standard_normal(Co) * 0.1).astype(np.float32)
+    lib = L.lib()
+    try:
+        L.check(lib.mrcnn_debug_set(b"halo_rounds", 0))
+        y0 = conv(x, w, 3, 1, None, shift, None, 1, dtype)
+    finally:
+        L.check(lib.mrcnn_debug_set(b"halo_rounds", 1))
+    y1 = conv(x, w, 3, 1, None, shift, None, 1, dtype)
+    np.testing.assert_array_equal(y1, y0)
+    np.testing.assert_array_equal(conv(x[7:9], w, 3, 1, None, shift, None, 1, dtype), y1[7:9])
+
+
 KCHUNK_SHAPES = [  # B, H, W, Cin, Cout, stride, residual — long-K 1x1 layers: 4 / 8 canonical chunks (conv_k_chunks)
     (1, 32, 32, 2048, 512, 1, False),      # C5 branch2a, single image: 8 M tiles -> four blocks per tile
     (2, 32, 32, 2048, 256, 1, True),       # the P5 lateral with a residual

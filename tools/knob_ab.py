@@ -33,6 +33,9 @@ ALL = PW + [
     ("C4 3x3 256->256 @64 b1", 1, 64, 64, 256, 256, 3, 1),
     ("C5 3x3 512->512 @32 b1", 1, 32, 32, 512, 512, 3, 1),
     ("C3 3x3 128->128 @128 b8", 8, 128, 128, 128, 128, 3, 1),
+    ("mask 3x3 256->256 x100", 100, 14, 14, 256, 256, 3, 1),
+    ("mask 3x3 256->256 x200", 200, 14, 14, 256, 256, 3, 1),
+    ("mask 3x3 256->256 x800", 800, 14, 14, 256, 256, 3, 1),
     ("C2 3x3 64->64 @256 b8", 8, 256, 256, 64, 64, 3, 1),
     ("C2 3x3 64->64 @256 b1", 1, 256, 256, 64, 64, 3, 1),
 ]
