@@ -66,6 +66,8 @@ MRCNN_API int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout,
  * four image rows x 64 columns tile the level and the grid fills the chip (default 2; 1 and 2 are bit-identical, "0" differs by summation noise: its K order is
  * the 128-row kernel's);
  * "halo_rounds" 0|1: 128 x 128 halo tiles whenever the grid covers 3/4 of the chip | 64 x 128 where they shorten a nearly empty last round (default 1; bit-identical);
+ * "mask_sel_wave" 0|1: the mask head's deconvolution + selected-class dot through the block-staged epilogue (128-column partial sums) | straight from the
+ * accumulators (64-column partial sums; default 1) — the two differ by summation noise;
  * "conv_scfuse" 0|1: a ResNet stage's shortcut convolution as its own launch | inside the launch of the `branch2c` that adds it (default 1; bit-identical);
  * "conv_kchunk" 0|1: the long-K (>= 2048) 1x1 layers of the split modes as one running sum | as 4 / 8 canonical K chunks folded in order
  * (default 1; the two differ by summation noise — the chunk count is a property of the layer, never of the batch);

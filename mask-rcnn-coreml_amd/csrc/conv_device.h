@@ -38,6 +38,7 @@ struct ConvArgs {
     const void* sc_in; const void* sc_wgt; const float* sc_scale; const float* sc_shift;
     long sc_in_sB, sc_in_sH, sc_in_sW;
     int sc_H, sc_W, sc_Cin, sc_stride;
+    int sel_part_cols;       // selected-class mode: output columns per partial sum (128: the block-staged form; 64: conv_epilogue_sel_wave)
 };
 
 static constexpr int BM_DEFAULT = 128;   // rows of the block tile = WM*TM*32
@@ -379,6 +380,60 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x16 (
                         *reinterpret_cast<uint4*>(out + o_row + n_store) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
                 }
             }
+        }
+    }
+    if (a.range_flag && out_of_range) atomicOr(a.range_flag, 1);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// conv_epilogue_sel_wave — the mask head's deconvolution in selected-class mode (ConvDesc::sel_partial; TimeDistributedMaskLayer.swift:52-89,
+// Conversion/task.py:108-116) straight from the accumulators: a lane holds 16 channels of ONE output pixel per column tile
+// (lane (pixel l31, kk), slot 4q + r <-> channel 32 j + 8 q + 4 kk + r), so the dot with the selected class's 1x1 filter is 16 TNS FMAs
+// per lane in a fixed order, one exchange with the partner lane (kk), and one store per pixel: no LDS tile, no block barrier, no
+// five-level cross-lane tree per row (the block-staged form's epilogue took as long as the layer's K loop: DESIGN.md section 6 (11)).
+//   partial[(b * 4 ohw + P) * (Cout / PC) + co / PC] = sum over this wave's PC = TNS * 32 columns;   tab: scale[BN] | shift[BN]
+// ----------------------------------------------------------------------------------------------------------------
+template <typename T, int BN, int TMS, int TNS>
+__device__ __forceinline__ void conv_epilogue_sel_wave(const ConvArgs& a, f32x16 (&acc)[TMS][TNS], const float* tab, int row0, int n0, int colrel0, int lane)
+{
+    constexpr int PC = TNS * 32;
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int ohw = a.OH * a.OW;
+    const int nb = n0 + colrel0;
+    const int qd = nb / a.Cout, co0 = nb - qd * a.Cout;          // the wave's columns lie inside one of the four output positions
+    const bool relu = a.act == ACT_RELU;
+    const int parts = a.Cout / PC;
+    bool out_of_range = false;
+#pragma unroll
+    for (int i = 0; i < TMS; ++i) {
+        const int m = row0 + i * 32 + l31;
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
+        const int b = mm / ohw, pix = mm - b * ohw, oh = pix / a.OW, ow = pix - oh * a.OW;
+        const int cid = ok ? a.sel_cid[b] : -1;
+        const float* const wr = a.sel_w + (size_t)(cid < 0 ? 0 : cid) * a.Cout + co0;
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < TNS; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cw = j * 32 + 8 * q + 4 * kk;                  // column inside the wave's PC
+                const int cl = colrel0 + cw;                             // ... inside the block tile
+                const float4 sc = *reinterpret_cast<const float4*>(tab + cl), sh = *reinterpret_cast<const float4*>(tab + BN + cl);
+                const float4 w = *reinterpret_cast<const float4*>(wr + cw);
+                float x[4] = {acc[i][j][4 * q] * sc.x + sh.x, acc[i][j][4 * q + 1] * sc.y + sh.y, acc[i][j][4 * q + 2] * sc.z + sh.z, acc[i][j][4 * q + 3] * sc.w + sh.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (relu) x[r] = fmaxf(x[r], 0.f);
+                    out_of_range = out_of_range || (ok && !(fabsf(x[r]) < 65504.0f));
+                    if constexpr (sizeof(T) == 2) x[r] = (float)(_Float16)x[r];          // the value the fp16 tensor would have held
+                }
+                dot += x[0] * w.x + x[1] * w.y + x[2] * w.z + x[3] * w.w;
+            }
+        dot += __shfl_xor(dot, 32);                                  // the partner lane's 16 TNS channels of the same pixel
+        if (kk == 0 && cid >= 0) {
+            const long P = (long)(2 * oh + (qd >> 1)) * (2 * a.OW) + (2 * ow + (qd & 1));
+            a.sel_partial[((long)b * 4 * ohw + P) * parts + co0 / PC] = dot;
         }
     }
     if (a.range_flag && out_of_range) atomicOr(a.range_flag, 1);

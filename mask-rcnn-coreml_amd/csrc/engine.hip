@@ -986,7 +986,7 @@ void Model::build_maskrcnn()
         msel_ws.mapping = (int32_t*)ar.alloc_b((size_t)Bm * max_det * 4);
         msel_ws.kept = (int32_t*)ar.alloc_b((size_t)Bm * 4);
         msel_ws.sel_cid = (int32_t*)ar.alloc_b((size_t)Bm * max_det * 4);
-        mask_partial = ar.alloc_f((size_t)Bm * max_det * 4 * mask_pool * mask_pool * (256 / 128));
+        mask_partial = ar.alloc_f((size_t)Bm * max_det * 4 * mask_pool * mask_pool * (256 / 64));        // (up to four partial sums per output pixel: conv_sel_part_cols)
         if (real) {
             prop_ws.bind(pws, Bm, A, K, max_prop);
             det_ws.bind(dws, Bm, max_prop, max_det);
@@ -1393,7 +1393,7 @@ void Model::enqueue_pipeline(hipStream_t s, int batch, const int* fit)
         // fp32 per batch of 8) is never written nor read back
         mask_select_classes(s, detections, (long)max_det * 6, 6, max_det, batch, nc, msel_ws, msel_ws.sel_cid);
         mask_head.forward_features(s, pooled_mask, batch * max_det, msel_ws.sel_cid, mask_partial);
-        mask_select_from_partials(s, mask_partial, mask_head.deconv.Cout / 128, HW, mask_head.final_b.as<float>(), nc, detections,
+        mask_select_from_partials(s, mask_partial, mask_head.deconv.Cout / conv_sel_part_cols(), HW, mask_head.final_b.as<float>(), nc, detections,
                                   (long)max_det * 6, 6, max_det, batch, msel_ws, mask_out, (long)max_det * HW, HW);
     } else {
         mask_head.forward_features(s, pooled_mask, batch * max_det);

@@ -198,6 +198,7 @@ bool conv_halo_tail_geometry_ok(int H, int W);                          // ... a
 // 256-column tensor between them never exists (kernels_conv_halo.hip: TAIL).  Bit-identical to conv_forward(d3); conv_forward(d1),
 // which is what runs when the pair does not qualify, the grid would not fill the chip, or mrcnn_debug_set("conv_tail", 0).
 bool conv_tail_fusable(const ConvDesc& d3, const ConvDesc& d1);
+int conv_sel_part_cols();       // selected-class mode: output columns per partial sum the next conv_forward will leave (64: wave-private form, 128: block-staged)
 void conv_forward_tail(hipStream_t s, const ConvDesc& d3, const ConvDesc& d1, const ConvDesc* sc = nullptr);      // sc: d1's shortcut convolution (conv_forward)
 
 // The stem in the split modes and the fp16 mode (kernels_conv_stem.hip): conv1 — described by d exactly as for conv_forward (7 row taps of 32 "channels"

@@ -480,6 +480,10 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN >= 8 ? 4 : 2) void k_conv_mfm
     if (a.dbg & 1024) { if (a.dbg == 12345678) static_cast<float*>(a.out)[t] = acc[0][0][0]; return; }
 #endif
     if constexpr (DIRECT_OK) {
+        if (direct && a.sel_partial) {           // selected-class mode, wave-private form (conv_forward sets direct for it only with 64-column parts)
+            if constexpr (BN == 128 && TM == 1 && TN == 2) conv_epilogue_sel_wave<T, BN, TM, TN>(a, acc, s_tab, m0 + wm * TM * 32, n0, wn * TN * 32, lane);
+            return;
+        }
         if (direct) {
             if constexpr (sizeof(T) == 4) {
                 // fp32 tensors (a.direct == 2): through a wave-private 32 x 36-float LDS tile (the operand ring is free: the K loop
@@ -582,6 +586,8 @@ static int g_tail = env_int("MRCNN_TAIL", 0);
 // sums with the shortcut's own scale / shift — the same fp32 operations, bit for bit (tests/test_gpu_engine.py), and the 4 x-wide shortcut
 // tensor is neither written nor read back (C2: 537 MB each way at batch 8).  "conv_scfuse" 0 / MRCNN_SCFUSE=0: the two launches.
 static int g_scfuse = env_int("MRCNN_SCFUSE", 1);
+static int g_sel_wave = env_int("MRCNN_SEL_WAVE", 1);         // selected-class mode of the mask head's deconvolution: 1 wave-private epilogue (64-column partial sums), 0 block-staged (128)
+int conv_sel_part_cols() { return g_sel_wave ? 64 : 128; }
 static int g_kchunk = env_int("MRCNN_KCHUNK", 1);
 static int g_ksplit = env_int("MRCNN_KSPLIT", 1);
 static int g_ksplit_below = env_int("MRCNN_KSPLIT_BELOW", 256);       // share tiles when the widest-tile grid has fewer blocks than this
@@ -650,6 +656,7 @@ bool conv_debug_set(const char* key, int value)
     else if (k == "conv_direct") g_direct = value;
     else if (k == "conv_min_blocks") g_min_blocks = value;
     else if (k == "conv_scfuse") g_scfuse = value;
+    else if (k == "mask_sel_wave") g_sel_wave = value;
     else if (k == "conv_kchunk") g_kchunk = value;
     else if (k == "conv_ksplit") g_ksplit = value;
     else if (k == "conv_ksplit_below") g_ksplit_below = value;
@@ -682,6 +689,7 @@ static void conv_fill_args(const ConvDesc& d, ConvArgs& a)
     a.dbg = pp_policy().dbg;
     a.sel_w = d.sel_w; a.sel_cid = d.sel_cid; a.sel_partial = d.sel_partial;
     a.kchunks = 1; a.ksplit = 1; a.ks_scratch = nullptr; a.ks_count = nullptr;
+    a.sel_part_cols = 128;
     a.sc_in = nullptr; a.sc_wgt = nullptr; a.sc_scale = nullptr; a.sc_shift = nullptr;
     a.sc_in_sB = a.sc_in_sH = a.sc_in_sW = 0; a.sc_H = a.sc_W = a.sc_Cin = 0; a.sc_stride = 1;
 }
@@ -821,7 +829,9 @@ void conv_forward(hipStream_t s, const ConvDesc& d_in, const ConvDesc* sc)
     // from the accumulators (conv_epilogue_direct: 32-B pieces per pixel and store, +0.9 % over the block-staged form).
     a.direct = (g_direct && (half || g_direct > 1) && a.vec_ok && !d.out2 && !d.deconv2 && d.act != ACT_SIGMOID && (!half || !a.out_f32)) ? 1 : 0;
     MRCNN_REQUIRE(!fuse || (a.direct && bn >= 64), MRCNN_ERR_INVALID, "conv: fused shortcut without the direct epilogue (conv_forward's own check should have said so)");
-    if (a.direct && half && g_direct > 2) a.direct = 2;      // fp16 tensors through wave-private tiles where the wave tile is 32 x 64 (the 128-column kernel)
+    if (a.direct && half && g_direct > 2) a.direct = 2;
+    // selected-class mode: the wave-private form (64-column partial sums straight from the accumulators) on the eight-wave 128-column kernel
+    if (d.sel_partial && g_sel_wave && bn == 128 && a.vec_ok && d.act != ACT_SIGMOID && d.Cout % 64 == 0) { a.direct = 1; a.sel_part_cols = 64; }      // fp16 tensors through wave-private tiles where the wave tile is 32 x 64 (the 128-column kernel)
     // Layers with a large GEMM: the 256×256 persistent ping-pong kernel (kernels_conv_pp.hip), one block per CU — when the
     // tiles fill whole rounds of the chip well enough (a static walk: the last round costs as much as a full one).
     int pp_bn = 0;
