@@ -829,9 +829,9 @@ void conv_forward(hipStream_t s, const ConvDesc& d_in, const ConvDesc* sc)
     // from the accumulators (conv_epilogue_direct: 32-B pieces per pixel and store, +0.9 % over the block-staged form).
     a.direct = (g_direct && (half || g_direct > 1) && a.vec_ok && !d.out2 && !d.deconv2 && d.act != ACT_SIGMOID && (!half || !a.out_f32)) ? 1 : 0;
     MRCNN_REQUIRE(!fuse || (a.direct && bn >= 64), MRCNN_ERR_INVALID, "conv: fused shortcut without the direct epilogue (conv_forward's own check should have said so)");
-    if (a.direct && half && g_direct > 2) a.direct = 2;
+    if (a.direct && half && g_direct > 2) a.direct = 2;      // fp16 tensors through wave-private tiles where the wave tile is 32 x 64 (the 128-column kernel)
     // selected-class mode: the wave-private form (64-column partial sums straight from the accumulators) on the eight-wave 128-column kernel
-    if (d.sel_partial && g_sel_wave && bn == 128 && a.vec_ok && d.act != ACT_SIGMOID && d.Cout % 64 == 0) { a.direct = 1; a.sel_part_cols = 64; }      // fp16 tensors through wave-private tiles where the wave tile is 32 x 64 (the 128-column kernel)
+    if (d.sel_partial && g_sel_wave && bn == 128 && a.vec_ok && d.act != ACT_SIGMOID && d.Cout % 64 == 0) { a.direct = 1; a.sel_part_cols = 64; }
     // Layers with a large GEMM: the 256×256 persistent ping-pong kernel (kernels_conv_pp.hip), one block per CU — when the
     // tiles fill whole rounds of the chip well enough (a static walk: the last round costs as much as a full one).
     int pp_bn = 0;
