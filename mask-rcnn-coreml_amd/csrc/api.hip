@@ -833,7 +833,7 @@ extern "C" int mrcnn_model_conv_profile_enable(mrcnn_model* model, int on)
 extern "C" int mrcnn_model_conv_profile_get(mrcnn_model* model, int tile, int64_t* launches, double* total_ms, double* total_flops)
 {
     return guarded([&] {
-        MRCNN_REQUIRE(model && launches && total_ms && total_flops && tile >= 0 && tile < 7, MRCNN_ERR_INVALID, "bad argument");
+        MRCNN_REQUIRE(model && launches && total_ms && total_flops && tile >= 0 && tile < 8, MRCNN_ERR_INVALID, "bad argument");
         HIP_CHECK(hipStreamSynchronize(model->m.stream));
         model->m.conv_profile.collect();
         const auto& sl = model->m.conv_profile.by_tile[tile];
@@ -1020,6 +1020,77 @@ extern "C" int mrcnn_conv2d_nhwc(const float* in, int batch, int h, int w, int c
         } else {
             HIP_CHECK(hipMemcpy(out, result, n_out * 4, hipMemcpyDeviceToHost));
         }
+    });
+}
+
+// An identity bottleneck block of the fp16 mode on caller (host) data — the unit tests/test_gpu_bneck.py compares bit for bit:
+// fused = 1: the single persistent launch (kernels_bneck.hip); 0: the three launches of the 128-row / ping-pong kernels.
+extern "C" int mrcnn_bottleneck_nhwc(const float* x, int batch, int h, int w, int cmid, const float* w1, const float* w2, const float* w3,
+                                     const float* s1, const float* h1, const float* s2, const float* h2, const float* s3, const float* h3,
+                                     int fused, int iters, float* out, float* avg_ms)
+{
+    return guarded([&] {
+        require_gpu();
+        MRCNN_REQUIRE(x && w1 && w2 && w3 && s1 && h1 && s2 && h2 && s3 && h3 && out && batch >= 1 && h >= 1 && w >= 1 && cmid >= 64 && cmid % 64 == 0,
+                      MRCNN_ERR_INVALID, "bad bottleneck_nhwc argument");
+        const int C = cmid, C4 = 4 * cmid;
+        auto half_dev = [&](const float* src, size_t n, DevBuf& d) {
+            std::vector<_Float16> t(n);
+            for (size_t i = 0; i < n; ++i) t[i] = (_Float16)src[i];
+            d.alloc(n * 2);
+            HIP_CHECK(hipMemcpy(d.p, t.data(), n * 2, hipMemcpyHostToDevice));
+        };
+        auto f32_dev = [&](const float* src, size_t n, DevBuf& d) {
+            d.alloc(n * 4);
+            HIP_CHECK(hipMemcpy(d.p, src, n * 4, hipMemcpyHostToDevice));
+        };
+        const size_t npix = (size_t)batch * h * w;
+        DevBuf dx, dy, dt1, dt2, dw1, dw2, dw3, ds1, dh1, ds2, dh2, ds3, dh3;
+        half_dev(x, npix * C4, dx);
+        half_dev(w1, (size_t)C * C4, dw1);
+        half_dev(w2, (size_t)C * 9 * C, dw2);
+        half_dev(w3, (size_t)C4 * C, dw3);
+        f32_dev(s1, C, ds1); f32_dev(h1, C, dh1); f32_dev(s2, C, ds2); f32_dev(h2, C, dh2); f32_dev(s3, C4, ds3); f32_dev(h3, C4, dh3);
+        dy.alloc(npix * C4 * 2); dt1.alloc(npix * C * 2); dt2.alloc(npix * C * 2);
+        HIP_CHECK(hipMemset(dy.p, 0xff, npix * C4 * 2));
+        auto desc = [&](const void* in, int cin, const void* wgt, int k, const float* sc, const float* sh, void* o, int cout) {
+            ConvDesc d;
+            d.dtype = MRCNN_F16; d.wdtype = MRCNN_F16;
+            d.in = in; d.B = batch; d.H = h; d.W = w; d.Cin = cin;
+            d.in_sW = cin; d.in_sH = (long)w * cin; d.in_sB = (long)h * w * cin;
+            d.wgt = wgt; d.KH = d.KW = k; d.stride = 1; d.padH = d.padW = k / 2;
+            d.scale = sc; d.shift = sh;
+            d.OH = h; d.OW = w; d.Cout = cout; d.Npad = cout;
+            d.out = o; d.out_sP = cout; d.out_sB = (long)h * w * cout; d.act = ACT_RELU;
+            return d;
+        };
+        ConvDesc da = desc(dx.p, C4, dw1.p, 1, ds1.as<float>(), dh1.as<float>(), dt1.p, C);
+        ConvDesc db = desc(dt1.p, C, dw2.p, 3, ds2.as<float>(), dh2.as<float>(), dt2.p, C);
+        ConvDesc dc = desc(dt2.p, C, dw3.p, 1, ds3.as<float>(), dh3.as<float>(), dy.p, C4);
+        dc.res = dx.p; dc.res_sW = C4; dc.res_sH = (long)w * C4; dc.res_sB = (long)h * w * C4;
+        MRCNN_REQUIRE(!fused || conv_bneck_fusable(da, db, dc), MRCNN_ERR_UNSUPPORTED, "bottleneck_nhwc: C %d at %dx%d does not qualify for the fused launch", C, h, w);
+        Stream st;
+        auto run = [&] {
+            if (fused) conv_bneck_forward(st.s, da, db, dc);
+            else { conv_forward(st.s, da); conv_forward(st.s, db); conv_forward(st.s, dc); }
+        };
+        run();
+        HIP_CHECK(hipStreamSynchronize(st.s));
+        if (iters > 0 && avg_ms) {
+            hipEvent_t e0, e1;
+            HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+            HIP_CHECK(hipEventRecord(e0, st.s));
+            for (int i = 0; i < iters; ++i) run();
+            HIP_CHECK(hipEventRecord(e1, st.s));
+            HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            *avg_ms = ms / iters;
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        }
+        std::vector<_Float16> t(npix * C4);
+        HIP_CHECK(hipMemcpy(t.data(), dy.p, t.size() * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < t.size(); ++i) out[i] = (float)t[i];
     });
 }
 

@@ -801,6 +801,22 @@ void Model::build_maskrcnn()
             });
         };
 
+        // fp16 mode — an identity bottleneck (every non-first block of a stage) as ONE persistent launch with both branch tensors on
+        // chip (kernels_bneck.hip; bit-identical to the three launches, which conv_bneck_forward runs when the block does not qualify
+        // or behind mrcnn_debug_set("conv_bneck", 0)).  The fused form reads halo pixels of x that neighbouring tiles own, so it cannot
+        // write in place: such stages ping-pong between two block-output tensors.
+        auto bneck_op = [&](const std::string& na, const std::string& nb, const std::string& nc, const Tensor4& xin, const Tensor4& ta, const Tensor4& tb,
+                            const Tensor4& out, int g_in, int g_a, int g_b, int g_out) {
+            const ConvDesc da = make_desc(na, xin, ta, 1, 0, ACT_RELU, nullptr, 0, g_in, g_a);
+            const ConvDesc db = make_desc(nb, ta, tb, 1, 1, ACT_RELU, nullptr, 0, g_a, g_b);
+            const ConvDesc dc = make_desc(nc, tb, out, 1, 0, ACT_RELU, &xin, 0, g_b, g_out);
+            add([da, db, dc](hipStream_t s, int batch) {
+                ConvDesc a = da, b = db, c = dc;
+                a.B = b.B = c.B = batch;
+                conv_bneck_forward(s, a, b, c);
+            });
+        };
+
         d_rgb = (uint8_t*)ar.alloc_b((size_t)Bm * H * W * 3);
         // C1: zero-padded NHWC4 (fp32) / NHWC8 (fp16) staging — 16 B per pixel either way — so the 7×7/2 conv
         // is 7 row-taps of one contiguous 128-B run each; then the 3×3/2 max pool
@@ -855,7 +871,8 @@ void Model::build_maskrcnn()
         int g_x = g_c1;                                           // group of the running tensor x
         int g_C[6] = {-1, -1, -1, -1, -1, -1};
         for (int st = 2; st <= 5; ++st) {
-            Tensor4 stage_ta, stage_tb;
+            Tensor4 stage_ta, stage_tb, stage_main, stage_alt;
+            bool stage_fused = false, x_is_main = true;
             // every block output of a stage shares ONE group: the blocks add their shortcut in place (res == out)
             const int g_stage = new_split_group("C" + std::to_string(st));
             for (auto& b : blocks[st]) {
@@ -864,10 +881,22 @@ void Model::build_maskrcnn()
                 const int stride = (first && st > 2) ? 2 : 1;
                 const int oh = x.H / stride, ow = x.W / stride;
                 if (first) { stage_ta = T(oh, ow, f1s[st]); stage_tb = T(oh, ow, f1s[st]); }      // the branch tensors are reused by every block of the stage
+                if (first && mode == MRCNN_F16 && blocks[st].size() > 1 && bneck_geometry_ok(f1s[st], oh, ow)) {
+                    stage_fused = true;
+                    stage_alt = T(oh, ow, f3s[st]);
+                }
                 const int g_a = new_split_group("res" + p + "_branch2a"), g_b = new_split_group("res" + p + "_branch2b");
                 Tensor4 ta = stage_ta;
-                conv_op("res" + p + "_branch2a", x, ta, stride, 0, ACT_RELU, nullptr, 0, g_x, g_a);
                 Tensor4 tb = stage_tb;
+                if (!first && stage_fused) {
+                    const Tensor4 to = x_is_main ? stage_alt : stage_main;
+                    bneck_op("res" + p + "_branch2a", "res" + p + "_branch2b", "res" + p + "_branch2c", x, ta, tb, to, g_x, g_a, g_b, g_stage);
+                    x = to;
+                    x_is_main = !x_is_main;
+                    g_x = g_stage;
+                    continue;
+                }
+                conv_op("res" + p + "_branch2a", x, ta, stride, 0, ACT_RELU, nullptr, 0, g_x, g_a);
                 Tensor4 sc = x;
                 ConvDesc dsc;
                 if (first) {
@@ -881,6 +910,7 @@ void Model::build_maskrcnn()
                 Tensor4 to = sc;
                 tail_op("res" + p + "_branch2b", "res" + p + "_branch2c", ta, tb, to, sc, g_a, g_b, g_stage, first ? &dsc : nullptr);
                 x = to;
+                if (first) stage_main = to;
                 g_x = g_stage;
             }
             Cf[st] = x;

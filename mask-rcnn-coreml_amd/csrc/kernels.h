@@ -152,7 +152,7 @@ struct ConvDesc {
 // has been synchronised) folds the elapsed times into per-tile-shape totals.
 struct ConvProfile {
     struct Slot { long launches = 0; double ms = 0, flops = 0; };
-    Slot by_tile[7];                 // 0: 128x128, 1: 128x64, 2: 128x32, 3: 128x128 run by 4 waves of 32x128 (split modes, long K), 4: 256x256 ping-pong,
+    Slot by_tile[8];                 // 7: a whole identity bottleneck of the fp16 mode in one launch (kernels_bneck.hip; flops of its three layers); 0: 128x128, 1: 128x64, 2: 128x32, 3: 128x128 run by 4 waves of 32x128 (split modes, long K), 4: 256x256 ping-pong,
                                      // 5: persistent halo tiles (3x3 stride 1, split modes), 6: halo tiles with the fused bottleneck tail (3x3 + 1x1)
     std::vector<hipEvent_t> pool;
     struct Shape { int M, N, K, tile; bool operator<(const Shape& o) const { return std::tie(M, N, K, tile) < std::tie(o.M, o.N, o.K, o.tile); } };
@@ -200,6 +200,19 @@ bool conv_halo_tail_geometry_ok(int H, int W);                          // ... a
 bool conv_tail_fusable(const ConvDesc& d3, const ConvDesc& d1);
 int conv_sel_part_cols();       // selected-class mode: output columns per partial sum the next conv_forward will leave (64: wave-private form, 128: block-staged)
 void conv_forward_tail(hipStream_t s, const ConvDesc& d3, const ConvDesc& d1, const ConvDesc* sc = nullptr);      // sc: d1's shortcut convolution (conv_forward)
+
+// An identity ResNet bottleneck of the fp16 mode — da: the 1x1 `branch2a` (4C -> C, ReLU), db: the 3x3 `branch2b` reading da's output
+// (C -> C, ReLU), dc: the 1x1 `branch2c` reading db's output (C -> 4C, + shortcut = da's input, ReLU), C in {64, 128, 256} — as ONE
+// persistent launch (kernels_bneck.hip): the two mid tensors never leave the chip.  BIT-IDENTICAL to conv_forward(da); conv_forward(db);
+// conv_forward(dc), which is what conv_bneck_forward runs when the triple does not qualify or mrcnn_debug_set("conv_bneck", 0).  The fused
+// form needs dc.out != da.in (a tile reads halo pixels its neighbours own); whether a triple qualifies is a property of the layers'
+// geometry only, never of the batch.
+bool conv_bneck_fusable(const ConvDesc& da, const ConvDesc& db, const ConvDesc& dc);
+bool conv_bneck_enabled();
+void conv_bneck_forward(hipStream_t s, const ConvDesc& da, const ConvDesc& db, const ConvDesc& dc);
+bool bneck_geometry_ok(int C, int H, int W);
+void bneck_launch(hipStream_t s, int C, const void* x, void* y, int B, int H, int W, const void* w1, const void* w2, const void* w3,
+                  const float* s1, const float* h1, const float* s2, const float* h2, const float* s3, const float* h3, int* range_flag, int n_cus);
 
 // The stem in the split modes and the fp16 mode (kernels_conv_stem.hip): conv1 — described by d exactly as for conv_forward (7 row taps of 32 "channels"
 // on the zero-padded NHWC4 input, 64 output columns, ReLU) — and the 3x3 stride-2 'same' max-pool behind it in ONE persistent launch;

@@ -1,0 +1,473 @@
+// kernels_bneck.hip — an identity ResNet bottleneck block of the fp16 mode as ONE persistent launch on gfx950.
+//
+// Reference layers: the `res<stage><block>_branch2a / 2b / 2c` convolutions + BatchNorm + ReLU and the shortcut add of every
+// non-first block of C2..C5 in MaskRCNN.mlmodel (Sources/maskrcnn/Python/Conversion/task.py:69-92; the layer list is the
+// Matterport ResNet graph):
+//     t1 = relu(bn(x  * W1))            1x1, 4C -> C
+//     t2 = relu(bn(t1 * W2))            3x3, C -> C, zero padding 1
+//     y  = relu(bn(t2 * W3) + x)        1x1, C -> 4C, + shortcut
+// Three launches of the 128-row kernels move x three times (2a's input, 2c's residual, the next block) and t1 / t2 twice each,
+// and every launch pays its own pipeline fill and epilogue drain on a grid that is one or two rounds deep (C4: 29 + 45 + 43 us
+// at batch 8 for 73 GFLOP, 621 TFLOP/s; C2: 276 us against a 107 us HBM floor — profiles/r04_conv_shapes_f16.txt).  Here a
+// block of 512 threads owns a TH x 16 output tile and runs the three GEMMs back to back with t1 and t2 ON CHIP:
+//   phase A  t1 on the tile's halo region ((TH+2) x 18 pixels, recomputed per tile) — x staged through an LDS ring in 32-channel
+//            steps (64-B rows), W1 beside it; the result goes to LDS as fp16 with out-of-image pixels ZERO (= the 3x3 layer's padding);
+//   phase B  the 3x3 layer as 9 taps x C/64 steps: activation fragments are SHIFTED windows of t1 in LDS (no im2col, no reload),
+//            W2 streams through the ring in 128-B rows; t2 goes back to LDS (over t1, which is dead by then);
+//   phase C  the 1x1 expansion in four chunks of C output columns: t2 from LDS, W3 through the ring, epilogue + residual + ReLU
+//            straight from the accumulators to HBM.
+// Only the weights stream from L2 in phases B / C, so the kernel needs fewer vector-memory instructions per MFMA than any
+// 128-row tile (the CU's memory front end, not the matrix pipe, bounds the fp16 kernels).
+//
+// BIT-IDENTICAL to the three launches (tests/test_gpu_bneck.py): every output sums its K in the same order — 64-channel steps,
+// tap-major for the 3x3 layer, four 16-wide MFMA groups per step, filter fragment as first MFMA operand — t1 / t2 are rounded to
+// fp16 exactly where the fp16 tensors of the three-launch form are, and the epilogue arithmetic is conv_epilogue_direct's.  Which
+// form runs is decided by the layer's geometry only (conv_bneck_fusable), never by the batch.
+//
+// The output must NOT alias the input: a tile reads the halo pixels its neighbours own.  (The three-launch form writes in place;
+// the engine gives fused stages a second tensor and ping-pongs.)
+#include <type_traits>
+
+#include "conv_device.h"
+
+namespace mrcnn {
+
+template <int C>
+struct BnCfg {
+    static constexpr int TH = C == 256 ? 8 : 16, TW = 16, P = TH * TW;      // output tile (pixels)
+    static constexpr int HWD = TW + 2, HP = (TH + 2) * HWD;                 // halo region: pitch 18 (even: see the bank analysis below), pixels
+    static constexpr int WM = P / 64, WN = 8 / WM;                          // 8 waves as WM x WN; wave tile 64 pixels x NB channels in phases B / C
+    static constexpr int HPAD = 96 * WM;                                    // GEMM rows of phase A (>= HP; wave tile 96 x NB)
+    static constexpr int NB = C / WN, TNW = NB / 32;
+    static constexpr int CB = C / 64;                                       // 64-channel blocks of the mid tensors
+    static constexpr int T1_BYTES = HP * C * 2, T2_BYTES = P * C * 2;
+    static constexpr int A_X = HPAD * 64, A_W = C * 64, A_STAGE = A_X + A_W;     // phase A: 32 channels per step, 64-B rows
+    static constexpr int B_STAGE = C * 128;                                      // phases B / C: 64 channels per step, 128-B filter rows
+    static constexpr int RING = 2 * A_STAGE > 2 * B_STAGE ? 2 * A_STAGE : 2 * B_STAGE;
+    // LDS map: the ring FIRST (LDS-DMA destinations stay below 128 KB), then t1 (t2 and phase C's table alias it), then the tables of phases A / B
+    static constexpr int OFF_T1 = RING, OFF_TABC = OFF_T1 + T2_BYTES, OFF_TABAB = OFF_T1 + T1_BYTES;
+    static constexpr int LDS = OFF_TABAB + 4 * C * 4;
+    static constexpr int NA = 4 * C / 32, NBS = 9 * CB, NCS = 4 * CB;       // K steps of the three phases
+    static constexpr int NXD = HPAD / 16, NAD = NXD + C / 16;               // phase A: 1-KB DMAs per step (x rows | W1 rows)
+    static_assert(HPAD >= HP && T2_BYTES + 8 * C * 4 <= T1_BYTES && LDS <= 163840 && NA % 2 == 0, "layout");
+};
+
+struct BneckArgs {
+    const _Float16* x; _Float16* y;
+    const _Float16 *w1, *w2, *w3;
+    const float *s1, *h1, *s2, *h2, *s3, *h3;
+    int B, H, W, tiles_x, tiles_y, ntiles;
+    int* range_flag;
+    int dbg;
+};
+
+typedef unsigned bn_srd_t __attribute__((ext_vector_type(4)));
+#define BN_BLDS(VOFF, SRD, SOFF, DST)                                                                          \
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(VOFF), "s"(SRD), "s"(SOFF), "s"(DST) : "memory", "m0");
+#define BN_VMCNT0 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define BN_MFMA(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, C_, 0, 0, 0);
+
+// fp32 runs of four channels (q = 2p | 2p + 1 of a 32 x 32 result tile) -> fp16, glued into 16 contiguous bytes per lane:
+// lane (l31, 0) channels 16p .. 16p+7, lane (l31, 1) channels 16p+8 .. 16p+15 (conv_epilogue_direct's store layout)
+__device__ __forceinline__ uint4 bn_pack16(const float4 va, const float4 vb)
+{
+    f16x4 ha4, hb4;
+    ha4[0] = (_Float16)va.x; ha4[1] = (_Float16)va.y; ha4[2] = (_Float16)va.z; ha4[3] = (_Float16)va.w;
+    hb4[0] = (_Float16)vb.x; hb4[1] = (_Float16)vb.y; hb4[2] = (_Float16)vb.z; hb4[3] = (_Float16)vb.w;
+    const uint2 pa = __builtin_bit_cast(uint2, ha4), pb = __builtin_bit_cast(uint2, hb4);
+    const auto sx = __builtin_amdgcn_permlane32_swap(pa.x, pb.x, false, false);
+    const auto sy = __builtin_amdgcn_permlane32_swap(pa.y, pb.y, false, false);
+    return make_uint4(sx[0], sy[0], sx[1], sy[1]);
+}
+// the inverse: 16 B in the store layout -> the two fp32 runs a lane accumulates (the swap is an involution)
+__device__ __forceinline__ void bn_unpack16(const uint4 r, float4& ra, float4& rb)
+{
+    const auto sx = __builtin_amdgcn_permlane32_swap(r.x, r.z, false, false);
+    const auto sy = __builtin_amdgcn_permlane32_swap(r.y, r.w, false, false);
+    const f16x4 h0 = __builtin_bit_cast(f16x4, make_uint2(sx[0], sy[0])), h1 = __builtin_bit_cast(f16x4, make_uint2(sx[1], sy[1]));
+    ra = make_float4((float)h0[0], (float)h0[1], (float)h0[2], (float)h0[3]);
+    rb = make_float4((float)h1[0], (float)h1[1], (float)h1[2], (float)h1[3]);
+}
+__device__ __forceinline__ bool bn_bad(const float4 v)
+{
+    return !(fabsf(v.x) < 65504.0f) || !(fabsf(v.y) < 65504.0f) || !(fabsf(v.z) < 65504.0f) || !(fabsf(v.w) < 65504.0f);
+}
+
+// LDS bank notes (MI355X_MICROARCH.md §LDS: ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} of
+// each half-wave, 64 banks of 4 B):
+//   * 128-B rows (ring of phases B / C, t2): 16-B chunk c of row r at c ^ ((r >> 1) & 7) — the kernel family's swizzle;
+//   * 64-B rows (ring of phase A): chunk c of row r at c ^ ((r >> 2) & 3);
+//   * t1: [64-channel block][halo pixel][128 B].  A 32-lane fragment covers two tile rows of 16 pixels, shifted by the tap: its
+//     lane groups read halo columns {dx + 0..3, dx + 12..15} of one halo row and {dx + 4..11} of the next, so the swizzle key is
+//     the halo COLUMN: chunk c of pixel (py, px) at c ^ ((px >> 1) & 7), and with an even pitch (18) the 128-B half of the
+//     256-B bank line is px & 1 — sixteen distinct (half, key) pairs for any tap.
+template <int C>
+__global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
+{
+    using K = BnCfg<C>;
+    constexpr int HP = K::HP, HWD = K::HWD, WN = K::WN, NB = K::NB, TNW = K::TNW, CB = K::CB, P = K::P;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[K::LDS];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int l31 = lane & 31, kk = lane >> 5;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
+
+    // ---- buffer resources (raw, stride 0): a lane offset beyond num_records deposits zeros in LDS ----
+    constexpr unsigned OOB = 0x80000000u;        // (+ any K-step offset stays out of range, no wrap)
+    const unsigned img_bytes = (unsigned)((size_t)a.H * a.W * 4 * C * 2);
+    bn_srd_t srdX, srdW1, srdW2, srdW3;
+    auto mk = [](const void* p, unsigned bytes) {
+        const unsigned long long u = (unsigned long long)(uintptr_t)p;
+        bn_srd_t r;
+        r[0] = __builtin_amdgcn_readfirstlane((unsigned)u);
+        r[1] = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32) & 0xffffu);
+        r[2] = bytes;
+        r[3] = 0x00020000u;
+        return r;
+    };
+    srdW1 = mk(a.w1, (unsigned)(C * 4 * C * 2));
+    srdW2 = mk(a.w2, (unsigned)(C * 9 * C * 2));
+    srdW3 = mk(a.w3, (unsigned)(4 * C * C * 2));
+
+    // ---- tables of phases A / B: scale | shift of t1, scale | shift of t2 (once per block) ----
+    float* const tabAB = reinterpret_cast<float*>(smem + K::OFF_TABAB);
+    float* const tabC = reinterpret_cast<float*>(smem + K::OFF_TABC);
+    for (int i = t; i < 4 * C; i += 512) {
+        const int w = i / C, c = i - w * C;
+        const float* src = w == 0 ? a.s1 : w == 1 ? a.h1 : w == 2 ? a.s2 : a.h2;
+        tabAB[i] = src ? src[c] : ((w & 1) ? 0.0f : 1.0f);
+    }
+
+    // ---- loop-invariant DMA lane geometry ----
+    // phase A (64-B rows, 16 rows per DMA): DMA u = wave + 8 j; u < NXD: x rows 16u.., else W1 rows 16(u - NXD)..
+    const int r16 = lane >> 2, c4 = (lane & 3) ^ ((lane >> 4) & 3);            // row inside the DMA, SOURCE chunk held at position lane & 3
+    unsigned w1off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int u = wave + 8 * j;
+        const int n = 16 * (u - K::NXD) + r16;
+        w1off[j] = (unsigned)(n * 4 * C * 2 + c4 * 16);
+    }
+    // phases B / C (128-B rows, 8 rows per DMA): DMA d = wave + 8 j, j < CB
+    unsigned w2off[CB], w3off[CB];
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+        const int row = 8 * (wave + 8 * j) + (lane >> 3);
+        const int c8 = (lane & 7) ^ ((row >> 1) & 7);
+        w2off[j] = (unsigned)(row * 9 * C * 2 + c8 * 16);
+        w3off[j] = (unsigned)(row * C * 2 + c8 * 16);
+    }
+    // ---- loop-invariant fragment addresses ----
+    const int sw64 = (l31 >> 2) & 3, sw128 = (l31 >> 1) & 7;
+    // phase A: x rows wm*96 + i*32 + l31, W1 rows wn*NB + j*32 + l31 (64-B rows); K group g: chunk 2g + kk
+    const unsigned axr = (unsigned)((wm * 96 + l31) * 64), awr = (unsigned)(K::A_X + (wn * NB + l31) * 64);
+    const unsigned a_c0 = (unsigned)(((0 + kk) ^ sw64) << 4), a_c1 = (unsigned)(((2 + kk) ^ sw64) << 4);
+    // phases B / C: filter rows wn*NB + j*32 + l31 (128-B rows)
+    const unsigned bwr = (unsigned)((wn * NB + l31) * 128);
+    unsigned w_c[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) w_c[g] = (unsigned)(((2 * g + kk) ^ sw128) << 4);
+    // phase B: output pixel p = wm*64 + i*32 + l31 -> (py, px) in the tile; tap (dy, dx) reads halo pixel (py + dy, px + dx)
+    unsigned t1row[2];          // byte offset of halo pixel (py, px) in block 0 of t1
+    int pxi[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p = wm * 64 + i * 32 + l31;
+        const int py = p >> 4, px = p & 15;
+        t1row[i] = (unsigned)(K::OFF_T1 + (py * HWD + px) * 128);
+        pxi[i] = px;
+    }
+    // phase C: t2 rows p (128-B rows per 64-channel block)
+    const unsigned t2row = (unsigned)(K::OFF_T1 + (wm * 64 + l31) * 128);
+
+    bool range_trip = false;
+    const int nblocks = a.ntiles;
+    const int q8 = nblocks >> 3, r8 = nblocks & 7;
+    __syncthreads();
+    for (int v = blockIdx.x; v < nblocks; v += gridDim.x) {
+        // XCD-aware bijective walk: the blocks of one XCD (blockIdx & 7) own a contiguous run of tiles (neighbours share halo rows and L2)
+        const int xcd = v & 7, local = v >> 3;
+        const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+        const int per_img = a.tiles_x * a.tiles_y;
+        const int b = tile / per_img, tr = tile - b * per_img;
+        const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
+        const int y0 = ty * K::TH, x0 = tx * K::TW;
+        const _Float16* const ximg = a.x + (size_t)b * a.H * a.W * 4 * C;
+        _Float16* const yimg = a.y + (size_t)b * a.H * a.W * 4 * C;
+        srdX = mk(ximg, img_bytes);
+
+        // x rows of this thread's phase-A DMAs: halo pixel r -> image pixel (y0 - 1 + r / 18, x0 - 1 + r % 18)
+        unsigned xoff[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int u = wave + 8 * j;
+            const int r = 16 * u + r16;
+            const int py = r / HWD, px = r - py * HWD;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            const bool ok = r < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            xoff[j] = ok ? (unsigned)(((size_t)gy * a.W + gx) * 4 * C * 2 + c4 * 16) : OOB;
+        }
+
+        // =========================== phase A: t1 = relu(bn(x * W1)) on the halo region ===========================
+        f32x16 acc1[3][TNW];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < TNW; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc1[i][j][e] = 0.0f;
+        // stage 0 at the bottom of the ring, stage 1 at its top
+#define BN_ISSUE_A(KS)                                                                                         \
+    {                                                                                                          \
+        const unsigned sb_ = lds0 + (((KS) & 1) ? (unsigned)(K::RING - K::A_STAGE) : 0u);                      \
+        const unsigned ko_ = (unsigned)(KS) * 64u;                                                             \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                        \
+            const int u = wave + 8 * j;                                                                        \
+            if (u < K::NXD) { BN_BLDS(xoff[j] + ko_, srdX, 0, sb_ + u * 1024) }                                \
+            else if (u < K::NAD) { BN_BLDS(w1off[j] + ko_, srdW1, 0, sb_ + K::A_X + (u - K::NXD) * 1024) }     \
+        }                                                                                                      \
+    }
+        BN_ISSUE_A(0)
+        for (int ks = 0; ks < K::NA; ++ks) {
+            BN_VMCNT0
+            __syncthreads();                           // step ks has landed for everyone; everyone is done reading step ks - 1
+            if (ks + 1 < K::NA) BN_ISSUE_A(ks + 1)
+            const unsigned char* const sb = smem + ((ks & 1) ? (K::RING - K::A_STAGE) : 0);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const unsigned co = g ? a_c1 : a_c0;
+                f16x8 xf[3], wf[TNW];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) xf[i] = *reinterpret_cast<const f16x8*>(sb + axr + i * 32 * 64 + co);
+#pragma unroll
+                for (int j = 0; j < TNW; ++j) wf[j] = *reinterpret_cast<const f16x8*>(sb + awr + j * 32 * 64 + co);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < TNW; ++j) BN_MFMA(wf[j], xf[i], acc1[i][j])
+            }
+        }
+        // epilogue A -> t1 (fp16, zero outside the image).  Nobody reads t1 / t2 any more: every wave passed the barriers of
+        // this phase after its last read of the previous tile's phase C.
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int r = wm * 96 + i * 32 + l31;
+            const int py = r / HWD, px = r - py * HWD;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            const bool valid = r < HP;
+            const bool inimg = valid && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            const unsigned swz = (unsigned)((px >> 1) & 7);
+#pragma unroll
+            for (int j = 0; j < TNW; ++j)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int cl = wn * NB + j * 32 + 16 * p + 4 * kk;
+                    const float4 sa = *reinterpret_cast<const float4*>(tabAB + cl), sb_ = *reinterpret_cast<const float4*>(tabAB + cl + 8);
+                    const float4 ha = *reinterpret_cast<const float4*>(tabAB + C + cl), hb = *reinterpret_cast<const float4*>(tabAB + C + cl + 8);
+                    float4 va = make_float4(acc1[i][j][8 * p + 0], acc1[i][j][8 * p + 1], acc1[i][j][8 * p + 2], acc1[i][j][8 * p + 3]);
+                    float4 vb = make_float4(acc1[i][j][8 * p + 4], acc1[i][j][8 * p + 5], acc1[i][j][8 * p + 6], acc1[i][j][8 * p + 7]);
+                    va.x = va.x * sa.x + ha.x; va.y = va.y * sa.y + ha.y; va.z = va.z * sa.z + ha.z; va.w = va.w * sa.w + ha.w;
+                    vb.x = vb.x * sb_.x + hb.x; vb.y = vb.y * sb_.y + hb.y; vb.z = vb.z * sb_.z + hb.z; vb.w = vb.w * sb_.w + hb.w;
+                    va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f); va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
+                    vb.x = fmaxf(vb.x, 0.f); vb.y = fmaxf(vb.y, 0.f); vb.z = fmaxf(vb.z, 0.f); vb.w = fmaxf(vb.w, 0.f);
+                    if (inimg) range_trip = range_trip || bn_bad(va) || bn_bad(vb);
+                    else { va = make_float4(0.f, 0.f, 0.f, 0.f); vb = va; }
+                    const uint4 pk = bn_pack16(va, vb);
+                    const int ch0 = wn * NB + j * 32 + 16 * p + 8 * kk;
+                    const unsigned off = (unsigned)(K::OFF_T1 + ((ch0 >> 6) * HP + r) * 128) + ((((unsigned)(ch0 & 63) >> 3) ^ swz) << 4);
+                    if (valid) *reinterpret_cast<uint4*>(smem + off) = pk;
+                }
+        }
+#undef BN_ISSUE_A
+
+        // =========================== phase B: t2 = relu(bn(conv3x3(t1))) ===========================
+        f32x16 acc[2][TNW];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TNW; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+#define BN_ISSUE_W(OFFS, SRD, SOFF, ST)                                                                        \
+    {                                                                                                          \
+        const unsigned sb_ = lds0 + (unsigned)(ST) * (unsigned)K::B_STAGE;                                     \
+        _Pragma("unroll") for (int j = 0; j < CB; ++j) { BN_BLDS(OFFS[j], SRD, SOFF, sb_ + (wave + 8 * j) * 1024) } \
+    }
+        __syncthreads();                               // t1 complete; the ring's last phase-A reads have retired
+        BN_ISSUE_W(w2off, srdW2, 0u, 0)
+        {
+            int tap = 0, cb = 0, dy = 0, dx = 0;
+            for (int s = 0; s < K::NBS; ++s) {
+                BN_VMCNT0
+                __syncthreads();
+                {
+                    int cb1 = cb + 1, tap1 = tap;
+                    if (cb1 == CB) { cb1 = 0; ++tap1; }
+                    if (s + 1 < K::NBS) BN_ISSUE_W(w2off, srdW2, (unsigned)((tap1 * C + cb1 * 64) * 2), (s + 1) & 1)
+                }
+                const unsigned char* const sb = smem + (s & 1) * K::B_STAGE;
+                const unsigned tapoff = (unsigned)((cb * HP + dy * HWD + dx) * 128);
+                unsigned ax[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) ax[i] = (unsigned)((((pxi[i] + dx) >> 1) & 7) << 4) ^ (unsigned)(kk << 4);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f16x8 af[2], wf[TNW];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f16x8*>(smem + t1row[i] + tapoff + (ax[i] ^ (unsigned)(g << 5)));
+#pragma unroll
+                    for (int j = 0; j < TNW; ++j) wf[j] = *reinterpret_cast<const f16x8*>(sb + bwr + j * 32 * 128 + w_c[g]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < TNW; ++j) BN_MFMA(wf[j], af[i], acc[i][j])
+                }
+                if (++cb == CB) { cb = 0; ++tap; if (++dx == 3) { dx = 0; ++dy; } }
+            }
+        }
+        __syncthreads();                               // every wave is done with t1: t2 and phase C's table may overwrite it
+        // phase C's table: scale | shift of the 4C output columns
+        for (int i = t; i < 8 * C; i += 512) {
+            const int w = i / (4 * C), c = i - w * 4 * C;
+            const float* src = w == 0 ? a.s3 : a.h3;
+            tabC[i] = src ? src[c] : (w ? 0.0f : 1.0f);
+        }
+        // the first W3 step rides under the epilogue (the ring is free: the barrier above retired phase B's last reads)
+        BN_ISSUE_W(w3off, srdW3, 0u, K::NBS & 1)
+        // epilogue B -> t2
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p_ = wm * 64 + i * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < TNW; ++j)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int cl = wn * NB + j * 32 + 16 * p + 4 * kk;
+                    const float4 sa = *reinterpret_cast<const float4*>(tabAB + 2 * C + cl), sb_ = *reinterpret_cast<const float4*>(tabAB + 2 * C + cl + 8);
+                    const float4 ha = *reinterpret_cast<const float4*>(tabAB + 3 * C + cl), hb = *reinterpret_cast<const float4*>(tabAB + 3 * C + cl + 8);
+                    float4 va = make_float4(acc[i][j][8 * p + 0], acc[i][j][8 * p + 1], acc[i][j][8 * p + 2], acc[i][j][8 * p + 3]);
+                    float4 vb = make_float4(acc[i][j][8 * p + 4], acc[i][j][8 * p + 5], acc[i][j][8 * p + 6], acc[i][j][8 * p + 7]);
+                    va.x = va.x * sa.x + ha.x; va.y = va.y * sa.y + ha.y; va.z = va.z * sa.z + ha.z; va.w = va.w * sa.w + ha.w;
+                    vb.x = vb.x * sb_.x + hb.x; vb.y = vb.y * sb_.y + hb.y; vb.z = vb.z * sb_.z + hb.z; vb.w = vb.w * sb_.w + hb.w;
+                    va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f); va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
+                    vb.x = fmaxf(vb.x, 0.f); vb.y = fmaxf(vb.y, 0.f); vb.z = fmaxf(vb.z, 0.f); vb.w = fmaxf(vb.w, 0.f);
+                    range_trip = range_trip || bn_bad(va) || bn_bad(vb);
+                    const uint4 pk = bn_pack16(va, vb);
+                    const int ch0 = wn * NB + j * 32 + 16 * p + 8 * kk;
+                    const unsigned off = (unsigned)(K::OFF_T1 + ((ch0 >> 6) * P + p_) * 128) + ((((unsigned)(ch0 & 63) >> 3) ^ (unsigned)sw128) << 4);
+                    *reinterpret_cast<uint4*>(smem + off) = pk;
+                }
+        }
+
+        // =========================== phase C: y = relu(bn(t2 * W3) + x), four chunks of C columns ===========================
+        {
+            int s = K::NBS;              // the ring's step counter runs on from phase B (stage = s & 1)
+            size_t grow[2];              // element offset of the lane's pixel in the image
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int p_ = wm * 64 + i * 32 + l31;
+                grow[i] = ((size_t)(y0 + (p_ >> 4)) * a.W + (x0 + (p_ & 15))) * (size_t)(4 * C);
+            }
+            for (int ch = 0; ch < 4; ++ch) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TNW; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+                // the shortcut of the chunk: requested ahead of its K loop (16 B = eight channels per lane, the store layout)
+                uint4 rv[2][TNW][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TNW; ++j)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+                            rv[i][j][p] = *reinterpret_cast<const uint4*>(ximg + grow[i] + ch * C + wn * NB + j * 32 + 16 * p + 8 * kk);
+                for (int kb = 0; kb < CB; ++kb, ++s) {
+                    BN_VMCNT0
+                    __syncthreads();
+                    {
+                        int kb1 = kb + 1, ch1 = ch;
+                        if (kb1 == CB) { kb1 = 0; ++ch1; }
+                        if (ch1 < 4) BN_ISSUE_W(w3off, srdW3, (unsigned)((ch1 * C * C + kb1 * 64) * 2), (s + 1) & 1)
+                    }
+                    const unsigned char* const sb = smem + (s & 1) * K::B_STAGE;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f16x8 af[2], wf[TNW];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f16x8*>(smem + t2row + (kb * P + i * 32) * 128 + w_c[g]);
+#pragma unroll
+                        for (int j = 0; j < TNW; ++j) wf[j] = *reinterpret_cast<const f16x8*>(sb + bwr + j * 32 * 128 + w_c[g]);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < TNW; ++j) BN_MFMA(wf[j], af[i], acc[i][j])
+                    }
+                }
+                // epilogue of the chunk: straight from the accumulators
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TNW; ++j)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            const int cl = ch * C + wn * NB + j * 32 + 16 * p + 4 * kk;
+                            const float4 sa = *reinterpret_cast<const float4*>(tabC + cl), sb_ = *reinterpret_cast<const float4*>(tabC + cl + 8);
+                            const float4 ha = *reinterpret_cast<const float4*>(tabC + 4 * C + cl), hb = *reinterpret_cast<const float4*>(tabC + 4 * C + cl + 8);
+                            float4 va = make_float4(acc[i][j][8 * p + 0], acc[i][j][8 * p + 1], acc[i][j][8 * p + 2], acc[i][j][8 * p + 3]);
+                            float4 vb = make_float4(acc[i][j][8 * p + 4], acc[i][j][8 * p + 5], acc[i][j][8 * p + 6], acc[i][j][8 * p + 7]);
+                            va.x = va.x * sa.x + ha.x; va.y = va.y * sa.y + ha.y; va.z = va.z * sa.z + ha.z; va.w = va.w * sa.w + ha.w;
+                            vb.x = vb.x * sb_.x + hb.x; vb.y = vb.y * sb_.y + hb.y; vb.z = vb.z * sb_.z + hb.z; vb.w = vb.w * sb_.w + hb.w;
+                            float4 ra, rb;
+                            bn_unpack16(rv[i][j][p], ra, rb);
+                            va.x += ra.x; va.y += ra.y; va.z += ra.z; va.w += ra.w;
+                            vb.x += rb.x; vb.y += rb.y; vb.z += rb.z; vb.w += rb.w;
+                            va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f); va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
+                            vb.x = fmaxf(vb.x, 0.f); vb.y = fmaxf(vb.y, 0.f); vb.z = fmaxf(vb.z, 0.f); vb.w = fmaxf(vb.w, 0.f);
+                            range_trip = range_trip || bn_bad(va) || bn_bad(vb);
+                            const uint4 pk = bn_pack16(va, vb);
+                            *reinterpret_cast<uint4*>(yimg + grow[i] + ch * C + wn * NB + j * 32 + 16 * p + 8 * kk) = pk;
+                        }
+            }
+        }
+#undef BN_ISSUE_W
+        __syncthreads();                               // the next tile's phase A restarts the ring at stage 0
+    }
+    if (a.range_flag && range_trip) atomicOr(a.range_flag, 1);
+}
+
+bool bneck_geometry_ok(int C, int H, int W)
+{
+    if (C == 256) return H % BnCfg<256>::TH == 0 && W % 16 == 0;
+    if (C == 128) return H % BnCfg<128>::TH == 0 && W % 16 == 0;
+    if (C == 64) return H % BnCfg<64>::TH == 0 && W % 16 == 0;
+    return false;
+}
+
+void bneck_launch(hipStream_t s, int C, const void* x, void* y, int B, int H, int W, const void* w1, const void* w2, const void* w3,
+                  const float* s1, const float* h1, const float* s2, const float* h2, const float* s3, const float* h3, int* range_flag, int n_cus)
+{
+    MRCNN_REQUIRE(bneck_geometry_ok(C, H, W), MRCNN_ERR_SHAPE, "bneck: C %d at %dx%d", C, H, W);
+    MRCNN_REQUIRE(x != y, MRCNN_ERR_INVALID, "bneck: the output must not alias the input");
+    MRCNN_REQUIRE((size_t)H * W * 4 * C * 2 < 0x80000000ull, MRCNN_ERR_SHAPE, "bneck: image of %dx%dx%d exceeds the 2-GB offset range", H, W, 4 * C);
+    BneckArgs a;
+    a.x = static_cast<const _Float16*>(x); a.y = static_cast<_Float16*>(y);
+    a.w1 = static_cast<const _Float16*>(w1); a.w2 = static_cast<const _Float16*>(w2); a.w3 = static_cast<const _Float16*>(w3);
+    a.s1 = s1; a.h1 = h1; a.s2 = s2; a.h2 = h2; a.s3 = s3; a.h3 = h3;
+    a.B = B; a.H = H; a.W = W;
+    const int th = C == 256 ? 8 : 16;
+    a.tiles_x = W / 16; a.tiles_y = H / th; a.ntiles = B * a.tiles_x * a.tiles_y;
+    a.range_flag = range_flag; a.dbg = 0;
+    int grid = n_cus > 0 ? n_cus / 8 * 8 : 256;
+    if (grid <= 0) grid = 8;
+    if (a.ntiles < grid) grid = a.ntiles;
+    if (C == 256) hipLaunchKernelGGL(k_bneck_h<256>, dim3(grid), dim3(512), 0, s, a);
+    else if (C == 128) hipLaunchKernelGGL(k_bneck_h<128>, dim3(grid), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(k_bneck_h<64>, dim3(grid), dim3(512), 0, s, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace mrcnn

@@ -573,6 +573,10 @@ static int g_tail_dbg = env_int("MRCNN_TAIL_DBG", 0);        // measurement only
 // 1x1 K loop 21 + epilogue 37, strictly additive — profiles/r04_tail_ablate_f32x3.txt), so OFF by default;
 // MRCNN_TAIL=1 / mrcnn_debug_set("conv_tail", 1) switch it on (tests keep it bit-identical)
 static int g_tail = env_int("MRCNN_TAIL", 0);
+// fp16 mode: identity bottleneck blocks (branch2a + branch2b + branch2c + shortcut) as ONE persistent launch with the two mid tensors on chip
+// (kernels_bneck.hip; bit-identical to the three launches).  MRCNN_BNECK=0 / mrcnn_debug_set("conv_bneck", 0): the three launches.
+static int g_bneck = env_int("MRCNN_BNECK", 1);
+bool conv_bneck_enabled() { return g_bneck != 0; }
 // Canonical K chunks (round 4): the long-K 1x1 layers of the split modes — K >= 2048: C5's `branch2a`, the P5
 // lateral, the box head's first inner product (K = 12 544) — sum their K steps as ((0 + P0) + P1) + ..., 4 / 8 equal chunks by the
 // layer's shape alone, at EVERY batch.  A grid that fills the chip runs the chunks in one block (a second accumulator set, folded at
@@ -663,6 +667,7 @@ bool conv_debug_set(const char* key, int value)
     else if (k == "conv_tail") g_tail = value;
     else if (k == "conv_stem") g_stem = value;
     else if (k == "conv_tail_dbg") g_tail_dbg = value;
+    else if (k == "conv_bneck") g_bneck = value;
     else return conv_halo_debug_set(key, value);
     return true;
 }
@@ -955,6 +960,48 @@ void conv_forward_tail(hipStream_t s, const ConvDesc& d3, const ConvDesc& d1, co
         prof->pending.push_back({6, fl, e0, e1, {a3.M, a1.ncols, a3.Ktot + a1.Ktot, 6}});
     }
     HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused identity bottleneck of the fp16 mode (kernels.h: conv_bneck_forward)
+// ------------------------------------------------------------------------------------------------
+bool conv_bneck_fusable(const ConvDesc& da, const ConvDesc& db, const ConvDesc& dc)
+{
+    auto f16 = [](const ConvDesc& d) { return d.dtype == MRCNN_F16 && (d.wdtype < 0 || d.wdtype == MRCNN_F16) && !d.out_f32; };
+    if (!f16(da) || !f16(db) || !f16(dc)) return false;
+    const int C = da.Cout, H = da.H, W = da.W;
+    if (!(C == 64 || C == 128 || C == 256) || !bneck_geometry_ok(C, H, W)) return false;
+    auto plain = [](const ConvDesc& d) { return !d.out2 && !d.deconv2 && !d.sel_partial && !d.head_w && d.res_shift == 0 && d.act == ACT_RELU && d.scale && d.shift; };
+    if (!plain(da) || !plain(db) || !plain(dc) || da.res || db.res) return false;
+    auto dense_in = [](const ConvDesc& d, int h, int w, int c) { return d.H == h && d.W == w && d.Cin == c && d.in_sW == c && d.in_sH == (long)w * c && d.in_sB == (long)h * w * c; };
+    auto dense_out = [](const ConvDesc& d, int h, int w, int c) { return d.OH == h && d.OW == w && d.Cout == c && d.out_sP == c && d.out_sB == (long)h * w * c; };
+    if (da.KH != 1 || da.KW != 1 || da.stride != 1 || da.padH || da.padW || !dense_in(da, H, W, 4 * C) || !dense_out(da, H, W, C)) return false;
+    if (db.KH != 3 || db.KW != 3 || db.stride != 1 || db.padH != 1 || db.padW != 1 || db.in != da.out || !dense_in(db, H, W, C) || !dense_out(db, H, W, C)) return false;
+    if (dc.KH != 1 || dc.KW != 1 || dc.stride != 1 || dc.padH || dc.padW || dc.in != db.out || !dense_in(dc, H, W, C) || !dense_out(dc, H, W, 4 * C)) return false;
+    if (dc.res != da.in || dc.res_sW != 4 * C || dc.res_sH != (long)W * 4 * C || dc.res_sB != (long)H * W * 4 * C) return false;
+    if (dc.out == da.in) return false;                // a tile reads halo pixels its neighbours own
+    if (da.B != db.B || da.B != dc.B) return false;
+    return true;
+}
+
+void conv_bneck_forward(hipStream_t s, const ConvDesc& da, const ConvDesc& db, const ConvDesc& dc)
+{
+    static int n_cus = [] { int dev = 0; hipDeviceProp_t p; (void)hipGetDevice(&dev); return hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }();
+    if (!g_bneck || !conv_bneck_fusable(da, db, dc)) {
+        conv_forward(s, da);
+        conv_forward_tail(s, db, dc, nullptr);
+        return;
+    }
+    ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
+    const int e0 = prof ? prof_event(prof, s) : 0;
+    bneck_launch(s, da.Cout, da.in, dc.out, da.B, da.H, da.W, da.wgt, db.wgt, dc.wgt, da.scale, da.shift, db.scale, db.shift, dc.scale, dc.shift,
+                 g_range_flag, n_cus);
+    if (prof) {
+        const int e1 = prof_event(prof, s);
+        const double M = (double)da.B * da.H * da.W, C = da.Cout;
+        const double fl = 2.0 * M * (4 * C * C + 9 * C * C + 4 * C * C);      // algorithmic flops of the three layers (the halo recompute is not work)
+        prof->pending.push_back({7, fl, e0, e1, {(int)M, 4 * da.Cout, 17 * da.Cout, 7}});
+    }
 }
 
 // ================================================================================================

@@ -1,0 +1,97 @@
+"""The fused identity bottleneck of the fp16 mode (kernels_bneck.hip) against the three launches it replaces.
+
+Reference layers: res<stage><block>_branch2a / 2b / 2c + BatchNorm + ReLU + shortcut of every non-first ResNet block
+(Sources/maskrcnn/Python/Conversion/task.py:69-92).  The fused launch keeps both mid tensors on chip; it must agree with
+conv_forward x 3 BIT FOR BIT (same K order, same fp16 roundings, same epilogue arithmetic) — which form runs depends on the
+layer's geometry and a debug knob, per-image results must not — and with an fp64 evaluation of the same fp16 operands within
+the fp16 output step.
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+L = importlib.import_module("mask-rcnn-coreml_amd._lib")
+
+
+def bneck(x, w1, w2, w3, bn, fused, iters=0):
+    B, H, W, C4 = x.shape
+    C = C4 // 4
+    out = np.empty((B, H, W, C4), np.float32)
+    ms = np.zeros(1, np.float32)
+    keep = [np.ascontiguousarray(a, np.float32) for a in (x, w1, w2, w3) + tuple(bn)]
+    L.check(L.lib().mrcnn_bottleneck_nhwc(keep[0].ctypes.data, B, H, W, C, *[k.ctypes.data for k in keep[1:]], int(fused), iters,
+                                           out.ctypes.data, ms.ctypes.data))
+    return out, float(ms[0])
+
+
+def make(C, B, H, W, seed=0):
+    rng = np.random.default_rng(seed)
+    x = np.maximum(rng.standard_normal((B, H, W, 4 * C)), 0).astype(np.float32)          # a post-ReLU block input
+    w1 = (rng.standard_normal((C, 4 * C)) * np.sqrt(2.0 / (4 * C))).astype(np.float32)
+    w2 = (rng.standard_normal((C, 3, 3, C)) * np.sqrt(2.0 / (9 * C))).astype(np.float32)
+    w3 = (rng.standard_normal((4 * C, C)) * np.sqrt(2.0 / C)).astype(np.float32)
+    bn = []
+    for n in (C, C, 4 * C):
+        bn.append((1.0 + 0.1 * rng.standard_normal(n)).astype(np.float32))
+        bn.append((0.1 * rng.standard_normal(n)).astype(np.float32))
+    return x, w1, w2, w3, bn
+
+
+def ref64(x, w1, w2, w3, bn):
+    """fp64 evaluation with the fp16 roundings of the fp16 mode (operands, both mid tensors, the output)."""
+    import torch
+    import torch.nn.functional as F
+    h = lambda a: torch.from_numpy(np.asarray(a, np.float32).astype(np.float16).astype(np.float64))
+    r16 = lambda t: torch.from_numpy(t.numpy().astype(np.float32).astype(np.float16).astype(np.float64))
+    v = lambda a: torch.from_numpy(np.asarray(a, np.float64))[None, :, None, None]
+    xx = h(x).permute(0, 3, 1, 2)
+    C = w1.shape[0]
+    t1 = r16(F.relu(F.conv2d(xx, h(w1).reshape(C, 4 * C, 1, 1)) * v(bn[0]) + v(bn[1])))
+    t2 = r16(F.relu(F.conv2d(t1, h(w2).permute(0, 3, 1, 2), padding=1) * v(bn[2]) + v(bn[3])))
+    y = F.relu(F.conv2d(t2, h(w3).reshape(4 * C, C, 1, 1)) * v(bn[4]) + v(bn[5]) + xx)
+    return y.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+SHAPES = [(256, 1, 8, 16), (256, 2, 16, 32), (256, 1, 64, 64), (128, 1, 16, 16), (128, 2, 32, 48), (64, 1, 16, 16), (64, 1, 48, 32), (64, 2, 32, 32)]
+
+
+@pytest.mark.parametrize("C,B,H,W", SHAPES)
+def test_fused_bottleneck_equals_the_three_launches_bitwise(C, B, H, W):
+    x, w1, w2, w3, bn = make(C, B, H, W, seed=C + H)
+    fused, _ = bneck(x, w1, w2, w3, bn, True)
+    three, _ = bneck(x, w1, w2, w3, bn, False)
+    assert np.isfinite(fused).all()
+    assert fused.shape == three.shape
+    nz = np.flatnonzero(fused.view(np.uint32) != three.view(np.uint32))
+    assert nz.size == 0, f"{nz.size} of {fused.size} outputs differ, first at {np.unravel_index(nz[0], fused.shape)}: {fused.flat[nz[0]]} vs {three.flat[nz[0]]}"
+
+
+@pytest.mark.parametrize("C,B,H,W", [(256, 1, 16, 32), (128, 1, 32, 32), (64, 1, 32, 32)])
+def test_fused_bottleneck_against_an_fp64_evaluation(C, B, H, W):
+    x, w1, w2, w3, bn = make(C, B, H, W, seed=7)
+    fused, _ = bneck(x, w1, w2, w3, bn, True)
+    want = ref64(x, w1, w2, w3, bn)
+    # one fp16 rounding of the output (2^-11 relative) + the flips of the mid tensors' roundings under fp32 summation noise
+    tol = 2e-3 * np.maximum(1.0, np.abs(want))
+    bad = np.abs(fused - want) > tol
+    assert bad.mean() < 1e-3, f"{bad.sum()} of {bad.size} outputs beyond 2e-3"
+    assert np.abs(fused - want).max() < 0.05 * max(1.0, np.abs(want).max())
+
+
+def test_images_of_a_batch_do_not_depend_on_the_batch():
+    C, H, W = 256, 16, 32
+    x, w1, w2, w3, bn = make(C, 3, H, W, seed=3)
+    whole, _ = bneck(x, w1, w2, w3, bn, True)
+    for i in range(3):
+        one, _ = bneck(x[i:i + 1], w1, w2, w3, bn, True)
+        assert np.array_equal(one[0].view(np.uint32), whole[i].view(np.uint32))
+
+
+def test_unsupported_geometry_is_refused_loudly():
+    x, w1, w2, w3, bn = make(64, 1, 24, 24)          # W % 16 != 0
+    with pytest.raises(L.MrcnnError):
+        bneck(x, w1, w2, w3, bn, True)
+    three, _ = bneck(x, w1, w2, w3, bn, False)        # the three launches take any geometry
+    assert np.isfinite(three).all()
