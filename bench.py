@@ -70,6 +70,7 @@ if ROOT not in sys.path:
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_FP16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: bf16/f16 MFMA dense peak (not the 2:1-sparse figure)
 GFLOP_PER_IMAGE_SURVEY = 777.3         # SURVEY.md §8(d), R101 1024² 81 classes
+GFLOP_BACKBONE_SURVEY = {"resnet101": 344.9, "resnet50": 189.8}     # SURVEY.md §8(d) "backbone convs" subset (C1-C5) at 1024²
 
 
 def main():
@@ -90,6 +91,7 @@ def main():
                          "f32: v_mfma_f32_32x32x2_f32 (round-1 headline, now under other_modes); f32s: two-part split; "
                          "f16: fp16 tensors + fp16 MFMA (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-probe", action="store_true", help="skip the in-process MFMA probe and the clock / power sampler (roofline.sustained_peak_live, clock_mhz)")
     ap.add_argument("--no-calibrate", action="store_true",
                     help="split modes: skip the calibration predict (every split exponent 0: the round-3 behaviour)")
     ap.add_argument("--cpu-images", type=int, default=5,
@@ -154,10 +156,11 @@ def main():
     m = models.load_maskrcnn(model_dir, max_batch=args.batch, compute_dtype=args.dtype)
     B = args.batch
     # Scale-aware split (include/maskrcnn_hip.h: mrcnn_model_calibrate_split): the split modes run with a power-of-two pre-scale
-    # per tensor group, chosen from ONE calibration predict on a canonical batch — the first images of the seed-1 stream, the
+    # per tensor group, chosen from ONE calibration predict on a canonical batch — two images of a separate seeded stream, the
     # same on every rank, so every rank holds the same exponent vector (per-image results do not depend on the rank).
     split_info = None
-    calib = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (min(B, 2), args.size, args.size, 3), dtype=np.uint8)).to(dev)
+    # (its OWN stream, seed 7: disjoint from the timed batch and from the end-to-end images, which come from the seed-1 stream)
+    calib = torch.from_numpy(np.random.default_rng(7).integers(0, 256, (min(B, 2), args.size, args.size, 3), dtype=np.uint8)).to(dev)
     if args.dtype in ("f32x3", "f32s") and not args.no_calibrate:
         split_info = m.calibrate_split(calib)
     # synthetic batch, uint8 uniform[0,255], seed 1; a different slice of the stream per rank
@@ -186,9 +189,16 @@ def main():
         if gather is not None:
             gather.wait()
 
+    # Same-run box normaliser: what the matrix cores of THIS box sustain right now — 1.5 s of back-to-back MFMAs on
+    # changing register operands, no operand traffic (mrcnn_bench_mfma_probe) — measured in this process before the warm-up; and the
+    # shader clock / socket power the board holds DURING the timed loop, sampled by a host thread through librocm_smi64.
+    live_probe = None
+    if rank == 0 and not args.no_live_probe:
+        live_probe = mfma_probe_live(1.5, args.dtype)
     for _ in range(args.warmup):
         step()
     drain()
+    sampler = SmiSampler(local_rank) if (rank == 0 and not args.no_live_probe) else None
     if not args.no_kernel_events:
         m.conv_profile_enable(True)
     m.enable_timing(True)
@@ -201,6 +211,8 @@ def main():
 
     fence()
     busy0, calls0 = m.get_int("gpu_busy_us"), m.get_int("predict_calls")
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     ev_steps = 0 if args.no_kernel_events else (min(args.event_steps, args.steps) if args.event_steps > 0 else args.steps)
     for i in range(args.steps):
@@ -210,6 +222,7 @@ def main():
     drain()                                            # the last exchange belongs to the timed region
     fence()
     elapsed = time.perf_counter() - t0
+    smi = sampler.stop() if sampler else None
     busy_s = (m.get_int("gpu_busy_us") - busy0) * 1e-6
     busy_calls = m.get_int("predict_calls") - calls0
     every = gather_elapsed(elapsed, world) if use_dist else [elapsed]
@@ -217,6 +230,7 @@ def main():
     elapsed = max(every)                                        # the job is as slow as its slowest rank
 
     prof = m.conv_profile() if not args.no_kernel_events else None
+    prof_groups = m.conv_profile_groups() if not args.no_kernel_events else None
     stages = m.stage_ms()
     n_prop = int(m.read_tensor("keep_count", 0)[0])
     n_det = int((det[0, :, 5] > 0).sum().item())
@@ -270,6 +284,7 @@ def main():
                 kname = {"128x128": f"k_conv_mfma_glds<{ktypes},128,1,2,4,2,{tail}>", "128x64": f"k_conv_mfma_glds<{ktypes},64,1,1,4,2,...>",
                          "128x32": f"k_conv_mfma_glds<{ktypes},32,1,1,4,1,...>", "128x128w4": f"k_conv_mfma_glds<{ktypes},128,1,4,4,1,{tail}>",
                          "128x256tail": f"k_conv_halo<{parts},2,false,false,2,3,TAIL> (3x3 + 1x1 + shortcut of a bottleneck block in one launch; opt-in)",
+                         "bneck": "k_bneck_h<C> (an identity bottleneck block — 1x1, 3x3, 1x1 + shortcut — as one persistent launch, both mid tensors on chip; C = 64 / 128 / 256)",
                          "256x256pp": "k_conv_pp<0>", "128xNhalo": f"k_conv_halo<{parts},TN,HEAD,.,TM,MAXPC,.,WN> (persistent halo tiles: 128 x 256 / 128 x 128 / 64 x 128, 256 x 64 / 128 x 64 for 64 columns; instantiations <{parts},2,false>, <{parts},2,true> = fused RPN heads, <{parts},1,false>, <{parts},2,false,.,1,5,.,1> = C2; k_conv_halo_lat on under-filled grids)"}[dom]
                 out["roofline"] = {
                     "kernel": kname, "bound": "mfma",
@@ -288,10 +303,34 @@ def main():
                                           "share_of_step_time": round(v[1] / (1e3 * elapsed * ev_steps / args.steps), 4)}
                                       for k, v in prof.items() if v[0]},
                     "all_conv_kernels": {"tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2),
+                                         "frac": round(all_fl / (all_ms * 1e-3) / 1e12 / peak, 4),
                                          "gflop_per_image": round(all_fl / (B * ev_steps) / 1e9, 2),
                                          "survey_gflop_per_image": GFLOP_PER_IMAGE_SURVEY,
                                          "share_of_step_time": round(all_ms / (1e3 * elapsed * ev_steps / args.steps), 4)},
                 }
+                if prof_groups and prof_groups["backbone"][0]:
+                    # the subset north_star's ">= 50 % MFMA roofline for the backbone convs" is worded on: conv1 + res2..res5 (C1-C5)
+                    bl, bms, bfl = prof_groups["backbone"]
+                    out["roofline"]["backbone_convs"] = {
+                        "tflops": round(bfl / (bms * 1e-3) / 1e12, 2), "frac": round(bfl / (bms * 1e-3) / 1e12 / peak, 4),
+                        "gflop_per_image": round(bfl / (B * ev_steps) / 1e9, 2), "survey_gflop_per_image": GFLOP_BACKBONE_SURVEY.get(args.arch),
+                        "launches_per_step": bl // ev_steps, "share_of_step_time": round(bms / (1e3 * elapsed * ev_steps / args.steps), 4),
+                        "what": "conv1 + the res2..res5 stages (SURVEY.md section 8d 'backbone convs'); every other convolution (FPN, RPN, heads) is in all_conv_kernels only"}
+                if live_probe:
+                    # held against what THIS box's matrix cores sustain in this process, the figure is comparable across boxes of the pool
+                    out["roofline"]["sustained_peak_live"] = {
+                        "value": round(live_probe["tflops"] / parts, 1), "unit": "TFLOP/s", "probe_tflops_executed": round(live_probe["tflops"], 1),
+                        "probe_mhz_equivalent": round(live_probe["mhz"], 0), "seconds": live_probe["seconds"],
+                        "how": "mrcnn_bench_mfma_probe in this process before the warm-up: every wave on back-to-back "
+                               + ("v_mfma_f32_32x32x2_f32" if args.dtype == "f32" else "v_mfma_f32_32x32x16_f16")
+                               + ", register operands changing per instruction, no operand traffic" + (f"; divided by the {parts} MFMA passes per algorithmic flop" if parts > 1 else "")}
+                    out["roofline"]["frac_of_live_sustained"] = round(achieved * parts / live_probe["tflops"], 4)
+                    out["roofline"]["all_conv_kernels"]["frac_of_live_sustained"] = round(all_fl / (all_ms * 1e-3) / 1e12 * parts / live_probe["tflops"], 4)
+                    if "backbone_convs" in out["roofline"]:
+                        out["roofline"]["backbone_convs"]["frac_of_live_sustained"] = round(out["roofline"]["backbone_convs"]["tflops"] * parts / live_probe["tflops"], 4)
+                if smi:
+                    out["roofline"]["clock_mhz"] = smi.get("sclk_mhz_mean")
+                    out["roofline"]["board"] = smi
                 out["profiles_ref"] = {
                     "note": "constants read from committed files under profiles/ — NOT measured in this run",
                     "traffic_bytes_per_launch_dominant_kernel": pmc_traffic(args.dtype, dom), "traffic_source": pmc_traffic_source(args.dtype),
@@ -426,6 +465,89 @@ def gather_elapsed(elapsed, world):
     return [float(e.item()) for e in every]
 
 
+def mfma_probe_live(seconds, dtype):
+    """The live roof of this box (include/maskrcnn_hip_test.h: mrcnn_bench_mfma_probe): executed TFLOP/s of the matrix instruction the
+    mode's convolutions issue, sustained over the last third of `seconds`."""
+    import ctypes as C
+    L = importlib.import_module("mask-rcnn-coreml_amd._lib")
+    tf, mhz = C.c_double(0), C.c_double(0)
+    try:
+        L.check(L.lib().mrcnn_bench_mfma_probe(float(seconds), L.F32 if dtype == "f32" else L.F16, C.byref(tf), C.byref(mhz)))
+    except Exception as e:                       # the probe is a diagnostic: never fail the bench line over it
+        sys.stderr.write(f"bench.py: live MFMA probe failed: {e}\n")
+        return None
+    return {"tflops": tf.value, "mhz": mhz.value, "seconds": seconds}
+
+
+class SmiSampler:
+    """Shader clock and socket power of one GPU sampled by a host thread through librocm_smi64 (the library behind rocm-smi: a call
+    takes ~0.1 ms, the CLI half a second) while the timed loop runs.  Diagnostic only: every failure degrades to None."""
+
+    def __init__(self, index):
+        import ctypes as C
+        self.C, self.index, self.lib, self.samples, self.thread, self.run = C, index, None, [], None, False
+        for name in ("librocm_smi64.so", "librocm_smi64.so.7", "/opt/rocm/lib/librocm_smi64.so"):
+            try:
+                self.lib = C.CDLL(name)
+                break
+            except OSError:
+                continue
+        try:
+            if self.lib is not None and self.lib.rsmi_init(C.c_uint64(0)) != 0:
+                self.lib = None
+        except Exception:
+            self.lib = None
+
+    def _once(self):
+        C = self.C
+
+        class Freq(C.Structure):
+            _fields_ = [("has_deep_sleep", C.c_bool), ("num_supported", C.c_uint32), ("current", C.c_uint32), ("frequency", C.c_uint64 * 33)]
+        f = Freq()
+        mhz = None
+        if self.lib.rsmi_dev_gpu_clk_freq_get(C.c_uint32(self.index), C.c_int(0), C.byref(f)) == 0 and f.current < 33:
+            mhz = f.frequency[f.current] / 1e6
+        w = None
+        p, t = C.c_uint64(0), C.c_int(0)
+        try:
+            if self.lib.rsmi_dev_power_get(C.c_uint32(self.index), C.byref(p), C.byref(t)) == 0:
+                w = p.value / 1e6
+        except AttributeError:
+            if self.lib.rsmi_dev_power_ave_get(C.c_uint32(self.index), C.c_uint32(0), C.byref(p)) == 0:
+                w = p.value / 1e6
+        return mhz, w
+
+    def start(self):
+        if self.lib is None:
+            return
+        import threading
+        self.run = True
+
+        def loop():
+            while self.run:
+                try:
+                    self.samples.append(self._once())
+                except Exception:
+                    break
+                time.sleep(0.004)
+        self.thread = threading.Thread(target=loop, daemon=True)
+        self.thread.start()
+
+    def stop(self):
+        if self.lib is None or self.thread is None:
+            return None
+        self.run = False
+        self.thread.join(timeout=2)
+        clk = [c for c, _ in self.samples if c]
+        pw = [w for _, w in self.samples if w]
+        if not clk and not pw:
+            return None
+        return {"samples": len(self.samples), "sclk_mhz_mean": round(sum(clk) / len(clk), 0) if clk else None,
+                "sclk_mhz_min": round(min(clk), 0) if clk else None, "sclk_mhz_max": round(max(clk), 0) if clk else None,
+                "power_w_mean": round(sum(pw) / len(pw), 0) if pw else None,
+                "how": "librocm_smi64 (rsmi_dev_gpu_clk_freq_get RSMI_CLK_TYPE_SYS / rsmi_dev_power_get) every ~4 ms from a host thread during the timed loop"}
+
+
 def sustained_peak(dtype, parts, achieved):
     """What the matrix cores of this board sustain for seconds with NO data movement (tools/probes/mfma_probe.hip under
     tools/mfma_power.sh, committed under profiles/): the fp16 MFMA on operands that change every instruction, the fp32 MFMA
@@ -444,7 +566,7 @@ def sustained_peak(dtype, parts, achieved):
     return None
 
 
-CLASS_KERNELS = {"128xNhalo": ("k_conv_halo<",), "128x256tail": ("k_conv_halo<",), "256x256pp": ("k_conv_pp<",), "128x128": (", 128, 1, 2, 4, 2,",), "128x64": (", 64, 1, 1, 4, 2,",),
+CLASS_KERNELS = {"bneck": ("k_bneck_h<",), "128xNhalo": ("k_conv_halo<",), "128x256tail": ("k_conv_halo<",), "256x256pp": ("k_conv_pp<",), "128x128": (", 128, 1, 2, 4, 2,",), "128x64": (", 64, 1, 1, 4, 2,",),
                  "128x32": (", 32, 1, 1, 4, 1,",), "128x128w4": (", 128, 1, 4, 4, 1,",)}
 
 

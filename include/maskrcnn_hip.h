@@ -168,9 +168,15 @@ typedef struct mrcnn_model mrcnn_model;
  * batch 8, against the fp32 CPU oracle): >= 95 % of the detections have a partner with the same class id and a box within 2e-3
  * (normalized coordinates), matched scores within 5e-4, matched masks within 3e-2; the fp32 modes' bars are 1e-4 / 1e-5 / 2e-4
  * with >= 99.9 % matched.
- * In MRCNN_F16 and MRCNN_F32S every convolution watches its outputs: if one leaves the fp16 range (|v| >= 65504,
- * which the next layer could not read), the synchronous predict fails with MRCNN_ERR_UNSUPPORTED instead of
- * returning saturated results (mrcnn_model_get_int key "range_overflows" counts such calls). */
+ * In MRCNN_F16, MRCNN_F32S and MRCNN_F32X3 every convolution watches its outputs for values leaving the fp16 range (|v| >= 65504,
+ * which the next layer could not read; mrcnn_model_get_int key "range_overflows" counts the predicts it trips on).
+ *   - Split modes (MRCNN_F32S / MRCNN_F32X3): such a predict is NOT failed — the reference's CPU path is fp32 activations x fp16 weights
+ *     (Conversion/task.py:90) and has no such failure.  The batch, still resident on the device, is measured (one calibration pass),
+ *     the split exponents are LOWERED to what it needs (never raised), and the batch is computed again before the call returns
+ *     (key "range_recoveries"); mrcnn_maskrcnn_collect does the same for a pipelined batch.  Only an enqueue-only predict
+ *     (mrcnn_maskrcnn_predict_async + mrcnn_model_check_range) leaves the re-run to the host.
+ *   - MRCNN_F16 (fp16 tensors, inherently range-limited): the synchronous predict fails with MRCNN_ERR_UNSUPPORTED instead of
+ *     returning saturated results. */
 MRCNN_API int mrcnn_model_load(int kind, const char* path, int max_batch, int compute_dtype,
                                mrcnn_model** out_model);
 MRCNN_API void mrcnn_model_destroy(mrcnn_model* model);
@@ -279,7 +285,7 @@ MRCNN_API int mrcnn_mask_predict(mrcnn_model* model, const float* feature_map, i
 
 /* Introspection: "num_classes", "image_height", "image_width", "max_proposals", "max_detections", "num_anchors",
  * "pre_nms_max_proposals", "pre_nms_count" (= min(num_anchors, pre_nms_max_proposals)), "mask_size" (side of the
- * square masks predict returns: 2 × the mask pool size = 28), "max_batch", "compute_dtype", "range_overflows",
+ * square masks predict returns: 2 × the mask pool size = 28), "max_batch", "compute_dtype", "range_overflows", "range_recoveries",
  * "graph_enabled", "graph_launches", "gpu_busy_us" / "predict_calls" (GPU time between the first and the last command of
  * the synchronous predicts of this handle, HIP events on the model's stream, and their count); any other key is looked up in
  * the artefact's integer metadata. */
@@ -322,6 +328,13 @@ MRCNN_API int mrcnn_model_check_range(mrcnn_model* model, int* tripped);
  *   mrcnn_model_split_group_stat   per group: name, exponent, max |a|, the three counters
  *   mrcnn_model_get/set_split_exponents   the exponents as a vector (one per group, 0 for the groups fp32 arithmetic consumes):
  *                          a sharded job calibrates on one rank — or offline — and sets the same vector on every rank.
+ *   stored exponents       `python -m mask-rcnn-coreml_amd.convert ... --calibrate <images>` writes the vector into MaskRCNN.mrcw
+ *                          ("split_exp.<group>" metadata); mrcnn_model_load applies it in the split modes, so the drop-in
+ *                          MaskRCNN().prediction(image) (ViewController.swift:37) runs calibrated without any extra call
+ *                          ("split_exponents_from_artefact" = 1, "split_calibrated" = 1).
+ *   range recovery         a batch that leaves the calibrated range lowers the exponents it needs and is computed again inside the
+ *                          call (see mrcnn_model_load above; "range_recoveries").  Later batches use the lowered vector: a sharded job
+ *                          that wants bit-equal results across ranks after a recovery re-distributes it with get / set.
  * MRCNN_F32 and MRCNN_F16 models return MRCNN_ERR_UNSUPPORTED from calibrate / set. */
 typedef struct mrcnn_split_group_stat {
     char    name[48];

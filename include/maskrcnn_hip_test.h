@@ -26,6 +26,9 @@ extern "C" {
 MRCNN_API int mrcnn_model_conv_profile_enable(mrcnn_model* model, int on);
 MRCNN_API int mrcnn_model_conv_profile_get(mrcnn_model* model, int tile, int64_t* launches, double* total_ms,
                                            double* total_flops);
+/* The same window split in two groups: 1 = the BACKBONE convolutions (conv1 and the res2..res5 stages: SURVEY.md section 8d's 344.9 GFLOP per image,
+ * the subset north_star's ">= 50 % MFMA roofline" is worded on), 0 = every other convolution (FPN, RPN, heads). */
+MRCNN_API int mrcnn_model_conv_profile_group(mrcnn_model* model, int group, int64_t* launches, double* total_ms, double* total_flops);
 /* The same totals broken down by GEMM shape (M = images*OH*OW, N = output columns, K = taps*Cin): writes at
  * most `capacity` records, *count = number of distinct shapes seen (call with capacity 0 to size the buffer). */
 typedef struct mrcnn_conv_shape_stat {
@@ -45,6 +48,13 @@ MRCNN_API int mrcnn_bench_conv(int batch, int h, int w, int cin, int cout, int k
 /* Same with an explicit element type (MRCNN_F32 | MRCNN_F16, fp32 accumulate). */
 MRCNN_API int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout, int ksize, int stride,
                                      int iters, int dtype, float* avg_ms, double* flops);
+
+/* What the matrix cores of THIS board sustain right now: every wave of the chip on back-to-back MFMAs (kind MRCNN_F16: v_mfma_f32_32x32x16_f16,
+ * MRCNN_F32: v_mfma_f32_32x32x2_f32) whose register operands change from one instruction to the next, no operand traffic, for `seconds`
+ * (<= 30); *tflops = the rate over the last third of the run, *mhz_equivalent (optional) = the shader clock it means at back-to-back issue.
+ * bench.py runs it in-process before the timed loop (`roofline.sustained_peak_live`): boxes of one pool differ by several per cent under
+ * the power cap, and this is what separates a kernel change from a box change. */
+MRCNN_API int mrcnn_bench_mfma_probe(double seconds, int kind, double* tflops, double* mhz_equivalent);
 
 /* One convolution of the engine's kernel family on caller (host) data — the unit the parity tests of the kernels use:
  * in (B,H,W,Cin) NHWC fp32, filters (Cout, k, k, Cin) fp32 (k = 1 | 3, 'same' padding k/2), optional per-channel

@@ -120,14 +120,77 @@ def convert(config_path: str = "model/config.json", weights_path: str = "model/w
     return paths
 
 
+def load_calibration_images(path: str, H: int, W: int, limit: int = 8) -> np.ndarray:
+    """Images for ``--calibrate``: a ``.npy`` file holding uint8 (N, H, W, 3), or a directory of image files (anything PIL opens),
+    each letterboxed to H x W the way the evaluate loop hands images over (``.scaleFit``, EvaluateCommand.swift:152-157)."""
+    if os.path.isfile(path) and path.endswith(".npy"):
+        a = np.load(path)
+        if a.dtype != np.uint8 or a.ndim != 4 or a.shape[1:] != (H, W, 3):
+            raise ConversionError(f"{path}: expected uint8 (N, {H}, {W}, 3), found {a.dtype} {a.shape}")
+        return np.ascontiguousarray(a[:limit])
+    if not os.path.isdir(path):
+        raise ConversionError(f"--calibrate {path}: neither a .npy file nor a directory of images")
+    from PIL import Image
+    from .evaluate import letterbox
+    out = []
+    for name in sorted(os.listdir(path)):
+        try:
+            img = np.asarray(Image.open(os.path.join(path, name)).convert("RGB"), dtype=np.uint8)
+        except Exception:
+            continue
+        out.append(letterbox(img, H, W))
+        if len(out) == limit:
+            break
+    if not out:
+        raise ConversionError(f"--calibrate {path}: no readable image")
+    return np.stack(out)
+
+
+def store_split_exponents(model_dir: str, names: List[str], exponents: List[int]) -> str:
+    """Rewrites ``MaskRCNN.mrcw`` with the exponent of every tensor group as ``split_exp.<group>`` metadata: mrcnn_model_load
+    applies them in the split modes, so a drop-in ``MaskRCNN().prediction(image)`` (ViewController.swift:37) runs calibrated
+    without an extra call.  Tensors and every other key are untouched."""
+    from .weights import read_mrcw
+    path = os.path.join(model_dir, "MaskRCNN.mrcw")
+    meta, tensors = read_mrcw(path)
+    meta = {k: v for k, v in meta.items() if not k.startswith("split_exp.")}
+    for n, e in zip(names, exponents):
+        meta["split_exp." + n] = int(e)
+    write_mrcw(path, meta, {k: np.array(v) for k, v in tensors.items()})
+    return path
+
+
+def calibrate_artefact(model_dir: str, images: np.ndarray, compute_dtype: str = "f32x3", verbose: bool = True) -> Dict[str, int]:
+    """Loads the converted artefacts on the GPU in a split mode, calibrates the scale-aware split on ``images`` (uint8 (N, H, W, 3))
+    and stores the exponent vector in the artefact.  Needs a gfx950 device (the calibration IS a predict of the engine)."""
+    from .models import load_maskrcnn
+    n = int(images.shape[0])
+    m = load_maskrcnn(model_dir, max_batch=n, compute_dtype=compute_dtype)
+    totals = m.calibrate_split(images)
+    rep = [g for g in m.split_report() if not g["fixed"]]
+    del m
+    store_split_exponents(model_dir, [g["name"] for g in rep], [g["exponent"] for g in rep])
+    if verbose:
+        print(f"calibrated the split on {n} images: exponents {totals['split_min_exponent']:+d} .. {totals['split_max_exponent']:+d} "
+              f"over {len(rep)} tensor groups, stored in {os.path.join(model_dir, 'MaskRCNN.mrcw')}")
+    return totals
+
+
 def main(argv: List[str] = None) -> int:
     ap = argparse.ArgumentParser(prog="maskrcnn convert", description="Converts trained model to .mrcw")
     ap.add_argument("--config", default="model/config.json", help="Path to config JSON file")
     ap.add_argument("--weights", default="model/weights.h5", help="Path to HDF5 weights file")
     ap.add_argument("--output_dir", default="products", help="Path to output directory")
     ap.add_argument("--weights_dtype", default="f16", choices=("f16", "f32"))
+    ap.add_argument("--calibrate", default=None, metavar="IMAGES",
+                    help="a .npy of uint8 (N,H,W,3) images or a directory of image files: calibrates the scale-aware split of the "
+                         "MRCNN_F32X3 / MRCNN_F32S modes on them (needs the GPU) and stores the exponents in MaskRCNN.mrcw")
     a = ap.parse_args(argv)
     convert(a.config, a.weights, a.output_dir, a.weights_dtype)
+    if a.calibrate:
+        cfg = ModelConfig.from_json(a.config) if a.config else ModelConfig()
+        H, W = int(cfg.input_image_shape[0]), int(cfg.input_image_shape[1])
+        calibrate_artefact(a.output_dir, load_calibration_images(a.calibrate, H, W))
     return 0
 
 

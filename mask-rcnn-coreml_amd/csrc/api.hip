@@ -310,7 +310,9 @@ struct ClassifierLayerImpl : mrcnn_layer {
         const float* chw = stage_rows(in[0].data, in[0].memspace, n, row, in[0].strides[0], ti);
         std::lock_guard<std::mutex> lk(model->eval_mu);   // the head's scratch is shared by every layer instance
         nchw_to_nhwc_forward(st.s, chw, n, C, ph, pw, hd.stage_in, hd.dtype);
-        hd.forward(st.s, hd.stage_in, (int)n, hd.cls6, 6);
+        conv_set_scratch(model->conv_scratch.ks_buf.p ? &model->conv_scratch : nullptr);      // (the mutex above serialises its users; the call synchronises below)
+        try { hd.forward(st.s, hd.stage_in, (int)n, hd.cls6, 6); } catch (...) { conv_set_scratch(nullptr); throw; }
+        conv_set_scratch(nullptr);
         HIP_CHECK(hipStreamSynchronize(st.s));
         const long ostride = out[0].strides[2];           // :63
         MRCNN_REQUIRE(ostride >= 6, MRCNN_ERR_SHAPE, "TimeDistributedClassifierLayer: output stride %ld < 6", ostride);
@@ -604,7 +606,9 @@ extern "C" int mrcnn_classifier_predict(mrcnn_model* model, const float* feature
             DevBuf ti;
             const float* chw = stage_rows(feature_map + (size_t)i0 * row, memspace, c, row, row, ti);
             nchw_to_nhwc_forward(s, chw, c, hd.C, hd.pool, hd.pool, hd.stage_in, hd.dtype);
-            hd.forward(s, hd.stage_in, c, nullptr, 0);
+            conv_set_scratch(model->m.conv_scratch.ks_buf.p ? &model->m.conv_scratch : nullptr);
+            try { hd.forward(s, hd.stage_in, c, nullptr, 0); } catch (...) { conv_set_scratch(nullptr); throw; }
+            conv_set_scratch(nullptr);
             HIP_CHECK(hipMemcpyAsync(probabilities + (size_t)i0 * hd.nc, hd.probs, (size_t)c * hd.nc * 4, back, s));
             HIP_CHECK(hipMemcpyAsync(bounding_boxes + (size_t)i0 * hd.nc * 4, hd.bbox, (size_t)c * hd.nc * 16, back, s));
             HIP_CHECK(hipStreamSynchronize(s));
@@ -657,6 +661,8 @@ extern "C" int mrcnn_model_get_int(mrcnn_model* model, const char* key, int64_t*
         else if (k == "pre_nms_count") *value = m.K;
         else if (k == "mask_size") *value = 2 * m.mask_pool;
         else if (k == "range_overflows") *value = m.range_overflows;
+        else if (k == "range_recoveries") *value = m.range_recoveries;
+        else if (k == "split_exponents_from_artefact") *value = m.exponents_from_artefact ? 1 : 0;
         // scale-aware split (mrcnn_model_calibrate_split): totals over the tensor groups of the last calibrate / diagnose pass
         else if (k == "split_groups") *value = (int64_t)m.sgroups.size();
         else if (k == "split_calibrated") *value = m.split_calibrated ? 1 : 0;
@@ -840,6 +846,15 @@ extern "C" int mrcnn_model_conv_profile_get(mrcnn_model* model, int tile, int64_
         *launches = sl.launches; *total_ms = sl.ms; *total_flops = sl.flops;
     });
 }
+
+extern "C" int mrcnn_model_conv_profile_group(mrcnn_model* model, int group, int64_t* launches, double* total_ms, double* total_flops)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model && launches && total_ms && total_flops && (group == 0 || group == 1), MRCNN_ERR_INVALID, "bad argument");
+        const auto& sl = model->m.conv_profile.by_group[group];
+        *launches = sl.launches; *total_ms = sl.ms; *total_flops = sl.flops;
+    });
+}
 extern "C" int mrcnn_model_conv_profile_shapes(mrcnn_model* model, mrcnn_conv_shape_stat* out, int capacity, int* count)
 {
     return guarded([&] {
@@ -925,9 +940,14 @@ extern "C" int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout
         hipEvent_t e0, e1;
         HIP_CHECK(hipEventCreate(&e0));
         HIP_CHECK(hipEventCreate(&e1));
-        for (int i = 0; i < 2; ++i) conv_forward(st.s, d);
-        HIP_CHECK(hipEventRecord(e0, st.s));
-        for (int i = 0; i < iters; ++i) conv_forward(st.s, d);
+        ConvScratch scratch;                          // the split modes' shared-tile K chunks measure as the engine runs them
+        if (ws == 2 && es == 4) { scratch.alloc(); conv_set_scratch(&scratch); }
+        try {
+            for (int i = 0; i < 2; ++i) conv_forward(st.s, d);
+            HIP_CHECK(hipEventRecord(e0, st.s));
+            for (int i = 0; i < iters; ++i) conv_forward(st.s, d);
+        } catch (...) { conv_set_scratch(nullptr); throw; }
+        conv_set_scratch(nullptr);
         HIP_CHECK(hipEventRecord(e1, st.s));
         HIP_CHECK(hipEventSynchronize(e1));
         float ms = 0;
@@ -1010,7 +1030,10 @@ extern "C" int mrcnn_conv2d_nhwc(const float* in, int batch, int h, int w, int c
             conv_halo_pack(st.s, dw.p, npad, cin, dwh);
             d.wgt_halo = dwh.p;
         }
-        conv_forward(st.s, d);
+        ConvScratch scratch;                          // one short-lived scratch for the call (kernels.h): the shared-tile K chunks need it
+        if (wdt != MRCNN_F32 && adt == MRCNN_F32) { scratch.alloc(); conv_set_scratch(&scratch); }
+        try { conv_forward(st.s, d); } catch (...) { conv_set_scratch(nullptr); throw; }
+        conv_set_scratch(nullptr);
         HIP_CHECK(hipStreamSynchronize(st.s));
         const void* const result = d.out;
         if (adt == MRCNN_F16) {
@@ -1068,8 +1091,11 @@ extern "C" int mrcnn_bottleneck_nhwc(const float* x, int batch, int h, int w, in
         ConvDesc db = desc(dt1.p, C, dw2.p, 3, ds2.as<float>(), dh2.as<float>(), dt2.p, C);
         ConvDesc dc = desc(dt2.p, C, dw3.p, 1, ds3.as<float>(), dh3.as<float>(), dy.p, C4);
         dc.res = dx.p; dc.res_sW = C4; dc.res_sH = (long)w * C4; dc.res_sB = (long)h * w * C4;
-        MRCNN_REQUIRE(!fused || conv_bneck_fusable(da, db, dc), MRCNN_ERR_UNSUPPORTED, "bottleneck_nhwc: C %d at %dx%d does not qualify for the fused launch", C, h, w);
         Stream st;
+        DevBuf dw2f, dw3f;
+        if (bneck_frag_wanted(3, 3, C, C)) { bneck_pack_frag(st.s, dw2.p, C, 9 * C, dw2f); db.wgt_frag = dw2f.p; }
+        if (bneck_frag_wanted(1, 1, C, C4)) { bneck_pack_frag(st.s, dw3.p, C4, C, dw3f); dc.wgt_frag = dw3f.p; }
+        MRCNN_REQUIRE(!fused || conv_bneck_fusable(da, db, dc), MRCNN_ERR_UNSUPPORTED, "bottleneck_nhwc: C %d at %dx%d does not qualify for the fused launch", C, h, w);
         auto run = [&] {
             if (fused) conv_bneck_forward(st.s, da, db, dc);
             else { conv_forward(st.s, da); conv_forward(st.s, db); conv_forward(st.s, dc); }

@@ -45,6 +45,7 @@ struct PackedConv {
     DevBuf wgt, scale, shift;     // wgt in `wdtype`; scale/shift always fp32
     std::vector<float> h_scale, h_shift;   // host copies of scale / shift (the scale-aware split derives per-op copies from them)
     DevBuf wgt_halo;              // 3x3 layers of the split modes: the same filters re-tiled for the halo kernel (conv_halo_pack)
+    DevBuf wgt_frag;              // fp16 mode, the layers of C4's identity bottlenecks: the same filters in MFMA-fragment order (bneck_pack_frag)
     int Cin = 0, Cout = 0, KH = 1, KW = 1, Npad = 0;
     int dtype = MRCNN_F32;        // activations
     int wdtype = MRCNN_F32;       // filters (fp16 with fp32 activations = split mode, MRCNN_F32S)
@@ -191,6 +192,7 @@ struct Model {
     bool fuse_mask_tail = true;        // MRCNN_FUSE_MASK_TAIL=0 / mrcnn_debug_set("mask_fused", 0): deconvolution output + k_mask_select
     StageTimer timer;
     ConvProfile conv_profile;
+    ConvScratch conv_scratch;         // scratch of the convolution family, allocated at load in the split modes (kernels.h), freed with the model
     // Optional: the ~200 launches of one predict captured once per batch size and replayed as a hipGraph
     // (the pipeline is static: every data-dependent count lives in device memory).  Off by default —
     // measured neutral on MI355X (the runtime already keeps the queue full; the gaps
@@ -214,6 +216,18 @@ struct Model {
     // one predict with every exponent 0 collecting max |a| per group, exponents chosen, (apply) a second predict that verifies
     // the choice and counts the inputs a split still cannot carry exactly; apply = false: diagnose only, exponents untouched
     void calibrate_split(const uint8_t* rgb, int batch, int h, int w, int memspace, bool apply);
+    // phase 1 of a calibration on `batch` images (fit: of size h x w, letterboxed): fills sgroups[].absmax with the true maxima (every
+    // exponent is left at the uniform value the pass ran with: the caller chooses and applies the new ones).  resident: the images are
+    // the ones the last predict left on the device (d_rgb / fit_src): no copy
+    void measure_split_groups(const uint8_t* rgb, int batch, int h, int w, int memspace, bool fit, bool resident);
+    static int split_exponent_for(float absmax);          // max |a| * 2^e in [2^11, 2^12)
+    // Range recovery (round 5): a predict of a split mode whose activations left the calibrated range is NOT failed — the reference's fp32
+    // path has no such failure (Conversion/task.py:90: only the weights are fp16).  The batch still resident on the device is measured
+    // (phase 1 above), every group's exponent is LOWERED to what this batch needs (never raised: earlier batches stay inside), and the
+    // batch is computed again; "range_recoveries" of mrcnn_model_get_int counts such calls.  false: not a split mode / still out of range.
+    bool recover_range(int batch, int h, int w, bool fit);
+    long range_recoveries = 0;
+    bool exponents_from_artefact = false;      // the exponent vector came with MaskRCNN.mrcw (convert.py --calibrate)
     DevBuf range_flag;          // 4 B: set by the conv epilogues in MRCNN_F16 / MRCNN_F32S when an activation leaves the fp16 range
     long range_overflows = 0;   // predicts that tripped it
     long graph_launches = 0;
@@ -245,7 +259,9 @@ struct Model {
     void load(int kind, const std::string& path, int max_batch, int dtype);
     void build_maskrcnn();
     // fit = true: the images are h×w of ANY size, letterboxed into the model's H×W inside the pre-processing kernel (.scaleFit)
-    void predict(const uint8_t* rgb, int batch, int h, int w, int memspace, float* det, float* masks, bool sync, bool fit = false);
+    // det / masks may be nullptr for internal passes (calibration, recovery measurement): nothing is copied out;
+    // resident: the images already sit in d_rgb / fit_src (no input copy)
+    void predict(const uint8_t* rgb, int batch, int h, int w, int memspace, float* det, float* masks, bool sync, bool fit = false, bool resident = false);
     // d_rgb (or, with fit geometry, fit_src) → detections / mask_out, launches only
     void enqueue_pipeline(hipStream_t s, int batch, const int* fit = nullptr);
     void drop_graphs();

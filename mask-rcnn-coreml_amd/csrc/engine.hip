@@ -294,6 +294,10 @@ PackedConv pack_conv_oihw(const MrcwFile& f, const std::string& conv, const std:
         conv_halo_pack(nullptr, pc.wgt.p, pc.Npad, I, pc.wgt_halo, 1);        // ... the 256 -> 1024 1x1 layers for the fused bottleneck tail
         HIP_CHECK(hipStreamSynchronize(nullptr));
     }
+    if (pc.dtype == MRCNN_F16 && pc.wdtype == MRCNN_F16 && O == pc.Npad && bneck_frag_wanted(KH, KW, I, O)) {
+        bneck_pack_frag(nullptr, pc.wgt.p, O, KH * KW * I, pc.wgt_frag);      // fp16 mode: C4's identity bottlenecks stream these straight into registers
+        HIP_CHECK(hipStreamSynchronize(nullptr));
+    }
     std::vector<float> sc, sh;
     fold_bn(f, conv, bn, O, pc.Npad, sc, sh);
     upload(pc.scale, sc);
@@ -640,6 +644,9 @@ void Model::load(int kind_, const std::string& path, int max_batch_, int dtype_)
     range_flag.alloc(sizeof(int));
     HIP_CHECK(hipMemset(range_flag.p, 0, sizeof(int)));
     nc = (int)file.get_int("num_classes");
+    // split modes: the shared-tile K chunks of the long-K 1x1 layers on under-filled grids (single images) and the opt-in fused
+    // bottleneck tail need device scratch — owned by this handle from load to destroy (kernels.h: ConvScratch)
+    if ((mode == MRCNN_F32S || mode == MRCNN_F32X3) && kind != MRCNN_MODEL_MASK) conv_scratch.alloc();
     if (kind == MRCNN_MODEL_CLASSIFIER) { cls_head.load(file, max_batch, mode); return; }
     if (kind == MRCNN_MODEL_MASK) { mask_head.load(file, max_batch, mode); return; }
     build_maskrcnn();
@@ -762,10 +769,12 @@ void Model::build_maskrcnn()
             d.wdtype = pc->wdtype;
             d.wgt = pc->wgt.p; d.KH = pc->KH; d.KW = pc->KW; d.stride = stride; d.padH = d.padW = pad;
             d.wgt_halo = pc->wgt_halo.p;
+            d.wgt_frag = pc->wgt_frag.p;
             d.scale = so ? so->scale.as<float>() : nullptr; d.shift = so ? so->shift.as<float>() : nullptr;
             d.OH = out.H; d.OW = out.W; d.Cout = pc->Cout; d.Npad = pc->Npad;
             d.out = out.p; d.out_sP = out.C; d.out_sB = out.sB();
             d.act = act;
+            d.group = name.compare(0, 3, "res") == 0 ? 1 : 0;          // conv profile: the backbone subset (C2..C5; conv1 is tagged below)
             if (res) { d.res = res->p; d.res_sB = res->sB(); d.res_sH = (long)res->W * res->C; d.res_sW = res->C; d.res_shift = res_shift; }
             return d;
         };
@@ -846,6 +855,7 @@ void Model::build_maskrcnn()
             d.OH = c1.H; d.OW = c1.W; d.Cout = pc->Cout; d.Npad = pc->Npad;
             d.out = c1.p; d.out_sP = c1.C; d.out_sB = c1.sB(); d.act = ACT_RELU;
             d.algo_k = 147;   // 7*7*3 real taps (the packed row is padded to 7*32)
+            d.group = 1;
             // split modes: conv1 and the max-pool behind it as ONE persistent launch (kernels_conv_stem.hip) — c1 is then neither
             // written nor read; bit-identical to the two launches, which remain for the other modes and behind "conv_stem" 0
             const size_t per_image = (size_t)c1.sB();
@@ -1035,9 +1045,24 @@ void Model::build_maskrcnn()
     }
     calib_buf.alloc(sgroups.size() * 32);
     HIP_CHECK(hipMemset(calib_buf.p, 0, sgroups.size() * 32));
-    if (const char* e = getenv("MRCNN_SPLIT_EXP")) {          // measurement / tests: one exponent for every non-fixed group
-        for (auto& g : sgroups) if (!g.fixed) g.exp = atoi(e);
-        apply_split_exponents();
+    const bool split_mode = mode == MRCNN_F32S || mode == MRCNN_F32X3;
+    if (split_mode) {
+        // exponents stored with the artefact (convert.py --calibrate: "split_exp.<group>" metadata): the drop-in prediction() needs no call
+        int found = 0;
+        for (auto& g : sgroups) {
+            const auto it = file.ints.find("split_exp." + g.name);
+            if (it == file.ints.end() || g.fixed) continue;
+            MRCNN_REQUIRE(it->second >= -60 && it->second <= 60, MRCNN_ERR_IO, "stored split exponent of group '%s' out of range", g.name.c_str());
+            g.exp = (int)it->second;
+            ++found;
+        }
+        if (found) { apply_split_exponents(); split_calibrated = true; exponents_from_artefact = true; }
+    }
+    if (const char* e = getenv("MRCNN_SPLIT_EXP")) {          // measurement / tests: one exponent for every non-fixed group (split modes only)
+        if (split_mode) {
+            for (auto& g : sgroups) if (!g.fixed) g.exp = atoi(e);
+            apply_split_exponents();
+        } else fprintf(stderr, "libmaskrcnn_hip: MRCNN_SPLIT_EXP ignored: compute mode %d carries no split exponents\n", mode);
     }
     taps["cls_probs"] = {cls_head.probs, (long)max_prop * nc, MRCNN_F32};
     taps["cls_bbox"] = {cls_head.bbox, (long)max_prop * nc * 4, MRCNN_F32};
@@ -1127,64 +1152,83 @@ void Model::apply_split_exponents()
     for (auto& op : mask_head.sop) refresh(op);
 }
 
+int Model::split_exponent_for(float absmax)
+{
+    if (!(absmax > 0.f)) return 0;
+    int k = 0;
+    (void)frexpf(absmax, &k);                      // absmax = m * 2^k, 0.5 <= m < 1
+    const int e = 12 - k;
+    return e < -24 ? -24 : (e > 48 ? 48 : e);
+}
+
+void Model::measure_split_groups(const uint8_t* rgb, int batch, int h, int w, int memspace, bool fit, bool resident)
+{
+    const size_t G = sgroups.size();
+    std::vector<unsigned> raw(G * 8);
+    // true magnitudes.  Every exponent 0 — or, when an activation of THIS model leaves the fp16 range there (the watchdog fails the
+    // pass: its maxima would be garbage), one uniform negative exponent that keeps it inside
+    int base = 0;
+    for (;;) {
+        for (auto& g : sgroups) g.exp = g.fixed ? 0 : base;
+        apply_split_exponents();
+        HIP_CHECK(hipMemset(calib_buf.p, 0, G * 32));
+        calib_phase = 1;
+        bool tripped = false;
+        try {
+            predict(rgb, batch, h, w, memspace, nullptr, nullptr, true, fit, resident);
+        } catch (const Error& e) {
+            calib_phase = 0;
+            if (e.code != MRCNN_ERR_UNSUPPORTED || base <= -36) throw;
+            tripped = true;
+        } catch (...) {
+            calib_phase = 0;
+            throw;
+        }
+        calib_phase = 0;
+        if (!tripped) break;
+        base -= 6;
+    }
+    HIP_CHECK(hipMemcpy(raw.data(), calib_buf.p, G * 32, hipMemcpyDeviceToHost));
+    for (size_t g = 0; g < G; ++g) {
+        float mx;
+        memcpy(&mx, &raw[g * 8], 4);
+        mx = ldexpf(mx, -sgroups[g].exp);               // stored = 2^e * value
+        sgroups[g].absmax = mx;
+        MRCNN_REQUIRE(mx == mx && mx < 3.0e38f, MRCNN_ERR_UNSUPPORTED, "calibrate_split: tensor group '%s' holds inf / NaN", sgroups[g].name.c_str());
+    }
+}
+
 void Model::calibrate_split(const uint8_t* rgb, int batch, int h, int w, int memspace, bool apply)
 {
     MRCNN_REQUIRE(kind == MRCNN_MODEL_MASKRCNN, MRCNN_ERR_INVALID, "calibrate_split called on a non-MaskRCNN model");
     MRCNN_REQUIRE(mode == MRCNN_F32S || mode == MRCNN_F32X3, MRCNN_ERR_UNSUPPORTED,
                   "calibrate_split: only the split modes (MRCNN_F32S, MRCNN_F32X3) carry activations through fp16 parts; this model is scale-invariant as it is");
+    MRCNN_REQUIRE(batch >= 1 && batch <= max_batch, MRCNN_ERR_SHAPE, "batch %d outside 1..%d", batch, max_batch);
     const size_t G = sgroups.size();
-    std::vector<float> det((size_t)batch * max_det * 6), msk((size_t)batch * max_det * 4 * mask_pool * mask_pool);
     std::vector<unsigned> raw(G * 8);
     std::vector<int> saved(G);
     for (size_t g = 0; g < G; ++g) saved[g] = sgroups[g].exp;
-    auto run = [&](int phase) {
-        HIP_CHECK(hipStreamSynchronize(stream));
+    try {
+        // ---- phase 1: true magnitudes ----
+        measure_split_groups(rgb, batch, h, w, memspace, false, false);
+        // ---- exponents: max |a| * 2^e in [2^11, 2^12) — 16x head room below the fp16 range, 0.5 = 2^-13 of the maximum exact ----
+        std::vector<int> chosen(G, 0);
+        for (size_t g = 0; g < G; ++g)
+            if (!sgroups[g].fixed) chosen[g] = split_exponent_for(sgroups[g].absmax);
+        // ---- phase 2: with the chosen exponents — verifies them (range watchdog) and counts what a split still cannot carry.
+        //      (The images are resident from phase 1: no second copy, and a device-side caller's buffer is read once.) ----
+        for (size_t g = 0; g < G; ++g) sgroups[g].exp = chosen[g];
+        apply_split_exponents();
         HIP_CHECK(hipMemset(calib_buf.p, 0, G * 32));
-        calib_phase = phase;
+        calib_phase = 2;
         try {
-            predict(rgb, batch, h, w, memspace, det.data(), msk.data(), true);
+            predict(rgb, batch, h, w, memspace, nullptr, nullptr, true, false, true);
         } catch (...) {
             calib_phase = 0;
             throw;
         }
         calib_phase = 0;
         HIP_CHECK(hipMemcpy(raw.data(), calib_buf.p, G * 32, hipMemcpyDeviceToHost));
-    };
-    try {
-        // ---- phase 1: true magnitudes.  Every exponent 0 — or, when an activation of THIS model leaves the fp16 range there
-        // (the watchdog fails the predict: its maxima would be garbage), one uniform negative exponent that keeps it inside ----
-        int base = 0;
-        for (;;) {
-            for (auto& g : sgroups) g.exp = g.fixed ? 0 : base;
-            apply_split_exponents();
-            try {
-                run(1);
-                break;
-            } catch (const Error& e) {
-                if (e.code != MRCNN_ERR_UNSUPPORTED || base <= -24) throw;
-                base -= 6;
-            }
-        }
-        for (size_t g = 0; g < G; ++g) {
-            float mx;
-            memcpy(&mx, &raw[g * 8], 4);
-            mx = ldexpf(mx, -sgroups[g].exp);               // stored = 2^e * value
-            sgroups[g].absmax = mx;
-            MRCNN_REQUIRE(mx == mx && mx < 3.0e38f, MRCNN_ERR_UNSUPPORTED, "calibrate_split: tensor group '%s' holds inf / NaN", sgroups[g].name.c_str());
-        }
-        // ---- exponents: max |a| * 2^e in [2^11, 2^12) — 16x head room below the fp16 range, 0.5 = 2^-13 of the maximum exact ----
-        std::vector<int> chosen(G, 0);
-        for (size_t g = 0; g < G; ++g) {
-            if (sgroups[g].fixed || !(sgroups[g].absmax > 0.f)) continue;
-            int k = 0;
-            (void)frexpf(sgroups[g].absmax, &k);           // absmax = m * 2^k, 0.5 <= m < 1
-            int e = 12 - k;
-            chosen[g] = e < -24 ? -24 : (e > 48 ? 48 : e);
-        }
-        // ---- phase 2: with the chosen exponents — verifies them (range watchdog) and counts what a split still cannot carry ----
-        for (size_t g = 0; g < G; ++g) sgroups[g].exp = chosen[g];
-        apply_split_exponents();
-        run(2);
         for (size_t g = 0; g < G; ++g) {
             unsigned long long c[3];
             memcpy(c, &raw[g * 8 + 2], 24);
@@ -1201,10 +1245,33 @@ void Model::calibrate_split(const uint8_t* rgb, int batch, int h, int w, int mem
     }
 }
 
-void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, float* det_out, float* masks_out, bool sync, bool fit)
+bool Model::recover_range(int batch, int h, int w, bool fit)
+{
+    if (!(mode == MRCNN_F32S || mode == MRCNN_F32X3) || kind != MRCNN_MODEL_MASKRCNN) return false;
+    const size_t G = sgroups.size();
+    std::vector<int> before(G);
+    for (size_t g = 0; g < G; ++g) before[g] = sgroups[g].exp;
+    try {
+        measure_split_groups(nullptr, batch, h, w, MRCNN_DEVICE, fit, true);
+    } catch (...) {
+        for (size_t g = 0; g < G; ++g) sgroups[g].exp = before[g];
+        apply_split_exponents();
+        throw;
+    }
+    // never raise an exponent: what earlier batches needed still fits
+    for (size_t g = 0; g < G; ++g) {
+        if (sgroups[g].fixed) { sgroups[g].exp = 0; continue; }
+        const int need = split_exponent_for(sgroups[g].absmax);
+        sgroups[g].exp = need < before[g] ? need : before[g];
+    }
+    apply_split_exponents();
+    return true;
+}
+
+void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, float* det_out, float* masks_out, bool sync, bool fit, bool resident)
 {
     MRCNN_REQUIRE(kind == MRCNN_MODEL_MASKRCNN, MRCNN_ERR_INVALID, "predict called on a non-MaskRCNN model");
-    MRCNN_REQUIRE(rgb && det_out && masks_out, MRCNN_ERR_INVALID, "null buffer");
+    MRCNN_REQUIRE((rgb || resident) && ((det_out && masks_out) || calib_phase), MRCNN_ERR_INVALID, "null buffer");
     MRCNN_REQUIRE(fit ? (h > 0 && w > 0 && h < 32768 && w < 32768) : (h == H && w == W), MRCNN_ERR_SHAPE,
                   "image is %dx%d, the model expects %dx%d (mrcnn_maskrcnn_predict_scalefit letterboxes any size)", h, w, H, W);
     MRCNN_REQUIRE(batch >= 1 && batch <= max_batch, MRCNN_ERR_SHAPE, "batch %d outside 1..%d", batch, max_batch);
@@ -1222,7 +1289,7 @@ void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, f
     HIP_CHECK(hipStreamIsCapturing(s, &outer_capture));
     const bool timed_call = sync && outer_capture == hipStreamCaptureStatusNone;
     if (timed_call) HIP_CHECK(hipEventRecord(ev_p0, s));
-    HIP_CHECK(hipMemcpyAsync(img_dst, rgb, img_bytes, memspace == MRCNN_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    if (!resident) HIP_CHECK(hipMemcpyAsync(img_dst, rgb, img_bytes, memspace == MRCNN_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
 
     hipStreamCaptureStatus caller_capture = hipStreamCaptureStatusNone;
     if (use_graph) HIP_CHECK(hipStreamIsCapturing(s, &caller_capture));
@@ -1254,13 +1321,14 @@ void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, f
     }
 
     const int HW = 4 * mask_pool * mask_pool;
-    const hipMemcpyKind back = memspace == MRCNN_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    HIP_CHECK(hipMemcpyAsync(det_out, detections, (size_t)batch * max_det * 6 * 4, back, s));
-    HIP_CHECK(hipMemcpyAsync(masks_out, mask_out, (size_t)batch * max_det * HW * 4, back, s));
+    // (the recovery path of collect() reads device images and writes host records: the direction of the record copies follows the pointers)
+    const hipMemcpyKind back = hipMemcpyDefault;
+    if (det_out) HIP_CHECK(hipMemcpyAsync(det_out, detections, (size_t)batch * max_det * 6 * 4, back, s));
+    if (masks_out) HIP_CHECK(hipMemcpyAsync(masks_out, mask_out, (size_t)batch * max_det * HW * 4, back, s));
     if (timed_call) HIP_CHECK(hipEventRecord(ev_p1, s));
     if (sync) {
         HIP_CHECK(hipStreamSynchronize(s));
-        if (timed_call) {
+        if (timed_call && !calib_phase) {              // (calibration / recovery passes are not the host's predicts)
             float ms = 0;
             HIP_CHECK(hipEventElapsedTime(&ms, ev_p0, ev_p1));
             gpu_busy_ms += ms;
@@ -1271,8 +1339,23 @@ void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, f
         if (mode != MRCNN_F32) {
             int tripped = 0;
             HIP_CHECK(hipMemcpy(&tripped, range_flag.p, sizeof(int), hipMemcpyDeviceToHost));
+            if (tripped && calib_phase)
+                fail(MRCNN_ERR_UNSUPPORTED, "an activation left the fp16 range during a calibration pass");       // (the caller steps the exponents down)
             if (tripped) {
                 ++range_overflows;
+                // split modes: this batch needs smaller exponents than the calibration images did — measure it where it sits, lower them,
+                // compute it again.  The reference's fp32 path handles any such input (Conversion/task.py:90).
+                if (outer_capture == hipStreamCaptureStatusNone && recover_range(batch, h, w, fit)) {
+                    ++range_recoveries;
+                    enqueue_pipeline(s, batch, fit ? fitgeo : nullptr);
+                    if (det_out) HIP_CHECK(hipMemcpyAsync(det_out, detections, (size_t)batch * max_det * 6 * 4, back, s));
+                    if (masks_out) HIP_CHECK(hipMemcpyAsync(masks_out, mask_out, (size_t)batch * max_det * HW * 4, back, s));
+                    HIP_CHECK(hipStreamSynchronize(s));
+                    timer.finish();
+                    if (conv_profile.active) conv_profile.collect();
+                    HIP_CHECK(hipMemcpy(&tripped, range_flag.p, sizeof(int), hipMemcpyDeviceToHost));
+                    if (!tripped) return;
+                }
                 fail(MRCNN_ERR_UNSUPPORTED, "an activation left the fp16 range (|v| >= 65504) in compute mode %s: the results of this call are "
                      "not valid; load the model with MRCNN_F32", mode == MRCNN_F16 ? "MRCNN_F16" : (mode == MRCNN_F32S ? "MRCNN_F32S" : "MRCNN_F32X3"));
             }
@@ -1288,6 +1371,9 @@ void Model::submit(const uint8_t* rgb_host, int batch, int h, int w)
     MRCNN_REQUIRE(h == H && w == W, MRCNN_ERR_SHAPE, "image is %dx%d, the model expects %dx%d", h, w, H, W);
     MRCNN_REQUIRE(batch >= 1 && batch <= max_batch, MRCNN_ERR_SHAPE, "batch %d outside 1..%d", batch, max_batch);
     MRCNN_REQUIRE(pipe_submitted - pipe_collected < 2, MRCNN_ERR_INVALID, "two batches are in flight already: call mrcnn_maskrcnn_collect first");
+    // the stage timer and the conv profile hold ONE batch's events: a second submission would re-record what the first one's collect reads
+    MRCNN_REQUIRE(pipe_submitted == pipe_collected || !(timer.enabled || conv_profile.active), MRCNN_ERR_INVALID,
+                  "stage timing / the conv profile are on: collect the batch in flight before submitting the next");
     PipeSlot& sl = pipe[pipe_submitted & 1];
     const int HW = 4 * mask_pool * mask_pool;
     if (!pipe_in) {
@@ -1326,6 +1412,11 @@ void Model::collect(float* det_host, float* masks_host, int* batch_out)
     PipeSlot& sl = pipe[pipe_collected & 1];
     const int HW = 4 * mask_pool * mask_pool;
     int tripped = 0;
+    // whatever happens below, the slot is handed back: a HIP error here must not leave it "in flight" for ever
+    struct Release {
+        Model* m; PipeSlot* sl;
+        ~Release() { sl->busy = false; ++m->pipe_collected; }
+    } release{this, &sl};
     HIP_CHECK(hipStreamWaitEvent(pipe_out, sl.ev_done, 0));
     HIP_CHECK(hipMemcpyAsync(det_host, sl.det.p, (size_t)sl.batch * max_det * 6 * 4, hipMemcpyDeviceToHost, pipe_out));
     HIP_CHECK(hipMemcpyAsync(masks_host, sl.mask.p, (size_t)sl.batch * max_det * HW * 4, hipMemcpyDeviceToHost, pipe_out));
@@ -1336,13 +1427,23 @@ void Model::collect(float* det_host, float* masks_host, int* batch_out)
         if (conv_profile.active) conv_profile.collect();
     }
     if (batch_out) *batch_out = sl.batch;
-    sl.busy = false;
-    ++pipe_collected;
     ++predict_calls;
     if (tripped) {
         ++range_overflows;
-        fail(MRCNN_ERR_UNSUPPORTED, "an activation left the fp16 range (|v| >= 65504) in a split / fp16 compute mode: the results of this batch are "
-             "not valid; calibrate the split (mrcnn_model_calibrate_split) or load the model with MRCNN_F32");
+        if (mode == MRCNN_F32S || mode == MRCNN_F32X3) {
+            // this slot's images are still on the device: compute the batch again through the synchronous entry, which lowers the exponents
+            // it needs (a newer batch already in flight was computed with the old ones and is checked at its own collect)
+            --predict_calls;
+            HIP_CHECK(hipStreamSynchronize(stream));                // (a newer batch in flight has finished: its records wait in its own slot)
+            HIP_CHECK(hipMemcpyAsync(d_rgb, sl.rgb.p, (size_t)sl.batch * H * W * 3, hipMemcpyDeviceToDevice, stream));
+            if (recover_range(sl.batch, H, W, false)) {
+                ++range_recoveries;
+                predict(nullptr, sl.batch, H, W, MRCNN_DEVICE, det_host, masks_host, true, false, true);
+                return;
+            }
+        }
+        fail(MRCNN_ERR_UNSUPPORTED, "an activation left the fp16 range (|v| >= 65504) in the fp16 compute mode: the results of this batch are "
+             "not valid; load the model with MRCNN_F32X3 or MRCNN_F32");
     }
 }
 
@@ -1351,6 +1452,7 @@ void Model::enqueue_pipeline(hipStream_t s, int batch, const int* fit)
     int* const rflag = mode != MRCNN_F32 ? range_flag.as<int>() : nullptr;
     if (rflag) HIP_CHECK(hipMemsetAsync(rflag, 0, sizeof(int), s));
     conv_set_range_flag(rflag);
+    conv_set_scratch(conv_scratch.ks_buf.p ? &conv_scratch : nullptr);
     timer.begin(s);
     conv_set_profiler(conv_profile.active ? &conv_profile : nullptr);
     {
@@ -1434,6 +1536,7 @@ void Model::enqueue_pipeline(hipStream_t s, int batch, const int* fit)
     timer.mark(s, "TimeDistributedMask-Eval");
     conv_set_profiler(nullptr);
     conv_set_range_flag(nullptr);
+    conv_set_scratch(nullptr);
 }
 
 void Model::read_tensor(const std::string& name, int image, float* dst, int64_t cap, int64_t* count)

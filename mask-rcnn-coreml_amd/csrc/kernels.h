@@ -103,6 +103,8 @@ struct ConvDesc {
     const void* wgt = nullptr;
     // the same filters re-tiled for the halo kernel (kernels_conv_halo.hip: conv_halo_pack); nullptr = not available
     const void* wgt_halo = nullptr;
+    // fp16 mode: the same filters in MFMA-fragment order for the fused bottleneck (kernels_bneck.hip: bneck_pack_frag); nullptr = not available
+    const void* wgt_frag = nullptr;
     int KH = 1, KW = 1, stride = 1, padH = 0, padW = 0;
     // epilogue: y = act(acc*scale[n] + shift[n] + residual)
     const float* scale = nullptr;
@@ -128,6 +130,8 @@ struct ConvDesc {
     long out_sH = 0, out_sW = 0;  // only used when deconv2
     // algorithmic reduction length per output (defaults to KH*KW*Cin; conv1 pads 147 → 224)
     int algo_k = 0;
+    // profile bookkeeping only: 1 = a backbone convolution (conv1, res2..res5), 0 = anything else (FPN, RPN, heads)
+    int group = 0;
     // deconv2 only — selected-class dot instead of the store (the mask head's last two layers fused): for input image
     // (= ROI row) b with class sel_cid[b] >= 0, every output pixel P contributes
     //   sel_partial[(b * 4*OH*OW + P) * (Cout/128) + h] = Σ_{co in 128-channel part h} y[P][co] * sel_w[sel_cid[b]][co]
@@ -157,7 +161,8 @@ struct ConvProfile {
     std::vector<hipEvent_t> pool;
     struct Shape { int M, N, K, tile; bool operator<(const Shape& o) const { return std::tie(M, N, K, tile) < std::tie(o.M, o.N, o.K, o.tile); } };
     std::map<Shape, Slot> by_shape;  // per GEMM shape (M = images·OH·OW, N = output columns, K = taps·Cin)
-    struct Pending { int tile; double flops; int e0, e1; Shape shape; };
+    struct Pending { int tile; double flops; int e0, e1; Shape shape; int group = 0; };
+    Slot by_group[2];                // ConvDesc::group: 0 = everything else, 1 = the backbone convolutions (C1..C5: north_star's roofline target is worded on them)
     std::vector<Pending> pending;
     int used = 0;
     bool active = false;
@@ -171,6 +176,17 @@ void boxes_one_time_init();
 // While set (thread-local), every conv launch ORs 1 into *device_flag when one of its outputs leaves the fp16
 // range (|v| >= 65504, inf or NaN): the watchdog of the fp16-MFMA modes, whose next layer reads it through fp16.
 void conv_set_range_flag(int* device_flag);
+// Device scratch of the convolution family (the partial sums + tile counters of shared-tile K chunks, the fused bottleneck tail's
+// parking buffer).  OWNED by whoever launches — a Model (allocated at load, freed with it), a stand-alone test entry (for the call) —
+// and handed to the launches of the calling thread like the range flag.  Without one the kernels that need it are not chosen
+// (a chunked layer sums its chunks in one block: the same bits), so nothing is ever allocated behind a caller's back or inside a
+// stream capture, and nothing outlives its owner.
+struct ConvScratch {
+    DevBuf ks_buf, ks_cnt, park;
+    void alloc();            // synchronous; call outside any stream capture
+    static size_t ks_bytes();
+};
+void conv_set_scratch(ConvScratch* c);    // thread-local; nullptr = none
 // Picks the tile shape from Cout; returns the N tile it will use so that callers can pad weights.
 int conv_n_tile(int Cout);
 // sc != nullptr: `sc` is the 1x1 convolution whose output is d's residual (a ResNet stage's shortcut): computed inside d's launch where the pair
@@ -211,8 +227,15 @@ bool conv_bneck_fusable(const ConvDesc& da, const ConvDesc& db, const ConvDesc& 
 bool conv_bneck_enabled();
 void conv_bneck_forward(hipStream_t s, const ConvDesc& da, const ConvDesc& db, const ConvDesc& dc);
 bool bneck_geometry_ok(int C, int H, int W);
+// w2f / w3f: W2 / W3 in MFMA-fragment order (bneck_pack_frag) — used by the C = 256 form, whose waves stream their filter fragments
+// straight from L2 into registers; nullptr selects the form with every operand staged through LDS
 void bneck_launch(hipStream_t s, int C, const void* x, void* y, int B, int H, int W, const void* w1, const void* w2, const void* w3,
-                  const float* s1, const float* h1, const float* s2, const float* h2, const float* s3, const float* h3, int* range_flag, int n_cus);
+                  const float* s1, const float* h1, const float* s2, const float* h2, const float* s3, const float* h3, int* range_flag, int n_cus,
+                  const void* w2f = nullptr, const void* w3f = nullptr);
+// [N][K] fp16 filters (K contiguous; N % 32 == 0, K % 16 == 0) -> 1-KB granules [N/32][K/16][lane 0..63][8]: lane (l31, kk) of granule (nt, kg)
+// holds filter row 32 nt + l31, k = 16 kg + 8 kk .. + 7 — the first MFMA operand of v_mfma_f32_32x32x16_f16, one coalesced 16-B load per lane
+void bneck_pack_frag(hipStream_t s, const void* wgt_std, int N, int K, DevBuf& out);
+bool bneck_frag_wanted(int KH, int KW, int Cin, int Cout);      // the filter shapes the C = 256 form reads in fragment order
 
 // The stem in the split modes and the fp16 mode (kernels_conv_stem.hip): conv1 — described by d exactly as for conv_forward (7 row taps of 32 "channels"
 // on the zero-padded NHWC4 input, 64 output columns, ReLU) — and the 3x3 stride-2 'same' max-pool behind it in ONE persistent launch;

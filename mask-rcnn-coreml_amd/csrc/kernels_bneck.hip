@@ -26,6 +26,7 @@
 //
 // The output must NOT alias the input: a tile reads the halo pixels its neighbours own.  (The three-launch form writes in place;
 // the engine gives fused stages a second tensor and ping-pongs.)
+#include <stdlib.h>
 #include <type_traits>
 
 #include "conv_device.h"
@@ -55,6 +56,7 @@ struct BnCfg {
 struct BneckArgs {
     const _Float16* x; _Float16* y;
     const _Float16 *w1, *w2, *w3;
+    const uint4 *w2f, *w3f;          // W2 / W3 in MFMA-fragment order (FRAG form)
     const float *s1, *h1, *s2, *h2, *s3, *h3;
     int B, H, W, tiles_x, tiles_y, ntiles;
     int* range_flag;
@@ -101,9 +103,14 @@ __device__ __forceinline__ bool bn_bad(const float4 v)
 //     lane groups read halo columns {dx + 0..3, dx + 12..15} of one halo row and {dx + 4..11} of the next, so the swizzle key is
 //     the halo COLUMN: chunk c of pixel (py, px) at c ^ ((px >> 1) & 7), and with an even pitch (18) the 128-B half of the
 //     256-B bank line is px & 1 — sixteen distinct (half, key) pairs for any tap.
-template <int C>
+// FRAG (C = 256): in phases B / C a wave owns 32 output channels x all 128 pixels of the tile and streams ITS filter fragments straight
+// from L2 into registers (bneck_pack_frag: one coalesced 1-KB load per 16-wide K group, eight groups ahead) — every filter byte is
+// loaded once per block, as through the ring, but there is no ring, no DMA issue in the loop and NO BARRIER inside the two phases
+// (t1 / t2 are read-only while they run): the two waves of a SIMD de-phase by themselves and keep the matrix pipe fed.
+template <int C, bool FRAG>
 __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
 {
+    static_assert(!FRAG || C == 256, "the fragment-streaming form is laid out for C = 256 (eight waves x 32 channels, 128-pixel tiles)");
     using K = BnCfg<C>;
     constexpr int HP = K::HP, HWD = K::HWD, WN = K::WN, NB = K::NB, TNW = K::TNW, CB = K::CB, P = K::P;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[K::LDS];
@@ -229,10 +236,10 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
         }                                                                                                      \
     }
         BN_ISSUE_A(0)
-        for (int ks = 0; ks < K::NA; ++ks) {
+        for (int ks = 0; ks < ((a.dbg & 1) ? 1 : K::NA); ++ks) {
             BN_VMCNT0
             __syncthreads();                           // step ks has landed for everyone; everyone is done reading step ks - 1
-            if (ks + 1 < K::NA) BN_ISSUE_A(ks + 1)
+            if (ks + 1 < K::NA && !(a.dbg & 1)) BN_ISSUE_A(ks + 1)
             const unsigned char* const sb = smem + ((ks & 1) ? (K::RING - K::A_STAGE) : 0);
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
@@ -281,6 +288,140 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
         }
 #undef BN_ISSUE_A
 
+        if constexpr (FRAG) {
+        // =========================== phases B and C, fragment-streaming form ===========================
+        constexpr int KG2 = 9 * C / 16, KG3 = C / 16, D = 8;          // 16-wide K groups of W2 / of one W3 round; fragments in flight
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+        const uint4* const wp2 = a.w2f + (size_t)wave * KG2 * 64 + lane;
+        uint4 wq[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) wq[d] = wp2[d * 64];
+        // output pixel p = i*32 + l31 -> (py, px) = (2i + (l31 >> 4), l31 & 15); tap (dy, dx) reads halo pixel (py + dy, px + dx)
+        const unsigned t1r = (unsigned)(K::OFF_T1 + ((l31 >> 4) * HWD + (l31 & 15)) * 128);
+        __syncthreads();                               // t1 complete
+        // activation fragments are requested one K group ahead (two register sets), the filter fragment of group kg + 8 right after the
+        // MFMAs that consumed this slot's (the slot's register is dead by then: no rotation copies)
+        auto a_addr = [&](int kg) {        // byte address of the fragment of pixel tile 0 for K group kg (tile i: + i * 2 * HWD * 128)
+            const int tap = kg >> 4, dy = tap / 3, dx = tap - 3 * dy, cb = (kg >> 2) & 3, g = kg & 3;
+            const unsigned swx = (unsigned)(((((l31 & 15) + dx) >> 1) & 7) << 4) ^ (unsigned)(kk << 4);
+            return t1r + (unsigned)((cb * HP + dy * HWD + dx) * 128) + (swx ^ (unsigned)(g << 5));
+        };
+        f16x8 af[2][4];
+        {
+            const unsigned ao = a_addr(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(smem + ao + i * 2 * HWD * 128);
+        }
+        for (int it = 0; it < ((a.dbg & 2) ? 1 : KG2 / D); ++it) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int kg = it * D + d;
+                {
+                    const int kn = kg + 1 < KG2 ? kg + 1 : kg;
+                    const unsigned ao = a_addr(kn);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[(d + 1) & 1][i] = *reinterpret_cast<const f16x8*>(smem + ao + i * 2 * HWD * 128);
+                }
+                const f16x8 wf = __builtin_bit_cast(f16x8, wq[d]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) BN_MFMA(wf, af[d & 1][i], acc[i])
+                int kgn = kg + D;
+                kgn = kgn < KG2 ? kgn : KG2 - 1;       // (the tail re-requests the last fragment: no branch in the stream)
+                wq[d] = wp2[kgn * 64];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // W3's first fragments ride under the epilogue; round r: output columns (8 r + wave) * 32 ..
+        const uint4* const wp3 = a.w3f + (size_t)wave * KG3 * 64 + lane;
+#pragma unroll
+        for (int d = 0; d < D; ++d) wq[d] = wp3[d * 64];
+        __syncthreads();                               // every wave is done with t1: t2 and phase C's table may overwrite it
+        for (int i = t; i < 8 * C; i += 512) {
+            const int w = i / (4 * C), c = i - w * 4 * C;
+            const float* src = w == 0 ? a.s3 : a.h3;
+            tabC[i] = src ? src[c] : (w ? 0.0f : 1.0f);
+        }
+        // epilogue B -> t2: channels 32 wave + 16 p + 8 kk .. of pixel i*32 + l31
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int cl = wave * 32 + 16 * p + 4 * kk;
+                const float4 sa = *reinterpret_cast<const float4*>(tabAB + 2 * C + cl), sb_ = *reinterpret_cast<const float4*>(tabAB + 2 * C + cl + 8);
+                const float4 ha = *reinterpret_cast<const float4*>(tabAB + 3 * C + cl), hb = *reinterpret_cast<const float4*>(tabAB + 3 * C + cl + 8);
+                float4 va = make_float4(acc[i][8 * p + 0], acc[i][8 * p + 1], acc[i][8 * p + 2], acc[i][8 * p + 3]);
+                float4 vb = make_float4(acc[i][8 * p + 4], acc[i][8 * p + 5], acc[i][8 * p + 6], acc[i][8 * p + 7]);
+                va.x = va.x * sa.x + ha.x; va.y = va.y * sa.y + ha.y; va.z = va.z * sa.z + ha.z; va.w = va.w * sa.w + ha.w;
+                vb.x = vb.x * sb_.x + hb.x; vb.y = vb.y * sb_.y + hb.y; vb.z = vb.z * sb_.z + hb.z; vb.w = vb.w * sb_.w + hb.w;
+                va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f); va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
+                vb.x = fmaxf(vb.x, 0.f); vb.y = fmaxf(vb.y, 0.f); vb.z = fmaxf(vb.z, 0.f); vb.w = fmaxf(vb.w, 0.f);
+                range_trip = range_trip || bn_bad(va) || bn_bad(vb);
+                const uint4 pk = bn_pack16(va, vb);
+                const int ch0 = wave * 32 + 16 * p + 8 * kk;
+                const unsigned off = (unsigned)(K::OFF_T1 + ((ch0 >> 6) * P + i * 32 + l31) * 128) + ((((unsigned)(ch0 & 63) >> 3) ^ (unsigned)sw128) << 4);
+                *reinterpret_cast<uint4*>(smem + off) = pk;
+            }
+        __syncthreads();                               // t2 and the table are complete
+        size_t grow[4];              // element offset of the lane's pixels in the image
+#pragma unroll
+        for (int i = 0; i < 4; ++i) grow[i] = ((size_t)(y0 + 2 * i + (l31 >> 4)) * a.W + (x0 + (l31 & 15))) * (size_t)(4 * C);
+        for (int r = 0; r < ((a.dbg & 4) ? 1 : 4); ++r) {
+            const int n0 = (r * 8 + wave) * 32;        // this wave's output columns of the round
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+            uint4 rv[4][2];           // the shortcut of the round, requested ahead of its K loop (16 B = eight channels per lane: the store layout)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) rv[i][p] = *reinterpret_cast<const uint4*>(ximg + grow[i] + n0 + 16 * p + 8 * kk);
+            f16x8 af[2][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(smem + K::OFF_T1 + (i * 32 + l31) * 128 + w_c[0]);
+#pragma unroll
+            for (int kg = 0; kg < KG3; ++kg) {
+                {
+                    const int kn = kg + 1 < KG3 ? kg + 1 : kg, kb = kn >> 2, g = kn & 3;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[(kg + 1) & 1][i] = *reinterpret_cast<const f16x8*>(smem + K::OFF_T1 + (kb * P + i * 32 + l31) * 128 + w_c[g]);
+                }
+                const f16x8 wf = __builtin_bit_cast(f16x8, wq[kg % D]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) BN_MFMA(wf, af[kg & 1][i], acc[i])
+                // the stream runs on into the next round's fragments (granule ((8 r' + wave) * KG3 + kg')); the last round re-requests its tail
+                int qn = r * KG3 + kg + D;
+                qn = qn < 4 * KG3 ? qn : 4 * KG3 - 1;
+                wq[kg % D] = wp3[(size_t)((qn / KG3) * 8 * KG3 + (qn % KG3)) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int cl = n0 + 16 * p + 4 * kk;
+                    const float4 sa = *reinterpret_cast<const float4*>(tabC + cl), sb_ = *reinterpret_cast<const float4*>(tabC + cl + 8);
+                    const float4 ha = *reinterpret_cast<const float4*>(tabC + 4 * C + cl), hb = *reinterpret_cast<const float4*>(tabC + 4 * C + cl + 8);
+                    float4 va = make_float4(acc[i][8 * p + 0], acc[i][8 * p + 1], acc[i][8 * p + 2], acc[i][8 * p + 3]);
+                    float4 vb = make_float4(acc[i][8 * p + 4], acc[i][8 * p + 5], acc[i][8 * p + 6], acc[i][8 * p + 7]);
+                    va.x = va.x * sa.x + ha.x; va.y = va.y * sa.y + ha.y; va.z = va.z * sa.z + ha.z; va.w = va.w * sa.w + ha.w;
+                    vb.x = vb.x * sb_.x + hb.x; vb.y = vb.y * sb_.y + hb.y; vb.z = vb.z * sb_.z + hb.z; vb.w = vb.w * sb_.w + hb.w;
+                    float4 ra, rb;
+                    bn_unpack16(rv[i][p], ra, rb);
+                    va.x += ra.x; va.y += ra.y; va.z += ra.z; va.w += ra.w;
+                    vb.x += rb.x; vb.y += rb.y; vb.z += rb.z; vb.w += rb.w;
+                    va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f); va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
+                    vb.x = fmaxf(vb.x, 0.f); vb.y = fmaxf(vb.y, 0.f); vb.z = fmaxf(vb.z, 0.f); vb.w = fmaxf(vb.w, 0.f);
+                    range_trip = range_trip || bn_bad(va) || bn_bad(vb);
+                    const uint4 pk = bn_pack16(va, vb);
+                    *reinterpret_cast<uint4*>(yimg + grow[i] + n0 + 16 * p + 8 * kk) = pk;
+                }
+        }
+        } else {
         // =========================== phase B: t2 = relu(bn(conv3x3(t1))) ===========================
         f32x16 acc[2][TNW];
 #pragma unroll
@@ -434,9 +575,36 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
             }
         }
 #undef BN_ISSUE_W
+        }
         __syncthreads();                               // the next tile's phase A restarts the ring at stage 0
     }
     if (a.range_flag && range_trip) atomicOr(a.range_flag, 1);
+}
+
+__global__ void k_bneck_pack_frag(const _Float16* __restrict__ w, int N, int Kt, uint4* __restrict__ out)
+{
+    // one thread per 16-B fragment piece: granule (nt, kg), lane (l31, kk) <- w[32 nt + l31][16 kg + 8 kk .. + 7]
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int KG = Kt / 16;
+    if (i >= (long)(N / 32) * KG * 64) return;
+    const int lane = (int)(i & 63);
+    const long gq = i >> 6;
+    const int kg = (int)(gq % KG), nt = (int)(gq / KG);
+    out[i] = *reinterpret_cast<const uint4*>(w + (size_t)(nt * 32 + (lane & 31)) * Kt + kg * 16 + (lane >> 5) * 8);
+}
+
+void bneck_pack_frag(hipStream_t s, const void* wgt_std, int N, int Kt, DevBuf& out)
+{
+    MRCNN_REQUIRE(N % 32 == 0 && Kt % 16 == 0, MRCNN_ERR_SHAPE, "bneck_pack_frag: [%d][%d]", N, Kt);
+    const long n = (long)(N / 32) * (Kt / 16) * 64;
+    out.alloc((size_t)n * 16);
+    hipLaunchKernelGGL(k_bneck_pack_frag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, static_cast<const _Float16*>(wgt_std), N, Kt, out.as<uint4>());
+    HIP_CHECK(hipGetLastError());
+}
+
+bool bneck_frag_wanted(int KH, int KW, int Cin, int Cout)
+{
+    return (KH == 3 && KW == 3 && Cin == 256 && Cout == 256) || (KH == 1 && KW == 1 && Cin == 256 && Cout == 1024);
 }
 
 bool bneck_geometry_ok(int C, int H, int W)
@@ -448,7 +616,8 @@ bool bneck_geometry_ok(int C, int H, int W)
 }
 
 void bneck_launch(hipStream_t s, int C, const void* x, void* y, int B, int H, int W, const void* w1, const void* w2, const void* w3,
-                  const float* s1, const float* h1, const float* s2, const float* h2, const float* s3, const float* h3, int* range_flag, int n_cus)
+                  const float* s1, const float* h1, const float* s2, const float* h2, const float* s3, const float* h3, int* range_flag, int n_cus,
+                  const void* w2f, const void* w3f)
 {
     MRCNN_REQUIRE(bneck_geometry_ok(C, H, W), MRCNN_ERR_SHAPE, "bneck: C %d at %dx%d", C, H, W);
     MRCNN_REQUIRE(x != y, MRCNN_ERR_INVALID, "bneck: the output must not alias the input");
@@ -456,17 +625,21 @@ void bneck_launch(hipStream_t s, int C, const void* x, void* y, int B, int H, in
     BneckArgs a;
     a.x = static_cast<const _Float16*>(x); a.y = static_cast<_Float16*>(y);
     a.w1 = static_cast<const _Float16*>(w1); a.w2 = static_cast<const _Float16*>(w2); a.w3 = static_cast<const _Float16*>(w3);
+    a.w2f = static_cast<const uint4*>(w2f); a.w3f = static_cast<const uint4*>(w3f);
     a.s1 = s1; a.h1 = h1; a.s2 = s2; a.h2 = h2; a.s3 = s3; a.h3 = h3;
     a.B = B; a.H = H; a.W = W;
     const int th = C == 256 ? 8 : 16;
     a.tiles_x = W / 16; a.tiles_y = H / th; a.ntiles = B * a.tiles_x * a.tiles_y;
-    a.range_flag = range_flag; a.dbg = 0;
+    a.range_flag = range_flag;
+    static const int dbg = getenv("MRCNN_BNECK_DBG") ? atoi(getenv("MRCNN_BNECK_DBG")) : 0;      // measurement only: 1 / 2 / 4 = phase A / B / C cut to one step (results invalid)
+    a.dbg = dbg;
     int grid = n_cus > 0 ? n_cus / 8 * 8 : 256;
     if (grid <= 0) grid = 8;
     if (a.ntiles < grid) grid = a.ntiles;
-    if (C == 256) hipLaunchKernelGGL(k_bneck_h<256>, dim3(grid), dim3(512), 0, s, a);
-    else if (C == 128) hipLaunchKernelGGL(k_bneck_h<128>, dim3(grid), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(k_bneck_h<64>, dim3(grid), dim3(512), 0, s, a);
+    if (C == 256 && w2f && w3f) hipLaunchKernelGGL((k_bneck_h<256, true>), dim3(grid), dim3(512), 0, s, a);
+    else if (C == 256) hipLaunchKernelGGL((k_bneck_h<256, false>), dim3(grid), dim3(512), 0, s, a);
+    else if (C == 128) hipLaunchKernelGGL((k_bneck_h<128, false>), dim3(grid), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((k_bneck_h<64, false>), dim3(grid), dim3(512), 0, s, a);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -520,6 +520,7 @@ void conv_set_range_flag(int* device_flag) { g_range_flag = device_flag; }
 void ConvProfile::reset()
 {
     for (auto& s : by_tile) s = Slot();
+    for (auto& s : by_group) s = Slot();
     by_shape.clear();
     pending.clear();
     used = 0;
@@ -534,6 +535,8 @@ void ConvProfile::collect()
         by_tile[pd.tile].flops += pd.flops;
         Slot& sh = by_shape[pd.shape];
         sh.launches += 1; sh.ms += ms; sh.flops += pd.flops;
+        Slot& gr = by_group[pd.group == 1 ? 1 : 0];
+        gr.launches += 1; gr.ms += ms; gr.flops += pd.flops;
     }
     pending.clear();
     used = 0;
@@ -717,24 +720,16 @@ int conv_k_chunks(const ConvDesc& d)
 // inside a capture).  Launches on one stream are ordered, and a launch leaves its counters at zero.
 static constexpr size_t KS_BYTES = 64u << 20;
 static constexpr int KS_TILES = 8192;
-static void ks_scratch(hipStream_t s, float** scratch, unsigned** count)
+static thread_local ConvScratch* g_scratch = nullptr;
+void conv_set_scratch(ConvScratch* c) { g_scratch = c; }
+size_t ConvScratch::ks_bytes() { return KS_BYTES; }
+void ConvScratch::alloc()
 {
-    struct Ks { DevBuf buf, cnt; };
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, Ks*> all;          // (device, stream): the null stream exists on every device
-    int dev = 0;
-    HIP_CHECK(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(mu);
-    Ks*& k = all[std::make_pair(dev, s)];
-    if (!k) {
-        k = new Ks;
-        k->buf.alloc(KS_BYTES);
-        k->cnt.alloc(KS_TILES * sizeof(unsigned));
-        HIP_CHECK(hipMemsetAsync(k->cnt.p, 0, KS_TILES * sizeof(unsigned), s));
-    }
-    *scratch = static_cast<float*>(k->buf.p);
-    *count = static_cast<unsigned*>(k->cnt.p);
+    ks_buf.alloc(KS_BYTES);
+    ks_cnt.alloc(KS_TILES * sizeof(unsigned));
+    HIP_CHECK(hipMemset(ks_cnt.p, 0, KS_TILES * sizeof(unsigned)));       // (every launch leaves the counters at zero)
 }
+ConvScratch* conv_current_scratch() { return g_scratch; }
 
 // May the epilogue use 16-B vector stores / residual loads for this layer?
 static int conv_vec_ok(const ConvDesc& d, const ConvArgs& a)
@@ -817,10 +812,12 @@ void conv_forward(hipStream_t s, const ConvDesc& d_in, const ConvDesc* sc)
         int bs = bn_max;
         while (bs > 32 && (long)a.tiles_m * (d.Npad / bs) * a.kchunks < g_min_blocks) bs >>= 1;
         const long tiles = (long)a.tiles_m * (d.Npad / bs);
-        if (tiles <= KS_TILES && (size_t)tiles * a.kchunks * BM_DEFAULT * bs * 4 <= KS_BYTES) {
+        // (the shared-tile form needs the owner's scratch: a launch without one keeps its chunks in one block — the same bits)
+        if (g_scratch && g_scratch->ks_buf.p && tiles <= KS_TILES && (size_t)tiles * a.kchunks * BM_DEFAULT * bs * 4 <= KS_BYTES) {
             bn = bs;
             a.ksplit = a.kchunks;
-            ks_scratch(s, &a.ks_scratch, &a.ks_count);
+            a.ks_scratch = g_scratch->ks_buf.as<float>();
+            a.ks_count = g_scratch->ks_cnt.as<unsigned>();
         }
     }
     a.vec_ok = conv_vec_ok(d, a);
@@ -873,7 +870,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d_in, const ConvDesc* sc)
         const int e1 = prof_event(prof, s);
         const double k = (d.algo_k > 0 ? d.algo_k : a.Ktot) + (fuse ? sc->Cin : 0);          // (a fused shortcut: both K loops)
         const int tile = halo ? 5 : pp_bn == 256 ? 4 : (wide_waves ? 3 : (bn == 128 ? 0 : (bn == 64 ? 1 : 2)));
-        prof->pending.push_back({tile, 2.0 * (double)a.M * (double)a.ncols * k, e0, e1, {a.M, a.ncols, a.Ktot, tile}});
+        prof->pending.push_back({tile, 2.0 * (double)a.M * (double)a.ncols * k, e0, e1, {a.M, a.ncols, a.Ktot, tile}, d.group});
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -907,7 +904,7 @@ void conv_stem_forward(hipStream_t s, const ConvDesc& d, void* pooled, int PH, i
         const long M = (long)d.B * d.OH * d.OW;
         const double k = d.algo_k > 0 ? d.algo_k : d.KH * d.KW * d.Cin;
         // (the 64-column class of the table: the layer it replaces ran there; the pool rides in the same launch)
-        prof->pending.push_back({1, 2.0 * (double)M * 64.0 * k, e0, e1, {(int)M, 64, d.KH * d.KW * d.Cin, 1}});
+        prof->pending.push_back({1, 2.0 * (double)M * 64.0 * k, e0, e1, {(int)M, 64, d.KH * d.KW * d.Cin, 1}, d.group});
     }
 }
 
@@ -933,7 +930,7 @@ void conv_forward_tail(hipStream_t s, const ConvDesc& d3, const ConvDesc& d1, co
     static int n_cus = [] { int dev = 0; hipDeviceProp_t p; (void)hipGetDevice(&dev); return hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }();
     const long tiles = ((long)d3.B * d3.OH * d3.OW + 127) / 128;
     ConvArgs a3, a1;
-    bool fuse = g_tail && g_halo && conv_tail_fusable(d3, d1) && tiles * 8 >= (long)n_cus * 7;       // a grid that fills the chip: one 128 x 256 tile per block
+    bool fuse = g_tail && g_halo && g_scratch && conv_tail_fusable(d3, d1) && tiles * 8 >= (long)n_cus * 7;       // a grid that fills the chip: one 128 x 256 tile per block (and an owner for the parking buffer)
     if (sc && fuse) { conv_forward(s, *sc); sc = nullptr; }          // (the fused tail reads its residual from memory: the shortcut runs as its own launch)
     if (fuse) {
         conv_fill_args(d3, a3);
@@ -957,7 +954,7 @@ void conv_forward_tail(hipStream_t s, const ConvDesc& d3, const ConvDesc& d1, co
         const int e1 = prof_event(prof, s);
         // one launch, two layers: algorithmic flops of both; the shape key is the 3x3 layer's M and K with the 1x1's N (tile class 6)
         const double fl = 2.0 * (double)a3.M * ((double)a3.ncols * a3.Ktot + (double)a1.ncols * a1.Ktot);
-        prof->pending.push_back({6, fl, e0, e1, {a3.M, a1.ncols, a3.Ktot + a1.Ktot, 6}});
+        prof->pending.push_back({6, fl, e0, e1, {a3.M, a1.ncols, a3.Ktot + a1.Ktot, 6}, d3.group});
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -995,12 +992,12 @@ void conv_bneck_forward(hipStream_t s, const ConvDesc& da, const ConvDesc& db, c
     ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
     const int e0 = prof ? prof_event(prof, s) : 0;
     bneck_launch(s, da.Cout, da.in, dc.out, da.B, da.H, da.W, da.wgt, db.wgt, dc.wgt, da.scale, da.shift, db.scale, db.shift, dc.scale, dc.shift,
-                 g_range_flag, n_cus);
+                 g_range_flag, n_cus, g_bneck >= 2 ? nullptr : db.wgt_frag, g_bneck >= 2 ? nullptr : dc.wgt_frag);      // ("conv_bneck" 2: every operand through LDS)
     if (prof) {
         const int e1 = prof_event(prof, s);
         const double M = (double)da.B * da.H * da.W, C = da.Cout;
         const double fl = 2.0 * M * (4 * C * C + 9 * C * C + 4 * C * C);      // algorithmic flops of the three layers (the halo recompute is not work)
-        prof->pending.push_back({7, fl, e0, e1, {(int)M, 4 * da.Cout, 17 * da.Cout, 7}});
+        prof->pending.push_back({7, fl, e0, e1, {(int)M, 4 * da.Cout, 17 * da.Cout, 7}, da.group});
     }
 }
 

@@ -41,6 +41,8 @@
 
 namespace mrcnn {
 
+ConvScratch* conv_current_scratch();      // kernels_conv.hip: the calling thread's scratch (conv_set_scratch)
+
 static int env_int_halo(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
 static constexpr int HALO_MAX_SLOT = 640;        // LDS pixel slots of one plane (region rows x LDS pitch <= this)
@@ -1147,18 +1149,18 @@ int conv_halo_forward(hipStream_t s, ConvArgs a, const ConvDesc& d, int parts, i
     if (grid >= 8) grid &= ~7;                  // a multiple of 8: every XCD runs the same number of blocks
     if (t1) {
         ha.t.direct = 1;
-        // the parking scratch: 64 KB per block, one buffer per stream (launches on one stream are ordered; two models on two
-        // streams must not share it), grown on demand and never freed (a static destructor would run after the HIP runtime's)
-        static std::mutex park_mu;
-        static std::map<std::pair<int, hipStream_t>, DevBuf*> parks;          // (device, stream)
-        int dev = 0;
-        HIP_CHECK(hipGetDevice(&dev));
+        // the parking scratch: 64 KB per block, in the launch owner's ConvScratch (kernels.h), grown on demand outside stream captures
         {
-            std::lock_guard<std::mutex> lk(park_mu);
-            DevBuf*& pk = parks[std::make_pair(dev, s)];
-            if (!pk) pk = new DevBuf;
-            if (pk->bytes < (size_t)grid * 65536) { HIP_CHECK(hipStreamSynchronize(s)); pk->alloc((size_t)grid * 65536); }
-            ha.t_park = pk->p;
+            ConvScratch* const sc = conv_current_scratch();
+            MRCNN_REQUIRE(sc, MRCNN_ERR_INVALID, "fused tail without a ConvScratch (conv_forward_tail checks)");
+            if (sc->park.bytes < (size_t)grid * 65536) {
+                hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+                HIP_CHECK(hipStreamIsCapturing(s, &cap));
+                MRCNN_REQUIRE(cap == hipStreamCaptureStatusNone, MRCNN_ERR_INVALID, "fused tail: the parking buffer must exist before a stream capture (run the predict once eagerly)");
+                HIP_CHECK(hipStreamSynchronize(s));
+                sc->park.alloc((size_t)grid * 65536);
+            }
+            ha.t_park = sc->park.p;
         }
         MRCNN_REQUIRE(g.maxpc <= 3, MRCNN_ERR_INVALID, "fused tail: the tile's input region needs more than three staging pieces (conv_halo_tail_geometry_ok)");
         if (parts == 3) hipLaunchKernelGGL((k_conv_halo<3, 2, false, false, 2, 3, true>), dim3(grid), dim3(512), 0, s, ha);

@@ -200,9 +200,18 @@ class MaskRCNN(_Model):
     def conv_profile(self):
         """{tile: (launches, total_ms, total_algorithmic_flops)} since conv_profile_enable()."""
         out = {}
-        for tile, name in enumerate(("128x128", "128x64", "128x32", "128x128w4", "256x256pp", "128xNhalo", "128x256tail")):
+        for tile, name in enumerate(("128x128", "128x64", "128x32", "128x128w4", "256x256pp", "128xNhalo", "128x256tail", "bneck")):
             n, ms, fl = C.c_int64(0), C.c_double(0), C.c_double(0)
             _lib.check(_lib.lib().mrcnn_model_conv_profile_get(self._h, tile, C.byref(n), C.byref(ms), C.byref(fl)))
+            out[name] = (int(n.value), float(ms.value), float(fl.value))
+        return out
+
+    def conv_profile_groups(self):
+        """{"backbone" | "other": (launches, total_ms, total_algorithmic_flops)} — conv1 + res2..res5 against everything else."""
+        out = {}
+        for grp, name in ((1, "backbone"), (0, "other")):
+            n, ms, fl = C.c_int64(0), C.c_double(0), C.c_double(0)
+            _lib.check(_lib.lib().mrcnn_model_conv_profile_group(self._h, grp, C.byref(n), C.byref(ms), C.byref(fl)))
             out[name] = (int(n.value), float(ms.value), float(fl.value))
         return out
 

@@ -383,7 +383,10 @@ def test_engine_sparse_outcomes(pkg, orc, weights_mod, tmp_path, mode):
 
 
 def test_engine_fp16_range_watchdog(pkg, small_model, weights_mod, tmp_path):
-    """Activations beyond the fp16 range: exact in MRCNN_F32, refused (not silently saturated) in MRCNN_F32S / MRCNN_F16."""
+    """Activations beyond the fp16 range: exact in MRCNN_F32; refused (not silently saturated) in MRCNN_F16, whose tensors ARE fp16;
+    the split modes — fp32 tensors — RECOVER since round 5 (the batch is measured on the device, the split exponents are lowered, the
+    batch is computed again inside the call: "range_recoveries") and agree with the exact-fp32 engine, because the reference's fp32
+    path has no such failure (Conversion/task.py:90).  The enqueue-only entry still only reports (check_range)."""
     models = __import__("importlib").import_module("mask-rcnn-coreml_amd.models")
     d, cfg = small_model
     hot = tmp_path / "hot"
@@ -398,12 +401,20 @@ def test_engine_fp16_range_watchdog(pkg, small_model, weights_mod, tmp_path):
     images = rand_images(1, cfg.image_height, cfg.image_width, seed=2)
     m32 = models.load_maskrcnn(str(hot), max_batch=1)
     det, _ = m32.predict(images)
+    p2 = m32.read_tensor("P2", 0)
     assert np.isfinite(det).all() and m32.get_int("range_overflows") == 0
-    for mode in ("f32s", "f32x3", "f16"):
+    m = models.load_maskrcnn(str(hot), max_batch=1, compute_dtype="f16")
+    with pytest.raises(Exception, match="left the fp16 range"):
+        m.predict(images)
+    assert m.get_int("range_overflows") == 1 and m.get_int("range_recoveries") == 0
+    for mode in ("f32s", "f32x3"):
         m = models.load_maskrcnn(str(hot), max_batch=1, compute_dtype=mode)
-        with pytest.raises(Exception, match="left the fp16 range"):
-            m.predict(images)
-        assert m.get_int("range_overflows") == 1
+        got, _ = m.predict(images)                  # trips, recovers, returns valid records
+        assert m.get_int("range_overflows") == 1 and m.get_int("range_recoveries") == 1
+        assert _rel(m.read_tensor("P2", 0), p2) < 5e-5, mode
+        assert np.isfinite(got).all()
+        m.predict(images)
+        assert m.get_int("range_recoveries") == 1   # the lowered exponents hold
     # the same handles are fine on in-range weights
     ok = models.load_maskrcnn(d, max_batch=1, compute_dtype="f32s")
     ok.predict(images)
@@ -691,3 +702,36 @@ def test_fused_shortcut_is_bit_identical_to_the_two_launches(pkg, weights_mod, t
     d1, m1 = m.predict(images[2:3])
     np.testing.assert_array_equal(d1[0], det[2])
     assert (det[..., 5] > 0).sum() > 0
+
+
+@pytest.mark.parametrize("arch,shape", [("resnet50", (320, 448, 3)), ("resnet101", (256, 256, 3))])
+def test_fused_bottleneck_blocks_leave_an_fp16_predict_bit_identical(pkg, weights_mod, tmp_path_factory, arch, shape):
+    """Round 5: in the fp16 mode every identity block of C2..C4 whose level tiles into TH x 16 pixels runs as ONE persistent launch with
+    both branch tensors on chip (kernels_bneck.hip).  Same K orders, same fp16 roundings, same epilogue arithmetic: a predict must not
+    change by one bit against mrcnn_debug_set("conv_bneck", 0) (the three launches over the same ping-pong tensors), on several images,
+    with stages that qualify (C2 at 80 x 112, C3 at 32 x 32 ...) next to stages that do not (C3 at 40 x 56), and per-image results must
+    not depend on the batch."""
+    import importlib
+    L = importlib.import_module("mask-rcnn-coreml_amd._lib")
+    models = importlib.import_module("mask-rcnn-coreml_amd.models")
+    d, cfg = make_model_dir(tmp_path_factory, pkg, weights_mod, "bneck" + arch, architecture=arch, input_image_shape=shape,
+                            num_classes=21, pre_nms_max_proposals=1000, max_proposals=128, max_detections=32)
+    B = 3
+    m = models.load_maskrcnn(d, max_batch=B, compute_dtype="f16")
+    images = rand_images(B, shape[0], shape[1], seed=5)
+    det, mask = m.predict(images)
+    names = ("P2", "P3", "P4", "P5", "rpn_probs", "rpn_deltas")
+    taps = {n: [m.read_tensor(n, b).copy() for b in range(B)] for n in names}
+    try:
+        L.check(L.lib().mrcnn_debug_set(b"conv_bneck", 0))
+        det2, mask2 = m.predict(images)
+        for n, want in taps.items():
+            for b in range(B):
+                np.testing.assert_array_equal(m.read_tensor(n, b), want[b], err_msg=f"{n} image {b}")
+    finally:
+        L.check(L.lib().mrcnn_debug_set(b"conv_bneck", 1))
+    np.testing.assert_array_equal(det, det2)
+    np.testing.assert_array_equal(mask, mask2)
+    d1, m1 = m.predict(images[2:3])
+    np.testing.assert_array_equal(d1[0], det[2])
+    assert np.isfinite(taps["P2"][0]).all()

@@ -188,22 +188,99 @@ def test_a_checkpoint_with_tiny_activations_is_fp32_grade_once_calibrated(pkg, w
 
 
 def test_a_checkpoint_that_leaves_the_fp16_range_runs_once_calibrated(pkg, weights_mod, tmp_path_factory):
-    """Activations 2^12 times the stock model's: uncalibrated, the range watchdog fails every predict (MRCNN_ERR_UNSUPPORTED,
-    "load the model with MRCNN_F32"); calibration finds negative exponents (its first pass steps a uniform exponent down until
-    the predict stays in range) and the mode then agrees with the fp32 oracle."""
+    """Activations 2^12 times the stock model's.  Round 4 failed every uncalibrated predict (MRCNN_ERR_UNSUPPORTED); since round 5 the
+    FIRST predict recovers by itself — the batch is measured where it sits on the device, the exponents are lowered, the batch is
+    computed again ("range_recoveries") — and later predicts run inside the range.  An explicit calibration gives the same grade."""
     from oracle.network import load_oracle_model
     d, cfg = _rescaled_model(tmp_path_factory, pkg, weights_mod, "huge_act", 12, 0)
     om = load_oracle_model(d)
     images = rand_images(1, 128, 128, seed=2)
     m = _models().load_maskrcnn(d, max_batch=1, compute_dtype="f32x3")
-    with pytest.raises(L.MrcnnError) as e:
-        m.predict(images)
-    assert e.value.code == 5 and m.get_int("range_overflows") == 1
-    m.calibrate_split(images)
+    first = _trunk_errors(m, om, cfg, images)                              # (an uncalibrated predict: trips, recovers, returns valid results)
+    assert max(first) < 2e-5, first
+    assert m.get_int("range_overflows") == 1 and m.get_int("range_recoveries") == 1
     assert m.get_int("split_min_exponent") < 0
+    again = _trunk_errors(m, om, cfg, images)
+    assert max(again) < 2e-5 and m.get_int("range_recoveries") == 1        # the lowered exponents hold: no second recovery
+    m.calibrate_split(images)
     cal = _trunk_errors(m, om, cfg, images)
     assert max(cal) < 2e-5, cal
-    assert m.get_int("range_overflows") >= 1                               # only the uncalibrated calls tripped it
+    assert m.get_int("range_overflows") == 1                               # calibration passes are not the host's predicts
+
+
+def test_an_input_far_above_the_calibrated_range_recovers_and_matches_the_oracle(pkg, weights_mod, tmp_path_factory):
+    """the headline mode must not fail on data the reference's fp32 path handles (Conversion/task.py:90).  A
+    positively homogeneous model is calibrated on a nearly mean-coloured image (|pixel - mean| < 1: every activation ~2^7 below
+    what a real image produces); the next image drives the activations 2^6 .. 2^9 above the calibrated maximum — past the 16x head
+    room.  The predict recovers (no error), agrees with the fp32 oracle end to end, both through the synchronous entry and through
+    submit / collect; images of one batch still do not depend on their batch mates."""
+    from oracle.network import load_oracle_model
+    d, cfg = _rescaled_model(tmp_path_factory, pkg, weights_mod, "recover", 0, 0)
+    om = load_oracle_model(d)
+    flat = np.empty((1, 128, 128, 3), np.uint8)
+    flat[...] = np.array([124, 117, 104], np.uint8)                         # mean pixel (123.7, 116.8, 103.9) + < 1
+    images = rand_images(2, 128, 128, seed=9)
+    for entry in ("predict", "collect"):
+        m = _models().load_maskrcnn(d, max_batch=2, compute_dtype="f32x3")
+        m.calibrate_split(flat)
+        hi = int(m.get_int("split_max_exponent"))
+        assert hi >= 12, hi                                                 # the calibration image really was tiny
+        if entry == "predict":
+            det, mask = m.predict(images)
+        else:
+            det = np.empty((2, m.max_detections, 6), np.float32)
+            mask = np.empty((2, m.max_detections, m.mask_size, m.mask_size), np.float32)
+            m.submit(images)
+            assert m.collect(det, mask) == 2
+        assert m.get_int("range_recoveries") == 1 and m.get_int("range_overflows") == 1
+        assert int(m.get_int("split_max_exponent")) < hi
+        pyr, _, _ = om.trunk(images)
+        shapes = cfg.feature_shapes()
+        for b in range(2):
+            err = [_rel(_nhwc_to_chw(m.read_tensor(f"P{l + 2}", b), shapes[l][0], shapes[l][1], 256), pyr[l][b]) for l in range(4)]
+            assert max(err) < 2e-5, (entry, b, err)
+        # batch independence with the recovered exponents
+        d1, m1 = m.predict(images[1:2])
+        np.testing.assert_array_equal(d1[0], det[1])
+        np.testing.assert_array_equal(m1[0], mask[1])
+        assert m.get_int("range_recoveries") == 1
+
+
+def test_exponents_stored_in_the_artefact_make_the_drop_in_load_calibrated(pkg, weights_mod, tmp_path_factory):
+    """`convert --calibrate` stores the exponent vector in MaskRCNN.mrcw; mrcnn_model_load applies it, so
+    MaskRCNN().prediction(image) (ViewController.swift:37) needs no extra call.  The reloaded model reproduces the calibrated one
+    bit for bit, a batch equals its single-image calls, and the tiny-activation checkpoint is fp32-grade straight from load."""
+    from oracle.network import load_oracle_model
+    convert = importlib.import_module("mask-rcnn-coreml_amd.convert")
+    d, cfg = _rescaled_model(tmp_path_factory, pkg, weights_mod, "stored_exp", -4, -6)
+    om = load_oracle_model(d)
+    images = rand_images(3, 128, 128, seed=2)
+    m = _models().load_maskrcnn(d, max_batch=3, compute_dtype="f32x3")
+    assert m.get_int("split_exponents_from_artefact") == 0 and m.get_int("split_calibrated") == 0
+    m.calibrate_split(images[:2])
+    want_e = m.split_exponents.copy()
+    det, mask = m.predict(images)
+    del m
+    convert.calibrate_artefact(d, images[:2], verbose=False)               # what `convert --calibrate` runs after writing the artefacts
+    meta, _ = weights_mod.read_mrcw(os.path.join(d, "MaskRCNN.mrcw"))
+    assert sum(k.startswith("split_exp.") for k in meta) >= 50
+    for dt in ("f32x3", "f32s"):
+        m2 = _models().load_maskrcnn(d, max_batch=3, compute_dtype=dt)
+        assert m2.get_int("split_exponents_from_artefact") == 1 and m2.get_int("split_calibrated") == 1
+        np.testing.assert_array_equal(m2.split_exponents, want_e)
+        d2, k2 = m2.predict(images)
+        if dt == "f32x3":
+            np.testing.assert_array_equal(d2, det)
+            np.testing.assert_array_equal(k2, mask)
+        for b in range(3):
+            d1, k1 = m2.predict(images[b:b + 1])
+            np.testing.assert_array_equal(d1[0], d2[b])
+            np.testing.assert_array_equal(k1[0], k2[b])
+        err = _trunk_errors(m2, om, cfg, images[:1])
+        assert max(err) < (2e-5 if dt == "f32x3" else 4e-5), (dt, err)
+        assert m2.get_int("range_recoveries") == 0
+    m16 = _models().load_maskrcnn(d, max_batch=1, compute_dtype="f16")      # modes without a split ignore the stored vector
+    assert m16.get_int("split_exponents_from_artefact") == 0
 
 
 def test_split_counters_mean_what_the_header_says(small_model):
