@@ -392,6 +392,7 @@ def main():
             # Two host image buffers alternate, as a host feeding a stream of batches would
             himg2 = himg.clone().pin_memory()
             bufs = (himg.numpy(), himg2.numpy())
+            m.enable_timing(False)            # (the stage timer holds ONE batch's events: the library refuses two submissions in flight while it is on)
             m.submit(bufs[0])
             for i in range(2):
                 m.submit(bufs[(i + 1) & 1]); m.collect(hdet.numpy(), hmask.numpy())

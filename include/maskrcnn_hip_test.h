@@ -92,9 +92,11 @@ MRCNN_API int mrcnn_debug_set(const char* key, int value);
 /* An identity ResNet bottleneck block of the fp16 mode on caller (host) data: x (B,H,W,4C) fp32 (rounded to fp16 on the host),
  * w1 (C,4C), w2 (C,3,3,C), w3 (4C,C) fp32 (rounded to fp16), folded BatchNorm scale / shift per layer; out (B,H,W,4C) = the fp16
  * values the block stores, widened.  fused = 1: ONE persistent launch with both mid tensors on chip (kernels_bneck.hip; needs
- * C in {64,128,256}, W % 16 == 0, H % 16 == 0 (C = 256: H % 8 == 0)); fused = 0: the three launches of the convolution family.
- * The two must agree bit for bit (tests/test_gpu_bneck.py).  iters > 0: *avg_ms = average time of `iters` further runs (HIP events).
- * "conv_bneck" 0|1 of mrcnn_debug_set switches the engine's use of the fused form (default 1; bit-identical). */
+ * C in {64,128,256}, W % 16 == 0, H % 16 == 0 (C = 256: H % 8 == 0)); fused = 2: the same with every operand staged through LDS (C = 256
+ * otherwise streams its filter fragments straight into registers); fused = 0: the three launches of the convolution family.
+ * All must agree bit for bit (tests/test_gpu_bneck.py).  iters > 0: *avg_ms = average time of `iters` further runs (HIP events).
+ * "conv_bneck" 0|1|2|3 of mrcnn_debug_set: the engine's identity bottlenecks of the fp16 mode as three launches | fused where the grid
+ * fills the chip (default) | fused, all-LDS form | fused at every grid size (bit-identical, all four). */
 MRCNN_API int mrcnn_bottleneck_nhwc(const float* x, int batch, int h, int w, int cmid, const float* w1, const float* w2, const float* w3,
                                     const float* s1, const float* h1, const float* s2, const float* h2, const float* s3, const float* h3,
                                     int fused, int iters, float* out, float* avg_ms);

@@ -1092,12 +1092,17 @@ extern "C" int mrcnn_bottleneck_nhwc(const float* x, int batch, int h, int w, in
         ConvDesc dc = desc(dt2.p, C, dw3.p, 1, ds3.as<float>(), dh3.as<float>(), dy.p, C4);
         dc.res = dx.p; dc.res_sW = C4; dc.res_sH = (long)w * C4; dc.res_sB = (long)h * w * C4;
         Stream st;
-        DevBuf dw2f, dw3f;
+        DevBuf dw1f, dw2f, dw3f;
+        if (bneck_frag_wanted(1, 1, C4, C)) { bneck_pack_frag(st.s, dw1.p, C, C4, dw1f); da.wgt_frag = dw1f.p; }
         if (bneck_frag_wanted(3, 3, C, C)) { bneck_pack_frag(st.s, dw2.p, C, 9 * C, dw2f); db.wgt_frag = dw2f.p; }
         if (bneck_frag_wanted(1, 1, C, C4)) { bneck_pack_frag(st.s, dw3.p, C4, C, dw3f); dc.wgt_frag = dw3f.p; }
         MRCNN_REQUIRE(!fused || conv_bneck_fusable(da, db, dc), MRCNN_ERR_UNSUPPORTED, "bottleneck_nhwc: C %d at %dx%d does not qualify for the fused launch", C, h, w);
         auto run = [&] {
-            if (fused) conv_bneck_forward(st.s, da, db, dc);
+            if (fused) {        // the fused launch whatever the grid size (conv_bneck_forward sends under-filled grids to the three launches)
+                static int n_cus = [] { int dev = 0; hipDeviceProp_t p; (void)hipGetDevice(&dev); return hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }();
+                bneck_launch(st.s, C, da.in, dc.out, batch, h, w, da.wgt, db.wgt, dc.wgt, da.scale, da.shift, db.scale, db.shift, dc.scale, dc.shift, nullptr, n_cus,
+                             fused == 2 ? nullptr : db.wgt_frag, fused == 2 ? nullptr : dc.wgt_frag, fused == 2 ? nullptr : da.wgt_frag);
+            }
             else { conv_forward(st.s, da); conv_forward(st.s, db); conv_forward(st.s, dc); }
         };
         run();

@@ -231,7 +231,7 @@ bool bneck_geometry_ok(int C, int H, int W);
 // straight from L2 into registers; nullptr selects the form with every operand staged through LDS
 void bneck_launch(hipStream_t s, int C, const void* x, void* y, int B, int H, int W, const void* w1, const void* w2, const void* w3,
                   const float* s1, const float* h1, const float* s2, const float* h2, const float* s3, const float* h3, int* range_flag, int n_cus,
-                  const void* w2f = nullptr, const void* w3f = nullptr);
+                  const void* w2f = nullptr, const void* w3f = nullptr, const void* w1f = nullptr);
 // [N][K] fp16 filters (K contiguous; N % 32 == 0, K % 16 == 0) -> 1-KB granules [N/32][K/16][lane 0..63][8]: lane (l31, kk) of granule (nt, kg)
 // holds filter row 32 nt + l31, k = 16 kg + 8 kk .. + 7 — the first MFMA operand of v_mfma_f32_32x32x16_f16, one coalesced 16-B load per lane
 void bneck_pack_frag(hipStream_t s, const void* wgt_std, int N, int K, DevBuf& out);

@@ -56,7 +56,7 @@ struct BnCfg {
 struct BneckArgs {
     const _Float16* x; _Float16* y;
     const _Float16 *w1, *w2, *w3;
-    const uint4 *w2f, *w3f;          // W2 / W3 in MFMA-fragment order (FRAG form)
+    const uint4 *w1f, *w2f, *w3f;    // W1 / W2 / W3 in MFMA-fragment order (FRAG form)
     const float *s1, *h1, *s2, *h2, *s3, *h3;
     int B, H, W, tiles_x, tiles_y, ntiles;
     int* range_flag;
@@ -216,6 +216,105 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
             xoff[j] = ok ? (unsigned)(((size_t)gy * a.W + gx) * 4 * C * 2 + c4 * 16) : OOB;
         }
 
+        if constexpr (FRAG) {
+        // =========================== phase A, fragment-streaming form ===========================
+        // A wave owns 32 channels of t1 for ALL 192 halo rows (six 32-row tiles) and streams ITS W1 fragments into registers, eight
+        // K groups ahead; x is shared by the eight waves, so it goes through LDS: 64-channel steps of [192 rows][128 B], two stages,
+        // written from registers (three 16-B pieces per thread and step, requested a whole step ahead through the image's buffer
+        // resource: out-of-image and padding rows read zeros).  Every load is one the compiler counts: no drained waits.
+        constexpr int KG1 = 4 * C / 16, NS1 = 4 * C / 64, D1 = 8;
+        f32x16 acc1[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc1[i][e] = 0.0f;
+        const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(ximg), 0, (int)img_bytes, 0x00020000);
+        typedef unsigned bn_u32x4 __attribute__((ext_vector_type(4)));
+        int xvo[3];                  // byte offset of this thread's three pieces (row q >> 3, chunk q & 7; q = t + 512 m) at K step 0
+        unsigned xls[3];             // ... and where they go in a stage
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const int q = t + 512 * m, r = q >> 3, c = q & 7;
+            const int py = r / HWD, px = r - py * HWD;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            const bool ok = r < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            xvo[m] = ok ? (int)(((size_t)gy * a.W + gx) * 4 * C * 2 + c * 16) : (int)OOB;
+            xls[m] = (unsigned)(r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+        }
+        const uint4* const wp1 = a.w1f + (size_t)wave * KG1 * 64 + lane;
+        uint4 wq1[D1];
+#pragma unroll
+        for (int d = 0; d < D1; ++d) wq1[d] = wp1[d * 64];
+        bn_u32x4 xr[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) xr[m] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvo[m], 0, 0);
+        __syncthreads();                               // (the previous tile's phase C has read the last of its LDS tile)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) *reinterpret_cast<bn_u32x4*>(smem + xls[m]) = xr[m];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) xr[m] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvo[m], 128, 0);
+        __syncthreads();
+        const unsigned xfr = (unsigned)(l31 * 128);    // fragment rows i*32 + l31 of a stage
+        for (int ks = 0; ks < ((a.dbg & 1) ? 1 : NS1); ks += 2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {              // two steps per trip: the stages and the eight fragment slots are compile-time
+                const unsigned char* const sb = smem + h * (192 * 128);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = h * 4 + g;
+                    f16x8 xf[6];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) xf[i] = *reinterpret_cast<const f16x8*>(sb + xfr + i * 32 * 128 + w_c[g]);
+                    const f16x8 wf = __builtin_bit_cast(f16x8, wq1[d]);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) BN_MFMA(wf, xf[i], acc1[i])
+                    int kgn = (ks + h) * 4 + g + D1;
+                    kgn = kgn < KG1 ? kgn : KG1 - 1;
+                    wq1[d] = wp1[kgn * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // step ks + h + 1 goes to the other stage (last read one step ago, behind the barrier), step ks + h + 2 is requested
+                unsigned char* const so = smem + (h ^ 1) * (192 * 128);
+#pragma unroll
+                for (int m = 0; m < 3; ++m) *reinterpret_cast<bn_u32x4*>(so + xls[m]) = xr[m];
+                {
+                    int kn = ks + h + 2;
+                    kn = kn < NS1 ? kn : NS1 - 1;
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) xr[m] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvo[m], kn * 128, 0);
+                }
+                __syncthreads();
+            }
+        }
+        // epilogue A -> t1 (fp16, zero outside the image): channels 32 wave + 16 p + 8 kk .. of halo row i*32 + l31
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int r = i * 32 + l31;
+            const int py = r / HWD, px = r - py * HWD;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            const bool valid = r < HP;
+            const bool inimg = valid && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            const unsigned swz = (unsigned)((px >> 1) & 7);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int cl = wave * 32 + 16 * p + 4 * kk;
+                const float4 sa = *reinterpret_cast<const float4*>(tabAB + cl), sb_ = *reinterpret_cast<const float4*>(tabAB + cl + 8);
+                const float4 ha = *reinterpret_cast<const float4*>(tabAB + C + cl), hb = *reinterpret_cast<const float4*>(tabAB + C + cl + 8);
+                float4 va = make_float4(acc1[i][8 * p + 0], acc1[i][8 * p + 1], acc1[i][8 * p + 2], acc1[i][8 * p + 3]);
+                float4 vb = make_float4(acc1[i][8 * p + 4], acc1[i][8 * p + 5], acc1[i][8 * p + 6], acc1[i][8 * p + 7]);
+                va.x = va.x * sa.x + ha.x; va.y = va.y * sa.y + ha.y; va.z = va.z * sa.z + ha.z; va.w = va.w * sa.w + ha.w;
+                vb.x = vb.x * sb_.x + hb.x; vb.y = vb.y * sb_.y + hb.y; vb.z = vb.z * sb_.z + hb.z; vb.w = vb.w * sb_.w + hb.w;
+                va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f); va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
+                vb.x = fmaxf(vb.x, 0.f); vb.y = fmaxf(vb.y, 0.f); vb.z = fmaxf(vb.z, 0.f); vb.w = fmaxf(vb.w, 0.f);
+                if (inimg) range_trip = range_trip || bn_bad(va) || bn_bad(vb);
+                else { va = make_float4(0.f, 0.f, 0.f, 0.f); vb = va; }
+                const uint4 pk = bn_pack16(va, vb);
+                const int ch0 = wave * 32 + 16 * p + 8 * kk;
+                const unsigned off = (unsigned)(K::OFF_T1 + ((ch0 >> 6) * HP + r) * 128) + ((((unsigned)(ch0 & 63) >> 3) ^ swz) << 4);
+                if (valid) *reinterpret_cast<uint4*>(smem + off) = pk;
+            }
+        }
+        } else {
         // =========================== phase A: t1 = relu(bn(x * W1)) on the halo region ===========================
         f32x16 acc1[3][TNW];
 #pragma unroll
@@ -287,6 +386,7 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
                 }
         }
 #undef BN_ISSUE_A
+        }
 
         if constexpr (FRAG) {
         // =========================== phases B and C, fragment-streaming form ===========================
@@ -366,20 +466,32 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
                 *reinterpret_cast<uint4*>(smem + off) = pk;
             }
         __syncthreads();                               // t2 and the table are complete
-        size_t grow[4];              // element offset of the lane's pixels in the image
-#pragma unroll
-        for (int i = 0; i < 4; ++i) grow[i] = ((size_t)(y0 + 2 * i + (l31 >> 4)) * a.W + (x0 + (l31 & 15))) * (size_t)(4 * C);
+        // Phase C moves its shortcut in and its output out in FULL LINES through a 64-KB tile in LDS (the ring's space, idle since phase A):
+        //   ybuf[128 pixels][512 B = the round's 256 columns], 16-B chunk c of pixel p at position c ^ (p & 15) — conflict-free both for the
+        //   epilogue's fragment-layout accesses (a lane group's 16 pixels are distinct mod 16) and for the row-wise store-out;
+        //   round r: the shortcut of columns 256 r .. arrives by LDS-DMA (two pixels = 1 KB per instruction, requested a whole K loop ahead),
+        //   each wave adds its 32 columns in place (read 16 B, unpack, + acc * scale + shift, ReLU, pack, write back), and the block writes
+        //   the tile out, two pixels x 512 contiguous bytes per store instruction.  (Straight from the accumulators a store instruction
+        //   covers 32 pixels x 32 B — scattered pieces issue 3x slower per CU, tools/probes/vmem_probe.hip — and phase C was the slowest
+        //   of the three: 28 us for 7.8 us of MFMAs, gpurun_out/bneck_phases.txt.)
+        // DMA / store geometry of this lane: instruction e = 8 wave + j moves pixels 2e, 2e + 1 = tile row `wave`, columns 2j + hi
+        const int hi = lane >> 5;
+        const unsigned yv = (unsigned)(hi * (4 * C * 2)) + (unsigned)((((lane & 31) ^ hi)) << 4);        // per-lane byte offset; instruction j: ^ (j << 5)
+        const unsigned yrow = (unsigned)((((size_t)(y0 + wave) * a.W + x0) * (size_t)(4 * C)) * 2);      // byte offset of the tile row in the image
+        const unsigned ybuf = lds0 + (unsigned)(wave * 8 * 1024);
+#define BN_RES_DMA(R)                                                                                          \
+    {                                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                        \
+            BN_BLDS(yv ^ (unsigned)(j << 5), srdX, yrow + (unsigned)(j * 2 * 4 * C * 2 + (R) * 512), ybuf + j * 1024) \
+        }                                                                                                      \
+    }
+        const __amdgpu_buffer_rsrc_t srdY = __builtin_amdgcn_make_buffer_rsrc(yimg, 0, (int)img_bytes, 0x00020000);
+        BN_RES_DMA(0)
         for (int r = 0; r < ((a.dbg & 4) ? 1 : 4); ++r) {
-            const int n0 = (r * 8 + wave) * 32;        // this wave's output columns of the round
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
-            uint4 rv[4][2];           // the shortcut of the round, requested ahead of its K loop (16 B = eight channels per lane: the store layout)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int p = 0; p < 2; ++p) rv[i][p] = *reinterpret_cast<const uint4*>(ximg + grow[i] + n0 + 16 * p + 8 * kk);
             f16x8 af[2][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(smem + K::OFF_T1 + (i * 32 + l31) * 128 + w_c[0]);
@@ -399,6 +511,9 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
                 wq[kg % D] = wp3[(size_t)((qn / KG3) * 8 * KG3 + (qn % KG3)) * 64];
                 __builtin_amdgcn_sched_barrier(0);
             }
+            BN_VMCNT0                                   // this wave's shortcut DMAs have landed (and, alas, its filter prefetch: DESIGN.md)
+            __syncthreads();                            // ... and everybody's
+            const int n0 = (r * 8 + wave) * 32;         // this wave's output columns of the round
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -410,17 +525,28 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
                     float4 vb = make_float4(acc[i][8 * p + 4], acc[i][8 * p + 5], acc[i][8 * p + 6], acc[i][8 * p + 7]);
                     va.x = va.x * sa.x + ha.x; va.y = va.y * sa.y + ha.y; va.z = va.z * sa.z + ha.z; va.w = va.w * sa.w + ha.w;
                     vb.x = vb.x * sb_.x + hb.x; vb.y = vb.y * sb_.y + hb.y; vb.z = vb.z * sb_.z + hb.z; vb.w = vb.w * sb_.w + hb.w;
+                    // pixel i*32 + l31 = tile row 2i + (l31 >> 4), column l31 & 15; chunk 4 wave + 2p + kk of its 512 B
+                    uint4* const slot = reinterpret_cast<uint4*>(smem + (i * 32 + l31) * 512 + (((wave * 4 + 2 * p + kk) ^ (l31 & 15)) << 4));
                     float4 ra, rb;
-                    bn_unpack16(rv[i][p], ra, rb);
+                    bn_unpack16(*slot, ra, rb);
                     va.x += ra.x; va.y += ra.y; va.z += ra.z; va.w += ra.w;
                     vb.x += rb.x; vb.y += rb.y; vb.z += rb.z; vb.w += rb.w;
                     va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f); va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
                     vb.x = fmaxf(vb.x, 0.f); vb.y = fmaxf(vb.y, 0.f); vb.z = fmaxf(vb.z, 0.f); vb.w = fmaxf(vb.w, 0.f);
                     range_trip = range_trip || bn_bad(va) || bn_bad(vb);
-                    const uint4 pk = bn_pack16(va, vb);
-                    *reinterpret_cast<uint4*>(yimg + grow[i] + n0 + 16 * p + 8 * kk) = pk;
+                    *slot = bn_pack16(va, vb);
                 }
+            __syncthreads();                            // the tile is complete
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                typedef unsigned bn_u32x4 __attribute__((ext_vector_type(4)));
+                const bn_u32x4 v = *reinterpret_cast<const bn_u32x4*>(smem + (wave * 8 + j) * 1024 + lane * 16);
+                __builtin_amdgcn_raw_buffer_store_b128(v, srdY, (int)(yv ^ (unsigned)(j << 5)), (int)(yrow + (unsigned)(j * 2 * 4 * C * 2 + r * 512)), 0);
+            }
+            __syncthreads();                            // ... and read out: the next round's shortcut may land
+            if (r + 1 < 4) BN_RES_DMA(r + 1)
         }
+#undef BN_RES_DMA
         } else {
         // =========================== phase B: t2 = relu(bn(conv3x3(t1))) ===========================
         f32x16 acc[2][TNW];
@@ -604,7 +730,7 @@ void bneck_pack_frag(hipStream_t s, const void* wgt_std, int N, int Kt, DevBuf& 
 
 bool bneck_frag_wanted(int KH, int KW, int Cin, int Cout)
 {
-    return (KH == 3 && KW == 3 && Cin == 256 && Cout == 256) || (KH == 1 && KW == 1 && Cin == 256 && Cout == 1024);
+    return (KH == 3 && KW == 3 && Cin == 256 && Cout == 256) || (KH == 1 && KW == 1 && Cin == 256 && Cout == 1024) || (KH == 1 && KW == 1 && Cin == 1024 && Cout == 256);
 }
 
 bool bneck_geometry_ok(int C, int H, int W)
@@ -617,7 +743,7 @@ bool bneck_geometry_ok(int C, int H, int W)
 
 void bneck_launch(hipStream_t s, int C, const void* x, void* y, int B, int H, int W, const void* w1, const void* w2, const void* w3,
                   const float* s1, const float* h1, const float* s2, const float* h2, const float* s3, const float* h3, int* range_flag, int n_cus,
-                  const void* w2f, const void* w3f)
+                  const void* w2f, const void* w3f, const void* w1f)
 {
     MRCNN_REQUIRE(bneck_geometry_ok(C, H, W), MRCNN_ERR_SHAPE, "bneck: C %d at %dx%d", C, H, W);
     MRCNN_REQUIRE(x != y, MRCNN_ERR_INVALID, "bneck: the output must not alias the input");
@@ -625,7 +751,7 @@ void bneck_launch(hipStream_t s, int C, const void* x, void* y, int B, int H, in
     BneckArgs a;
     a.x = static_cast<const _Float16*>(x); a.y = static_cast<_Float16*>(y);
     a.w1 = static_cast<const _Float16*>(w1); a.w2 = static_cast<const _Float16*>(w2); a.w3 = static_cast<const _Float16*>(w3);
-    a.w2f = static_cast<const uint4*>(w2f); a.w3f = static_cast<const uint4*>(w3f);
+    a.w1f = static_cast<const uint4*>(w1f); a.w2f = static_cast<const uint4*>(w2f); a.w3f = static_cast<const uint4*>(w3f);
     a.s1 = s1; a.h1 = h1; a.s2 = s2; a.h2 = h2; a.s3 = s3; a.h3 = h3;
     a.B = B; a.H = H; a.W = W;
     const int th = C == 256 ? 8 : 16;
@@ -636,7 +762,7 @@ void bneck_launch(hipStream_t s, int C, const void* x, void* y, int B, int H, in
     int grid = n_cus > 0 ? n_cus / 8 * 8 : 256;
     if (grid <= 0) grid = 8;
     if (a.ntiles < grid) grid = a.ntiles;
-    if (C == 256 && w2f && w3f) hipLaunchKernelGGL((k_bneck_h<256, true>), dim3(grid), dim3(512), 0, s, a);
+    if (C == 256 && w1f && w2f && w3f) hipLaunchKernelGGL((k_bneck_h<256, true>), dim3(grid), dim3(512), 0, s, a);
     else if (C == 256) hipLaunchKernelGGL((k_bneck_h<256, false>), dim3(grid), dim3(512), 0, s, a);
     else if (C == 128) hipLaunchKernelGGL((k_bneck_h<128, false>), dim3(grid), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((k_bneck_h<64, false>), dim3(grid), dim3(512), 0, s, a);

@@ -984,7 +984,12 @@ bool conv_bneck_fusable(const ConvDesc& da, const ConvDesc& db, const ConvDesc& 
 void conv_bneck_forward(hipStream_t s, const ConvDesc& da, const ConvDesc& db, const ConvDesc& dc)
 {
     static int n_cus = [] { int dev = 0; hipDeviceProp_t p; (void)hipGetDevice(&dev); return hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }();
-    if (!g_bneck || !conv_bneck_fusable(da, db, dc)) {
+    // One tile per block: a grid that leaves the chip under-filled (single images: 32 tiles at C4) runs the three launches, whose narrower
+    // tiles spread over more CUs — the two forms agree bit for bit, so the choice may follow the batch (measured at batch 1, fp16 mode:
+    // 2.66 ms per image with the three launches, 3.59 fused everywhere; batch 8: 9.87 -> 9.52 ms fused)
+    const int C_ = da.Cout;
+    const long ntiles = (long)da.B * (da.H / (C_ == 256 ? 8 : 16)) * (da.W / 16);
+    if (!g_bneck || !conv_bneck_fusable(da, db, dc) || (g_bneck < 3 && ntiles * 8 < (long)n_cus * 7)) {      // ("conv_bneck" 3: fused at every grid size, tests)
         conv_forward(s, da);
         conv_forward_tail(s, db, dc, nullptr);
         return;
@@ -992,7 +997,7 @@ void conv_bneck_forward(hipStream_t s, const ConvDesc& da, const ConvDesc& db, c
     ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
     const int e0 = prof ? prof_event(prof, s) : 0;
     bneck_launch(s, da.Cout, da.in, dc.out, da.B, da.H, da.W, da.wgt, db.wgt, dc.wgt, da.scale, da.shift, db.scale, db.shift, dc.scale, dc.shift,
-                 g_range_flag, n_cus, g_bneck >= 2 ? nullptr : db.wgt_frag, g_bneck >= 2 ? nullptr : dc.wgt_frag);      // ("conv_bneck" 2: every operand through LDS)
+                 g_range_flag, n_cus, g_bneck >= 2 ? nullptr : db.wgt_frag, g_bneck >= 2 ? nullptr : dc.wgt_frag, g_bneck >= 2 ? nullptr : da.wgt_frag);      // ("conv_bneck" 2: every operand through LDS)
     if (prof) {
         const int e1 = prof_event(prof, s);
         const double M = (double)da.B * da.H * da.W, C = da.Cout;

@@ -719,9 +719,14 @@ def test_fused_bottleneck_blocks_leave_an_fp16_predict_bit_identical(pkg, weight
     B = 3
     m = models.load_maskrcnn(d, max_batch=B, compute_dtype="f16")
     images = rand_images(B, shape[0], shape[1], seed=5)
+    L.check(L.lib().mrcnn_debug_set(b"conv_bneck", 3))          # fused at EVERY grid size (by default an under-filled grid takes the three launches)
     det, mask = m.predict(images)
     names = ("P2", "P3", "P4", "P5", "rpn_probs", "rpn_deltas")
     taps = {n: [m.read_tensor(n, b).copy() for b in range(B)] for n in names}
+    L.check(L.lib().mrcnn_debug_set(b"conv_bneck", 1))          # the default policy: same bits
+    det1, mask1 = m.predict(images)
+    np.testing.assert_array_equal(det, det1)
+    np.testing.assert_array_equal(mask, mask1)
     try:
         L.check(L.lib().mrcnn_debug_set(b"conv_bneck", 0))
         det2, mask2 = m.predict(images)
@@ -732,6 +737,10 @@ def test_fused_bottleneck_blocks_leave_an_fp16_predict_bit_identical(pkg, weight
         L.check(L.lib().mrcnn_debug_set(b"conv_bneck", 1))
     np.testing.assert_array_equal(det, det2)
     np.testing.assert_array_equal(mask, mask2)
-    d1, m1 = m.predict(images[2:3])
+    L.check(L.lib().mrcnn_debug_set(b"conv_bneck", 3))
+    try:
+        d1, m1 = m.predict(images[2:3])
+    finally:
+        L.check(L.lib().mrcnn_debug_set(b"conv_bneck", 1))
     np.testing.assert_array_equal(d1[0], det[2])
     assert np.isfinite(taps["P2"][0]).all()
