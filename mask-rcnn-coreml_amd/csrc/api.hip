@@ -839,7 +839,7 @@ extern "C" int mrcnn_model_conv_profile_enable(mrcnn_model* model, int on)
 extern "C" int mrcnn_model_conv_profile_get(mrcnn_model* model, int tile, int64_t* launches, double* total_ms, double* total_flops)
 {
     return guarded([&] {
-        MRCNN_REQUIRE(model && launches && total_ms && total_flops && tile >= 0 && tile < 8, MRCNN_ERR_INVALID, "bad argument");
+        MRCNN_REQUIRE(model && launches && total_ms && total_flops && tile >= 0 && tile < 9, MRCNN_ERR_INVALID, "bad argument");
         HIP_CHECK(hipStreamSynchronize(model->m.stream));
         model->m.conv_profile.collect();
         const auto& sl = model->m.conv_profile.by_tile[tile];
@@ -940,6 +940,8 @@ extern "C" int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout
         hipEvent_t e0, e1;
         HIP_CHECK(hipEventCreate(&e0));
         HIP_CHECK(hipEventCreate(&e1));
+        DevBuf dw3h;
+        if (ws == 2 && es == 2 && stride == 1 && conv3x3h_packable(ksize, ksize, cin, cout, npad)) { conv3x3h_pack(st.s, dw.p, cout, cin, dw3h); d.wgt_c3h = dw3h.p; }
         ConvScratch scratch;                          // the split modes' shared-tile K chunks measure as the engine runs them
         if (ws == 2 && es == 4) { scratch.alloc(); conv_set_scratch(&scratch); }
         try {
@@ -1030,6 +1032,8 @@ extern "C" int mrcnn_conv2d_nhwc(const float* in, int batch, int h, int w, int c
             conv_halo_pack(st.s, dw.p, npad, cin, dwh);
             d.wgt_halo = dwh.p;
         }
+        DevBuf dw3h;
+        if (adt == MRCNN_F16 && conv3x3h_packable(ksize, ksize, cin, cout, npad)) { conv3x3h_pack(st.s, dw.p, cout, cin, dw3h); d.wgt_c3h = dw3h.p; }
         ConvScratch scratch;                          // one short-lived scratch for the call (kernels.h): the shared-tile K chunks need it
         if (wdt != MRCNN_F32 && adt == MRCNN_F32) { scratch.alloc(); conv_set_scratch(&scratch); }
         try { conv_forward(st.s, d); } catch (...) { conv_set_scratch(nullptr); throw; }

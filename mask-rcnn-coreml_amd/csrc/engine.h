@@ -45,6 +45,7 @@ struct PackedConv {
     DevBuf wgt, scale, shift;     // wgt in `wdtype`; scale/shift always fp32
     std::vector<float> h_scale, h_shift;   // host copies of scale / shift (the scale-aware split derives per-op copies from them)
     DevBuf wgt_halo;              // 3x3 layers of the split modes: the same filters re-tiled for the halo kernel (conv_halo_pack)
+    DevBuf wgt_c3h;               // fp16 mode, 3x3 layers with 256 | 512 output columns: the filters in k_conv3x3_h's stream order (conv3x3h_pack)
     DevBuf wgt_frag;              // fp16 mode, the layers of C4's identity bottlenecks: the same filters in MFMA-fragment order (bneck_pack_frag)
     int Cin = 0, Cout = 0, KH = 1, KW = 1, Npad = 0;
     int dtype = MRCNN_F32;        // activations

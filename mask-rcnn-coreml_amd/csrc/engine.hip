@@ -294,6 +294,10 @@ PackedConv pack_conv_oihw(const MrcwFile& f, const std::string& conv, const std:
         conv_halo_pack(nullptr, pc.wgt.p, pc.Npad, I, pc.wgt_halo, 1);        // ... the 256 -> 1024 1x1 layers for the fused bottleneck tail
         HIP_CHECK(hipStreamSynchronize(nullptr));
     }
+    if (pc.dtype == MRCNN_F16 && pc.wdtype == MRCNN_F16 && conv3x3h_packable(KH, KW, I, O, pc.Npad)) {
+        conv3x3h_pack(nullptr, pc.wgt.p, O, I, pc.wgt_c3h);
+        HIP_CHECK(hipStreamSynchronize(nullptr));
+    }
     if (pc.dtype == MRCNN_F16 && pc.wdtype == MRCNN_F16 && O == pc.Npad && bneck_frag_wanted(KH, KW, I, O)) {
         bneck_pack_frag(nullptr, pc.wgt.p, O, KH * KW * I, pc.wgt_frag);      // fp16 mode: C4's identity bottlenecks stream these straight into registers
         HIP_CHECK(hipStreamSynchronize(nullptr));
@@ -770,6 +774,7 @@ void Model::build_maskrcnn()
             d.wgt = pc->wgt.p; d.KH = pc->KH; d.KW = pc->KW; d.stride = stride; d.padH = d.padW = pad;
             d.wgt_halo = pc->wgt_halo.p;
             d.wgt_frag = pc->wgt_frag.p;
+            d.wgt_c3h = pc->wgt_c3h.p;
             d.scale = so ? so->scale.as<float>() : nullptr; d.shift = so ? so->shift.as<float>() : nullptr;
             d.OH = out.H; d.OW = out.W; d.Cout = pc->Cout; d.Npad = pc->Npad;
             d.out = out.p; d.out_sP = out.C; d.out_sB = out.sB();
@@ -963,6 +968,7 @@ void Model::build_maskrcnn()
             d.wdtype = pc->wdtype;
             d.wgt = pc->wgt.p; d.KH = 3; d.KW = 3; d.stride = 1; d.padH = d.padW = 1;
             d.wgt_halo = pc->wgt_halo.p;
+            d.wgt_c3h = pc->wgt_c3h.p;
             d.scale = so_d ? so_d->scale.as<float>() : nullptr; d.shift = so_d ? so_d->shift.as<float>() : nullptr;
             d.OH = fh[l]; d.OW = fw[l]; d.Cout = 512; d.Npad = pc->Npad;
             d.out = rpn_feat; d.out_sP = 512; d.out_sB = (long)fh[l] * fw[l] * 512; d.act = ACT_RELU;

@@ -105,6 +105,8 @@ struct ConvDesc {
     const void* wgt_halo = nullptr;
     // fp16 mode: the same filters in MFMA-fragment order for the fused bottleneck (kernels_bneck.hip: bneck_pack_frag); nullptr = not available
     const void* wgt_frag = nullptr;
+    // fp16 mode, 3x3 stride-1 layers: the filters in the stream order of k_conv3x3_h (kernels_conv3x3_h.hip: conv3x3h_pack); nullptr = not available
+    const void* wgt_c3h = nullptr;
     int KH = 1, KW = 1, stride = 1, padH = 0, padW = 0;
     // epilogue: y = act(acc*scale[n] + shift[n] + residual)
     const float* scale = nullptr;
@@ -156,7 +158,7 @@ struct ConvDesc {
 // has been synchronised) folds the elapsed times into per-tile-shape totals.
 struct ConvProfile {
     struct Slot { long launches = 0; double ms = 0, flops = 0; };
-    Slot by_tile[8];                 // 7: a whole identity bottleneck of the fp16 mode in one launch (kernels_bneck.hip; flops of its three layers); 0: 128x128, 1: 128x64, 2: 128x32, 3: 128x128 run by 4 waves of 32x128 (split modes, long K), 4: 256x256 ping-pong,
+    Slot by_tile[9];                 // 8: 16 x 16 halo tiles x 256 columns of the fp16 mode's 3x3 layers (kernels_conv3x3_h.hip); 7: a whole identity bottleneck of the fp16 mode in one launch (kernels_bneck.hip; flops of its three layers); 0: 128x128, 1: 128x64, 2: 128x32, 3: 128x128 run by 4 waves of 32x128 (split modes, long K), 4: 256x256 ping-pong,
                                      // 5: persistent halo tiles (3x3 stride 1, split modes), 6: halo tiles with the fused bottleneck tail (3x3 + 1x1)
     std::vector<hipEvent_t> pool;
     struct Shape { int M, N, K, tile; bool operator<(const Shape& o) const { return std::tie(M, N, K, tile) < std::tie(o.M, o.N, o.K, o.tile); } };
@@ -236,6 +238,15 @@ void bneck_launch(hipStream_t s, int C, const void* x, void* y, int B, int H, in
 // holds filter row 32 nt + l31, k = 16 kg + 8 kk .. + 7 — the first MFMA operand of v_mfma_f32_32x32x16_f16, one coalesced 16-B load per lane
 void bneck_pack_frag(hipStream_t s, const void* wgt_std, int N, int K, DevBuf& out);
 bool bneck_frag_wanted(int KH, int KW, int Cin, int Cout);      // the filter shapes the C = 256 form reads in fragment order
+
+// The 3x3 stride-1 'same' layers of the fp16 mode with 256 | 512 output columns (kernels_conv3x3_h.hip): 16 x 16 halo tiles resident in LDS per
+// 64-channel block, filter fragments streamed into registers, K order (channel block, tap, group) — its own: whether a layer runs here is
+// decided by the layer alone (conv3x3h_eligible), never by the batch.  mrcnn_debug_set("conv_c3h", 0) sends such layers back to the
+// 128-row / ping-pong kernels (their tap-major order: results differ by summation noise).
+void conv3x3h_pack(hipStream_t s, const void* wgt_std, int N, int Cin, DevBuf& out);
+bool conv3x3h_packable(int KH, int KW, int Cin, int Cout, int Npad);
+bool conv3x3h_eligible(const ConvDesc& d);
+void conv3x3h_launch(hipStream_t s, const ConvDesc& d, int* range_flag, int n_cus);
 
 // The stem in the split modes and the fp16 mode (kernels_conv_stem.hip): conv1 — described by d exactly as for conv_forward (7 row taps of 32 "channels"
 // on the zero-padded NHWC4 input, 64 output columns, ReLU) — and the 3x3 stride-2 'same' max-pool behind it in ONE persistent launch;

@@ -579,6 +579,8 @@ static int g_tail = env_int("MRCNN_TAIL", 0);
 // fp16 mode: identity bottleneck blocks (branch2a + branch2b + branch2c + shortcut) as ONE persistent launch with the two mid tensors on chip
 // (kernels_bneck.hip; bit-identical to the three launches).  MRCNN_BNECK=0 / mrcnn_debug_set("conv_bneck", 0): the three launches.
 static int g_bneck = env_int("MRCNN_BNECK", 1);
+// fp16 mode: 3x3 stride-1 layers with 256 | 512 output columns on the halo-tile / fragment-streaming kernel (kernels_conv3x3_h.hip; its own K order)
+static int g_c3h = env_int("MRCNN_C3H", 1);
 bool conv_bneck_enabled() { return g_bneck != 0; }
 // Canonical K chunks (round 4): the long-K 1x1 layers of the split modes — K >= 2048: C5's `branch2a`, the P5
 // lateral, the box head's first inner product (K = 12 544) — sum their K steps as ((0 + P0) + P1) + ..., 4 / 8 equal chunks by the
@@ -671,6 +673,7 @@ bool conv_debug_set(const char* key, int value)
     else if (k == "conv_stem") g_stem = value;
     else if (k == "conv_tail_dbg") g_tail_dbg = value;
     else if (k == "conv_bneck") g_bneck = value;
+    else if (k == "conv_c3h") g_c3h = value;
     else return conv_halo_debug_set(key, value);
     return true;
 }
@@ -781,6 +784,18 @@ void conv_forward(hipStream_t s, const ConvDesc& d_in, const ConvDesc* sc)
     if (fuse) { d.res = nullptr; d.res_sB = d.res_sH = d.res_sW = 0; }
     const bool half = d.dtype == MRCNN_F16;
     const int wdtype = d.wdtype < 0 ? d.dtype : d.wdtype;
+    if (half && g_c3h && conv3x3h_eligible(d)) {
+        static int n_cus_c3h = [] { int dev = 0; hipDeviceProp_t p; (void)hipGetDevice(&dev); return hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }();
+        ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
+        const int e0 = prof ? prof_event(prof, s) : 0;
+        conv3x3h_launch(s, d, g_range_flag, n_cus_c3h);
+        if (prof) {
+            const int e1 = prof_event(prof, s);
+            const double M = (double)d.B * d.OH * d.OW;
+            prof->pending.push_back({8, 2.0 * M * d.Cout * 9.0 * d.Cin, e0, e1, {(int)M, d.Cout, 9 * d.Cin, 8}, d.group});
+        }
+        return;
+    }
     // fp32 activations, fp16 filters: two-pass (wdtype F16) or exact three-pass (wdtype F32X3, a filter-side tag) fp16 MFMA
     const bool split = d.dtype == MRCNN_F32 && (wdtype == MRCNN_F16 || wdtype == MRCNN_F32X3);
     MRCNN_REQUIRE(d.dtype == MRCNN_F32 || half, MRCNN_ERR_UNSUPPORTED, "conv: dtype %d", d.dtype);

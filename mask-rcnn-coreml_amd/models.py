@@ -200,7 +200,7 @@ class MaskRCNN(_Model):
     def conv_profile(self):
         """{tile: (launches, total_ms, total_algorithmic_flops)} since conv_profile_enable()."""
         out = {}
-        for tile, name in enumerate(("128x128", "128x64", "128x32", "128x128w4", "256x256pp", "128xNhalo", "128x256tail", "bneck")):
+        for tile, name in enumerate(("128x128", "128x64", "128x32", "128x128w4", "256x256pp", "128xNhalo", "128x256tail", "bneck", "c3h")):
             n, ms, fl = C.c_int64(0), C.c_double(0), C.c_double(0)
             _lib.check(_lib.lib().mrcnn_model_conv_profile_get(self._h, tile, C.byref(n), C.byref(ms), C.byref(fl)))
             out[name] = (int(n.value), float(ms.value), float(fl.value))
