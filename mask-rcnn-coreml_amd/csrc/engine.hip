@@ -740,6 +740,10 @@ void Model::build_maskrcnn()
         convs[n] = pack_conv_oihw(f, n, "", mode);
     convs["rpn_heads"] = pack_stacked_1x1(f, {"rpn_class_raw", "rpn_bbox_pred"}, mode);
     MRCNN_REQUIRE(convs["rpn_heads"].Cout == 6 * na, MRCNN_ERR_IO, "RPN head width %d != 6*anchors_per_location", convs["rpn_heads"].Cout);
+    if (mode == MRCNN_F16 && convs["rpn_heads"].Npad == 32 && convs["rpn_heads"].Cin % 16 == 0) {       // fp16 mode: heads fused into the shared 3x3 layer (kernels_conv3x3_h.hip)
+        bneck_pack_frag(nullptr, convs["rpn_heads"].wgt.p, 32, convs["rpn_heads"].Cin, rpn_head_frag);
+        HIP_CHECK(hipStreamSynchronize(nullptr));
+    }
     if (convs["rpn_heads"].wdtype != convs["rpn_heads"].dtype && convs["rpn_heads"].Npad == 32) {       // split modes: heads fused into the shared 3x3 layer
         conv_halo_pack_head(nullptr, convs["rpn_heads"].wgt.p, 32, convs["rpn_heads"].Cin, rpn_head_frag);
         HIP_CHECK(hipStreamSynchronize(nullptr));
@@ -992,18 +996,24 @@ void Model::build_maskrcnn()
             f.head_out = rpn_logits + lvl_off[l] * 2; f.head_out_sP = 2 * na; f.head_out_sB = (long)A * 2;
             f.head_out2 = rpn_deltas + lvl_off[l] * 4; f.head_out2_sP = 4 * na; f.head_out2_sB = (long)A * 4;
             f.head_split = 2 * na; f.head_cols = 6 * na;
-            const bool fuse = rpn_head_frag.p && d.wgt_halo && conv_halo_head_eligible(f);
+            // fp16 mode: the same fusion on the halo-tile kernel of kernels_conv3x3_h.hip, on the levels with >= 16384 pixels per image (P2, P3 at 1024^2 — P4's 16 tiles per image would leave half the chip idle at batch 8:
+            // a property of the level, like the split modes' rule); bit-identical to that kernel followed by the separate head launch
+            const bool fuse16 = mode == MRCNN_F16 && rpn_head_frag.p && d.wgt_c3h && (long)fh[l] * fw[l] >= 16384 && conv3x3h_eligible(f);
+            const bool fuse = fuse16 || (mode != MRCNN_F16 && rpn_head_frag.p && d.wgt_halo && conv_halo_head_eligible(f));
             const int g_r = g_rpn[l];
             const size_t per_image = (size_t)fh[l] * fw[l] * 512;
-            add([d, e, f, fuse, self, g_r, per_image](hipStream_t s, int batch) {
+            add([d, e, f, fuse, fuse16, self, g_r, per_image](hipStream_t s, int batch) {
                 // (a calibration pass needs the 512-channel tensor: it runs the two-launch form)
-                if (fuse && conv_halo_enabled() && !self->calib_phase) {
+                const int c3h = conv_c3h_mode();
+                if (fuse && (fuse16 ? (c3h == 1 || c3h == 2) : conv_halo_enabled()) && !self->calib_phase) {
                     ConvDesc x = f; x.B = batch;
                     x.head_mul = ldexpf(1.0f, -self->sgroups[(size_t)g_r].exp);       // the fused heads see 2^e * relu(...): undone on their sums (exact)
                     conv_forward(s, x);
                     return;
                 }
-                ConvDesc x = d; x.B = batch; conv_forward(s, x);
+                ConvDesc x = d; x.B = batch;
+                x.prefer_c3h = fuse16 && c3h == 3;               // (the fused form's own 3x3 kernel followed by the separate head launch: bit-identical to the fusion)
+                conv_forward(s, x);
                 if (self->calib_phase) self->observe_split(s, g_r, d.out, per_image * batch);
                 ConvDesc y = e; y.B = batch; conv_forward(s, y);
             });

@@ -107,6 +107,7 @@ struct ConvDesc {
     const void* wgt_frag = nullptr;
     // fp16 mode, 3x3 stride-1 layers: the filters in the stream order of k_conv3x3_h (kernels_conv3x3_h.hip: conv3x3h_pack); nullptr = not available
     const void* wgt_c3h = nullptr;
+    int prefer_c3h = 0;          // run on that kernel even without a fused head (the engine's A/B of the head fusion: "conv_c3h" 3)
     int KH = 1, KW = 1, stride = 1, padH = 0, padW = 0;
     // epilogue: y = act(acc*scale[n] + shift[n] + residual)
     const float* scale = nullptr;
@@ -247,6 +248,7 @@ void conv3x3h_pack(hipStream_t s, const void* wgt_std, int N, int Cin, DevBuf& o
 bool conv3x3h_packable(int KH, int KW, int Cin, int Cout, int Npad);
 bool conv3x3h_eligible(const ConvDesc& d);
 void conv3x3h_launch(hipStream_t s, const ConvDesc& d, int* range_flag, int n_cus);
+int conv_c3h_mode();                        // mrcnn_debug_set("conv_c3h") / MRCNN_C3H: 0 never | 1 where the RPN heads ride along (default) | 2 every eligible layer | 3 as 1 with the heads as their own launch
 
 // The stem in the split modes and the fp16 mode (kernels_conv_stem.hip): conv1 — described by d exactly as for conv_forward (7 row taps of 32 "channels"
 // on the zero-padded NHWC4 input, 64 output columns, ReLU) — and the 3x3 stride-2 'same' max-pool behind it in ONE persistent launch;

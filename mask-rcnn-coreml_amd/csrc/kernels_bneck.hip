@@ -47,10 +47,14 @@ struct BnCfg {
     static constexpr int RING = 2 * A_STAGE > 2 * B_STAGE ? 2 * A_STAGE : 2 * B_STAGE;
     // LDS map: the ring FIRST (LDS-DMA destinations stay below 128 KB), then t1 (t2 and phase C's table alias it), then the tables of phases A / B
     static constexpr int OFF_T1 = RING, OFF_TABC = OFF_T1 + T2_BYTES, OFF_TABAB = OFF_T1 + T1_BYTES;
-    static constexpr int LDS = OFF_TABAB + 4 * C * 4;
+    // C = 64: phase C's shortcut / output tiles of a chunk ([256 pixels][128 B], full-line traffic): one in the ring's idle part, one behind the tables
+    static constexpr bool YTILE = C == 64;
+    static constexpr int OFF_Y0 = 2 * B_STAGE, OFF_Y1 = OFF_TABAB + 4 * C * 4, Y_BYTES = P * C * 2;
+    static constexpr int LDS = OFF_TABAB + 4 * C * 4 + (YTILE ? Y_BYTES : 0);
     static constexpr int NA = 4 * C / 32, NBS = 9 * CB, NCS = 4 * CB;       // K steps of the three phases
     static constexpr int NXD = HPAD / 16, NAD = NXD + C / 16;               // phase A: 1-KB DMAs per step (x rows | W1 rows)
     static_assert(HPAD >= HP && T2_BYTES + 8 * C * 4 <= T1_BYTES && LDS <= 163840 && NA % 2 == 0, "layout");
+    static_assert(!YTILE || OFF_Y0 + Y_BYTES <= RING, "the first chunk tile lives in the ring's idle part");
 };
 
 struct BneckArgs {
@@ -565,7 +569,7 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
         BN_ISSUE_W(w2off, srdW2, 0u, 0)
         {
             int tap = 0, cb = 0, dy = 0, dx = 0;
-            for (int s = 0; s < K::NBS; ++s) {
+            for (int s = 0; s < ((a.dbg & 2) ? 1 : K::NBS); ++s) {
                 BN_VMCNT0
                 __syncthreads();
                 {
@@ -636,6 +640,78 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
                 const int p_ = wm * 64 + i * 32 + l31;
                 grow[i] = ((size_t)(y0 + (p_ >> 4)) * a.W + (x0 + (p_ & 15))) * (size_t)(4 * C);
             }
+            if constexpr (K::YTILE) {
+            // ---- C = 64: the shortcut comes in and the output leaves in FULL LINES through LDS chunk tiles (as the C = 256 form does): straight
+            //      from the accumulators a store instruction covers 32 pixels x 32 B, and such scattered pieces issue 3x slower per CU — the
+            //      block is memory-bound (276 us as three launches against a 107 us HBM floor), so that was its largest term ----
+            static_assert(TNW == 1 && CB == 1, "C = 64");
+            const int hi8 = lane >> 3;
+            unsigned yv[2];              // per-lane byte offset of DMA / store instruction e = 4 wave + j (pixels 8e .. 8e+7 = tile row 2 wave + (j >> 1), columns 8 (j & 1) + hi8): j & 1
+#pragma unroll
+            for (int o = 0; o < 2; ++o) yv[o] = (unsigned)(hi8 * (4 * C * 2)) + (unsigned)((((lane & 7) ^ ((4 * o + (lane >> 4)) & 7))) << 4);
+            const unsigned ysoff = (unsigned)((((size_t)(y0 + 2 * wave) * a.W + x0) * (size_t)(4 * C)) * 2);
+            const __amdgpu_buffer_rsrc_t srdY = __builtin_amdgcn_make_buffer_rsrc(yimg, 0, (int)img_bytes, 0x00020000);
+#define BN_YOFF(J, CH) (ysoff + (unsigned)((((J) >> 1) * a.W + ((J) & 1) * 8) * (4 * C * 2) + (CH) * C * 2))
+#define BN_RES_DMA(CH)                                                                                         \
+    {                                                                                                          \
+        const unsigned yb_ = lds0 + (unsigned)(((CH) & 1) ? K::OFF_Y1 : K::OFF_Y0) + (unsigned)(wave * 4 * 1024); \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) { BN_BLDS(yv[j & 1], srdX, BN_YOFF(j, CH), yb_ + j * 1024) } \
+    }
+            BN_RES_DMA(0)
+            BN_RES_DMA(1)
+            for (int ch = 0; ch < ((a.dbg & 4) ? 1 : 4); ++ch, ++s) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][0][e] = 0.0f;
+                BN_VMCNT0                                   // W3's step and this chunk's shortcut tile have landed (this wave's share)
+                __syncthreads();                            // ... everybody's; the tile of chunk ch - 1 has been read out
+                if (ch + 1 < 4) BN_ISSUE_W(w3off, srdW3, (unsigned)(((ch + 1) * C * C) * 2), (s + 1) & 1)
+                if (ch >= 1 && ch + 1 < 4) BN_RES_DMA(ch + 1)
+                const unsigned char* const sb = smem + (s & 1) * K::B_STAGE;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f16x8 af[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f16x8*>(smem + t2row + (i * 32) * 128 + w_c[g]);
+                    const f16x8 wf = *reinterpret_cast<const f16x8*>(sb + bwr + w_c[g]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) BN_MFMA(wf, af[i], acc[i][0])
+                }
+                unsigned char* const yt = smem + ((ch & 1) ? K::OFF_Y1 : K::OFF_Y0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const int cl = ch * C + wn * NB + 16 * p + 4 * kk;
+                        const float4 sa = *reinterpret_cast<const float4*>(tabC + cl), sb_ = *reinterpret_cast<const float4*>(tabC + cl + 8);
+                        const float4 ha = *reinterpret_cast<const float4*>(tabC + 4 * C + cl), hb = *reinterpret_cast<const float4*>(tabC + 4 * C + cl + 8);
+                        float4 va = make_float4(acc[i][0][8 * p + 0], acc[i][0][8 * p + 1], acc[i][0][8 * p + 2], acc[i][0][8 * p + 3]);
+                        float4 vb = make_float4(acc[i][0][8 * p + 4], acc[i][0][8 * p + 5], acc[i][0][8 * p + 6], acc[i][0][8 * p + 7]);
+                        va.x = va.x * sa.x + ha.x; va.y = va.y * sa.y + ha.y; va.z = va.z * sa.z + ha.z; va.w = va.w * sa.w + ha.w;
+                        vb.x = vb.x * sb_.x + hb.x; vb.y = vb.y * sb_.y + hb.y; vb.z = vb.z * sb_.z + hb.z; vb.w = vb.w * sb_.w + hb.w;
+                        const int pl = wm * 64 + i * 32 + l31;           // tile pixel; its 128 B hold the chunk's 64 columns, 16-B piece c at c ^ ((pl >> 1) & 7)
+                        uint4* const slot = reinterpret_cast<uint4*>(yt + pl * 128 + (((wn * 4 + 2 * p + kk) ^ ((pl >> 1) & 7)) << 4));
+                        float4 ra, rb;
+                        bn_unpack16(*slot, ra, rb);
+                        va.x += ra.x; va.y += ra.y; va.z += ra.z; va.w += ra.w;
+                        vb.x += rb.x; vb.y += rb.y; vb.z += rb.z; vb.w += rb.w;
+                        va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f); va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
+                        vb.x = fmaxf(vb.x, 0.f); vb.y = fmaxf(vb.y, 0.f); vb.z = fmaxf(vb.z, 0.f); vb.w = fmaxf(vb.w, 0.f);
+                        range_trip = range_trip || bn_bad(va) || bn_bad(vb);
+                        *slot = bn_pack16(va, vb);
+                    }
+                __syncthreads();                            // the chunk tile is complete
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    typedef unsigned bn_u32x4 __attribute__((ext_vector_type(4)));
+                    const bn_u32x4 v_ = *reinterpret_cast<const bn_u32x4*>(yt + (wave * 4 + j) * 1024 + lane * 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(v_, srdY, (int)yv[j & 1], (int)BN_YOFF(j, ch), 0);
+                }
+            }
+#undef BN_RES_DMA
+#undef BN_YOFF
+            } else {
             for (int ch = 0; ch < 4; ++ch) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -700,6 +776,7 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
                         }
             }
         }
+            }
 #undef BN_ISSUE_W
         }
         __syncthreads();                               // the next tile's phase A restarts the ring at stage 0

@@ -580,7 +580,10 @@ static int g_tail = env_int("MRCNN_TAIL", 0);
 // (kernels_bneck.hip; bit-identical to the three launches).  MRCNN_BNECK=0 / mrcnn_debug_set("conv_bneck", 0): the three launches.
 static int g_bneck = env_int("MRCNN_BNECK", 1);
 // fp16 mode: 3x3 stride-1 layers with 256 | 512 output columns on the halo-tile / fragment-streaming kernel (kernels_conv3x3_h.hip; its own K order)
+// 0: never; 1 (default): where the RPN's heads ride in its epilogue (the engine's P2..P4 levels) — as a plain 3x3 layer it equals the ping-pong kernel
+// on the large levels and loses on under-filled grids (profiles/r05_c3h_ab.txt); 2: every eligible layer (tests, A/B); 3: as 1, heads as their own launch (A/B)
 static int g_c3h = env_int("MRCNN_C3H", 1);
+int conv_c3h_mode() { return g_c3h; }
 bool conv_bneck_enabled() { return g_bneck != 0; }
 // Canonical K chunks (round 4): the long-K 1x1 layers of the split modes — K >= 2048: C5's `branch2a`, the P5
 // lateral, the box head's first inner product (K = 12 544) — sum their K steps as ((0 + P0) + P1) + ..., 4 / 8 equal chunks by the
@@ -784,7 +787,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d_in, const ConvDesc* sc)
     if (fuse) { d.res = nullptr; d.res_sB = d.res_sH = d.res_sW = 0; }
     const bool half = d.dtype == MRCNN_F16;
     const int wdtype = d.wdtype < 0 ? d.dtype : d.wdtype;
-    if (half && g_c3h && conv3x3h_eligible(d)) {
+    if (half && g_c3h && (d.head_w || d.prefer_c3h || g_c3h == 2) && conv3x3h_eligible(d)) {
         static int n_cus_c3h = [] { int dev = 0; hipDeviceProp_t p; (void)hipGetDevice(&dev); return hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }();
         ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
         const int e0 = prof ? prof_event(prof, s) : 0;

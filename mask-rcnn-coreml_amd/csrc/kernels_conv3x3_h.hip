@@ -36,13 +36,21 @@ struct C3hArgs {
     int B, H, W, Cin, Cout, act;
     int tiles_x, tiles_y, npass, nunits;
     int* range_flag;
+    // HEAD: a 1x1 head over the layer's output fused in (the RPN's class / box heads, ConvDesc::head_*): the layer's own output is not stored
+    const uint4* head_wf;            // [32][Cout] head filters in fragment order (bneck_pack_frag)
+    const float* head_bias;
+    float *head_out, *head_out2;
+    long head_out_sB, head_out_sP, head_out2_sB, head_out2_sP;
+    int head_split, head_cols;
+    float head_mul;
 };
 
 #define C3H_MFMA(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, C_, 0, 0, 0);
 
 namespace {
 constexpr int HWD = 18, HP = 324, STAGE = HP * 128, YB = 256 * 512;
-constexpr int OFF_TAB = YB, LDS_BYTES = YB + 2 * 256 * 4;
+constexpr int OFF_TAB = YB, OFF_HW = YB + 2 * 256 * 4, HW_LANES = 36, HW_BYTES = 32 * HW_LANES * 16, LDS_BYTES = OFF_HW + HW_BYTES;
+// (OFF_HW: HEAD — the heads' filter fragments, rows 0..17 of each 1-KB granule only: 18 real head columns, 2 x 18 lanes x 16 B per 16-wide K group, 32 groups)
 typedef unsigned c3h_u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint4 c3h_pack16(const float4 va, const float4 vb)
@@ -61,6 +69,13 @@ __device__ __forceinline__ bool c3h_bad(const float4 v)
 }
 }  // namespace
 
+// HEAD = true (the RPN's shared layer on the levels whose heads ride along): a unit is a whole TILE — its output-column passes run back to
+// back in one block — and after each pass's epilogue, with the ReLU'd 256 x 256 piece sitting in LDS as fp16 (exactly what the layer
+// would have stored), wave w multiplies pixels 32 w .. of it with the heads' filters: 16 MFMAs per pass into ONE 32 x 32 accumulator
+// that runs over all passes (K = Cout in ascending order, 64-channel steps of four groups: the order of the separate head launch, so the
+// logits / deltas agree with it bit for bit).  The Cout-channel tensor (1.07 GB at P2 for a batch of 8 in fp32 terms, 537 MB in fp16) is
+// neither written nor read back, and the head launches disappear.
+template <bool HEAD>
 __global__ __launch_bounds__(512) void k_conv3x3_h(const C3hArgs a)
 {
     constexpr int D = 4;                       // filter fragments in flight per wave (a K group is eight MFMAs: >= 1 000 clocks of cover)
@@ -87,13 +102,23 @@ __global__ __launch_bounds__(512) void k_conv3x3_h(const C3hArgs a)
     const unsigned frow = (unsigned)(((l31 >> 4) * HWD + (l31 & 15)) * 128);
     const unsigned kk4 = (unsigned)(kk << 4);
 
+    if constexpr (HEAD) {
+        // the heads' filters stay in LDS for the life of the block (every unit multiplies with them: 16 dependent MFMAs per pass, and a
+        // 1-KB load from L2 in front of each cost 106 us on the P2 level)
+        for (int i = t; i < 32 * HW_LANES; i += 512) {
+            const int kg = i / HW_LANES, r = i - kg * HW_LANES, hk = r / 18, row = r - hk * 18;
+            *reinterpret_cast<uint4*>(smem + OFF_HW + i * 16) = kg * 16 < a.Cout ? a.head_wf[(size_t)kg * 64 + hk * 32 + row] : make_uint4(0u, 0u, 0u, 0u);
+        }
+        __syncthreads();
+    }
     bool range_trip = false;
     const int q8 = a.nunits >> 3, r8 = a.nunits & 7;
     for (int v = blockIdx.x; v < a.nunits; v += gridDim.x) {
         // XCD-aware bijective walk: the blocks of one XCD own a contiguous run of units (the passes of a tile adjacent)
         const int xcd = v & 7, local = v >> 3;
         const int unit = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
-        const int tile = unit / a.npass, pass = unit - tile * a.npass;
+        const int tile = HEAD ? unit : unit / a.npass;
+        const int pass0 = HEAD ? 0 : unit - tile * a.npass, pass1 = HEAD ? a.npass : pass0 + 1;
         const int per_img = a.tiles_x * a.tiles_y;
         const int b = tile / per_img, tr = tile - b * per_img;
         const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
@@ -108,6 +133,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_h(const C3hArgs a)
             const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
             xo[m] = ok ? (int)((((size_t)gy * a.in_sH + (size_t)gx * a.in_sW) + (size_t)(t & 7) * 8) * 2) : (int)0x80000000u;
         }
+        f32x16 hacc;                 // (HEAD: assigned in the head section of every pass: never live across a K loop)
+        for (int pass = pass0; pass < pass1; ++pass) {
         // this wave's filter stream: granules ((pass * 8 + wave) * KGU + q), q = 0 .. KGU - 1
         const uint4* const wp = a.wf + (size_t)(pass * 8 + wave) * KGU * 64 + lane;
         uint4 wq[D];
@@ -204,17 +231,67 @@ __global__ __launch_bounds__(512) void k_conv3x3_h(const C3hArgs a)
                 *reinterpret_cast<uint4*>(smem + (i * 32 + l31) * 512 + (((wave * 4 + 2 * p + kk) ^ (l31 & 15)) << 4)) = c3h_pack16(va, vb);
             }
         __syncthreads();
-        _Float16* const oimg = a.out + (size_t)b * a.out_sB + (size_t)pass * 256;
+        if constexpr (HEAD) {
+            const int p = wave * 32 + l31;               // this lane's pixel of the tile
+            const int hrow = l31 < 18 ? l31 : 17;
+            if (pass > pass0) {
+                const float4* const hs = reinterpret_cast<const float4*>(a.out) + (size_t)unit * 2048;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int e = t + 512 * j, px_ = e >> 5, slot = e & 31;          // a wave instruction = two pixels x 512 contiguous bytes
-            const int py = px_ >> 4, pxx = px_ & 15;
-            const uint4 val = *reinterpret_cast<const uint4*>(smem + px_ * 512 + slot * 16);
-            const int c = slot ^ (px_ & 15);
-            if (y0 + py < a.H && x0 + pxx < a.W)
-                *reinterpret_cast<uint4*>(oimg + ((size_t)(y0 + py) * a.W + (x0 + pxx)) * a.out_sP + c * 8) = val;
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const float4 v4 = hs[e4 * 512 + t];
+                    hacc[4 * e4] = v4.x; hacc[4 * e4 + 1] = v4.y; hacc[4 * e4 + 2] = v4.z; hacc[4 * e4 + 3] = v4.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) hacc[e] = 0.0f;
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                uint4 hwv = *reinterpret_cast<const uint4*>(smem + OFF_HW + (((pass * 16 + g) * HW_LANES + kk * 18 + hrow) << 4));
+                if (l31 >= 18) hwv = make_uint4(0u, 0u, 0u, 0u);          // head columns 18..31 do not exist
+                const f16x8 hw = __builtin_bit_cast(f16x8, hwv);
+                const f16x8 av = *reinterpret_cast<const f16x8*>(smem + p * 512 + (((2 * g + kk) ^ (p & 15)) << 4));
+                C3H_MFMA(hw, av, hacc)
+            }
+        } else {
+            _Float16* const oimg = a.out + (size_t)b * a.out_sB + (size_t)pass * 256;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int e = t + 512 * j, px_ = e >> 5, slot = e & 31;          // a wave instruction = two pixels x 512 contiguous bytes
+                const int py = px_ >> 4, pxx = px_ & 15;
+                const uint4 val = *reinterpret_cast<const uint4*>(smem + px_ * 512 + slot * 16);
+                const int c = slot ^ (px_ & 15);
+                if (y0 + py < a.H && x0 + pxx < a.W)
+                    *reinterpret_cast<uint4*>(oimg + ((size_t)(y0 + py) * a.W + (x0 + pxx)) * a.out_sP + c * 8) = val;
+            }
         }
-        __syncthreads();             // the tile has left the LDS: the next unit may stage
+        __syncthreads();             // the tile has left the LDS (or the heads have read it): the next pass / unit may stage
+        if constexpr (HEAD) {
+            // Between passes the heads' running sums wait in MEMORY, not in registers (live across the K loop they cost 64 spilled dwords
+            // inside it): 32 KB per unit in the layer's own output tensor, which exists (the un-fused levels use it) and is not written here.
+            if (pass + 1 < pass1) {
+                float4* const hs = reinterpret_cast<float4*>(a.out) + (size_t)unit * 2048;
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) hs[e4 * 512 + t] = make_float4(hacc[4 * e4], hacc[4 * e4 + 1], hacc[4 * e4 + 2], hacc[4 * e4 + 3]);
+            }
+        }
+        }
+        if constexpr (HEAD) {
+            // lane (l31, kk): pixel 32 wave + l31, head columns 8q + 4kk + r
+            const int p = wave * 32 + l31, py = p >> 4, px = p & 15;
+            if (y0 + py < a.H && x0 + px < a.W) {
+                const size_t pix = (size_t)(y0 + py) * a.W + (x0 + px);
+                float* const o1 = a.head_out + (size_t)b * a.head_out_sB + pix * a.head_out_sP;
+                float* const o2 = a.head_out2 + (size_t)b * a.head_out2_sB + pix * a.head_out2_sP;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int c = 8 * (e >> 2) + 4 * kk + (e & 3);
+                    const float vv = hacc[e] * a.head_mul + (c < a.head_cols ? a.head_bias[c] : 0.0f);
+                    if (c < a.head_split) o1[c] = vv;
+                    else if (c < a.head_cols) o2[c - a.head_split] = vv;
+                }
+            }
+        }
     }
     if (a.range_flag && range_trip) atomicOr(a.range_flag, 1);
 }
@@ -253,7 +330,9 @@ bool conv3x3h_eligible(const ConvDesc& d)
     const int wdt = d.wdtype < 0 ? d.dtype : d.wdtype;
     if (d.dtype != MRCNN_F16 || wdt != MRCNN_F16 || d.out_f32 || !d.wgt_c3h) return false;
     if (!conv3x3h_packable(d.KH, d.KW, d.Cin, d.Cout, d.Npad) || d.stride != 1 || d.padH != 1 || d.padW != 1) return false;
-    if (d.OH != d.H || d.OW != d.W || d.res || d.out2 || d.deconv2 || d.sel_partial || d.head_w || d.act == ACT_SIGMOID) return false;
+    if (d.OH != d.H || d.OW != d.W || d.res || d.out2 || d.deconv2 || d.sel_partial || d.act == ACT_SIGMOID) return false;
+    if (d.head_w && (long)d.B * ((d.H + 15) / 16) * ((d.W + 15) / 16) * 32768 > (long)d.B * d.out_sB * 2) return false;      // (the heads' partial sums wait in the output tensor)
+    if (d.head_w && !(d.Cout <= 512 && d.head_out && d.head_out2 && d.head_cols > 0 && d.head_cols <= 18 && d.head_split <= d.head_cols && d.act == ACT_RELU)) return false;
     auto al = [](const void* p, size_t n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
     if (!al(d.in, 16) || !al(d.out, 16) || d.in_sW % 8 || d.in_sH % 8 || d.in_sB % 8 || d.out_sP % 8 || d.out_sB % 8) return false;
     if (d.out_sB < (long)d.OH * d.OW * d.out_sP) return false;
@@ -272,12 +351,18 @@ void conv3x3h_launch(hipStream_t s, const ConvDesc& d, int* range_flag, int n_cu
     a.out_sB = d.out_sB; a.out_sP = d.out_sP;
     a.B = d.B; a.H = d.H; a.W = d.W; a.Cin = d.Cin; a.Cout = d.Cout; a.act = d.act;
     a.tiles_x = (d.W + 15) / 16; a.tiles_y = (d.H + 15) / 16; a.npass = d.Cout / 256;
-    a.nunits = d.B * a.tiles_x * a.tiles_y * a.npass;
+    const bool head = d.head_w != nullptr;
+    a.nunits = d.B * a.tiles_x * a.tiles_y * (head ? 1 : a.npass);
     a.range_flag = range_flag;
+    a.head_wf = static_cast<const uint4*>(d.head_w); a.head_bias = d.head_bias;
+    a.head_out = d.head_out; a.head_out2 = d.head_out2;
+    a.head_out_sB = d.head_out_sB; a.head_out_sP = d.head_out_sP; a.head_out2_sB = d.head_out2_sB; a.head_out2_sP = d.head_out2_sP;
+    a.head_split = d.head_split; a.head_cols = d.head_cols; a.head_mul = d.head_mul;
     int grid = n_cus > 0 ? n_cus / 8 * 8 : 256;
     if (grid <= 0) grid = 8;
     if (a.nunits < grid) grid = a.nunits;
-    hipLaunchKernelGGL(k_conv3x3_h, dim3(grid), dim3(512), 0, s, a);
+    if (head) hipLaunchKernelGGL(k_conv3x3_h<true>, dim3(grid), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(k_conv3x3_h<false>, dim3(grid), dim3(512), 0, s, a);
     HIP_CHECK(hipGetLastError());
 }
 

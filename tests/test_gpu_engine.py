@@ -744,3 +744,39 @@ def test_fused_bottleneck_blocks_leave_an_fp16_predict_bit_identical(pkg, weight
         L.check(L.lib().mrcnn_debug_set(b"conv_bneck", 1))
     np.testing.assert_array_equal(d1[0], det[2])
     assert np.isfinite(taps["P2"][0]).all()
+
+
+def test_fp16_fused_rpn_heads_equal_the_separate_head_launches(pkg, weights_mod, tmp_path_factory):
+    """Round 5: in the fp16 mode the RPN's class / box heads ride in the epilogue of the shared 3x3 layer on the levels with >= 16384 pixels
+    (kernels_conv3x3_h.hip, HEAD): the 512-channel tensor is neither written nor read.  Against the same 3x3 kernel followed by the
+    separate head launch ("conv_c3h" 3) the logits and deltas — hence every later stage — must agree BIT FOR BIT; against the older
+    kernels of the 3x3 layer ("conv_c3h" 0: another K order) within fp16 summation noise; and images must not depend on the batch."""
+    import importlib
+    L = importlib.import_module("mask-rcnn-coreml_amd._lib")
+    models = importlib.import_module("mask-rcnn-coreml_amd.models")
+    d, cfg = make_model_dir(tmp_path_factory, pkg, weights_mod, "rpnhead16", architecture="resnet50", input_image_shape=(1024, 768, 3),
+                            num_classes=21, pre_nms_max_proposals=1000, max_proposals=128, max_detections=32)
+    B = 2
+    m = models.load_maskrcnn(d, max_batch=B, compute_dtype="f16")
+    images = rand_images(B, 1024, 768, seed=13)
+    det, mask = m.predict(images)                         # default: heads fused where a level has >= 16384 pixels: P2 (256 x 192) here; P3 (128 x 96) and up: separate
+    probs = [m.read_tensor("rpn_probs", b).copy() for b in range(B)]
+    deltas = [m.read_tensor("rpn_deltas", b).copy() for b in range(B)]
+    try:
+        L.check(L.lib().mrcnn_debug_set(b"conv_c3h", 3))
+        det3, mask3 = m.predict(images)
+        for b in range(B):
+            np.testing.assert_array_equal(m.read_tensor("rpn_probs", b), probs[b])
+            np.testing.assert_array_equal(m.read_tensor("rpn_deltas", b), deltas[b])
+        np.testing.assert_array_equal(det3, det)
+        np.testing.assert_array_equal(mask3, mask)
+        L.check(L.lib().mrcnn_debug_set(b"conv_c3h", 0))
+        m.predict(images)
+        for b in range(B):
+            assert np.abs(m.read_tensor("rpn_probs", b) - probs[b]).max() < 5e-3
+            assert np.abs(m.read_tensor("rpn_deltas", b) - deltas[b]).max() < 5e-2 * max(1.0, np.abs(deltas[b]).max())
+    finally:
+        L.check(L.lib().mrcnn_debug_set(b"conv_c3h", 1))
+    d1, m1 = m.predict(images[1:2])
+    np.testing.assert_array_equal(d1[0], det[1])
+    assert np.isfinite(probs[0]).all() and (det[..., 5] > 0).sum() > 0

@@ -28,7 +28,7 @@ rows = m.conv_profile_shapes()
 tot = sum(r[5] for r in rows)
 print(f"{'M':>8} {'N':>5} {'K':>6} tile  n/step   us/launch  TFLOP/s  share")
 for M, N, K, tile, n, ms, fl in sorted(rows, key=lambda r: -r[5]):
-    print(f"{M:8d} {N:5d} {K:6d} {('128', '64', '32', '128w4', 'pp256', 'halo')[tile]:>5} {n / steps:7.1f} {ms / n * 1e3:11.1f} {fl / ms / 1e9:8.1f} {ms / tot * 100:6.1f}%")
+    print(f"{M:8d} {N:5d} {K:6d} {('128', '64', '32', '128w4', 'pp256', 'halo', 'tail', 'bneck', 'c3h')[tile]:>5} {n / steps:7.1f} {ms / n * 1e3:11.1f} {fl / ms / 1e9:8.1f} {ms / tot * 100:6.1f}%")
 m.conv_profile_enable(False)
 import time
 m.predict(img)
