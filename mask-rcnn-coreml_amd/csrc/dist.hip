@@ -313,6 +313,18 @@ static void reserve_exchange(mrcnn_dist* d, const Geometry& g)
     if (d->statuses.size() != (size_t)d->world * TRAILER) d->statuses.assign((size_t)d->world * TRAILER, 0);    // never re-assigned under an in-flight D2H
 }
 
+// Last resort of a rank that cannot reach the collective: tear the communicator down so that the peers' ncclAllGather FAILS instead of
+// blocking for ever — ncclCommAbort where librccl exports it, else ncclCommDestroy (which may itself wait for the peers: the documented
+// worst case is then a hang of THIS rank, which the job's launcher times out, rather than of every other rank).
+static void release_peers(mrcnn_dist* d)
+{
+    Rccl& r = rccl();
+    if (!d->comm) return;
+    if (r.CommAbort) (void)r.CommAbort(d->comm);
+    else if (r.CommDestroy) (void)r.CommDestroy(d->comm);
+    d->comm = nullptr;
+}
+
 // local results (n_local records, `in_space`) → every rank's records in global image order (`out_space`).
 // Issued on stream `s`; `status` != 0 sends zeroed records.  Does not synchronise.
 // The contract: once the arguments every rank sees alike have been checked, NOTHING rank-local may keep this
@@ -327,6 +339,9 @@ static void issue_exchange(mrcnn_dist* d, Model& m, hipStream_t s, const float* 
     d->plan = plan_entries(global_batch, d->world, d->g);
     const Geometry& g = d->g;
     const int n_local = d->plan[d->rank].end - d->plan[d->rank].begin;
+    // (rank-uniform prologue: a handle whose communicator an earlier failure aborted is refused HERE, before anything is enqueued
+    //  and before a peer could be left alone in the collective — every rank of that job saw the same abort)
+    MRCNN_REQUIRE(d->comm, MRCNN_ERR_INVALID, "the communicator of this handle was aborted by an earlier failure");
     reserve_exchange(d, g);
     // ---- from here on: rank-local failures travel as the status word ------------------------------------------------
     std::string local_msg;
@@ -342,18 +357,23 @@ static void issue_exchange(mrcnn_dist* d, Model& m, hipStream_t s, const float* 
         } catch (const Error& e) {
             (void)hipGetLastError();
             if (attempt == 1) {          // not even a zeroed slot can be enqueued: release the peers, then raise
-                Rccl& r = rccl();
-                if (r.CommAbort && d->comm) { (void)r.CommAbort(d->comm); d->comm = nullptr; }
+                release_peers(d);
                 fail(e.code ? e.code : MRCNN_ERR_HIP, "rank %d cannot take part in the all-gather (%s); communicator aborted", d->rank, e.msg.c_str());
             }
             status = e.code ? e.code : MRCNN_ERR_HIP;      // second attempt: zeroed records + this status
             local_msg = e.msg;
         }
     }
-    HIP_CHECK(hipEventRecord(d->ev_packed, s));
+    {
+        // a failing event record is a rank-local failure like a failing pack: the peers must not block in the collective
+        const hipError_t ee = hipEventRecord(d->ev_packed, s);
+        if (ee != hipSuccess) {
+            release_peers(d);
+            fail(MRCNN_ERR_HIP, "rank %d: hipEventRecord before the all-gather failed (%s); communicator aborted", d->rank, hipGetErrorString(ee));
+        }
+    }
     // ---- the one collective of the path ---------------------------------------------------------------------------
     Rccl& r = rccl();
-    MRCNN_REQUIRE(d->comm, MRCNN_ERR_INVALID, "the communicator of this handle was aborted by an earlier failure");
     nccl_check(r, r.AllGather(d->send.p, d->recv.p, g.slot, /*ncclFloat*/ 7, d->comm, s), "ncclAllGather");
     c.unpacking = true;
     unpack_slots(c, g, d->plan, d->recv.as<float>(), out_det, out_masks);

@@ -509,9 +509,13 @@ void MaskHead::load(const MrcwFile& f, int capacity_rows, int dtype_)
 
 // process-wide A/B switch of the fused mask tail (tests, tools/e2e_ab.py): mrcnn_debug_set("mask_fused", 0 | 1)
 static int g_fuse_mask_tail = 1;
+// level-parallel region of the trunk (engine.h): -1 = the model's own limit (batches up to 2), n >= 0 = batches up to n (0: never).
+// MRCNN_LEVEL_PARALLEL / mrcnn_debug_set("level_parallel", n).  Results do not depend on it (the same launches, other streams).
+static int g_level_parallel = getenv("MRCNN_LEVEL_PARALLEL") ? atoi(getenv("MRCNN_LEVEL_PARALLEL")) : -1;
 bool engine_debug_set(const char* key, int value)
 {
     if (std::string(key) == "mask_fused") { g_fuse_mask_tail = value; return true; }
+    if (std::string(key) == "level_parallel") { g_level_parallel = value; return true; }
     return false;
 }
 
@@ -617,6 +621,11 @@ Model::~Model()
     if (pipe_out) (void)hipStreamDestroy(pipe_out);
     if (ev_p0) (void)hipEventDestroy(ev_p0);
     if (ev_p1) (void)hipEventDestroy(ev_p1);
+    for (int b = 0; b < N_SIDE; ++b) {
+        if (ev_join[b]) (void)hipEventDestroy(ev_join[b]);
+        if (side[b]) (void)hipStreamDestroy(side[b]);
+    }
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
 
@@ -654,6 +663,12 @@ void Model::load(int kind_, const std::string& path, int max_batch_, int dtype_)
     if (kind == MRCNN_MODEL_CLASSIFIER) { cls_head.load(file, max_batch, mode); return; }
     if (kind == MRCNN_MODEL_MASK) { mask_head.load(file, max_batch, mode); return; }
     build_maskrcnn();
+    // the side streams of the level-parallel region (engine.h): created here, never inside a launch (a caller may be capturing)
+    for (int b = 0; b < N_SIDE; ++b) {
+        HIP_CHECK(hipStreamCreateWithFlags(&side[b], hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_join[b], hipEventDisableTiming));
+    }
+    HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
 }
 
 void Model::build_maskrcnn()
@@ -756,13 +771,15 @@ void Model::build_maskrcnn()
     for (int pass = 0; pass < 2; ++pass) {
         ar.off = 0;
         trunk_ops.clear();
+        trunk_branch.clear();
         taps.clear();
         sgroups.clear();
         sops.clear();
         const bool real = pass == 1;
         const int dt = dtype;
         auto T = [&](int h, int w, int c) { Tensor4 t; t.H = h; t.W = w; t.C = c; t.p = ar.alloc_e((size_t)Bm * h * w * c, dt); return t; };
-        auto add = [&](Op op) { if (real) trunk_ops.push_back(std::move(op)); };
+        int cur_branch = 0;          // stream of the ops being recorded (Model::trunk_branch)
+        auto add = [&](Op op) { if (real) { trunk_ops.push_back(std::move(op)); trunk_branch.push_back(cur_branch); } };
         // split groups (engine.h: SplitGroup): g_in / g_out of every convolution; a residual rides in the output's group
         const int g_img = new_split_group("image", true);        // pixel - mean: written by the pre-processing kernel, exponent 0
         const int g_zero = new_split_group("outputs", true);      // logits, box deltas, probabilities: consumed by fp32 arithmetic
@@ -945,10 +962,13 @@ void Model::build_maskrcnn()
         const Tensor4 Ls[4] = {L2, L3, L4, L5};
         const char* pn[4] = {"fpn_p2", "fpn_p3", "fpn_p4", "fpn_p5"};
         const char* tn[4] = {"P2", "P3", "P4", "P5"};
+        fork_at = trunk_ops.size();                               // the laterals are done: from here the levels are independent
         for (int l = 0; l < 4; ++l) {
             P[l] = T(Ls[l].H, Ls[l].W, 256);
             g_P[l] = new_split_group(tn[l]);
+            cur_branch = l;
             conv_op(pn[l], Ls[l], P[l], 1, 1, ACT_NONE, nullptr, 0, g_L, g_P[l]);
+            cur_branch = 0;
             taps[tn[l]] = {P[l].p, P[l].sB(), dt, g_P[l]};
             MRCNN_REQUIRE(P[l].H == fh[l] && P[l].W == fw[l], MRCNN_ERR_SHAPE, "pyramid level %d shape mismatch", l + 2);
         }
@@ -958,8 +978,12 @@ void Model::build_maskrcnn()
         rpn_deltas = ar.alloc_f((size_t)Bm * A * 4);
         taps["rpn_probs"] = {rpn_probs, (long)A * 2, MRCNN_F32};
         taps["rpn_deltas"] = {rpn_deltas, (long)A * 4, MRCNN_F32};
-        void* rpn_feat = ar.alloc_e((size_t)Bm * P[0].H * P[0].W * 512, dt);
+        // the shared layer's 512-channel tensor, one per branch of the level-parallel region: P2 | P3 | P4 | P5 and P6 (same stream)
+        void* rpn_feat_l[5];
+        for (int l = 0; l < 5; ++l) rpn_feat_l[l] = l == 4 ? rpn_feat_l[3] : ar.alloc_e((size_t)Bm * fh[l] * fw[l] * 512, dt);
         for (int l = 0; l < 5; ++l) {
+            void* const rpn_feat = rpn_feat_l[l];
+            cur_branch = l < 4 ? l : 3;
             const Tensor4& src = P[l < 4 ? l : 3];
             const int sub = l < 4 ? 1 : 2;
             const PackedConv* pc = &convs.at("rpn_conv_shared");
@@ -1018,6 +1042,8 @@ void Model::build_maskrcnn()
                 ConvDesc y = e; y.B = batch; conv_forward(s, y);
             });
         }
+        cur_branch = 0;
+        join_at = trunk_ops.size();
         {
             float* lg = rpn_logits; float* pr = rpn_probs; const long per = A;
             add([=](hipStream_t s, int batch) { softmax_pairs_forward(s, lg, pr, per * batch); });
@@ -1478,7 +1504,22 @@ void Model::enqueue_pipeline(hipStream_t s, int batch, const int* fit)
             preprocess_scalefit_forward(s, fit_src.as<uint8_t>(), batch, fit[0], fit[1], H, W, fit[2], fit[3], fit[4], fit[5], 3, mean, stem_in, dtype);
             first = 1;
         }
-        for (size_t i = first; i < trunk_ops.size(); ++i) trunk_ops[i](s, batch);
+        // (a calibration pass observes tensors on the model's stream, the stage timer and the conv profile bracket launches on it: those run serially)
+        const int pmax = g_level_parallel >= 0 ? g_level_parallel : branch_max_batch;
+        const bool parallel = side[0] && batch <= pmax && fork_at < join_at && !calib_phase && !conv_profile.active && !timer.enabled;
+        for (size_t i = first; i < trunk_ops.size(); ++i) {
+            if (parallel && i == fork_at) {
+                HIP_CHECK(hipEventRecord(ev_fork, s));
+                for (int b = 0; b < N_SIDE; ++b) HIP_CHECK(hipStreamWaitEvent(side[b], ev_fork, 0));
+            }
+            if (parallel && i == join_at)
+                for (int b = 0; b < N_SIDE; ++b) {
+                    HIP_CHECK(hipEventRecord(ev_join[b], side[b]));
+                    HIP_CHECK(hipStreamWaitEvent(s, ev_join[b], 0));
+                }
+            const int br = parallel && i >= fork_at && i < join_at ? trunk_branch[i] : 0;
+            trunk_ops[i](br > 0 ? side[br - 1] : s, batch);
+        }
     }
     timer.mark(s, "Trunk");
     // ProposalLayer

@@ -80,11 +80,24 @@ public final class MaskRCNN {
     /// Scale-aware split (`.f32x3` / `.f32s` only): one calibration predict on a representative image picks a power-of-two exponent per
     /// tensor group (folded into the layers at no run-time cost) so that the mode carries activations like fp32 whatever the
     /// checkpoint's scale; returns the number of inputs the split still cannot carry exactly.  `apply: false` only diagnoses.
+    /// OPTIONAL since round 5: an artefact converted with `convert --calibrate` carries the exponents (`exponentsFromArtefact`), and a
+    /// prediction that leaves the calibrated range lowers them and runs again inside the call (`rangeRecoveries`) instead of throwing.
     @discardableResult
     public func calibrateSplit(image rgb: UnsafePointer<UInt8>, apply: Bool = true) throws -> Int64 {
         try check(mrcnn_model_calibrate_split(handle, rgb, 1, height, width, Int32(MRCNN_HOST.rawValue), apply ? 1 : 0))
         var n: Int64 = 0
         try check(mrcnn_model_get_int(handle, "split_inexact_inputs", &n))
+        return n
+    }
+
+    /// Whether `mrcnn_model_load` found the split exponents in MaskRCNN.mrcw, and how many predictions recovered from a range trip so far.
+    public var exponentsFromArtefact: Bool {
+        var n: Int64 = 0
+        return mrcnn_model_get_int(handle, "split_exponents_from_artefact", &n) == 0 && n != 0
+    }
+    public var rangeRecoveries: Int64 {
+        var n: Int64 = 0
+        _ = mrcnn_model_get_int(handle, "range_recoveries", &n)
         return n
     }
 

@@ -261,6 +261,25 @@ def split_scale_curve(dtype, shape=(2, 32, 32, 256, 128, 3), seed=3):
     return out
 
 
+def split_scale_curve_calibrated(dtype, shape=(2, 32, 32, 256, 128, 3), seed=3):
+    """The same curve with the engine's calibration applied (Model::calibrate_split's rule: the tensor is STORED as 2^p * value with
+    max |a| * 2^p in [2^11, 2^12), the consumer's scale carries 2^-p — both exact): [(e, relative error, p)]."""
+    B, H, W, Ci, Co, k = shape
+    rng = np.random.default_rng(seed)
+    x = np.maximum(rng.standard_normal((B, H, W, Ci)), 0).astype(np.float32) * 4.0
+    w = (rng.standard_normal((Co, k, k, Ci)) * np.sqrt(2.0 / (k * k * Ci))).astype(np.float16).astype(np.float32)
+    one, zero = np.ones(Co, np.float32), np.zeros(Co, np.float32)
+    out = []
+    for e in SCALES:
+        xs = np.ldexp(x, e).astype(np.float32)
+        ref = torch_ref(xs, w, k, 1, one, zero, None, 0, dtype=dtype)
+        _, kx = np.frexp(float(np.abs(xs).max()))
+        p = 12 - int(kx)
+        got = conv(np.ldexp(xs, p).astype(np.float32), w, k, 1, np.ldexp(one, -p).astype(np.float32), zero, None, act=0, dtype=dtype).astype(np.float64)
+        out.append((e, float(np.abs(got - ref).max() / np.abs(ref).max()), p))
+    return out
+
+
 @pytest.mark.parametrize("dtype", ["f32x3", "f32s", "f32"])
 def test_split_modes_scale_curve_stays_inside_the_documented_bound(dtype):
     """VERDICT r2 item 1(b) / ADVICE r2: the three-part split is exact only for 0.5 <= |a| < 65504; below, an activation is

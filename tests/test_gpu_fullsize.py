@@ -172,16 +172,22 @@ def test_headline_end_to_end_agreement_with_the_oracle(pkg, full_model, e2e_orac
     m.calibrate_split(images[:2])
     hd, hk, hpool = _hip_predict_with_taps(m, images)
     tot = matched = flips = behind = 0
+    head_tot = head_matched = 0          # the first four images of the fixed seed: ALL matched, next to the fractional bar over all 16
     for b in range(N_E2E):
         a = ev.detection_agreement(hd[b], od[b], 1e-4, hk[b], ok[b])
         assert a["n_a"] == a["n_b"] == cfg.max_detections, (b, a)
         assert a["max_score_diff"] < 1e-5 and a["max_mask_diff"] < 2e-4, (b, a)
         tot += a["n_a"]; matched += a["matched"]
+        if b < 4:
+            head_tot += a["n_a"]; head_matched += a["matched"]
         why = ev.mask_flip_causes(hd[b], od[b], hpool[b], opool[b], hk[b], ok[b])
         assert why["write_set_ok"], f"image {b}: a side's masks are not the compacted rows its own zero-sample predicate keeps"
         assert not why["unexplained"], f"image {b}: a kept / dropped difference that is NOT the removeZeros cliff: {why['unexplained']}"
         flips += why["flips"]; behind += why["masks_behind_flip"]
     assert matched >= 0.999 * tot, (matched, tot)
+    # a fixed-seed equality beside the fraction: these 400 detections have matched one for one since round 2; a K-order change that
+    # swaps a near-tie HERE is worth a look at the taps before the expectation is moved
+    assert head_matched == head_tot, (head_matched, head_tot)
     print(f"e2e f32x3 vs oracle: {matched}/{tot} detections, {flips} removeZeros flips (all explained), {behind} masks behind a flip")
     pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None
 

@@ -27,7 +27,7 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 
 
 def run(shape, v):
-    L.check(lib.mrcnn_debug_set(b"conv_c3h", v))
+    L.check(lib.mrcnn_debug_set(b"conv_c3h", 2 if v else 0))      # 2: every eligible layer on the kernel
     ms, fl = C.c_float(0), C.c_double(0)
     L.check(lib.mrcnn_bench_conv_dtype(*shape[1:], iters, L.F16, C.byref(ms), C.byref(fl)))
     return ms.value * 1e3, fl.value / ms.value / 1e9

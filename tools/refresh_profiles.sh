@@ -4,7 +4,7 @@
 # Outputs land in gpurun_out/profiles_<round>/ (merged back by gpurun); copy them into profiles/ and commit.
 # Counter passes follow MI355X_MICROARCH.md: --pmc in its own run with --kernel-trace only, FETCH_SIZE and WRITE_SIZE separately.
 set -u
-RND=${1:-r04}
+RND=${1:-r05}
 MODES=${2:-"f32x3 f16 f32s f32"}
 R=$(pwd)
 OUT=$R/gpurun_out/profiles_$RND
@@ -29,13 +29,26 @@ for dt in $MODES; do
   done
   python $R/tools/pmc_digest.py $OUT/${RND}_pmc_kernels_$dt.json $OUT/${RND}_kernel_stats_$dt.csv /tmp/pmc_${dt}_1 /tmp/pmc_${dt}_2 /tmp/pmc_${dt}_3 /tmp/pmc_${dt}_4 /tmp/pmc_${dt}_5 > $OUT/${RND}_pmc_kernels_$dt.txt
   python - <<PY
-import json
+import json, sys
+sys.path.insert(0, "$R")
+import bench                                   # the SAME class table bench.py names its dominant kernel by
 d = json.load(open("$OUT/${RND}_pmc_kernels_$dt.json"))["kernels"]
-conv = {k: v for k, v in d.items() if k.startswith("k_conv") and "hbm_bytes_per_launch" in v}
-k = max(conv, key=lambda k: conv[k].get("percent_of_gpu_time", 0))
-json.dump({"kernel": k, "launches_sampled": conv[k]["launches_sampled"], "hbm_bytes_per_launch_corrected": conv[k]["hbm_bytes_per_launch"],
-           "FETCH_SIZE_avg_KB_raw": conv[k]["counters_avg_per_launch"]["FETCH_SIZE"], "WRITE_SIZE_avg_KB": conv[k]["counters_avg_per_launch"]["WRITE_SIZE"],
-           "note": "dominant conv kernel of bench.py --dtype $dt; 2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes (tools/refresh_profiles.sh)"},
+conv = {k: v for k, v in d.items() if (k.startswith("k_conv") or k.startswith("k_bneck")) and "hbm_bytes_per_launch" in v}
+cls = {}
+for name, tags in bench.CLASS_KERNELS.items():
+    if name == "128x256tail":
+        continue
+    sel = {k: v for k, v in conv.items() if any(t in k for t in tags)}
+    if sel:
+        cls[name] = sel
+dom = max(cls, key=lambda c: sum(v.get("percent_of_gpu_time", 0) for v in cls[c].values()))
+sel = cls[dom]
+n = sum(v["launches_sampled"] for v in sel.values())
+json.dump({"tile_class": dom, "kernels": sorted(sel), "launches_sampled": n,
+           "percent_of_gpu_time": round(sum(v.get("percent_of_gpu_time", 0) for v in sel.values()), 2),
+           "hbm_bytes_per_launch_corrected": round(sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in sel.values()) / n),
+           "note": "dominant conv tile CLASS of bench.py --dtype $dt (the class bench.py's roofline names: largest summed share of GPU time), launch-weighted over its "
+                   "instantiations; 2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes (tools/refresh_profiles.sh)"},
           open("$OUT/${RND}_pmc_traffic_$dt.json", "w"), indent=1)
 PY
 done
@@ -46,6 +59,11 @@ if [ "${MODES_ONLY:-0}" = 1 ]; then
   exit 0
 fi
 timeout 300 python tools/conv_ab.py 3 10 1 f16 > $OUT/${RND}_conv_ab_f16.txt 2>/dev/null
+# round 5 (fp16 mode): the fused identity bottleneck against the three launches, its phase ablation, the 3x3 halo-tile kernel against the ping-pong kernel
+timeout 300 python tools/bneck_ab.py 8 20 2>/dev/null | grep -v amdgpu > $OUT/${RND}_bneck_ab_f16.txt
+{ BNECK_ONLY=C4 timeout 300 bash tools/bneck_phases.sh 8; BNECK_ONLY=C2 timeout 300 bash tools/bneck_phases.sh 8; } 2>/dev/null | grep -v amdgpu > $OUT/${RND}_bneck_phases_f16.txt
+timeout 300 python tools/c3h_ab.py 3 10 2>/dev/null | grep -v amdgpu > $OUT/${RND}_c3h_ab_f16.txt
+{ for kv in "conv_bneck 0 1" "conv_c3h 0 1"; do timeout 300 python tools/e2e_ab.py f16 $kv 3 10 2>/dev/null | tail -1; done; BATCH=1 timeout 300 python tools/e2e_ab.py f16 conv_bneck 0 1 3 20 2>/dev/null | tail -1; } > $OUT/${RND}_e2e_ab_f16.txt
 for dt in f32x3 f32s; do timeout 300 python tools/halo_ab.py 3 10 $dt 2>/dev/null | grep -v amdgpu > $OUT/${RND}_halo_ab_$dt.txt; done
 timeout 200 python tools/halo_ablate.py f32x3 2>/dev/null | grep -v amdgpu > $OUT/${RND}_halo_ablate_f32x3.txt
 # round 4: the halo kernel's tile geometries (MRCNN_HALO_GEO=0 = round 3's one-row tiles, five staging pieces, pitch W + 2) — timing and LDS conflicts per layer

@@ -15,3 +15,10 @@ print(f"{'e':>4s} " + " ".join(f"{m:>12s}" for m in ("f32", "f32x3", "f32s")) + 
 cur = {m: t.split_scale_curve(m) for m in ("f32", "f32x3", "f32s")}
 for i, e in enumerate(t.SCALES):
     print(f"{e:4d} " + " ".join(f"{cur[m][i][1]:12.3e}" for m in ("f32", "f32x3", "f32s")) + f" {cur['f32x3'][i][2]:12.3e}")
+
+print()
+print("the same tensor with the engine's calibration (stored as 2^p * value, max |a| * 2^p in [2^11, 2^12); the consumer's scale carries 2^-p):")
+print(f"{'e':>4s} {'p':>4s} " + " ".join(f"{m:>12s}" for m in ("f32x3", "f32s")))
+cal = {m: t.split_scale_curve_calibrated(m) for m in ("f32x3", "f32s")}
+for i, e in enumerate(t.SCALES):
+    print(f"{e:4d} {cal['f32x3'][i][2]:4d} " + " ".join(f"{cal[m][i][1]:12.3e}" for m in ("f32x3", "f32s")))
