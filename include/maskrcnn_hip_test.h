@@ -100,6 +100,10 @@ MRCNN_API int mrcnn_debug_set(const char* key, int value);
 MRCNN_API int mrcnn_bottleneck_nhwc(const float* x, int batch, int h, int w, int cmid, const float* w1, const float* w2, const float* w3,
                                     const float* s1, const float* h1, const float* s2, const float* h2, const float* s3, const float* h3,
                                     int fused, int iters, float* out, float* avg_ms);
+/* The stage-ENTRY block of C2 (res2a; fp16 mode): x (B,H,W,C) with C = 64, w1 (C,C), w2 (C,3,3,C), w3 (4C,C), ws (4C,C) = the shortcut convolution
+ * `branch1`; bn[8] = scale / shift of branch2a, 2b, 2c, branch1 in that order; out (B,H,W,4C).  fused = 1: one launch, 0: the four launches — bit for bit. */
+MRCNN_API int mrcnn_bottleneck_first_nhwc(const float* x, int batch, int h, int w, int cmid, const float* w1, const float* w2, const float* w3, const float* ws,
+                                          const float* const bn[8], int fused, int iters, float* out, float* avg_ms);
 
 #ifdef __cplusplus
 }

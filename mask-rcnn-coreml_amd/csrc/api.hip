@@ -1129,6 +1129,73 @@ extern "C" int mrcnn_bottleneck_nhwc(const float* x, int batch, int h, int w, in
     });
 }
 
+// The stage-entry block (res2a of the fp16 mode: x (B,H,W,C) -> (B,H,W,4C), shortcut = the 1x1 convolution ws of x) — fused = 1: one launch
+// (kernels_bneck.hip, FIRST form); 0: the four launches.  tests/test_gpu_bneck.py compares them bit for bit.
+extern "C" int mrcnn_bottleneck_first_nhwc(const float* x, int batch, int h, int w, int cmid, const float* w1, const float* w2, const float* w3, const float* ws,
+                                           const float* const bn[8], int fused, int iters, float* out, float* avg_ms)
+{
+    return guarded([&] {
+        require_gpu();
+        MRCNN_REQUIRE(x && w1 && w2 && w3 && ws && bn && out && batch >= 1 && h >= 1 && w >= 1 && cmid >= 64 && cmid % 64 == 0, MRCNN_ERR_INVALID, "bad bottleneck_first_nhwc argument");
+        const int C = cmid, C4 = 4 * cmid;
+        auto half_dev = [&](const float* src, size_t n, DevBuf& d) {
+            std::vector<_Float16> t(n);
+            for (size_t i = 0; i < n; ++i) t[i] = (_Float16)src[i];
+            d.alloc(n * 2);
+            HIP_CHECK(hipMemcpy(d.p, t.data(), n * 2, hipMemcpyHostToDevice));
+        };
+        const size_t npix = (size_t)batch * h * w;
+        DevBuf dx, dy, dsc, dt1, dt2, dw1, dw2, dw3, dws, dbn[8];
+        half_dev(x, npix * C, dx);
+        half_dev(w1, (size_t)C * C, dw1); half_dev(w2, (size_t)C * 9 * C, dw2); half_dev(w3, (size_t)C4 * C, dw3); half_dev(ws, (size_t)C4 * C, dws);
+        const int bn_n[8] = {C, C, C, C, C4, C4, C4, C4};
+        for (int i = 0; i < 8; ++i) { dbn[i].alloc((size_t)bn_n[i] * 4); HIP_CHECK(hipMemcpy(dbn[i].p, bn[i], (size_t)bn_n[i] * 4, hipMemcpyHostToDevice)); }
+        dy.alloc(npix * C4 * 2); dsc.alloc(npix * C4 * 2); dt1.alloc(npix * C * 2); dt2.alloc(npix * C * 2);
+        HIP_CHECK(hipMemset(dy.p, 0xff, npix * C4 * 2));
+        auto desc = [&](const void* in, int cin, const void* wgt, int k, int bi, void* o, int cout, int act) {
+            ConvDesc d;
+            d.dtype = MRCNN_F16; d.wdtype = MRCNN_F16;
+            d.in = in; d.B = batch; d.H = h; d.W = w; d.Cin = cin;
+            d.in_sW = cin; d.in_sH = (long)w * cin; d.in_sB = (long)h * w * cin;
+            d.wgt = wgt; d.KH = d.KW = k; d.stride = 1; d.padH = d.padW = k / 2;
+            d.scale = dbn[bi].as<float>(); d.shift = dbn[bi + 1].as<float>();
+            d.OH = h; d.OW = w; d.Cout = cout; d.Npad = cout;
+            d.out = o; d.out_sP = cout; d.out_sB = (long)h * w * cout; d.act = act;
+            return d;
+        };
+        ConvDesc da = desc(dx.p, C, dw1.p, 1, 0, dt1.p, C, ACT_RELU);
+        ConvDesc db = desc(dt1.p, C, dw2.p, 3, 2, dt2.p, C, ACT_RELU);
+        ConvDesc dc = desc(dt2.p, C, dw3.p, 1, 4, dy.p, C4, ACT_RELU);
+        ConvDesc ds = desc(dx.p, C, dws.p, 1, 6, dsc.p, C4, ACT_NONE);
+        dc.res = dsc.p; dc.res_sW = C4; dc.res_sH = (long)w * C4; dc.res_sB = (long)h * w * C4;
+        MRCNN_REQUIRE(!fused || conv_bneck_first_fusable(da, db, dc, ds), MRCNN_ERR_UNSUPPORTED, "bottleneck_first_nhwc: C %d at %dx%d does not qualify for the fused launch", C, h, w);
+        Stream st;
+        static int n_cus = [] { int dev = 0; hipDeviceProp_t p; (void)hipGetDevice(&dev); return hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }();
+        auto run = [&] {
+            if (fused) bneck_launch(st.s, C, da.in, dc.out, batch, h, w, da.wgt, db.wgt, dc.wgt, da.scale, da.shift, db.scale, db.shift, dc.scale, dc.shift, nullptr, n_cus,
+                                    nullptr, nullptr, nullptr, ds.wgt, ds.scale, ds.shift);
+            else { conv_forward(st.s, da); conv_forward(st.s, ds); conv_forward(st.s, db); conv_forward(st.s, dc); }
+        };
+        run();
+        HIP_CHECK(hipStreamSynchronize(st.s));
+        if (iters > 0 && avg_ms) {
+            hipEvent_t e0, e1;
+            HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+            HIP_CHECK(hipEventRecord(e0, st.s));
+            for (int i = 0; i < iters; ++i) run();
+            HIP_CHECK(hipEventRecord(e1, st.s));
+            HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            *avg_ms = ms / iters;
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        }
+        std::vector<_Float16> t(npix * C4);
+        HIP_CHECK(hipMemcpy(t.data(), dy.p, t.size() * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < t.size(); ++i) out[i] = (float)t[i];
+    });
+}
+
 // ================================================================================================
 // anchors on demand (MaskRCNNConfig.swift:14 "TODO: generate the anchors on demand")
 // Host code.  Restates the published Matterport generator the reference's converter dumps to

@@ -509,7 +509,7 @@ void MaskHead::load(const MrcwFile& f, int capacity_rows, int dtype_)
 
 // process-wide A/B switch of the fused mask tail (tests, tools/e2e_ab.py): mrcnn_debug_set("mask_fused", 0 | 1)
 static int g_fuse_mask_tail = 1;
-// level-parallel region of the trunk (engine.h): -1 = the model's own limit (batches up to 2), n >= 0 = batches up to n (0: never).
+// level-parallel region of the trunk (engine.h; measured slower, off by default): -1 = the model's own limit (0: never), n >= 0 = batches up to n.
 // MRCNN_LEVEL_PARALLEL / mrcnn_debug_set("level_parallel", n).  Results do not depend on it (the same launches, other streams).
 static int g_level_parallel = getenv("MRCNN_LEVEL_PARALLEL") ? atoi(getenv("MRCNN_LEVEL_PARALLEL")) : -1;
 bool engine_debug_set(const char* key, int value)
@@ -929,6 +929,25 @@ void Model::build_maskrcnn()
                     bneck_op("res" + p + "_branch2a", "res" + p + "_branch2b", "res" + p + "_branch2c", x, ta, tb, to, g_x, g_a, g_b, g_stage);
                     x = to;
                     x_is_main = !x_is_main;
+                    g_x = g_stage;
+                    continue;
+                }
+                if (first && mode == MRCNN_F16 && stride == 1 && x.C == f1s[st] && f1s[st] == 64 && bneck_geometry_ok(f1s[st], oh, ow)) {
+                    // fp16 mode, the entry block of C2: branch2a + 2b + 2c AND the shortcut convolution branch1 in one launch (kernels_bneck.hip, FIRST
+                    // form; bit-identical to the four launches, which conv_bneck_first_forward runs where the block does not qualify)
+                    const Tensor4 sc1 = T(oh, ow, f3s[st]);         // the shortcut tensor of the four-launch form (unused by the fused one)
+                    const Tensor4 out1 = T(oh, ow, f3s[st]);
+                    const ConvDesc da = make_desc("res" + p + "_branch2a", x, ta, 1, 0, ACT_RELU, nullptr, 0, g_x, g_a);
+                    const ConvDesc db = make_desc("res" + p + "_branch2b", ta, tb, 1, 1, ACT_RELU, nullptr, 0, g_a, g_b);
+                    const ConvDesc ds = make_desc("res" + p + "_branch1", x, sc1, 1, 0, ACT_NONE, nullptr, 0, g_x, g_stage);
+                    const ConvDesc dc = make_desc("res" + p + "_branch2c", tb, out1, 1, 0, ACT_RELU, &sc1, 0, g_b, g_stage);
+                    add([da, db, dc, ds](hipStream_t s, int batch) {
+                        ConvDesc a = da, b = db, c = dc, e = ds;
+                        a.B = b.B = c.B = e.B = batch;
+                        conv_bneck_first_forward(s, a, b, c, e);
+                    });
+                    x = out1;
+                    stage_main = out1;
                     g_x = g_stage;
                     continue;
                 }

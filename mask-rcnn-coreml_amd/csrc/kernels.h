@@ -227,6 +227,11 @@ void conv_forward_tail(hipStream_t s, const ConvDesc& d3, const ConvDesc& d1, co
 // form needs dc.out != da.in (a tile reads halo pixels its neighbours own); whether a triple qualifies is a property of the layers'
 // geometry only, never of the batch.
 bool conv_bneck_fusable(const ConvDesc& da, const ConvDesc& db, const ConvDesc& dc);
+// The stage-ENTRY block of C2 in the fp16 mode (res2a: stride 1, 64 -> 64 -> 64 -> 256, shortcut = the 1x1 convolution ds = `branch1` of the
+// block's input, whose output is dc's residual) as one launch of the same kernel (FIRST form): bit-identical to conv_forward(da);
+// conv_forward(ds); conv_forward(db); conv_forward(dc), which run when the block does not qualify / the grid under-fills the chip / "conv_bneck" 0.
+bool conv_bneck_first_fusable(const ConvDesc& da, const ConvDesc& db, const ConvDesc& dc, const ConvDesc& ds);
+void conv_bneck_first_forward(hipStream_t s, const ConvDesc& da, const ConvDesc& db, const ConvDesc& dc, const ConvDesc& ds);
 bool conv_bneck_enabled();
 void conv_bneck_forward(hipStream_t s, const ConvDesc& da, const ConvDesc& db, const ConvDesc& dc);
 bool bneck_geometry_ok(int C, int H, int W);
@@ -234,7 +239,8 @@ bool bneck_geometry_ok(int C, int H, int W);
 // straight from L2 into registers; nullptr selects the form with every operand staged through LDS
 void bneck_launch(hipStream_t s, int C, const void* x, void* y, int B, int H, int W, const void* w1, const void* w2, const void* w3,
                   const float* s1, const float* h1, const float* s2, const float* h2, const float* s3, const float* h3, int* range_flag, int n_cus,
-                  const void* w2f = nullptr, const void* w3f = nullptr, const void* w1f = nullptr);
+                  const void* w2f = nullptr, const void* w3f = nullptr, const void* w1f = nullptr,
+                  const void* ws = nullptr, const float* ss = nullptr, const float* hs = nullptr);      // ws / ss / hs: the stage-entry form (C = 64)
 // [N][K] fp16 filters (K contiguous; N % 32 == 0, K % 16 == 0) -> 1-KB granules [N/32][K/16][lane 0..63][8]: lane (l31, kk) of granule (nt, kg)
 // holds filter row 32 nt + l31, k = 16 kg + 8 kk .. + 7 — the first MFMA operand of v_mfma_f32_32x32x16_f16, one coalesced 16-B load per lane
 void bneck_pack_frag(hipStream_t s, const void* wgt_std, int N, int K, DevBuf& out);

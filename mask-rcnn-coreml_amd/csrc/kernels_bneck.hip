@@ -53,15 +53,15 @@ struct BnCfg {
     static constexpr int LDS = OFF_TABAB + 4 * C * 4 + (YTILE ? Y_BYTES : 0);
     static constexpr int NA = 4 * C / 32, NBS = 9 * CB, NCS = 4 * CB;       // K steps of the three phases
     static constexpr int NXD = HPAD / 16, NAD = NXD + C / 16;               // phase A: 1-KB DMAs per step (x rows | W1 rows)
-    static_assert(HPAD >= HP && T2_BYTES + 8 * C * 4 <= T1_BYTES && LDS <= 163840 && NA % 2 == 0, "layout");
+    static_assert(HPAD >= HP && T2_BYTES + 8 * C * 4 * (C == 64 ? 2 : 1) <= T1_BYTES && LDS <= 163840 && NA % 2 == 0, "layout");
     static_assert(!YTILE || OFF_Y0 + Y_BYTES <= RING, "the first chunk tile lives in the ring's idle part");
 };
 
 struct BneckArgs {
     const _Float16* x; _Float16* y;
-    const _Float16 *w1, *w2, *w3;
+    const _Float16 *w1, *w2, *w3, *ws;   // ws: the stage-entry form's shortcut filters [4C][C] (branch1)
     const uint4 *w1f, *w2f, *w3f;    // W1 / W2 / W3 in MFMA-fragment order (FRAG form)
-    const float *s1, *h1, *s2, *h2, *s3, *h3;
+    const float *s1, *h1, *s2, *h2, *s3, *h3, *ss, *hs;
     int B, H, W, tiles_x, tiles_y, ntiles;
     int* range_flag;
     int dbg;
@@ -111,9 +111,15 @@ __device__ __forceinline__ bool bn_bad(const float4 v)
 // from L2 into registers (bneck_pack_frag: one coalesced 1-KB load per 16-wide K group, eight groups ahead) — every filter byte is
 // loaded once per block, as through the ring, but there is no ring, no DMA issue in the loop and NO BARRIER inside the two phases
 // (t1 / t2 are read-only while they run): the two waves of a SIMD de-phase by themselves and keep the matrix pipe fed.
-template <int C, bool FRAG>
+// FIRST (C = 64, stride 1): the stage's ENTRY block (res2a) — its input has C channels, not 4C, and the shortcut is not x but the 1x1
+// convolution `branch1` of x (+ BatchNorm, no ReLU), which the three-launch form stores as an fp16 tensor and reads back as branch2c's
+// residual.  Here phase A's K is C, and phase C multiplies the tile's own x pixels (one 32-KB LDS tile) with branch1's filters beside
+// t2 x W3: y = relu((t2 W3) s3 + h3 + fp16((x Ws) ss + hs)) — the rounding of the shortcut where the tensor would have been: bit-identical.
+template <int C, bool FRAG, bool FIRST = false>
 __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
 {
+    static_assert(!FIRST || (C == 64 && !FRAG), "the stage-entry form is laid out for C = 64");
+    constexpr int CIN = FIRST ? C : 4 * C;                 // channels of the block's input
     static_assert(!FRAG || C == 256, "the fragment-streaming form is laid out for C = 256 (eight waves x 32 channels, 128-pixel tiles)");
     using K = BnCfg<C>;
     constexpr int HP = K::HP, HWD = K::HWD, WN = K::WN, NB = K::NB, TNW = K::TNW, CB = K::CB, P = K::P;
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
 
     // ---- buffer resources (raw, stride 0): a lane offset beyond num_records deposits zeros in LDS ----
     constexpr unsigned OOB = 0x80000000u;        // (+ any K-step offset stays out of range, no wrap)
-    const unsigned img_bytes = (unsigned)((size_t)a.H * a.W * 4 * C * 2);
+    const unsigned img_bytes = (unsigned)((size_t)a.H * a.W * CIN * 2);       // of x; y always has 4C channels
     bn_srd_t srdX, srdW1, srdW2, srdW3;
     auto mk = [](const void* p, unsigned bytes) {
         const unsigned long long u = (unsigned long long)(uintptr_t)p;
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
         r[3] = 0x00020000u;
         return r;
     };
-    srdW1 = mk(a.w1, (unsigned)(C * 4 * C * 2));
+    srdW1 = mk(a.w1, (unsigned)(C * CIN * 2));
     srdW2 = mk(a.w2, (unsigned)(C * 9 * C * 2));
     srdW3 = mk(a.w3, (unsigned)(4 * C * C * 2));
 
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
     for (int j = 0; j < 4; ++j) {
         const int u = wave + 8 * j;
         const int n = 16 * (u - K::NXD) + r16;
-        w1off[j] = (unsigned)(n * 4 * C * 2 + c4 * 16);
+        w1off[j] = (unsigned)(n * CIN * 2 + c4 * 16);
     }
     // phases B / C (128-B rows, 8 rows per DMA): DMA d = wave + 8 j, j < CB
     unsigned w2off[CB], w3off[CB];
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
         const int b = tile / per_img, tr = tile - b * per_img;
         const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
         const int y0 = ty * K::TH, x0 = tx * K::TW;
-        const _Float16* const ximg = a.x + (size_t)b * a.H * a.W * 4 * C;
+        const _Float16* const ximg = a.x + (size_t)b * a.H * a.W * CIN;
         _Float16* const yimg = a.y + (size_t)b * a.H * a.W * 4 * C;
         srdX = mk(ximg, img_bytes);
 
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
             const int py = r / HWD, px = r - py * HWD;
             const int gy = y0 - 1 + py, gx = x0 - 1 + px;
             const bool ok = r < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-            xoff[j] = ok ? (unsigned)(((size_t)gy * a.W + gx) * 4 * C * 2 + c4 * 16) : OOB;
+            xoff[j] = ok ? (unsigned)(((size_t)gy * a.W + gx) * CIN * 2 + c4 * 16) : OOB;
         }
 
         if constexpr (FRAG) {
@@ -339,10 +345,12 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
         }                                                                                                      \
     }
         BN_ISSUE_A(0)
-        for (int ks = 0; ks < ((a.dbg & 1) ? 1 : K::NA); ++ks) {
+        constexpr int NA_ = CIN / 32;
+        static_assert(NA_ % 2 == 0, "phase A ends on ring stage 1");
+        for (int ks = 0; ks < ((a.dbg & 1) ? 1 : NA_); ++ks) {
             BN_VMCNT0
             __syncthreads();                           // step ks has landed for everyone; everyone is done reading step ks - 1
-            if (ks + 1 < K::NA && !(a.dbg & 1)) BN_ISSUE_A(ks + 1)
+            if (ks + 1 < NA_ && !(a.dbg & 1)) BN_ISSUE_A(ks + 1)
             const unsigned char* const sb = smem + ((ks & 1) ? (K::RING - K::A_STAGE) : 0);
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
@@ -605,7 +613,7 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
             tabC[i] = src ? src[c] : (w ? 0.0f : 1.0f);
         }
         // the first W3 step rides under the epilogue (the ring is free: the barrier above retired phase B's last reads)
-        BN_ISSUE_W(w3off, srdW3, 0u, K::NBS & 1)
+        if constexpr (!FIRST) BN_ISSUE_W(w3off, srdW3, 0u, K::NBS & 1)
         // epilogue B -> t2
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -640,7 +648,92 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
                 const int p_ = wm * 64 + i * 32 + l31;
                 grow[i] = ((size_t)(y0 + (p_ >> 4)) * a.W + (x0 + (p_ & 15))) * (size_t)(4 * C);
             }
-            if constexpr (K::YTILE) {
+            if constexpr (FIRST) {
+            // ---- stage-entry block: the shortcut is branch1(x), formed here from the tile's own x pixels ----
+            static_assert(TNW == 1 && CB == 1, "C = 64");
+            constexpr int FST = 2 * K::B_STAGE;          // a stage = W3's step | Ws's step of a chunk (16 KB), two stages
+            const bn_srd_t srdWs = mk(a.ws, (unsigned)(4 * C * C * 2));
+            float* const tabS = tabC + 8 * C;            // scale | shift of branch1 (behind branch2c's table)
+            for (int i = t; i < 8 * C; i += 512) {
+                const int w = i / (4 * C), c = i - w * 4 * C;
+                const float* src = w == 0 ? a.ss : a.hs;
+                tabS[i] = src ? src[c] : (w ? 0.0f : 1.0f);
+            }
+            // the tile's x pixels -> LDS [256 pixels][128 B] (the chunk-tile area behind the tables), 16-B piece c of pixel p at c ^ ((p >> 1) & 7)
+            {
+                const int hi8 = lane >> 3;
+                const unsigned xs0 = (unsigned)((((size_t)(y0 + 2 * wave) * a.W + x0) * (size_t)CIN) * 2);
+                const unsigned xb_ = lds0 + (unsigned)K::OFF_Y1 + (unsigned)(wave * 4 * 1024);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned vo = (unsigned)(hi8 * (CIN * 2)) + (unsigned)((((lane & 7) ^ ((4 * (j & 1) + (lane >> 4)) & 7))) << 4);
+                    BN_BLDS(vo, srdX, xs0 + (unsigned)((((j >> 1) * a.W + (j & 1) * 8) * (CIN * 2))), xb_ + j * 1024)
+                }
+            }
+#define BN_ISSUE_W2(CH, ST)                                                                                    \
+    {                                                                                                          \
+        const unsigned sb_ = lds0 + (unsigned)(ST) * (unsigned)FST;                                            \
+        BN_BLDS(w3off[0], srdW3, (unsigned)(((CH) * C * C) * 2), sb_ + wave * 1024)                            \
+        BN_BLDS(w3off[0], srdWs, (unsigned)(((CH) * C * C) * 2), sb_ + K::B_STAGE + wave * 1024)               \
+    }
+            BN_ISSUE_W2(0, 0)
+            f32x16 accs[2];
+            for (int ch = 0; ch < ((a.dbg & 4) ? 1 : 4); ++ch) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { acc[i][0][e] = 0.0f; accs[i][e] = 0.0f; }
+                BN_VMCNT0
+                __syncthreads();                            // this chunk's filters (and, first time, t2 / the x tile / the tables) are in place
+                if (ch + 1 < 4) BN_ISSUE_W2(ch + 1, (ch + 1) & 1)
+                const unsigned char* const sb = smem + (ch & 1) * FST;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f16x8 af[2], xf[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        af[i] = *reinterpret_cast<const f16x8*>(smem + t2row + (i * 32) * 128 + w_c[g]);
+                        xf[i] = *reinterpret_cast<const f16x8*>(smem + K::OFF_Y1 + (wm * 64 + i * 32 + l31) * 128 + w_c[g]);
+                    }
+                    const f16x8 wf = *reinterpret_cast<const f16x8*>(sb + bwr + w_c[g]);
+                    const f16x8 wsf = *reinterpret_cast<const f16x8*>(sb + K::B_STAGE + bwr + w_c[g]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) { BN_MFMA(wf, af[i], acc[i][0]) BN_MFMA(wsf, xf[i], accs[i]) }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int pl = wm * 64 + i * 32 + l31;
+                    const size_t go = ((size_t)(y0 + (pl >> 4)) * a.W + (x0 + (pl & 15))) * (size_t)(4 * C);
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const int cl = ch * C + wn * NB + 16 * p + 4 * kk;
+                        const float4 sa = *reinterpret_cast<const float4*>(tabC + cl), sb_ = *reinterpret_cast<const float4*>(tabC + cl + 8);
+                        const float4 ha = *reinterpret_cast<const float4*>(tabC + 4 * C + cl), hb = *reinterpret_cast<const float4*>(tabC + 4 * C + cl + 8);
+                        const float4 ta = *reinterpret_cast<const float4*>(tabS + cl), tb = *reinterpret_cast<const float4*>(tabS + cl + 8);
+                        const float4 ua = *reinterpret_cast<const float4*>(tabS + 4 * C + cl), ub = *reinterpret_cast<const float4*>(tabS + 4 * C + cl + 8);
+                        float4 va = make_float4(acc[i][0][8 * p + 0], acc[i][0][8 * p + 1], acc[i][0][8 * p + 2], acc[i][0][8 * p + 3]);
+                        float4 vb = make_float4(acc[i][0][8 * p + 4], acc[i][0][8 * p + 5], acc[i][0][8 * p + 6], acc[i][0][8 * p + 7]);
+                        float4 ra = make_float4(accs[i][8 * p + 0], accs[i][8 * p + 1], accs[i][8 * p + 2], accs[i][8 * p + 3]);
+                        float4 rb = make_float4(accs[i][8 * p + 4], accs[i][8 * p + 5], accs[i][8 * p + 6], accs[i][8 * p + 7]);
+                        va.x = va.x * sa.x + ha.x; va.y = va.y * sa.y + ha.y; va.z = va.z * sa.z + ha.z; va.w = va.w * sa.w + ha.w;
+                        vb.x = vb.x * sb_.x + hb.x; vb.y = vb.y * sb_.y + hb.y; vb.z = vb.z * sb_.z + hb.z; vb.w = vb.w * sb_.w + hb.w;
+                        ra.x = ra.x * ta.x + ua.x; ra.y = ra.y * ta.y + ua.y; ra.z = ra.z * ta.z + ua.z; ra.w = ra.w * ta.w + ua.w;
+                        rb.x = rb.x * tb.x + ub.x; rb.y = rb.y * tb.y + ub.y; rb.z = rb.z * tb.z + ub.z; rb.w = rb.w * tb.w + ub.w;
+                        range_trip = range_trip || bn_bad(ra) || bn_bad(rb);
+                        // the shortcut as the fp16 tensor the three-launch form stores
+                        ra.x = (float)(_Float16)ra.x; ra.y = (float)(_Float16)ra.y; ra.z = (float)(_Float16)ra.z; ra.w = (float)(_Float16)ra.w;
+                        rb.x = (float)(_Float16)rb.x; rb.y = (float)(_Float16)rb.y; rb.z = (float)(_Float16)rb.z; rb.w = (float)(_Float16)rb.w;
+                        va.x += ra.x; va.y += ra.y; va.z += ra.z; va.w += ra.w;
+                        vb.x += rb.x; vb.y += rb.y; vb.z += rb.z; vb.w += rb.w;
+                        va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f); va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
+                        vb.x = fmaxf(vb.x, 0.f); vb.y = fmaxf(vb.y, 0.f); vb.z = fmaxf(vb.z, 0.f); vb.w = fmaxf(vb.w, 0.f);
+                        range_trip = range_trip || bn_bad(va) || bn_bad(vb);
+                        *reinterpret_cast<uint4*>(yimg + go + ch * C + wn * NB + 16 * p + 8 * kk) = bn_pack16(va, vb);
+                    }
+                }
+            }
+#undef BN_ISSUE_W2
+            } else if constexpr (K::YTILE) {
             // ---- C = 64: the shortcut comes in and the output leaves in FULL LINES through LDS chunk tiles (as the C = 256 form does): straight
             //      from the accumulators a store instruction covers 32 pixels x 32 B, and such scattered pieces issue 3x slower per CU — the
             //      block is memory-bound (276 us as three launches against a 107 us HBM floor), so that was its largest term ----
@@ -820,8 +913,10 @@ bool bneck_geometry_ok(int C, int H, int W)
 
 void bneck_launch(hipStream_t s, int C, const void* x, void* y, int B, int H, int W, const void* w1, const void* w2, const void* w3,
                   const float* s1, const float* h1, const float* s2, const float* h2, const float* s3, const float* h3, int* range_flag, int n_cus,
-                  const void* w2f, const void* w3f, const void* w1f)
+                  const void* w2f, const void* w3f, const void* w1f, const void* ws, const float* ss, const float* hs)
 {
+    const bool first = ws != nullptr;          // the stage-entry form: x has C channels, the shortcut is the convolution ws of x
+    MRCNN_REQUIRE(!first || C == 64, MRCNN_ERR_SHAPE, "bneck: the stage-entry form exists for C = 64");
     MRCNN_REQUIRE(bneck_geometry_ok(C, H, W), MRCNN_ERR_SHAPE, "bneck: C %d at %dx%d", C, H, W);
     MRCNN_REQUIRE(x != y, MRCNN_ERR_INVALID, "bneck: the output must not alias the input");
     MRCNN_REQUIRE((size_t)H * W * 4 * C * 2 < 0x80000000ull, MRCNN_ERR_SHAPE, "bneck: image of %dx%dx%d exceeds the 2-GB offset range", H, W, 4 * C);
@@ -829,6 +924,7 @@ void bneck_launch(hipStream_t s, int C, const void* x, void* y, int B, int H, in
     a.x = static_cast<const _Float16*>(x); a.y = static_cast<_Float16*>(y);
     a.w1 = static_cast<const _Float16*>(w1); a.w2 = static_cast<const _Float16*>(w2); a.w3 = static_cast<const _Float16*>(w3);
     a.w1f = static_cast<const uint4*>(w1f); a.w2f = static_cast<const uint4*>(w2f); a.w3f = static_cast<const uint4*>(w3f);
+    a.ws = static_cast<const _Float16*>(ws); a.ss = ss; a.hs = hs;
     a.s1 = s1; a.h1 = h1; a.s2 = s2; a.h2 = h2; a.s3 = s3; a.h3 = h3;
     a.B = B; a.H = H; a.W = W;
     const int th = C == 256 ? 8 : 16;
@@ -842,6 +938,7 @@ void bneck_launch(hipStream_t s, int C, const void* x, void* y, int B, int H, in
     if (C == 256 && w1f && w2f && w3f) hipLaunchKernelGGL((k_bneck_h<256, true>), dim3(grid), dim3(512), 0, s, a);
     else if (C == 256) hipLaunchKernelGGL((k_bneck_h<256, false>), dim3(grid), dim3(512), 0, s, a);
     else if (C == 128) hipLaunchKernelGGL((k_bneck_h<128, false>), dim3(grid), dim3(512), 0, s, a);
+    else if (first) hipLaunchKernelGGL((k_bneck_h<64, false, true>), dim3(grid), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((k_bneck_h<64, false>), dim3(grid), dim3(512), 0, s, a);
     HIP_CHECK(hipGetLastError());
 }

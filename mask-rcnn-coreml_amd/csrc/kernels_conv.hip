@@ -1024,6 +1024,47 @@ void conv_bneck_forward(hipStream_t s, const ConvDesc& da, const ConvDesc& db, c
     }
 }
 
+bool conv_bneck_first_fusable(const ConvDesc& da, const ConvDesc& db, const ConvDesc& dc, const ConvDesc& ds)
+{
+    auto f16 = [](const ConvDesc& d) { return d.dtype == MRCNN_F16 && (d.wdtype < 0 || d.wdtype == MRCNN_F16) && !d.out_f32; };
+    if (!f16(da) || !f16(db) || !f16(dc) || !f16(ds)) return false;
+    const int C = da.Cout, H = da.H, W = da.W;
+    if (C != 64 || da.Cin != C || !bneck_geometry_ok(C, H, W)) return false;
+    auto plain = [](const ConvDesc& d, int act) { return !d.out2 && !d.deconv2 && !d.sel_partial && !d.head_w && d.res_shift == 0 && d.act == act && d.scale && d.shift; };
+    if (!plain(da, ACT_RELU) || !plain(db, ACT_RELU) || !plain(dc, ACT_RELU) || !plain(ds, ACT_NONE) || da.res || db.res || ds.res) return false;
+    auto dense_in = [](const ConvDesc& d, int h, int w, int c) { return d.H == h && d.W == w && d.Cin == c && d.in_sW == c && d.in_sH == (long)w * c && d.in_sB == (long)h * w * c; };
+    auto dense_out = [](const ConvDesc& d, int h, int w, int c) { return d.OH == h && d.OW == w && d.Cout == c && d.out_sP == c && d.out_sB == (long)h * w * c; };
+    auto pw = [](const ConvDesc& d) { return d.KH == 1 && d.KW == 1 && d.stride == 1 && !d.padH && !d.padW; };
+    if (!pw(da) || !dense_in(da, H, W, C) || !dense_out(da, H, W, C)) return false;
+    if (!pw(ds) || ds.in != da.in || !dense_in(ds, H, W, C) || !dense_out(ds, H, W, 4 * C)) return false;
+    if (db.KH != 3 || db.KW != 3 || db.stride != 1 || db.padH != 1 || db.padW != 1 || db.in != da.out || !dense_in(db, H, W, C) || !dense_out(db, H, W, C)) return false;
+    if (!pw(dc) || dc.in != db.out || !dense_in(dc, H, W, C) || !dense_out(dc, H, W, 4 * C)) return false;
+    if (dc.res != ds.out || dc.res_sW != 4 * C || dc.res_sH != (long)W * 4 * C || dc.res_sB != (long)H * W * 4 * C) return false;
+    if (dc.out == da.in || da.B != db.B || da.B != dc.B || da.B != ds.B) return false;
+    return true;
+}
+
+void conv_bneck_first_forward(hipStream_t s, const ConvDesc& da, const ConvDesc& db, const ConvDesc& dc, const ConvDesc& ds)
+{
+    static int n_cus = [] { int dev = 0; hipDeviceProp_t p; (void)hipGetDevice(&dev); return hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }();
+    const long ntiles = (long)da.B * (da.H / 16) * (da.W / 16);
+    if (!g_bneck || !conv_bneck_first_fusable(da, db, dc, ds) || (g_bneck < 3 && ntiles * 8 < (long)n_cus * 7)) {
+        conv_forward(s, da);
+        conv_forward_tail(s, db, dc, &ds);
+        return;
+    }
+    ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
+    const int e0 = prof ? prof_event(prof, s) : 0;
+    bneck_launch(s, da.Cout, da.in, dc.out, da.B, da.H, da.W, da.wgt, db.wgt, dc.wgt, da.scale, da.shift, db.scale, db.shift, dc.scale, dc.shift,
+                 g_range_flag, n_cus, nullptr, nullptr, nullptr, ds.wgt, ds.scale, ds.shift);
+    if (prof) {
+        const int e1 = prof_event(prof, s);
+        const double M = (double)da.B * da.H * da.W, C = da.Cout;
+        const double fl = 2.0 * M * (C * C + 9 * C * C + 4 * C * C + 4 * C * C);       // branch2a, 2b, 2c and branch1
+        prof->pending.push_back({7, fl, e0, e1, {(int)M, 4 * da.Cout, 18 * da.Cout, 7}, da.group});
+    }
+}
+
 // ================================================================================================
 // element-wise helpers
 // ================================================================================================

@@ -98,3 +98,54 @@ def test_unsupported_geometry_is_refused_loudly():
         bneck(x, w1, w2, w3, bn, True)
     three, _ = bneck(x, w1, w2, w3, bn, False)        # the three launches take any geometry
     assert np.isfinite(three).all()
+
+
+def bneck_first(x, w1, w2, w3, ws, bn8, fused, iters=0):
+    import ctypes as C
+    B, H, W, Cc = x.shape
+    out = np.empty((B, H, W, 4 * Cc), np.float32)
+    ms = np.zeros(1, np.float32)
+    keep = [np.ascontiguousarray(a, np.float32) for a in (x, w1, w2, w3, ws) + tuple(bn8)]
+    arr = (C.c_void_p * 8)(*[k.ctypes.data for k in keep[5:]])
+    L.check(L.lib().mrcnn_bottleneck_first_nhwc(keep[0].ctypes.data, B, H, W, Cc, *[k.ctypes.data for k in keep[1:5]], arr, int(fused), iters,
+                                                 out.ctypes.data, ms.ctypes.data))
+    return out, float(ms[0])
+
+
+def make_first(C, B, H, W, seed=0):
+    rng = np.random.default_rng(seed)
+    x = np.maximum(rng.standard_normal((B, H, W, C)), 0).astype(np.float32)               # the max-pooled stem output
+    w1 = (rng.standard_normal((C, C)) * np.sqrt(2.0 / C)).astype(np.float32)
+    w2 = (rng.standard_normal((C, 3, 3, C)) * np.sqrt(2.0 / (9 * C))).astype(np.float32)
+    w3 = (rng.standard_normal((4 * C, C)) * np.sqrt(2.0 / C)).astype(np.float32)
+    ws = (rng.standard_normal((4 * C, C)) * np.sqrt(2.0 / C)).astype(np.float32)
+    bn = []
+    for n in (C, C, 4 * C, 4 * C):
+        bn.append((1.0 + 0.1 * rng.standard_normal(n)).astype(np.float32))
+        bn.append((0.1 * rng.standard_normal(n)).astype(np.float32))
+    return x, w1, w2, w3, ws, bn
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 16, 16), (2, 32, 48), (1, 64, 64), (3, 16, 32)])
+def test_fused_stage_entry_block_equals_the_four_launches_bitwise(B, H, W):
+    """res2a of the fp16 mode (stride 1, 64 channels in, shortcut = the 1x1 convolution branch1 of the input): one launch against
+    branch2a, branch1, branch2b, branch2c as four — the shortcut is rounded to fp16 where its tensor would have been."""
+    x, w1, w2, w3, ws, bn = make_first(64, B, H, W, seed=H + W)
+    fused, _ = bneck_first(x, w1, w2, w3, ws, bn, True)
+    four, _ = bneck_first(x, w1, w2, w3, ws, bn, False)
+    assert np.isfinite(fused).all()
+    nz = np.flatnonzero(fused.view(np.uint32) != four.view(np.uint32))
+    assert nz.size == 0, f"{nz.size} of {fused.size} outputs differ, first at {np.unravel_index(nz[0], fused.shape)}: {fused.flat[nz[0]]} vs {four.flat[nz[0]]}"
+    # and against fp64 with the fp16 roundings of the mode
+    import torch
+    import torch.nn.functional as F
+    h = lambda a: torch.from_numpy(np.asarray(a, np.float32).astype(np.float16).astype(np.float64))
+    r16 = lambda t: torch.from_numpy(t.numpy().astype(np.float32).astype(np.float16).astype(np.float64))
+    v = lambda a: torch.from_numpy(np.asarray(a, np.float64))[None, :, None, None]
+    xx = h(x).permute(0, 3, 1, 2)
+    t1 = r16(F.relu(F.conv2d(xx, h(w1).reshape(64, 64, 1, 1)) * v(bn[0]) + v(bn[1])))
+    t2 = r16(F.relu(F.conv2d(t1, h(w2).permute(0, 3, 1, 2), padding=1) * v(bn[2]) + v(bn[3])))
+    sc = r16(F.conv2d(xx, h(ws).reshape(256, 64, 1, 1)) * v(bn[6]) + v(bn[7]))
+    y = F.relu(F.conv2d(t2, h(w3).reshape(256, 64, 1, 1)) * v(bn[4]) + v(bn[5]) + sc).permute(0, 2, 3, 1).numpy()
+    bad = np.abs(fused - y) > 2e-3 * np.maximum(1.0, np.abs(y))
+    assert bad.mean() < 1e-3
