@@ -16,10 +16,10 @@ for dt in $MODES; do
 done
 python tools/conv_layer_table.py f32x3 5 1 > $OUT/${RND}_conv_shapes_f32x3_batch1.txt 2>/dev/null
 cd /tmp
-BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-modes --no-kernel-events"
+BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-modes --no-kernel-events --no-live-probe"
 for dt in $MODES; do
   rm -rf /tmp/prof_$dt
-  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$dt -o p -- python $R/bench.py --steps 5 --warmup 2 --dtype $dt --no-cpu-baseline --no-other-modes > $OUT/stats_$dt.json 2> $OUT/stats_$dt.err
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$dt -o p -- python $R/bench.py --steps 5 --warmup 2 --dtype $dt --no-cpu-baseline --no-other-modes --no-live-probe > $OUT/stats_$dt.json 2> $OUT/stats_$dt.err
   db=$(find /tmp/prof_$dt -name "*.db" | head -1)
   python $R/tools/rocpd_summary.py $db $OUT/${RND}_kernel_stats_$dt.csv
   i=0
@@ -77,14 +77,14 @@ bash tools/pmc_halo_probe.sh f32x3 "8 256 256 256 512 3 1" "GRBM_GUI_ACTIVE SQ_V
 [ -x tools/probes/vmem_probe ] && timeout 120 ./tools/probes/vmem_probe 2048 > $OUT/${RND}_vmem_probe.txt 2>&1
 python tools/split_scale_curve.py 2>/dev/null | grep -v amdgpu > $OUT/${RND}_split_scale_curve.txt
 # stage-attributed trace: roctx ranges with the reference's signpost names (marker trace + kernel trace, no counters)
-( cd /tmp && rm -rf /tmp/mk && timeout 300 rocprofv3 --marker-trace --kernel-trace --stats --output-format csv -d /tmp/mk -o m -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-modes --no-kernel-events > /dev/null 2> $OUT/marker.err; f=$(find /tmp/mk -name "*marker*stats*.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${RND}_marker_stats_f32x3.csv; f=$(find /tmp/mk -name "*marker_api_trace.csv" | head -1); [ -n "$f" ] && head -80 $f > $OUT/${RND}_marker_trace_head_f32x3.csv )
+( cd /tmp && rm -rf /tmp/mk && timeout 300 rocprofv3 --marker-trace --kernel-trace --stats --output-format csv -d /tmp/mk -o m -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-modes --no-kernel-events --no-live-probe > /dev/null 2> $OUT/marker.err; f=$(find /tmp/mk -name "*marker*stats*.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${RND}_marker_stats_f32x3.csv; f=$(find /tmp/mk -name "*marker_api_trace.csv" | head -1); [ -n "$f" ] && head -80 $f > $OUT/${RND}_marker_trace_head_f32x3.csv )
 timeout 200 bash tools/power_probe.sh > $OUT/${RND}_power_probe.txt 2>&1
 timeout 200 bash tools/mfma_power.sh > $OUT/${RND}_mfma_power.txt 2>&1
 timeout 400 python tools/fp64_trunk_parity.py --out $OUT/${RND}_fp64_trunk_parity.json > $OUT/fp64.log 2>&1
 # round 4 (late): canonical K chunks and the halo kernel's latency form — knob A/Bs on single layers; where a single image's time goes
 { for kv in "conv_ksplit 0 1" "conv_kchunk 0 1" "halo_lat 0 1" "halo_lat 0 2"; do timeout 200 python tools/knob_ab.py $kv f32x3 3 20 all 2>/dev/null | grep -v amdgpu; done; } > $OUT/${RND}_knob_ab_f32x3.txt
 ( cd /tmp && export TMPDIR=/tmp
-  for b in 1 8; do rm -rf /tmp/tr$b; timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr$b -o t -- python $R/bench.py --batch $b --steps 5 --warmup 2 --no-cpu-baseline --e2e-images 0 --no-other-modes --no-kernel-events > /dev/null 2>&1; done
+  for b in 1 8; do rm -rf /tmp/tr$b; timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr$b -o t -- python $R/bench.py --batch $b --steps 5 --warmup 2 --no-cpu-baseline --e2e-images 0 --no-other-modes --no-kernel-events --no-live-probe > /dev/null 2>&1; done
   { echo "# batch 1"; python $R/tools/trace_gaps.py /tmp/tr1; echo "# batch 8"; python $R/tools/trace_gaps.py /tmp/tr8; } > $OUT/${RND}_trace_gaps_f32x3.txt
   python $R/tools/trace_gaps.py /tmp/tr1 --list > $OUT/${RND}_trace_b1_kernels_f32x3.txt )
 # per-GPU slices of the other BASELINE configs (configs[2]: ResNet50; configs[3]: fp16; configs[4]: 1536², 2 classes, pre_nms 12000) and the batch sweep
