@@ -194,3 +194,33 @@ def test_convert_command_end_to_end(pkg, weights_mod, anchors_mod, conv, hdf5, t
     subprocess.run([CONDA_PY, str(script), str(tmp_path / "k.npz"), str(tmp_path / "latest.h5"), "latest"], check=True, timeout=600)
     with pytest.raises(hdf5.HDF5FormatError, match="not supported"):
         conv.convert(str(model_dir / "config.json"), str(tmp_path / "latest.h5"), str(tmp_path / "p3"), verbose=False)
+
+
+def test_stored_split_exponents_ride_in_the_artefact_metadata(weights_mod, conv, tmp_path):
+    """`convert --calibrate` (round 5): the exponent vector of the scale-aware split goes into MaskRCNN.mrcw as `split_exp.<group>` integer
+    metadata — what mrcnn_model_load applies (engine.hip) — leaving every tensor and every other key untouched; storing again replaces the old
+    vector instead of accumulating keys; the image loader of the flag takes uint8 (N,H,W,3) .npy files and refuses anything else."""
+    d = tmp_path / "products"
+    d.mkdir()
+    t = {"conv1/kernel": np.arange(24, dtype="<f2").reshape(2, 3, 2, 2), "bn_conv1/gamma": np.ones(2, "<f2")}
+    meta = {"kind": "MaskRCNN", "num_classes": 81, "bn_eps": 1e-3}
+    weights_mod.write_mrcw(str(d / "MaskRCNN.mrcw"), meta, t)
+    conv.store_split_exponents(str(d), ["C1", "res2a_branch2a", "P2"], [5, -3, 8])
+    m2, t2 = weights_mod.read_mrcw(str(d / "MaskRCNN.mrcw"))
+    assert m2["split_exp.C1"] == 5 and m2["split_exp.res2a_branch2a"] == -3 and m2["split_exp.P2"] == 8
+    assert m2["kind"] == "MaskRCNN" and m2["num_classes"] == 81 and m2["bn_eps"] == pytest.approx(1e-3)
+    assert set(t2) == set(t) and all(np.array_equal(t2[k], t[k]) and t2[k].dtype == t[k].dtype for k in t)
+    conv.store_split_exponents(str(d), ["C1"], [7])
+    m3, _ = weights_mod.read_mrcw(str(d / "MaskRCNN.mrcw"))
+    assert m3["split_exp.C1"] == 7 and "split_exp.P2" not in m3 and sum(k.startswith("split_exp.") for k in m3) == 1
+    imgs = np.random.default_rng(0).integers(0, 256, (3, 8, 8, 3), dtype=np.uint8)
+    np.save(str(tmp_path / "cal.npy"), imgs)
+    got = conv.load_calibration_images(str(tmp_path / "cal.npy"), 8, 8, limit=2)
+    assert got.shape == (2, 8, 8, 3) and np.array_equal(got, imgs[:2])
+    with pytest.raises(conv.ConversionError):
+        conv.load_calibration_images(str(tmp_path / "cal.npy"), 16, 16)
+    np.save(str(tmp_path / "bad.npy"), imgs.astype(np.float32))
+    with pytest.raises(conv.ConversionError):
+        conv.load_calibration_images(str(tmp_path / "bad.npy"), 8, 8)
+    with pytest.raises(conv.ConversionError):
+        conv.load_calibration_images(str(tmp_path / "nothing-here"), 8, 8)

@@ -106,3 +106,41 @@ def test_bench_under_torchrun_with_rccl_leg():
     assert j["rccl"]["native_shares_process_copy"] == 1
     pr = j["per_rank_ms_per_step"]
     assert len(pr["ranks"]) == 1 and pr["min"] == pr["max"] == pr["ranks"][0] and abs(pr["max"] - j["ms_per_step"]) < 1e-6
+
+
+def test_mfma_probe_and_profile_groups_behind_the_test_header():
+    """The two measurement entries bench.py's round-5 fields rest on: the in-process MFMA probe (plausible rates for both matrix
+    instructions, clock equivalent inside the part's range) and the backbone / other split of the conv profile (every launch in exactly
+    one group; the backbone's algorithmic work per image = conv1 + res2..res5 of the architecture)."""
+    import ctypes as C
+    import importlib
+    import tempfile
+    import numpy as np
+    L = importlib.import_module("mask-rcnn-coreml_amd._lib")
+    tf, mhz = C.c_double(0), C.c_double(0)
+    L.check(L.lib().mrcnn_bench_mfma_probe(0.3, L.F16, C.byref(tf), C.byref(mhz)))
+    assert 800 < tf.value < 2600 and 800 < mhz.value < 2600, (tf.value, mhz.value)
+    L.check(L.lib().mrcnn_bench_mfma_probe(0.3, L.F32, C.byref(tf), C.byref(mhz)))
+    assert 80 < tf.value < 160 and 1200 < mhz.value < 2600, (tf.value, mhz.value)
+    with pytest.raises(L.MrcnnError):
+        L.check(L.lib().mrcnn_bench_mfma_probe(0.3, L.F32S, C.byref(tf), None))
+    pkg = importlib.import_module("mask-rcnn-coreml_amd")
+    models = importlib.import_module("mask-rcnn-coreml_amd.models")
+    weights = importlib.import_module("mask-rcnn-coreml_amd.weights")
+    cfg = pkg.ModelConfig(architecture="resnet50", input_image_shape=(256, 256, 3), num_classes=21, pre_nms_max_proposals=500, max_proposals=64, max_detections=16)
+    d = tempfile.mkdtemp(prefix="mrcnn_grp_")
+    weights.save_synthetic_models(d, cfg, seed=0, forced_load=True)
+    for mode in ("f32x3", "f16"):
+        m = models.load_maskrcnn(d, max_batch=2, compute_dtype=mode)
+        img = np.random.default_rng(0).integers(0, 256, (2, 256, 256, 3), dtype=np.uint8)
+        m.predict(img)
+        m.conv_profile_enable(True)
+        m.predict(img)
+        m.conv_profile_enable(False)
+        tiles, groups = m.conv_profile(), m.conv_profile_groups()
+        assert sum(v[0] for v in tiles.values()) == groups["backbone"][0] + groups["other"][0] > 0
+        assert abs(sum(v[2] for v in tiles.values()) - groups["backbone"][2] - groups["other"][2]) < 1e-6 * groups["other"][2]
+        # ResNet-50 backbone at 1024^2 is 189.8 GFLOP per image (SURVEY 8d); at 256^2 a sixteenth of it
+        per_image = groups["backbone"][2] / 2 / 1e9
+        assert abs(per_image - 189.8 / 16) < 0.06 * 189.8 / 16, per_image
+        del m

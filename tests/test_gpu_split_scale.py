@@ -295,3 +295,25 @@ def test_split_counters_mean_what_the_header_says(small_model):
     # calibrated: the stored inputs below 0.5 are below 2^-12 of their tensor's maximum, a strict subset of those below 2^-8 of it
     for g in m.split_report():
         assert g["inexact_inputs"] <= g["small_inputs"] <= g["inputs_counted"], g
+
+
+def test_calibration_from_a_device_tensor_equals_calibration_from_host_memory(small_model):
+    """calibrate_split with MRCNN_DEVICE images used to stage its throw-away outputs in pageable host vectors behind a
+    device-to-device copy kind.  The passes now copy nothing out; a CUDA tensor and the same images in host memory must give the same
+    exponents, the same diagnostics and bit-equal predicts; a batch beyond max_batch is refused before anything runs."""
+    import torch
+    d, cfg = small_model
+    images = rand_images(2, cfg.image_height, cfg.image_width, seed=6)
+    ma = _models().load_maskrcnn(d, max_batch=2, compute_dtype="f32x3")
+    mb = _models().load_maskrcnn(d, max_batch=2, compute_dtype="f32x3")
+    ra = ma.calibrate_split(images)
+    rb = mb.calibrate_split(torch.from_numpy(images).to("cuda:0"))
+    assert ra == rb
+    np.testing.assert_array_equal(ma.split_exponents, mb.split_exponents)
+    da, ka = ma.predict(images)
+    db, kb = mb.predict(images)
+    np.testing.assert_array_equal(da, db)
+    np.testing.assert_array_equal(ka, kb)
+    assert ma.get_int("range_overflows") == 0 and ma.get_int("predict_calls") == 1          # calibration passes are not the host's predicts
+    with pytest.raises(L.MrcnnError):
+        ma.calibrate_split(rand_images(3, cfg.image_height, cfg.image_width, seed=6))
