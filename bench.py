@@ -70,7 +70,9 @@ if ROOT not in sys.path:
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_FP16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: bf16/f16 MFMA dense peak (not the 2:1-sparse figure)
 GFLOP_PER_IMAGE_SURVEY = 777.3         # SURVEY.md §8(d), R101 1024² 81 classes
-GFLOP_BACKBONE_SURVEY = {"resnet101": 344.9, "resnet50": 189.8}     # SURVEY.md §8(d) "backbone convs" subset (C1-C5) at 1024²
+# C1..C5 at 1024²: the sum of SURVEY.md §8(d)'s per-stage figures (C1 4.93, C2 27.92, C3 39.73, C4 213.14 | 57.98, C5 30.60).  BASELINE.md §2's
+# column "of which backbone C1-C5" prints 344.9 / 189.8 — that is this sum PLUS the box head's 28.62 (a slip in the table, kept there unedited).
+GFLOP_BACKBONE_SURVEY = {"resnet101": 316.32, "resnet50": 161.16}
 
 
 def main():
