@@ -649,6 +649,13 @@ void Model::load(int kind_, const std::string& path, int max_batch_, int dtype_)
     const char* want = kind == MRCNN_MODEL_MASKRCNN ? "MaskRCNN" : kind == MRCNN_MODEL_CLASSIFIER ? "Classifier" : "Mask";
     MRCNN_REQUIRE(file.get_string("kind") == want, MRCNN_ERR_IO, "'%s' holds a %s model, expected %s", path.c_str(),
                   file.get_string("kind").c_str(), want);
+    if (const char* cm = getenv("MRCNN_CU_MASK_PROBE")) {
+        // measurement only (tools/dual_stream_probe.py): the handle's stream on a subset of the CUs — 8 hexadecimal words, "w0,w1,...,w7"
+        uint32_t words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int n = 0;
+        for (const char* p = cm; *p && n < 8; ++n) { words[n] = (uint32_t)strtoul(p, nullptr, 16); p = strchr(p, ','); if (!p) { ++n; break; } ++p; }
+        HIP_CHECK(hipExtStreamCreateWithCUMask(&stream, 8, words));
+    } else
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     own_stream = true;
     if (const char* e = getenv("MRCNN_GRAPH")) use_graph = atoi(e) != 0;
