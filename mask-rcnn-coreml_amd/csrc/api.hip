@@ -971,7 +971,7 @@ extern "C" int mrcnn_debug_set(const char* key, int value)
     return guarded([&] {
         MRCNN_REQUIRE(key, MRCNN_ERR_INVALID, "null key");
         if (strcmp(key, "conv2d_alias_res") == 0) { g_conv2d_alias_res = value; return; }
-        MRCNN_REQUIRE(conv_debug_set(key, value) || engine_debug_set(key, value), MRCNN_ERR_INVALID, "unknown debug key '%s'", key);
+        MRCNN_REQUIRE(conv_debug_set(key, value) || boxes_debug_set(key, value) || engine_debug_set(key, value), MRCNN_ERR_INVALID, "unknown debug key '%s'", key);
     });
 }
 

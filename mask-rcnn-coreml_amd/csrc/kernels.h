@@ -198,6 +198,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d, const ConvDesc* sc = nullptr
 // Test / measurement switches of the kernel choice ("conv_pp" 0|1, "conv_pp_split" 0|1, "conv_pp_min_tiles", "conv_pp_min_kt",
 // "conv_pp_min_fill" percent, "conv_pp_dbg" ablation bits); false = unknown key.
 bool conv_debug_set(const char* key, int value);
+bool boxes_debug_set(const char* key, int value);    // kernels_boxes.hip: "proposal_rank_sort", "nms_col_splits", "nms_class_fast" (no output bit depends on them)
 // Halo kernel (kernels_conv_halo.hip): 3x3 stride-1 layers of the split modes.  conv_halo_pack re-tiles [Npad][9][Cin] fp16
 // filters (device) into its granule layout; conv_halo_eligible says whether a layer can run on it (a property of the layer's
 // geometry and mode only — never of the batch: the K order of the kernel differs from the 128-row kernel's).

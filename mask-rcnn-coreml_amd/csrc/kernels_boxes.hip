@@ -18,6 +18,7 @@
 //     set.  Early exit at maxProposals kept.
 // Compiled with -ffp-contract=off (see device_math.h).
 #include <mutex>
+#include <string>
 
 #include "device_math.h"
 #include "kernels.h"
@@ -27,6 +28,30 @@ namespace mrcnn {
 static constexpr int CHUNK = 1024;   // scores per block in the select passes (256 threads × 4)
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static int boxes_env_int(const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; }
+// Run-time switches (A/B and bit-identity tests; mrcnn_debug_set): none of them changes an output bit
+static int g_rank_sort = boxes_env_int("MRCNN_RANK_SORT", 1);       // "proposal_rank_sort": 1 rank counting over the chip (k_rank_decode), 0 the one-block bitonic sort
+static int g_nms_splits = boxes_env_int("MRCNN_NMS_SPLITS", 0);     // "nms_col_splits": column splits of k_nms_mask's grid; 0 = by policy (nms_col_splits)
+static int g_nms_fast = boxes_env_int("MRCNN_NMS_FAST", 1);         // "nms_class_fast": 1 the per-class limit test on the chunk's own candidates, 0 the round-4 test (count + 64)
+bool boxes_debug_set(const char* key, int value)
+{
+    const std::string k = key;
+    if (k == "proposal_rank_sort") g_rank_sort = value;
+    else if (k == "nms_col_splits") g_nms_splits = value;
+    else if (k == "nms_class_fast") g_nms_fast = value;
+    else return false;
+    return true;
+}
+// Column splits of the suppression-matrix launch.  Row block rb owns the column chunks rb .. W-1, so with a fixed split the blocks
+// of row 0 walk W / 16 chunks one after the other while the chip idles (single image, W = 94: six rounds, 79 us): as many splits as
+// keep the launch within the chip's wave slots — every wave at most one chunk on a single image (22 us) — and never fewer than four.
+static int nms_col_splits(int W, int B)
+{
+    if (g_nms_splits > 0) return g_nms_splits;
+    if (W < 16) return 1;
+    const long full = (W + 3) / 4, fit = 16384 / ((long)W * B * 4);
+    return (int)(fit < 4 ? 4 : fit > full ? full : fit);
+}
 static inline int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
 // ------------------------------------------------------------------------------------------------
@@ -369,6 +394,49 @@ __global__ __launch_bounds__(1024) void k_sort_decode_lds(const uint64_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same order by RANK COUNTING on the whole chip (round 5): the K candidate keys are distinct (score key << 32 | anchor
+// index), so the position of key i in the sorted order is the number of keys below it — K x K compares with no dependency
+// between them, against the 91 dependent stages of the bitonic network in one block per image (91 us on 1 .. 8 of the chip's
+// 256 CUs whatever the batch).  A block owns 64 keys (one per lane); its four waves each count over a quarter of every
+// 2048-key chunk staged in LDS (wave-uniform addresses: broadcast reads), and wave 0 adds the four counts and writes the
+// decoded box at its rank.  Same keys, same order, same decode: the outputs are the bitonic kernel's, bit for bit
+// (tests/test_gpu_boxes.py; "proposal_rank_sort" 0 / MRCNN_RANK_SORT=0 keeps the old kernel).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rank_decode(const uint64_t* __restrict__ cand, int K, int Kpad,
+                                                     const float* __restrict__ deltas, long deltas_sB,
+                                                     const float* __restrict__ anchors, float4 stdv,
+                                                     int32_t* __restrict__ topk_idx, float* __restrict__ boxes)
+{
+    constexpr int CH = 2048;
+    __shared__ __attribute__((aligned(16))) uint64_t sk[CH];
+    __shared__ int s_cnt[4][64];
+    const int b = blockIdx.y, t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(t >> 6));
+    const uint64_t* c = cand + (size_t)b * Kpad;
+    const int i = blockIdx.x * 64 + lane;
+    const uint64_t mine = i < K ? c[i] : 0ull;
+    int cnt = 0;
+    for (int base = 0; base < K; base += CH) {
+        if (base) __syncthreads();
+#pragma unroll
+        for (int e = t; e < CH; e += 256) sk[e] = base + e < K ? c[base + e] : ~0ull;        // (padding: never below a key)
+        __syncthreads();
+        const ulonglong2* p = reinterpret_cast<const ulonglong2*>(sk + wv * (CH / 4));
+#pragma unroll 8
+        for (int j = 0; j < CH / 8; ++j) {
+            const ulonglong2 v = p[j];
+            cnt += (v.x < mine ? 1 : 0) + (v.y < mine ? 1 : 0);
+        }
+    }
+    s_cnt[wv][lane] = cnt;
+    __syncthreads();
+    if (wv == 0 && i < K) {
+        const int rank = s_cnt[0][lane] + s_cnt[1][lane] + s_cnt[2][lane] + s_cnt[3][lane];
+        decode_sorted(mine, rank, b, K, deltas + (size_t)b * deltas_sB, anchors, stdv, topk_idx, boxes);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // NMS part 1: suppression bit-matrix.  Bit j of mask[i][cb] ⇔ column box (cb*64+j) > i, same class, IoU > thr; only the
 // words cb >= (i / 64) are computed.  Block (rb, split) = 4 waves holding the 64 rows rb*64.. in registers (one row per
 // lane); wave w of split s walks the column chunks cb = rb + 4 s + w, + 4·gridDim.y, ... (a wave-private LDS slot holds
@@ -451,7 +519,7 @@ __global__ __launch_bounds__(256) void k_nms_scan(const float* __restrict__ boxe
                                                   const uint64_t* __restrict__ mask, long mask_sB, int W,
                                                   int max_keep, int per_class_max,
                                                   int32_t* __restrict__ keep_idx, long keep_sB,
-                                                  int32_t* __restrict__ keep_count)
+                                                  int32_t* __restrict__ keep_count, int class_fast)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int32_t* kept = reinterpret_cast<int32_t*>(smem);                           // [max_keep] rows kept so far
@@ -524,7 +592,23 @@ __global__ __launch_bounds__(256) void k_nms_scan(const float* __restrict__ boxe
             // of rounds is the depth of the longest suppression chain in the chunk (typically 2-4) instead of one serial step per
             // kept candidate.  The per-class limit couples candidates through a running count: chunks in which a class could reach
             // it (count + 64 > limit), or with class ids beyond the counter table, take the serial loop below.
-            const bool fast = per_class_max <= 0 || __ballot(inr && (!small_cls || mycnt + 64 > per_class_max)) == 0ull;
+            // (round 5: a class can gain at most as many keeps as it has ALIVE candidates in this chunk — the round-4 test assumed 64 of them and
+            //  sent every chunk behind a class's 36th keep down the serial loop: 5 us per chunk of a 1000-row detection scan)
+            int gain = 64;
+            if (class_fast && per_class_max > 0) {
+                // candidates of a class that already holds its limit are refused whatever happens (and a refused candidate suppresses nothing)
+                m &= ~__ballot(inr && small_cls && mycnt >= per_class_max);
+                gain = 0;
+                uint64_t todo = m;
+                while (todo != 0ull) {                              // one step per distinct class among the alive candidates
+                    const int l = __builtin_ctzll(todo);
+                    const int c = __builtin_amdgcn_readlane(mycls, l);
+                    const uint64_t eq = __ballot(mycls == c) & m;
+                    if (mycls == c) gain = __popcll(eq);
+                    todo &= ~eq;
+                }
+            }
+            const bool fast = per_class_max <= 0 || __ballot(inr && ((m >> lane) & 1ull || !class_fast) && (!small_cls || mycnt + gain > per_class_max)) == 0ull;
             if (fast) {
                 const bool alive = (m >> lane) & 1ull;
                 uint64_t P = alive ? diag : 0ull;
@@ -648,6 +732,9 @@ void proposal_forward(hipStream_t s, const ProposalWorkspace& ws, const float* p
     boxes_one_time_init();
     const float4 stdv = make_float4(std4[0], std4[1], std4[2], std4[3]);
 #define MRCNN_SORT(KERNEL) hipLaunchKernelGGL(KERNEL, dim3(B), dim3(1024), sort_lds, s, ws.cand, K, ws.Kpad, deltas, deltas_sB, anchors, stdv, ws.topk_idx, ws.boxes)
+    if (g_rank_sort)
+        hipLaunchKernelGGL(k_rank_decode, dim3((K + 63) / 64, B), dim3(256), 0, s, ws.cand, K, ws.Kpad, deltas, deltas_sB, anchors, stdv, ws.topk_idx, ws.boxes);
+    else
     switch (ws.Kpad / 1024) {
     case 1: MRCNN_SORT(k_sort_decode<1>); break;
     case 2: MRCNN_SORT(k_sort_decode<2>); break;
@@ -660,11 +747,11 @@ void proposal_forward(hipStream_t s, const ProposalWorkspace& ws, const float* p
     trace_pop();                             // (k_sort_decode also covers Proposal-Gathering and Proposal-Compute: gather, x std, decode, clip)
     const long boxes_sB = (long)K * 4, mask_sB = (long)K * ws.W;
     trace_push("Proposal-NMS");
-    hipLaunchKernelGGL(k_nms_mask, dim3(ws.W, ws.W >= 16 ? 4 : 1, B), dim3(256), 0, s, ws.boxes, boxes_sB, (const int32_t*)nullptr, 0L,
+    hipLaunchKernelGGL(k_nms_mask, dim3(ws.W, nms_col_splits(ws.W, B), B), dim3(256), 0, s, ws.boxes, boxes_sB, (const int32_t*)nullptr, 0L,
                        (const int32_t*)nullptr, K, nms_thr, ws.nms_mask, mask_sB, ws.W);
     hipLaunchKernelGGL(k_nms_scan, dim3(B), dim3(256), (size_t)ws.max_keep * 4, s, ws.boxes, boxes_sB, (const int32_t*)nullptr, 0L,
                        (const int32_t*)nullptr, K, ws.nms_mask, mask_sB, ws.W, ws.max_keep, 0, ws.keep_idx,
-                       (long)ws.max_keep, ws.keep_count);
+                       (long)ws.max_keep, ws.keep_count, g_nms_fast);
     trace_pop();
     trace_push("Proposal-Copy");
     hipLaunchKernelGGL(k_write_rois, dim3(B), dim3(256), 0, s, ws.boxes, boxes_sB, ws.keep_idx, (long)ws.max_keep,
@@ -822,7 +909,7 @@ void detection_forward(hipStream_t s, const DetectionWorkspace& ws, const float*
     const size_t scan_lds = (size_t)N * 8;
     MRCNN_REQUIRE(scan_lds <= 64 * 1024, MRCNN_ERR_UNSUPPORTED, "DetectionLayer: too many regions (%d)", N);
     hipLaunchKernelGGL(k_nms_scan, dim3(B), dim3(256), scan_lds, s, ws.boxes, boxes_sB, ws.cls, (long)N, ws.count, 0,
-                       ws.nms_mask, mask_sB, ws.W, N, ws.max_det, ws.keep_idx, (long)N, ws.keep_count);
+                       ws.nms_mask, mask_sB, ws.W, N, ws.max_det, ws.keep_idx, (long)N, ws.keep_count, g_nms_fast);
     hipLaunchKernelGGL(k_det_finalize, dim3(B), dim3(1024), (size_t)ws.Npad * 8, s, ws.boxes, ws.score, ws.cls, ws.keep_idx,
                        ws.keep_count, N, ws.Npad, ws.max_det, out, out_sB, row_stride);
     HIP_CHECK(hipGetLastError());

@@ -297,6 +297,61 @@ def test_detection_layer_per_class_limit(pkg, orc):
     np.testing.assert_array_equal(out, want)
 
 
+@pytest.mark.parametrize("maxd,nc", [(20, 4), (100, 2), (7, 81)])
+def test_detection_layer_classes_saturate_mid_scan(pkg, orc, maxd, nc):
+    """1000 rows in few classes, a mix of overlapping and disjoint boxes: classes reach maxDetections in the middle of the scan, some inside a
+    64-row chunk — the chunk-parallel resolve (exact while a class's count + its alive candidates of the chunk stay within the limit; classes at
+    the limit drop out) and the serial one must agree with the oracle, and the round-4 / round-5 forms of the test with each other."""
+    lib = __import__("importlib").import_module("mask-rcnn-coreml_amd._lib")
+    n = 1000
+    rng = np.random.default_rng(100 + maxd)
+    y1 = rng.random(n) * 0.9; x1 = rng.random(n) * 0.9
+    wh = np.where(rng.random(n) < 0.5, 0.02, 0.15)
+    rois = np.stack([y1, x1, y1 + wh, x1 + wh * (0.5 + rng.random(n))], 1).astype(np.float32)
+    cls = np.zeros((n, 6), dtype=np.float32)
+    cls[:, :4] = 0.1 * rng.standard_normal((n, 4)).astype(np.float32)
+    cls[:, 4] = rng.integers(0, nc, n).astype(np.float32)            # class 0 = background: dropped
+    cls[:, 5] = (0.6 + 0.4 * rng.random(n)).astype(np.float32)
+    params = {"maxDetections": maxd, "scoreThreshold": 0.7, "nmsIOUThreshold": 0.3}
+    ML = pkg.MLMultiArray
+    want = orc.detection_layer(rois, cls, maxd, 0.7, 0.3)
+    outs = []
+    try:
+        for fast in (1, 0):
+            lib.check(lib.lib().mrcnn_debug_set(b"nms_class_fast", fast))
+            out = np.full((maxd, 6), np.float32(np.nan), dtype=np.float32)
+            pkg.DetectionLayer(params).evaluate([ML(rois), ML(cls)], [ML(out)])
+            outs.append(out)
+    finally:
+        lib.check(lib.lib().mrcnn_debug_set(b"nms_class_fast", 1))
+    np.testing.assert_array_equal(outs[0], want)
+    np.testing.assert_array_equal(outs[1], want)
+
+
+def test_box_path_knobs_change_no_bit(pkg, anchors_mod, orc, tmp_path):
+    """Round 5's forms of the proposal path — rank counting instead of the one-block bitonic sort, one column chunk per wave in the
+    suppression-matrix launch — against the round-4 forms and the oracle: the same bits (full size: 261 888 anchors, 6000 -> 1000)."""
+    lib = __import__("importlib").import_module("mask-rcnn-coreml_amd._lib")
+    cfg, anchors = _anchors_for(pkg, anchors_mod, 1024, tmp_path)
+    A = anchors.shape[0]
+    rng = np.random.default_rng(31)
+    fg = rng.random(A, dtype=np.float32)
+    fg[rng.integers(0, A, 5000)] = np.float32(0.999)                  # ties across the selection threshold
+    probs = np.stack([1 - fg, fg], axis=1).astype(np.float32)
+    deltas = (0.5 * rng.standard_normal((A, 4))).astype(np.float32)
+    params = dict(cfg.proposal_layer_params())
+    want = orc.proposal_layer(probs, deltas, anchors, params["preNMSMaxProposals"], params["maxProposals"], 0.7)
+    try:
+        for rank, splits in ((1, 0), (0, 4), (1, 4), (0, 0), (1, 7)):
+            lib.check(lib.lib().mrcnn_debug_set(b"proposal_rank_sort", rank))
+            lib.check(lib.lib().mrcnn_debug_set(b"nms_col_splits", splits))
+            got = _run_proposal(pkg, probs, deltas, params)
+            np.testing.assert_array_equal(got, want, err_msg=f"rank sort {rank}, column splits {splits}")
+    finally:
+        lib.check(lib.lib().mrcnn_debug_set(b"proposal_rank_sort", 1))
+        lib.check(lib.lib().mrcnn_debug_set(b"nms_col_splits", 0))
+
+
 def test_classifier_layer(pkg, orc, small_model):
     """TimeDistributedClassifierLayer: sub-model in fp32 MFMA vs torch fp32 (tolerance: 2e-4
     relative to the largest |value| per tensor), then class id bit-exact on the GPU's own probs."""
