@@ -566,6 +566,10 @@ int conv_n_tile(int Cout)
 static int env_int(const char* name, int dflt);
 static int g_min_blocks = 448;   // narrow the N tile while the grid has fewer blocks than this: 7/8 of two blocks per CU (the
                                  // box head's 504 tiles of 128 columns beat 1008 of 64: +1.1 % end to end, tools/e2e_ab.py)
+static int g_min_blocks_split = 256;      // fp32 tensors (split modes): one block per CU is enough — a narrower tile re-reads the 4-byte activations once more per
+                                 // column tile, and on a single image that L2 traffic is what the 1x1 layers wait for: 448 -> 256 is +1.2 .. 1.8 % on one image,
+                                 // +0.1 % at batch 8 (profiles/r05_box_path_ab.txt); fp16 tensors keep 448 (-0.3 % at batch 8 with 256).  Same bits either way.
+static inline int min_blocks_for(bool split_mode) { return split_mode ? g_min_blocks_split : g_min_blocks; }
 static int g_direct = env_int("MRCNN_DIRECT", 3);   // 0: every layer through the block-staged epilogue; 1: fp16 tensors straight from the accumulators;
                                  // 2: also fp32 tensors through wave-private LDS tiles (conv_epilogue_wave); 3: also the fp16 tensors of the
                                  // 128-column kernel (conv_epilogue_wave_h: full-line residual loads and stores; +3.6 % end to end in fp16 mode)
@@ -666,7 +670,8 @@ bool conv_debug_set(const char* key, int value)
     else if (k == "conv_tn4") g_tn4 = value;
     else if (k == "conv_halo") g_halo = value;
     else if (k == "conv_direct") g_direct = value;
-    else if (k == "conv_min_blocks") g_min_blocks = value;
+    else if (k == "conv_min_blocks") g_min_blocks = g_min_blocks_split = value;
+    else if (k == "conv_min_blocks_split") g_min_blocks_split = value;
     else if (k == "conv_scfuse") g_scfuse = value;
     else if (k == "mask_sel_wave") g_sel_wave = value;
     else if (k == "conv_kchunk") g_kchunk = value;
@@ -772,7 +777,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d_in, const ConvDesc* sc)
         const int bn_max = conv_n_tile(d_in.Cout);
         int bn = bn_max;
         const long tiles_m = ((long)d_in.B * d_in.OH * d_in.OW + BM_DEFAULT - 1) / BM_DEFAULT;
-        while (bn > 32 && tiles_m * (d_in.Npad / bn) < g_min_blocks) bn >>= 1;
+        while (bn > 32 && tiles_m * (d_in.Npad / bn) < min_blocks_for(true)) bn >>= 1;          // (fused shortcuts exist in the split modes only)
         ConvDesc probe = d_in;
         probe.res = nullptr;
         ConvArgs pa;
@@ -815,7 +820,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d_in, const ConvDesc* sc)
     MRCNN_REQUIRE(d.Npad % bn_max == 0 && d.Npad >= a.ncols, MRCNN_ERR_SHAPE, "conv: Npad %d incompatible with tile %d", d.Npad, bn_max);
     a.tiles_m = (a.M + BM_DEFAULT - 1) / BM_DEFAULT;
     int bn = bn_max;
-    while (bn > 32 && !d.sel_partial && (long)a.tiles_m * (d.Npad / bn) < g_min_blocks) bn >>= 1;     // (selected-class mode: fixed 128-channel parts)
+    while (bn > 32 && !d.sel_partial && (long)a.tiles_m * (d.Npad / bn) < min_blocks_for(split)) bn >>= 1;     // (selected-class mode: fixed 128-channel parts)
     if (fuse) {
         a.sc_in = sc->in; a.sc_wgt = sc->wgt; a.sc_scale = sc->scale; a.sc_shift = sc->shift;
         a.sc_in_sB = sc->in_sB; a.sc_in_sH = sc->in_sH; a.sc_in_sW = sc->in_sW;
@@ -828,7 +833,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d_in, const ConvDesc* sc)
     if (a.kchunks > 1 && g_ksplit && (long)a.tiles_m * (d.Npad / bn_max) < g_ksplit_below) {
         // an under-filled grid: one block per (tile, chunk), the N tile as wide as the shared grid allows
         int bs = bn_max;
-        while (bs > 32 && (long)a.tiles_m * (d.Npad / bs) * a.kchunks < g_min_blocks) bs >>= 1;
+        while (bs > 32 && (long)a.tiles_m * (d.Npad / bs) * a.kchunks < min_blocks_for(true)) bs >>= 1;
         const long tiles = (long)a.tiles_m * (d.Npad / bs);
         // (the shared-tile form needs the owner's scratch: a launch without one keeps its chunks in one block — the same bits)
         if (g_scratch && g_scratch->ks_buf.p && tiles <= KS_TILES && (size_t)tiles * a.kchunks * BM_DEFAULT * bs * 4 <= KS_BYTES) {
