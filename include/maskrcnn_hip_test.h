@@ -83,6 +83,11 @@ MRCNN_API int mrcnn_bench_mfma_probe(double seconds, int kind, double* tflops, d
  * (default 1; the two differ by summation noise — the chunk count is a property of the layer, never of the batch);
  * "conv_ksplit" 0|1 and "conv_ksplit_below" n: chunked layers whose widest-tile grid has fewer than n (256) blocks give every chunk its
  * own block, the last one to finish folds the partial sums | never (bit-identical to each other).
+ * "conv_min_blocks_split" n: the same threshold for the split modes alone (default 256 = one block per CU; fp16 tensors keep 448; bit-identical);
+ * box path (kernels_boxes.hip; none changes an output bit): "proposal_rank_sort" 0|1: the K pre-NMS candidates ordered by one bitonic-sort block per
+ * image | by rank counting over the whole chip (default 1); "nms_col_splits" n: column splits of the suppression-matrix grid (0 = by policy: as many
+ * as the chip's wave slots hold, at least 4); "nms_class_fast" 0|1: DetectionLayer's per-class limit tested per chunk as count + 64 | as count + the
+ * chunk's own alive candidates of the class, classes at the limit dropping out (default 1).
  * The switches are PROCESS-WIDE test / measurement knobs: not thread-safe; a choice captured in a hipGraph stays captured. */
 MRCNN_API int mrcnn_conv2d_nhwc(const float* in, int batch, int h, int w, int cin, const float* filters, int cout,
                                 int ksize, int stride, const float* scale, const float* shift, const float* residual,
