@@ -88,19 +88,26 @@ template <> __device__ __forceinline__ void st4<_Float16>(_Float16* p, float4 v)
 
 // NHWC: block = one ROI; thread = (channel quad, point group).  fp16 maps: the bilinear arithmetic
 // is the same fp32 sequence on the widened samples, rounded once to fp16 on store.
+// Round 5: the kernel was INSTRUCTION bound, not memory bound — every thread recomputed its point's sample (two float divisions, floor /
+// ceil, the range test) and four run-time integer divisions per element: ~150 VALU instructions around four loads, 125 us for 200 MB
+// of fp16 output.  Now the (at most 256) points of a pass are sampled ONCE, one per thread, into an LDS table (corner offsets, weights),
+// and the element loop reads its point's entry (wave-uniform address when C >= 256: a broadcast) and indexes by shift / mask.
+// The arithmetic per sample and per element is unchanged: the same bits (tests/test_gpu_layers.py against the oracle).
 template <typename T>
 __global__ __launch_bounds__(256) void k_roi_align_nhwc(PyramidMaps maps, int C, const float* __restrict__ rois,
                                                         long rois_sB, long roi_stride, int P, double ratio,
                                                         T* __restrict__ out, long out_sB, long out_row_stride,
                                                         int32_t* __restrict__ row_flags)
 {
+    __shared__ int4 s_off[256];        // element offsets of the four corners (top-left, top-right, bottom-left, bottom-right); x < 0: outside the map
+    __shared__ float2 s_w[256];        // (lx, ly)
     const int roi = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
     const RoiGeom g = roi_geom(rois + (size_t)b * rois_sB + (size_t)roi * roi_stride, ratio);
     T* o = out + (size_t)b * out_sB + (size_t)roi * out_row_stride;
     const int C4 = C >> 2;
-    const int total = P * P * C4;
+    const int npts = P * P;
     if (g.level < 0) {
-        for (int e = t; e < total; e += 256) st4<T>(o + (size_t)e * 4, make_float4(0, 0, 0, 0));
+        for (int e = t; e < npts * C4; e += 256) st4<T>(o + (size_t)e * 4, make_float4(0, 0, 0, 0));
         if (row_flags && t == 0) row_flags[(size_t)b * gridDim.x + roi] = 0;
         return;
     }
@@ -111,24 +118,41 @@ __global__ __launch_bounds__(256) void k_roi_align_nhwc(PyramidMaps maps, int C,
     const int H = maps.H[g.level], W = maps.W[g.level];
     const T* m = static_cast<const T*>(maps.data[g.level]) + (size_t)b * maps.sB[g.level];
     const float mul = maps.mul[g.level];               // 1, or the exact power of two between this level's split exponent and the output's
-    for (int e = t; e < total; e += 256) {
-        const int cq = e % C4, pt = e / C4;
-        const int py = pt / P, px = pt % P;
-        const Sample s = make_sample(g, H, W, P, py, px);
-        float4 v = make_float4(0, 0, 0, 0);
-        if (s.ok) {
-            const float4 tl = ld4<T>(m + ((size_t)s.t * W + s.l) * C + cq * 4);
-            const float4 tr = ld4<T>(m + ((size_t)s.t * W + s.r) * C + cq * 4);
-            const float4 bl = ld4<T>(m + ((size_t)s.b * W + s.l) * C + cq * 4);
-            const float4 br = ld4<T>(m + ((size_t)s.b * W + s.r) * C + cq * 4);
-            v.x = bilerp(tl.x, tr.x, bl.x, br.x, s.lx, s.ly);
-            v.y = bilerp(tl.y, tr.y, bl.y, br.y, s.lx, s.ly);
-            v.z = bilerp(tl.z, tr.z, bl.z, br.z, s.lx, s.ly);
-            v.w = bilerp(tl.w, tr.w, bl.w, br.w, s.lx, s.ly);
-            v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
+    const bool pow2 = (C4 & (C4 - 1)) == 0;
+    const int sh = 31 - __builtin_clz((unsigned)(C4 > 0 ? C4 : 1));
+    for (int p0 = 0; p0 < npts; p0 += 256) {
+        const int np = min(256, npts - p0);
+        if (p0) __syncthreads();
+        if (t < np) {
+            const int pt = p0 + t;
+            const int py = pt / P, px = pt - py * P;
+            const Sample s = make_sample(g, H, W, P, py, px);
+            s_off[t] = s.ok ? make_int4((s.t * W + s.l) * C, (s.t * W + s.r) * C, (s.b * W + s.l) * C, (s.b * W + s.r) * C) : make_int4(-1, 0, 0, 0);
+            s_w[t] = make_float2(s.lx, s.ly);
         }
-        all_nonzero &= (v.x != 0.0f && v.y != 0.0f && v.z != 0.0f && v.w != 0.0f) ? 1 : 0;
-        st4<T>(o + ((size_t)pt * C4 + cq) * 4, v);
+        __syncthreads();
+        const int total = np * C4;
+        for (int e = t; e < total; e += 256) {
+            const int pl = pow2 ? e >> sh : e / C4;
+            const int cq = pow2 ? e & (C4 - 1) : e - pl * C4;
+            const int4 of = s_off[pl];
+            float4 v = make_float4(0, 0, 0, 0);
+            if (of.x >= 0) {
+                const float2 w = s_w[pl];
+                const T* mc = m + cq * 4;
+                const float4 tl = ld4<T>(mc + of.x);
+                const float4 tr = ld4<T>(mc + of.y);
+                const float4 bl = ld4<T>(mc + of.z);
+                const float4 br = ld4<T>(mc + of.w);
+                v.x = bilerp(tl.x, tr.x, bl.x, br.x, w.x, w.y);
+                v.y = bilerp(tl.y, tr.y, bl.y, br.y, w.x, w.y);
+                v.z = bilerp(tl.z, tr.z, bl.z, br.z, w.x, w.y);
+                v.w = bilerp(tl.w, tr.w, bl.w, br.w, w.x, w.y);
+                v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
+            }
+            all_nonzero &= (v.x != 0.0f && v.y != 0.0f && v.z != 0.0f && v.w != 0.0f) ? 1 : 0;
+            st4<T>(o + ((size_t)p0 * C4 + e) * 4, v);
+        }
     }
     if (row_flags) {                                   // wave-uniform branch: kernel argument
         all_nonzero = __syncthreads_and(all_nonzero);
