@@ -69,7 +69,8 @@ MRCNN_API int mrcnn_bench_mfma_probe(double seconds, int kind, double* tflops, d
  * persistent halo kernel of the 3x3 layers of the split modes (its K order is its own: results differ from "0" by summation noise);
  * "halo_geo" 0|1: its round-3 tile geometries | two-row tiles, region-sized staging, conflict-free LDS pitch (bit-identical);
  * "conv_tail" 0|1: bottleneck tails as two launches | one fused launch where the grid fills the chip (bit-identical; default 0: measured slower);
- * "conv_stem" 0|1: split modes, conv1 and the max-pool as two launches | one fused launch (bit-identical; default 1);
+ * "conv_stem" 0|1|2: conv1 and the max-pool as two launches | one fused launch (default; split modes: bit-identical to 0) | fp16 tensors: the fused launch in
+ * round 4's four-K-group form (bit-identical to 0; the default compact form — two K groups per kernel row, half the MFMAs — differs from it by summation noise);
  * "halo_lat" 0|1|2: 3x3 layers on grids under 3/8 of the chip (single images at C5 / P5): the eight-wave 64 x 128 tiles | 64 x 64 tiles on
  * four waves with deep prefetch (default) | that form for every grid under 3/4 (bit-identical);
  * "halo_n64" 0|1|2: 64-column 3x3 layers of the split modes on the 64-column 128-row kernel | on the halo kernel as 128 x 64 tiles | and as 256 x 64 tiles where

@@ -266,7 +266,7 @@ bool conv_stem_eligible(const ConvDesc& d);
 bool conv_stem_enabled();
 void conv_stem_forward(hipStream_t s, const ConvDesc& d, void* pooled, int PH, int PW);
 void conv_stem_launch(hipStream_t s, const void* in, int B, int Hp, int Wp, const void* wgt, const float* scale, const float* shift, int CH, int CW,
-                      void* out, int PH, int PW, int parts, int* range_flag, int n_cus);
+                      void* out, int PH, int PW, int parts, int* range_flag, int n_cus, bool compact = true);
 
 // uint8 RGB (B,H,W,3) → fp32 (B, H+2*pad, W+2*pad, 4) minus mean, zero border, channel 3 = 0.
 void preprocess_forward(hipStream_t s, const uint8_t* rgb, int B, int H, int W, int pad, const float mean[3],

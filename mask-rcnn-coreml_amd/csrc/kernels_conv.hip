@@ -573,7 +573,7 @@ static inline int min_blocks_for(bool split_mode) { return split_mode ? g_min_bl
 static int g_direct = env_int("MRCNN_DIRECT", 3);   // 0: every layer through the block-staged epilogue; 1: fp16 tensors straight from the accumulators;
                                  // 2: also fp32 tensors through wave-private LDS tiles (conv_epilogue_wave); 3: also the fp16 tensors of the
                                  // 128-column kernel (conv_epilogue_wave_h: full-line residual loads and stores; +3.6 % end to end in fp16 mode)
-static int g_stem = env_int("MRCNN_STEM", 1);        // split modes: conv1 + max-pool as one persistent launch (kernels_conv_stem.hip; bit-identical to the two launches)
+static int g_stem = env_int("MRCNN_STEM", 1);        // conv1 + max-pool as one persistent launch (kernels_conv_stem.hip; split modes: bit-identical to the two launches); 2: fp16 tensors in round 4's four-group form (bit-identical to the two launches; 1 = the compact form: summation noise apart)
 static int g_tail_dbg = env_int("MRCNN_TAIL_DBG", 0);        // measurement only: ablation bits of the fused tail's 1x1 phase (1 no epilogue, 2 no K loop)
 // Bottleneck tails (3x3 + 1x1) as one persistent launch when the grid fills the chip: bit-identical to the two launches, and
 // measured SLOWER (C4, batch 8: 180 us against 88 + 75; ablations: 3x3 loop 91 + barriers / prologues 7 + staging and parking 21 +
@@ -921,7 +921,7 @@ void conv_stem_forward(hipStream_t s, const ConvDesc& d, void* pooled, int PH, i
     const int e0 = prof ? prof_event(prof, s) : 0;
     const int wdtype = d.wdtype < 0 ? d.dtype : d.wdtype;
     conv_stem_launch(s, d.in, d.B, d.H, d.W, d.wgt, d.scale, d.shift, d.OH, d.OW, pooled, PH, PW,
-                     d.dtype == MRCNN_F16 ? 1 : (wdtype == MRCNN_F32X3 ? 3 : 2), g_range_flag, n_cus);
+                     d.dtype == MRCNN_F16 ? 1 : (wdtype == MRCNN_F32X3 ? 3 : 2), g_range_flag, n_cus, g_stem != 2);
     if (prof) {
         const int e1 = prof_event(prof, s);
         const long M = (long)d.B * d.OH * d.OW;

@@ -65,16 +65,23 @@ __device__ __forceinline__ void stem_split4(const u32x4_t v, u32x2_t (&part)[3])
 }
 
 // PARTS = 2 | 3: the split modes (fp32 tensors, 4 channels per pixel, two 16-wide K groups per kernel row = 4 pixels each);
-// PARTS = 1: the fp16 mode (fp16 tensors, 8 channels per pixel, four K groups per row = 2 pixels each; no split, filters through LDS).
-template <int PARTS>
+// PARTS = 1: the fp16 mode (fp16 tensors staged as 8 channels per pixel).  COMPACT (round 5, the default): only the first four channels of a
+//   staged pixel exist (3 + one zero), so the planes keep 8 B per pixel and a kernel row is the split modes' TWO K groups of 4 pixels
+//   each — half the MFMAs, and the 14 x 2 filter fragments fit in registers (gathered once from the 8-channel packing) instead of
+//   being re-read from LDS for every tile (84 LDS fragment reads per 56 MFMAs bound the four-group form: 242 us against 260 for the
+//   split modes' three passes).  The zero products a group no longer carries change how the 16 products of an MFMA are grouped: results
+//   agree with the four-group form / the two launches to fp32 summation noise, not bit for bit (tests: within one fp16 ulp).
+//   !COMPACT: round 4's four groups of 2 pixels x 8 channels, filters through LDS ("conv_stem" 2: A/B and the bit-identity test).
+template <int PARTS, bool COMPACT = true>
 __global__ __launch_bounds__(512, 2) void k_conv_stem(const StemArgs a)
 {
-    constexpr bool F16 = PARTS == 1;
+    constexpr bool F16 = PARTS == 1 && !COMPACT;      // the four-group form
+    constexpr bool H8 = PARTS == 1;                   // fp16 tensors: a staged pixel is 16 B of fp16 (8 channels)
     constexpr int PXB = F16 ? 16 : 8;                 // bytes of a pixel in a plane
     constexpr int NG = F16 ? 4 : 2;                   // K groups per kernel row
     constexpr int NGR = 7 * NG;                       // ... per output
     constexpr int PLANE = IR * IC * PXB;              // one part of the input patch
-    constexpr int WF = F16 ? NGR * 2 * 1024 : 0;      // fp16: the filter fragments live in LDS (28 groups x 2 would be 224 registers)
+    constexpr int WF = F16 ? NGR * 2 * 1024 : 0;      // four-group form: the filter fragments live in LDS (28 groups x 2 would be 224 registers)
     constexpr int CT = NQ * 64 * 4;                   // activated conv outputs [q][64], 16-B chunk c of row q at c ^ (q & 7)
     constexpr int NPX = (IR * IC + 511) / 512;        // input pixels a thread stages per tile (3)
     __shared__ __attribute__((aligned(16))) unsigned char smem[PARTS * PLANE + CT + 2 * 64 * 4 + WF];
@@ -95,8 +102,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_stem(const StemArgs a)
 #pragma unroll
         for (int g = 0; g < NGR; ++g)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (H8) {
+                    // gathered from the 8-channel packing [64][7][64] (k = kw * 8 + ci): pixels kw = 4 G + 2 kk and kw + 1, four channels each
+                    const _Float16* src = a.wgt + ((size_t)(j * 32 + l31) * 7 + g / NG) * 64 + (4 * (g % NG) + 2 * kk) * 8;
+                    const uint2 p0 = *reinterpret_cast<const uint2*>(src), p1 = *reinterpret_cast<const uint2*>(src + 8);
+                    bw[g][j] = make_uint4(p0.x, p0.y, p1.x, p1.y);
+                } else
                 bw[g][j] = *reinterpret_cast<const uint4*>(a.wgt + ((size_t)(j * 32 + l31) * 7 + g / NG) * (16 * NG) + 16 * (g % NG) + 8 * kk);
+            }
     } else {
         for (int e = t; e < NGR * 2 * 64; e += 512) {
             const int ln = e & 63, j = (e >> 6) & 1, g = e >> 7;
@@ -136,6 +150,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_stem(const StemArgs a)
             const int e = t + 512 * i;
             if (e < IR * IC) {
                 if constexpr (F16) *reinterpret_cast<u32x4_t*>(planes + e * 16) = px[i];
+                else if constexpr (H8) *reinterpret_cast<u32x2_t*>(planes + e * 8) = u32x2_t{px[i][0], px[i][1]};        // channels 0..3 of the pixel
                 else {
                     u32x2_t part[3];
                     stem_split4<PARTS>(px[i], part);
@@ -167,7 +182,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_stem(const StemArgs a)
             for (int p = 0; p < PARTS; ++p)
                 fa[p] = *reinterpret_cast<const uint4*>(planes + p * PLANE + a_base + ((g / NG) * IC + (F16 ? 2 : 4) * (g % NG)) * PXB);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = F16 ? *reinterpret_cast<const uint4*>(wf + ((g * 2 + j) * 64 + lane) * 16) : bw[F16 ? 0 : g][j];
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (F16) fb[j] = *reinterpret_cast<const uint4*>(wf + ((g * 2 + j) * 64 + lane) * 16);
+                else fb[j] = bw[g][j];
+            }
 #pragma unroll
             for (int p = 0; p < PARTS; ++p)
 #pragma unroll
@@ -209,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_stem(const StemArgs a)
                 }
             }
             const size_t o = (((size_t)b * a.PH + pr0 + pr) * a.PW + pc0 + pc) * 64 + ch4 * 4;
-            if constexpr (F16) store4<_Float16>(static_cast<_Float16*>(a.out) + o, m);         // (max commutes with the monotone rounding: one rounding, like the two launches)
+            if constexpr (H8) store4<_Float16>(static_cast<_Float16*>(a.out) + o, m);         // (max commutes with the monotone rounding: one rounding, like the two launches)
             else *reinterpret_cast<float4*>(static_cast<float*>(a.out) + o) = m;
         }
         __syncthreads();          // the planes hold the next tile; the conv tile may be overwritten
@@ -219,7 +237,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_stem(const StemArgs a)
 
 // in: padded (B, Hp, Wp) x 16 B; out: pooled (B, PH, PW, 64).  parts = 2 | 3 (split modes, fp32 tensors) | 1 (fp16 tensors).
 void conv_stem_launch(hipStream_t s, const void* in, int B, int Hp, int Wp, const void* wgt, const float* scale, const float* shift, int CH, int CW,
-                      void* out, int PH, int PW, int parts, int* range_flag, int n_cus)
+                      void* out, int PH, int PW, int parts, int* range_flag, int n_cus, bool compact)
 {
     StemArgs a;
     a.in = in; a.wgt = static_cast<const _Float16*>(wgt); a.scale = scale; a.shift = shift; a.out = out;
@@ -230,7 +248,8 @@ void conv_stem_launch(hipStream_t s, const void* in, int B, int Hp, int Wp, cons
     const int grid = a.n_tiles < n_cus ? a.n_tiles : n_cus;
     if (parts == 3) hipLaunchKernelGGL(k_conv_stem<3>, dim3(grid), dim3(512), 0, s, a);
     else if (parts == 2) hipLaunchKernelGGL(k_conv_stem<2>, dim3(grid), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(k_conv_stem<1>, dim3(grid), dim3(512), 0, s, a);
+    else if (compact) hipLaunchKernelGGL((k_conv_stem<1, true>), dim3(grid), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((k_conv_stem<1, false>), dim3(grid), dim3(512), 0, s, a);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -656,6 +656,18 @@ def test_fused_stem_is_bit_identical_to_conv1_plus_maxpool(pkg, weights_mod, tmp
     det, mask = m.predict(images)
     taps = {n: [m.read_tensor(n, b).copy() for b in range(B)] for n in ("rpn_probs", "rpn_deltas", "P2", "P5")}
     try:
+        if dtype == "f16":
+            # round 5: the default fp16 form drops the zero channels of the staged pixels (two K groups per kernel row instead of four): the 16
+            # products of an MFMA group differently, so it agrees with the four-group form ("conv_stem" 2) to summation noise — a rare one-ulp
+            # flip of an fp16 output — while the four-group form stays bit-identical to the two launches
+            L.check(L.lib().mrcnn_debug_set(b"conv_stem", 2))
+            det, mask = m.predict(images)
+            for n, compact in taps.items():
+                for b in range(B):
+                    four = m.read_tensor(n, b)
+                    # (measured: 2.8e-3 on an RPN probability — one fp16 ulp of a stem output, carried through 50 fp16 layers)
+                    assert np.abs(four - compact[b]).max() <= 6e-3 * max(1.0, np.abs(four).max()), n
+            taps = {n: [m.read_tensor(n, b).copy() for b in range(B)] for n in taps}
         L.check(L.lib().mrcnn_debug_set(b"conv_stem", 0))
         det2, mask2 = m.predict(images)
         for n, want in taps.items():
@@ -665,6 +677,7 @@ def test_fused_stem_is_bit_identical_to_conv1_plus_maxpool(pkg, weights_mod, tmp
         L.check(L.lib().mrcnn_debug_set(b"conv_stem", 1))
     np.testing.assert_array_equal(det, det2)
     np.testing.assert_array_equal(mask, mask2)
+    det, mask = m.predict(images)
     d1, m1 = m.predict(images[2:3])
     np.testing.assert_array_equal(d1[0], det[2])
     assert (det[..., 5] > 0).sum() > 0
