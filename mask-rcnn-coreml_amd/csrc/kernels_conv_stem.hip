@@ -72,9 +72,14 @@ __device__ __forceinline__ void stem_split4(const u32x4_t v, u32x2_t (&part)[3])
 //   split modes' three passes).  The zero products a group no longer carries change how the 16 products of an MFMA are grouped: results
 //   agree with the four-group form / the two launches to fp32 summation noise, not bit for bit (tests: within one fp16 ulp).
 //   !COMPACT: round 4's four groups of 2 pixels x 8 channels, filters through LDS ("conv_stem" 2: A/B and the bit-identity test).
+//   The compact form also splits the block's work by COLUMN block between the waves (wave = 64 conv outputs x 32 channels instead of 32 x 64): half the
+//   filter fragments per wave (56 registers), so that the kernel fits 128 registers and TWO blocks share a CU (75 KB of LDS each) — one block's
+//   barrier-separated phases (patch load, MFMAs, activation, pool, store: 4.4 us per tile, 0.5 us of it MFMAs) run under the other's.  Same sums per output.
 template <int PARTS, bool COMPACT = true>
-__global__ __launch_bounds__(512, 2) void k_conv_stem(const StemArgs a)
+__global__ __launch_bounds__(512, (PARTS == 1 && COMPACT) ? 4 : 2) void k_conv_stem(const StemArgs a)
 {
+    constexpr bool WS = PARTS == 1 && COMPACT;        // waves split by column block: NR row tiles x NJ column blocks per wave
+    constexpr int NR = WS ? 2 : 1, NJ = WS ? 1 : 2;
     constexpr bool F16 = PARTS == 1 && !COMPACT;      // the four-group form
     constexpr bool H8 = PARTS == 1;                   // fp16 tensors: a staged pixel is 16 B of fp16 (8 channels)
     constexpr int PXB = F16 ? 16 : 8;                 // bytes of a pixel in a plane
@@ -97,15 +102,16 @@ __global__ __launch_bounds__(512, 2) void k_conv_stem(const StemArgs a)
     // ---- filter fragments stay in REGISTERS for the life of the block (every wave multiplies all 14 groups x 2 column blocks once
     // per tile: through LDS they were 40 % of the fragment reads): group g = 2 kh + G, column block j: lane (n, kk) holds
     // W[32 j + n][kh][16 G + 8 kk .. + 8] ------------------------------------------------------------------------------------------
-    uint4 bw[F16 ? 1 : NGR][2];
+    const int jb0 = WS ? (wave & 1) : 0;              // first column block of this wave
+    uint4 bw[F16 ? 1 : NGR][NJ];
     if constexpr (!F16) {
 #pragma unroll
         for (int g = 0; g < NGR; ++g)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 if constexpr (H8) {
                     // gathered from the 8-channel packing [64][7][64] (k = kw * 8 + ci): pixels kw = 4 G + 2 kk and kw + 1, four channels each
-                    const _Float16* src = a.wgt + ((size_t)(j * 32 + l31) * 7 + g / NG) * 64 + (4 * (g % NG) + 2 * kk) * 8;
+                    const _Float16* src = a.wgt + ((size_t)((jb0 + j) * 32 + l31) * 7 + g / NG) * 64 + (4 * (g % NG) + 2 * kk) * 8;
                     const uint2 p0 = *reinterpret_cast<const uint2*>(src), p1 = *reinterpret_cast<const uint2*>(src + 8);
                     bw[g][j] = make_uint4(p0.x, p0.y, p1.x, p1.y);
                 } else
@@ -120,12 +126,18 @@ __global__ __launch_bounds__(512, 2) void k_conv_stem(const StemArgs a)
     }
     if (t < 64) { tab[t] = a.scale ? a.scale[t] : 1.0f; tab[64 + t] = a.shift ? a.shift[t] : 0.0f; }
     // this lane's conv output inside the tile and the plane offset of its tap (0, 0) input pixel pair
-    const int q = wave * 32 + l31;
-    const bool q_real = q < CR * CC;                    // rows 231..255 of the eighth block are padding: they multiply conv output 0's window and are never read
-    const int qa = q_real ? q : 0;
-    const int qr = qa / CC, qc = qa - qr * CC;
-    // split modes: a lane's fragment of a group = 2 neighbouring pixels (8 B each); fp16: one pixel (16 B)
-    const unsigned a_base = F16 ? (unsigned)(((2 * qr) * IC + 2 * qc + kk) * 16) : (unsigned)(((2 * qr) * IC + 2 * qc + 2 * kk) * 8);
+    int qv[NR];
+    bool q_realv[NR];
+    unsigned a_basev[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        qv[r] = (WS ? (wave >> 1) * 64 + r * 32 : wave * 32) + l31;
+        q_realv[r] = qv[r] < CR * CC;                   // rows 231..255 of the eighth block are padding: they multiply conv output 0's window and are never read
+        const int qa = q_realv[r] ? qv[r] : 0;
+        const int qr = qa / CC, qc = qa - qr * CC;
+        // split modes / compact fp16: a lane's fragment of a group = 2 neighbouring pixels (8 B each); four-group fp16: one pixel (16 B)
+        a_basev[r] = F16 ? (unsigned)(((2 * qr) * IC + 2 * qc + kk) * 16) : (unsigned)(((2 * qr) * IC + 2 * qc + 2 * kk) * 8);
+    }
     bool oor = false;
     const int per_img = a.tiles_r * a.tiles_c;
 
@@ -170,42 +182,50 @@ __global__ __launch_bounds__(512, 2) void k_conv_stem(const StemArgs a)
         const int r0 = 2 * pr0, c0 = 2 * pc0;                       // first conv output of the patch
         load_patch(tile + gridDim.x);
         // ---- 7 kernel rows x 2 groups x PARTS x 2 column blocks ----------------------------------------------------------
-        f32x16 acc[2];
+        f32x16 acc[2];                  // [r * NJ + j]
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
 #pragma unroll
         for (int g = 0; g < NGR; ++g) {
-            uint4 fa[PARTS], fb[2];
+            uint4 fa[NR][PARTS], fb[NJ];
 #pragma unroll
-            for (int p = 0; p < PARTS; ++p)
-                fa[p] = *reinterpret_cast<const uint4*>(planes + p * PLANE + a_base + ((g / NG) * IC + (F16 ? 2 : 4) * (g % NG)) * PXB);
+            for (int r = 0; r < NR; ++r)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+                for (int p = 0; p < PARTS; ++p)
+                    fa[r][p] = *reinterpret_cast<const uint4*>(planes + p * PLANE + a_basev[r] + ((g / NG) * IC + (F16 ? 2 : 4) * (g % NG)) * PXB);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
                 if constexpr (F16) fb[j] = *reinterpret_cast<const uint4*>(wf + ((g * 2 + j) * 64 + lane) * 16);
                 else fb[j] = bw[g][j];
             }
 #pragma unroll
-            for (int p = 0; p < PARTS; ++p)
+            for (int r = 0; r < NR; ++r)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j]), __builtin_bit_cast(f16x8, fa[p]), acc[j], 0, 0, 0);
+                for (int p = 0; p < PARTS; ++p)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[r * NJ + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[j]), __builtin_bit_cast(f16x8, fa[r][p]), acc[r * NJ + j], 0, 0, 0);
         }
         // ---- activate, park: lane (q, kk), slot 4 g4 + r  <->  channel 32 j + 8 g4 + 4 kk + r ---------------------------------
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const int c = j * 32 + 8 * g4 + 4 * kk;
+                const int jb = jb0 + j, q = qv[r];
+                const f32x16& ac = acc[r * NJ + j];
+                const int c = jb * 32 + 8 * g4 + 4 * kk;
                 const float4 sc = *reinterpret_cast<const float4*>(tab + c), sh = *reinterpret_cast<const float4*>(tab + 64 + c);
                 float4 y;
-                y.x = fmaxf(acc[j][4 * g4 + 0] * sc.x + sh.x, 0.f);
-                y.y = fmaxf(acc[j][4 * g4 + 1] * sc.y + sh.y, 0.f);
-                y.z = fmaxf(acc[j][4 * g4 + 2] * sc.z + sh.z, 0.f);
-                y.w = fmaxf(acc[j][4 * g4 + 3] * sc.w + sh.w, 0.f);
-                oor = oor || (q_real && (!(y.x < 65504.0f) || !(y.y < 65504.0f) || !(y.z < 65504.0f) || !(y.w < 65504.0f)));
-                const int chunk = j * 8 + 2 * g4 + kk;
+                y.x = fmaxf(ac[4 * g4 + 0] * sc.x + sh.x, 0.f);
+                y.y = fmaxf(ac[4 * g4 + 1] * sc.y + sh.y, 0.f);
+                y.z = fmaxf(ac[4 * g4 + 2] * sc.z + sh.z, 0.f);
+                y.w = fmaxf(ac[4 * g4 + 3] * sc.w + sh.w, 0.f);
+                oor = oor || (q_realv[r] && (!(y.x < 65504.0f) || !(y.y < 65504.0f) || !(y.z < 65504.0f) || !(y.w < 65504.0f)));
+                const int chunk = jb * 8 + 2 * g4 + kk;
                 *reinterpret_cast<float4*>(&ct[q * 64 + ((chunk ^ (q & 7)) << 2)]) = y;
             }
         __syncthreads();          // every wave has left the MFMAs (the planes are free) and the conv tile is complete
@@ -245,7 +265,8 @@ void conv_stem_launch(hipStream_t s, const void* in, int B, int Hp, int Wp, cons
     a.tiles_r = (PH + PR - 1) / PR; a.tiles_c = (PW + PC - 1) / PC;
     a.n_tiles = B * a.tiles_r * a.tiles_c;
     a.range_flag = range_flag;
-    const int grid = a.n_tiles < n_cus ? a.n_tiles : n_cus;
+    const int slots = n_cus * ((parts == 1 && compact) ? 2 : 1);             // the compact fp16 form: two blocks per CU
+    const int grid = a.n_tiles < slots ? a.n_tiles : slots;
     if (parts == 3) hipLaunchKernelGGL(k_conv_stem<3>, dim3(grid), dim3(512), 0, s, a);
     else if (parts == 2) hipLaunchKernelGGL(k_conv_stem<2>, dim3(grid), dim3(512), 0, s, a);
     else if (compact) hipLaunchKernelGGL((k_conv_stem<1, true>), dim3(grid), dim3(512), 0, s, a);
