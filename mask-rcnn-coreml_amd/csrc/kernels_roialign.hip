@@ -70,6 +70,7 @@ __device__ __forceinline__ float bilerp(float tl, float tr, float bl, float br, 
 }
 
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
 template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
 template <> __device__ __forceinline__ float4 ld4<_Float16>(const _Float16* p)
@@ -111,6 +112,10 @@ __global__ __launch_bounds__(256) void k_roi_align_nhwc(PyramidMaps maps, int C,
         if (row_flags && t == 0) row_flags[(size_t)b * gridDim.x + roi] = 0;
         return;
     }
+    // fp16 maps with C % 8 == 0: items of EIGHT channels (16-B loads and stores: half the vector-memory instructions of the gather)
+    constexpr bool HALF = sizeof(T) == 2;
+    const bool wide = HALF && (C & 7) == 0;
+    const int CI = wide ? C >> 3 : C4;                 // items per point
     // removeZeros predicate of the mask layer (TimeDistributedClassifierLayer.swift:116-127: a row is kept iff every
     // element != 0), evaluated on the fp32 samples BEFORE the store rounds them — the decision the reference's fp32
     // pipeline takes; an fp16 store would flush |v| < 3e-8 to zero and drop a valid detection.
@@ -118,8 +123,8 @@ __global__ __launch_bounds__(256) void k_roi_align_nhwc(PyramidMaps maps, int C,
     const int H = maps.H[g.level], W = maps.W[g.level];
     const T* m = static_cast<const T*>(maps.data[g.level]) + (size_t)b * maps.sB[g.level];
     const float mul = maps.mul[g.level];               // 1, or the exact power of two between this level's split exponent and the output's
-    const bool pow2 = (C4 & (C4 - 1)) == 0;
-    const int sh = 31 - __builtin_clz((unsigned)(C4 > 0 ? C4 : 1));
+    const bool pow2 = (CI & (CI - 1)) == 0;
+    const int sh = 31 - __builtin_clz((unsigned)(CI > 0 ? CI : 1));
     for (int p0 = 0; p0 < npts; p0 += 256) {
         const int np = min(256, npts - p0);
         if (p0) __syncthreads();
@@ -131,7 +136,30 @@ __global__ __launch_bounds__(256) void k_roi_align_nhwc(PyramidMaps maps, int C,
             s_w[t] = make_float2(s.lx, s.ly);
         }
         __syncthreads();
-        const int total = np * C4;
+        const int total = np * CI;
+        if constexpr (HALF) {
+            if (wide) {
+                for (int e = t; e < total; e += 256) {
+                    const int pl = pow2 ? e >> sh : e / CI;
+                    const int c8 = pow2 ? e & (CI - 1) : e - pl * CI;
+                    const int4 of = s_off[pl];
+                    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (of.x >= 0) {
+                        const float2 w = s_w[pl];
+                        const T* mc = m + c8 * 8;
+                        const f16x8_t tl = *reinterpret_cast<const f16x8_t*>(mc + of.x), tr = *reinterpret_cast<const f16x8_t*>(mc + of.y);
+                        const f16x8_t bl = *reinterpret_cast<const f16x8_t*>(mc + of.z), br = *reinterpret_cast<const f16x8_t*>(mc + of.w);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = bilerp((float)tl[k], (float)tr[k], (float)bl[k], (float)br[k], w.x, w.y) * mul;
+                    }
+                    f16x8_t hv;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { all_nonzero &= v[k] != 0.0f ? 1 : 0; hv[k] = (_Float16)v[k]; }
+                    *reinterpret_cast<f16x8_t*>(o + ((size_t)p0 * CI + e) * 8) = hv;
+                }
+                continue;
+            }
+        }
         for (int e = t; e < total; e += 256) {
             const int pl = pow2 ? e >> sh : e / C4;
             const int cq = pow2 ? e & (C4 - 1) : e - pl * C4;
