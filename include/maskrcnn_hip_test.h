@@ -89,6 +89,8 @@ MRCNN_API int mrcnn_bench_mfma_probe(double seconds, int kind, double* tflops, d
  * image | by rank counting over the whole chip (default 1); "nms_col_splits" n: column splits of the suppression-matrix grid (0 = by policy: as many
  * as the chip's wave slots hold, at least 4); "nms_class_fast" 0|1: DetectionLayer's per-class limit tested per chunk as count + 64 | as count + the
  * chunk's own alive candidates of the class, classes at the limit dropping out (default 1).
+ * Measurement-only environment variable read by mrcnn_model_load: MRCNN_CU_MASK_PROBE="w0,...,w7" (hexadecimal) creates the handle's stream on that subset of the
+ * CUs (hipExtStreamCreateWithCUMask) — tools/dual_stream_probe.py's question whether two half batches on disjoint halves of the chip beat one batch on all of it (no).
  * The switches are PROCESS-WIDE test / measurement knobs: not thread-safe; a choice captured in a hipGraph stays captured. */
 MRCNN_API int mrcnn_conv2d_nhwc(const float* in, int batch, int h, int w, int cin, const float* filters, int cout,
                                 int ksize, int stride, const float* scale, const float* shift, const float* residual,
