@@ -113,6 +113,16 @@ MRCNN_API int mrcnn_bottleneck_nhwc(const float* x, int batch, int h, int w, int
 MRCNN_API int mrcnn_bottleneck_first_nhwc(const float* x, int batch, int h, int w, int cmid, const float* w1, const float* w2, const float* w3, const float* ws,
                                           const float* const bn[8], int fused, int iters, float* out, float* avg_ms);
 
+/* The consecutive identity blocks of a C = 256 stage (C4's 22 in ResNet-101) on caller data: x (B,H,W,1024), stacked operands w1 (n,256,1024),
+ * w2 (n,256,3,3,256), w3 (n,1024,256), bn = {s1,h1,s2,h2: (n,256); s3,h3: (n,1024)}.  form 1: ONE launch in which a tile's block l waits for its
+ * neighbour tiles' block l - 1 (kernels_bneck.hip, STAGE form); form 0: one fused launch per block.  Bit-identical (tests/test_gpu_bneck.py).
+ * out (B,H,W,1024) = the last block's output; *status_flag (optional) = the launch's flag word (bit 0 fp16 range, bit 1 "no progress").
+ * "conv_bneck_stage" 0|1 of mrcnn_debug_set: the engine's C4 identity blocks of the fp16 mode one launch per block (default) | one launch per stage
+ * (measured equal: profiles/r06_bneck_stage_ab.txt). */
+MRCNN_API int mrcnn_bottleneck_stage_nhwc(const float* x, int batch, int h, int w, int nlayers, const float* w1, const float* w2, const float* w3,
+                                          const float* const bn[6], int form, int iters, float* out, float* avg_ms, int* status_flag);
+
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
 # declared in include/maskrcnn_hip_test.h (test / measurement entry points of the same library)
 TEST_SYMBOLS = [
     "mrcnn_bench_conv", "mrcnn_bench_conv_dtype", "mrcnn_model_conv_profile_enable", "mrcnn_model_conv_profile_get",
-    "mrcnn_model_conv_profile_shapes", "mrcnn_conv2d_nhwc", "mrcnn_debug_set", "mrcnn_bottleneck_nhwc", "mrcnn_bench_mfma_probe", "mrcnn_model_conv_profile_group", "mrcnn_bottleneck_first_nhwc",
+    "mrcnn_model_conv_profile_shapes", "mrcnn_conv2d_nhwc", "mrcnn_debug_set", "mrcnn_bottleneck_nhwc", "mrcnn_bench_mfma_probe", "mrcnn_model_conv_profile_group", "mrcnn_bottleneck_first_nhwc", "mrcnn_bottleneck_stage_nhwc",
 ]
 
 
@@ -147,6 +147,7 @@ def lib():
     L.mrcnn_debug_set.argtypes = [cp, C.c_int]
     L.mrcnn_bench_mfma_probe.argtypes = [C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.mrcnn_bottleneck_first_nhwc.argtypes = [vp] + [C.c_int] * 4 + [vp] * 5 + [C.c_int, C.c_int, vp, vp]
+    L.mrcnn_bottleneck_stage_nhwc.argtypes = [vp] + [C.c_int] * 4 + [vp] * 4 + [C.c_int, C.c_int, vp, vp, vp]
     L.mrcnn_bottleneck_nhwc.argtypes = [vp] + [C.c_int] * 4 + [vp] * 9 + [C.c_int, C.c_int, vp, vp]
     L.mrcnn_model_check_range.argtypes = [vp, ip]
     L.mrcnn_model_calibrate_split.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]

@@ -1196,6 +1196,83 @@ extern "C" int mrcnn_bottleneck_first_nhwc(const float* x, int batch, int h, int
     });
 }
 
+// The identity blocks of a C = 256 stage on caller data (tests/test_gpu_bneck.py): nlayers blocks with stacked operands — w1 (n,C,4C), w2 (n,C,3,3,C),
+// w3 (n,4C,C), bn[6] = s1,h1,s2,h2 (n,C) and s3,h3 (n,4C).  form 1: ONE launch (kernels_bneck.hip, STAGE form: tiles wait for their neighbours' previous
+// block); form 0: one fused launch per block.  out = the last block's output.  status_flag (optional) receives the launch's flag word (bit 1: no progress).
+extern "C" int mrcnn_bottleneck_stage_nhwc(const float* x, int batch, int h, int w, int nlayers, const float* w1, const float* w2, const float* w3,
+                                           const float* const bn[6], int form, int iters, float* out, float* avg_ms, int* status_flag)
+{
+    return guarded([&] {
+        require_gpu();
+        MRCNN_REQUIRE(x && w1 && w2 && w3 && bn && out && batch >= 1 && h >= 1 && w >= 1 && nlayers >= 1, MRCNN_ERR_INVALID, "bad bottleneck_stage_nhwc argument");
+        const int C = 256, C4 = 1024;
+        MRCNN_REQUIRE(bneck_geometry_ok(C, h, w), MRCNN_ERR_UNSUPPORTED, "bottleneck_stage_nhwc: %dx%d does not qualify", h, w);
+        auto half_dev = [&](const float* src, size_t n, DevBuf& d) {
+            std::vector<_Float16> t(n);
+            for (size_t i = 0; i < n; ++i) t[i] = (_Float16)src[i];
+            d.alloc(n * 2);
+            HIP_CHECK(hipMemcpy(d.p, t.data(), n * 2, hipMemcpyHostToDevice));
+        };
+        const size_t npix = (size_t)batch * h * w;
+        DevBuf dx, dx0, dy, dbn[6], flag;
+        half_dev(x, npix * C4, dx0);
+        dx.alloc(npix * C4 * 2); dy.alloc(npix * C4 * 2);
+        flag.alloc(sizeof(int));
+        const size_t bn_n[6] = {(size_t)C, (size_t)C, (size_t)C, (size_t)C, (size_t)C4, (size_t)C4};
+        for (int i = 0; i < 6; ++i) { dbn[i].alloc(bn_n[i] * nlayers * 4); HIP_CHECK(hipMemcpy(dbn[i].p, bn[i], bn_n[i] * nlayers * 4, hipMemcpyHostToDevice)); }
+        Stream st;
+        std::vector<DevBuf> dw(3 * (size_t)nlayers), df(3 * (size_t)nlayers);
+        const size_t rb = bneck_layer_record_bytes();
+        std::vector<unsigned char> recs(rb * nlayers);
+        for (int l = 0; l < nlayers; ++l) {
+            half_dev(w1 + (size_t)l * C * C4, (size_t)C * C4, dw[3 * l]);
+            half_dev(w2 + (size_t)l * C * 9 * C, (size_t)C * 9 * C, dw[3 * l + 1]);
+            half_dev(w3 + (size_t)l * C4 * C, (size_t)C4 * C, dw[3 * l + 2]);
+            bneck_pack_frag(st.s, dw[3 * l].p, C, C4, df[3 * l]);
+            bneck_pack_frag(st.s, dw[3 * l + 1].p, C, 9 * C, df[3 * l + 1]);
+            bneck_pack_frag(st.s, dw[3 * l + 2].p, C4, C, df[3 * l + 2]);
+            bneck_layer_record(recs.data() + l * rb, df[3 * l].p, df[3 * l + 1].p, df[3 * l + 2].p, dbn[0].as<float>() + (size_t)l * C, dbn[1].as<float>() + (size_t)l * C,
+                               dbn[2].as<float>() + (size_t)l * C, dbn[3].as<float>() + (size_t)l * C, dbn[4].as<float>() + (size_t)l * C4, dbn[5].as<float>() + (size_t)l * C4);
+        }
+        const int ntiles = batch * (h / 8) * (w / 16);
+        DevBuf tab(recs.size() + (size_t)ntiles * sizeof(unsigned));
+        HIP_CHECK(hipMemcpy(tab.p, recs.data(), recs.size(), hipMemcpyHostToDevice));
+        unsigned* const done = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(tab.p) + recs.size());
+        static int n_cus = [] { int dev = 0; hipDeviceProp_t p; (void)hipGetDevice(&dev); return hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }();
+        auto run = [&] {
+            HIP_CHECK(hipMemcpyAsync(dx.p, dx0.p, npix * C4 * 2, hipMemcpyDeviceToDevice, st.s));      // (the blocks overwrite the input tensor from the second one on)
+            HIP_CHECK(hipMemsetAsync(flag.p, 0, sizeof(int), st.s));
+            if (form == 1) bneck_stage_launch(st.s, tab.p, nlayers, dx.p, dy.p, batch, h, w, done, flag.as<int>(), n_cus);
+            else
+                for (int l = 0; l < nlayers; ++l) {
+                    void* const pi = (l & 1) ? dy.p : dx.p;
+                    void* const po = (l & 1) ? dx.p : dy.p;
+                    bneck_launch(st.s, C, pi, po, batch, h, w, dw[3 * l].p, dw[3 * l + 1].p, dw[3 * l + 2].p, dbn[0].as<float>() + (size_t)l * C, dbn[1].as<float>() + (size_t)l * C,
+                                 dbn[2].as<float>() + (size_t)l * C, dbn[3].as<float>() + (size_t)l * C, dbn[4].as<float>() + (size_t)l * C4, dbn[5].as<float>() + (size_t)l * C4,
+                                 flag.as<int>(), n_cus, df[3 * l + 1].p, df[3 * l + 2].p, df[3 * l].p);
+                }
+        };
+        run();
+        HIP_CHECK(hipStreamSynchronize(st.s));
+        if (status_flag) HIP_CHECK(hipMemcpy(status_flag, flag.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (iters > 0 && avg_ms) {
+            hipEvent_t e0, e1;
+            HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+            HIP_CHECK(hipEventRecord(e0, st.s));
+            for (int i = 0; i < iters; ++i) run();
+            HIP_CHECK(hipEventRecord(e1, st.s));
+            HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            *avg_ms = ms / iters;        // (includes the input copy and the two memsets of a run: the same for both forms)
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        }
+        std::vector<_Float16> t(npix * C4);
+        HIP_CHECK(hipMemcpy(t.data(), (nlayers & 1) ? dy.p : dx.p, t.size() * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < t.size(); ++i) out[i] = (float)t[i];
+    });
+}
+
 // ================================================================================================
 // anchors on demand (MaskRCNNConfig.swift:14 "TODO: generate the anchors on demand")
 // Host code.  Restates the published Matterport generator the reference's converter dumps to

@@ -177,6 +177,7 @@ struct Model {
     // activations
     DevBuf arena;
     std::vector<Op> trunk_ops;
+    std::vector<std::unique_ptr<DevBuf>> stage_tabs;   // fp16 mode: per-block operand tables + tile counters of the whole-stage bottleneck launches (kernels.h: bneck_stage_launch)
     // Level-parallel region of the trunk (round 5): once the FPN's lateral chain is done, level l's output 3x3 layer and its RPN launches
     // depend on nothing but that level (P6 on P5) — on a single image most of these launches cover a fraction of the chip, so the levels
     // P3.. run on side streams beside P2 (fork behind the laterals, join in front of the soft-max).  trunk_branch[i]: stream of op i

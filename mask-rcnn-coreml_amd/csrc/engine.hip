@@ -782,6 +782,7 @@ void Model::build_maskrcnn()
         taps.clear();
         sgroups.clear();
         sops.clear();
+        stage_tabs.clear();
         const bool real = pass == 1;
         const int dt = dtype;
         auto T = [&](int h, int w, int c) { Tensor4 t; t.H = h; t.W = w; t.C = c; t.p = ar.alloc_e((size_t)Bm * h * w * c, dt); return t; };
@@ -847,15 +848,41 @@ void Model::build_maskrcnn()
         // chip (kernels_bneck.hip; bit-identical to the three launches, which conv_bneck_forward runs when the block does not qualify
         // or behind mrcnn_debug_set("conv_bneck", 0)).  The fused form reads halo pixels of x that neighbouring tiles own, so it cannot
         // write in place: such stages ping-pong between two block-output tensors.
+        // Round 6: the consecutive identity blocks of a stage are ONE op — where every block takes the fragment-streaming form (C4) they
+        // run as ONE launch whose tiles wait for their neighbours' previous block (conv_bneck_stage_forward; bit-identical to the
+        // per-block launches, which it falls back to).  The launch reads its per-block operands from a table on the device.
+        std::vector<BneckTriple> stage_blocks;
         auto bneck_op = [&](const std::string& na, const std::string& nb, const std::string& nc, const Tensor4& xin, const Tensor4& ta, const Tensor4& tb,
                             const Tensor4& out, int g_in, int g_a, int g_b, int g_out) {
-            const ConvDesc da = make_desc(na, xin, ta, 1, 0, ACT_RELU, nullptr, 0, g_in, g_a);
-            const ConvDesc db = make_desc(nb, ta, tb, 1, 1, ACT_RELU, nullptr, 0, g_a, g_b);
-            const ConvDesc dc = make_desc(nc, tb, out, 1, 0, ACT_RELU, &xin, 0, g_b, g_out);
-            add([da, db, dc](hipStream_t s, int batch) {
-                ConvDesc a = da, b = db, c = dc;
-                a.B = b.B = c.B = batch;
-                conv_bneck_forward(s, a, b, c);
+            BneckTriple t;
+            t.a = make_desc(na, xin, ta, 1, 0, ACT_RELU, nullptr, 0, g_in, g_a);
+            t.b = make_desc(nb, ta, tb, 1, 1, ACT_RELU, nullptr, 0, g_a, g_b);
+            t.c = make_desc(nc, tb, out, 1, 0, ACT_RELU, &xin, 0, g_b, g_out);
+            stage_blocks.push_back(t);
+        };
+        auto bneck_stage_flush = [&](int tiles_per_image) {
+            if (stage_blocks.empty()) return;
+            const std::vector<BneckTriple> blocks = stage_blocks;
+            stage_blocks.clear();
+            void* tab = nullptr;
+            unsigned* done = nullptr;
+            bool frag = blocks.size() >= 2;
+            for (auto& t : blocks) frag = frag && t.a.wgt_frag && t.b.wgt_frag && t.c.wgt_frag;
+            if (real && frag) {
+                const size_t rb = bneck_layer_record_bytes();
+                std::vector<unsigned char> h(rb * blocks.size());
+                for (size_t i = 0; i < blocks.size(); ++i)
+                    bneck_layer_record(h.data() + i * rb, blocks[i].a.wgt_frag, blocks[i].b.wgt_frag, blocks[i].c.wgt_frag, blocks[i].a.scale, blocks[i].a.shift,
+                                       blocks[i].b.scale, blocks[i].b.shift, blocks[i].c.scale, blocks[i].c.shift);
+                stage_tabs.emplace_back(new DevBuf(h.size() + (size_t)Bm * tiles_per_image * sizeof(unsigned)));
+                HIP_CHECK(hipMemcpy(stage_tabs.back()->p, h.data(), h.size(), hipMemcpyHostToDevice));
+                tab = stage_tabs.back()->p;
+                done = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(tab) + h.size());
+            }
+            add([blocks, tab, done](hipStream_t s, int batch) {
+                std::vector<BneckTriple> b = blocks;
+                for (auto& t : b) t.a.B = t.b.B = t.c.B = batch;
+                conv_bneck_stage_forward(s, b.data(), (int)b.size(), tab, done);
             });
         };
 
@@ -975,6 +1002,7 @@ void Model::build_maskrcnn()
                 if (first) stage_main = to;
                 g_x = g_stage;
             }
+            bneck_stage_flush((x.H / (f1s[st] == 256 ? 8 : 16)) * (x.W / 16));
             Cf[st] = x;
             g_C[st] = g_stage;
         }
@@ -1407,6 +1435,9 @@ void Model::predict(const uint8_t* rgb, int batch, int h, int w, int memspace, f
         if (mode != MRCNN_F32) {
             int tripped = 0;
             HIP_CHECK(hipMemcpy(&tripped, range_flag.p, sizeof(int), hipMemcpyDeviceToHost));
+            if (tripped & 2)
+                fail(MRCNN_ERR_HIP, "a whole-stage bottleneck launch made no progress for ~0.1 s (its grid was not resident as a whole: are compute units masked off or "
+                 "held by another process?): the results of this call are not valid; mrcnn_debug_set(\"conv_bneck_stage\", 0) runs one launch per block");
             if (tripped && calib_phase)
                 fail(MRCNN_ERR_UNSUPPORTED, "an activation left the fp16 range during a calibration pass");       // (the caller steps the exponents down)
             if (tripped) {
@@ -1496,6 +1527,9 @@ void Model::collect(float* det_host, float* masks_host, int* batch_out)
     }
     if (batch_out) *batch_out = sl.batch;
     ++predict_calls;
+    if (tripped & 2)
+        fail(MRCNN_ERR_HIP, "a whole-stage bottleneck launch made no progress for ~0.1 s (its grid was not resident as a whole: are compute units masked off or "
+         "held by another process?): the results of this call are not valid; mrcnn_debug_set(\"conv_bneck_stage\", 0) runs one launch per block");
     if (tripped) {
         ++range_overflows;
         if (mode == MRCNN_F32S || mode == MRCNN_F32X3) {

@@ -242,6 +242,19 @@ void bneck_launch(hipStream_t s, int C, const void* x, void* y, int B, int H, in
                   const float* s1, const float* h1, const float* s2, const float* h2, const float* s3, const float* h3, int* range_flag, int n_cus,
                   const void* w2f = nullptr, const void* w3f = nullptr, const void* w1f = nullptr,
                   const void* ws = nullptr, const float* ss = nullptr, const float* hs = nullptr);      // ws / ss / hs: the stage-entry form (C = 64)
+// The identity blocks of a C = 256 stage (C4) as ONE launch — kernels_bneck.hip, STAGE form: a tile's block l starts when its <= 9 neighbour
+// tiles have published block l - 1 (per-tile counters `done`, device-scope stores / loads), no launch gap or drain between blocks; BIT-IDENTICAL
+// to nlayers calls of bneck_launch.  layers_dev: nlayers records of bneck_layer_record_bytes() bytes written by bneck_layer_record (host) and
+// copied to the device; pp0 = the stage's input, pp1 = its ping-pong partner (result in pp[nlayers & 1]); done: >= B * tiles counters.
+// range_flag (required): bit 0 as everywhere, bit 1 = a tile waited ~0.1 s for a neighbour (the grid was not resident as a whole): results invalid.
+void bneck_stage_launch(hipStream_t s, const void* layers_dev, int nlayers, void* pp0, void* pp1, int B, int H, int W, unsigned* done, int* range_flag, int n_cus);
+size_t bneck_layer_record_bytes();
+void bneck_layer_record(void* dst, const void* w1f, const void* w2f, const void* w3f, const float* s1, const float* h1, const float* s2, const float* h2,
+                        const float* s3, const float* h3);
+struct BneckTriple { ConvDesc a, b, c; };
+// conv_bneck_forward over the consecutive identity blocks of a stage: ONE launch where every block takes the fragment-streaming form, the grid
+// fills the chip and mrcnn_debug_set("conv_bneck_stage", 1) (opt-in: measured equal); the per-block launches otherwise.  layers_dev / done as above (owned by the caller).
+void conv_bneck_stage_forward(hipStream_t s, const BneckTriple* blocks, int n, const void* layers_dev, unsigned* done);
 // [N][K] fp16 filters (K contiguous; N % 32 == 0, K % 16 == 0) -> 1-KB granules [N/32][K/16][lane 0..63][8]: lane (l31, kk) of granule (nt, kg)
 // holds filter row 32 nt + l31, k = 16 kg + 8 kk .. + 7 — the first MFMA operand of v_mfma_f32_32x32x16_f16, one coalesced 16-B load per lane
 void bneck_pack_frag(hipStream_t s, const void* wgt_std, int N, int K, DevBuf& out);

@@ -27,6 +27,7 @@
 // The output must NOT alias the input: a tile reads the halo pixels its neighbours own.  (The three-launch form writes in place;
 // the engine gives fused stages a second tensor and ping-pongs.)
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 #include "conv_device.h"
@@ -57,6 +58,12 @@ struct BnCfg {
     static_assert(!YTILE || OFF_Y0 + Y_BYTES <= RING, "the first chunk tile lives in the ring's idle part");
 };
 
+// one identity block of a stage launched as ONE kernel (STAGE form): its filters in fragment order and its folded BatchNorm vectors
+struct BneckLayer {
+    const uint4 *w1f, *w2f, *w3f;
+    const float *s1, *h1, *s2, *h2, *s3, *h3;
+};
+
 struct BneckArgs {
     const _Float16* x; _Float16* y;
     const _Float16 *w1, *w2, *w3, *ws;   // ws: the stage-entry form's shortcut filters [4C][C] (branch1)
@@ -65,11 +72,19 @@ struct BneckArgs {
     int B, H, W, tiles_x, tiles_y, ntiles;
     int* range_flag;
     int dbg;
+    // STAGE form: block l reads pp[l & 1] and writes pp[(l + 1) & 1]; done[tile] = blocks this tile has completed (zeroed by the host before the launch)
+    const BneckLayer* layers;
+    int nlayers;
+    _Float16* pp[2];
+    unsigned* done;
 };
 
 typedef unsigned bn_srd_t __attribute__((ext_vector_type(4)));
 #define BN_BLDS(VOFF, SRD, SOFF, DST)                                                                          \
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(VOFF), "s"(SRD), "s"(SOFF), "s"(DST) : "memory", "m0");
+// the same DMA at DEVICE scope (sc1: fetched past the non-coherent L2 lines of this XCD) — STAGE form, whose input was written by other XCDs in this launch
+#define BN_BLDS_DEV(VOFF, SRD, SOFF, DST)                                                                      \
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen sc1 lds" ::"v"(VOFF), "s"(SRD), "s"(SOFF), "s"(DST) : "memory", "m0");
 #define BN_VMCNT0 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #define BN_MFMA(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, C_, 0, 0, 0);
 
@@ -115,10 +130,25 @@ __device__ __forceinline__ bool bn_bad(const float4 v)
 // convolution `branch1` of x (+ BatchNorm, no ReLU), which the three-launch form stores as an fp16 tensor and reads back as branch2c's
 // residual.  Here phase A's K is C, and phase C multiplies the tile's own x pixels (one 32-KB LDS tile) with branch1's filters beside
 // t2 x W3: y = relu((t2 W3) s3 + h3 + fp16((x Ws) ss + hs)) — the rounding of the shortcut where the tensor would have been: bit-identical.
-template <int C, bool FRAG, bool FIRST = false>
+// STAGE (FRAG form; round 6): ALL identity blocks of the stage in one launch.  The block that owns tile T runs T through
+// block l = 0, 1, .. of the stage; block l of T starts when T's <= 9 neighbour tiles (3 x 3, same image) have PUBLISHED block l - 1 — their
+// outputs are the halo pixels phase A reads, and they have finished reading the tensor block l overwrites (the stage ping-pongs between two
+// tensors, and the neighbourhood is symmetric: the same condition covers both hazards).  done[tile] counts a tile's finished blocks; outputs are
+// stored, and inputs loaded, at DEVICE scope (sc1: written through / fetched past this XCD's non-coherent L2 lines — the protocol of the 128-row
+// kernel's K-chunk fold, kernels_conv.hip), a tile publishes behind vmcnt(0) + barrier with a device-scope atomic.  No launch gap, no drain
+// behind the slowest tile, and the next block's first filter fragments are requested BEFORE the wait.  MEASURED EQUAL to one launch per block
+// (profiles/r06_bneck_stage_ab.txt: 22 blocks at batch 8 2 242 against 2 268 us, whole model x1.000; de-phasing the images by up to a tile time
+// gains nothing either): the "fixed" 25-29 us of a block are the tile's OWN dependent chain — cold operand fetches, the
+// phase borders' epilogues and barriers — not launch gaps, and one tile per CU leaves nothing to overlap them with.  So the form is OPT-IN
+// (mrcnn_debug_set("conv_bneck_stage", 1)); it stays as the evidence and as a tested building block.  Progress needs every block of the grid
+// resident (grid <= CUs, one block per CU: bneck_stage_launch); a wait that outlasts ~0.1 s trips bit 1 of the range flag and ends the launch
+// (the host reports MRCNN_ERR_HIP) instead of hanging.  Every tile runs exactly the arithmetic of the per-block launches: BIT-IDENTICAL.
+template <int C, bool FRAG, bool FIRST = false, bool STAGE = false>
 __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
 {
     static_assert(!FIRST || (C == 64 && !FRAG), "the stage-entry form is laid out for C = 64");
+    static_assert(!STAGE || FRAG, "the whole-stage form exists for the fragment-streaming kernel");
+    constexpr int DEV = STAGE ? 16 : 0;                    // cache policy of the buffer builtins that touch x / y: sc1 = device scope
     constexpr int CIN = FIRST ? C : 4 * C;                 // channels of the block's input
     static_assert(!FRAG || C == 256, "the fragment-streaming form is laid out for C = 256 (eight waves x 32 channels, 128-pixel tiles)");
     using K = BnCfg<C>;
@@ -150,11 +180,6 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
     // ---- tables of phases A / B: scale | shift of t1, scale | shift of t2 (once per block) ----
     float* const tabAB = reinterpret_cast<float*>(smem + K::OFF_TABAB);
     float* const tabC = reinterpret_cast<float*>(smem + K::OFF_TABC);
-    for (int i = t; i < 4 * C; i += 512) {
-        const int w = i / C, c = i - w * C;
-        const float* src = w == 0 ? a.s1 : w == 1 ? a.h1 : w == 2 ? a.s2 : a.h2;
-        tabAB[i] = src ? src[c] : ((w & 1) ? 0.0f : 1.0f);
-    }
 
     // ---- loop-invariant DMA lane geometry ----
     // phase A (64-B rows, 16 rows per DMA): DMA u = wave + 8 j; u < NXD: x rows 16u.., else W1 rows 16(u - NXD)..
@@ -201,6 +226,24 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
     bool range_trip = false;
     const int nblocks = a.ntiles;
     const int q8 = nblocks >> 3, r8 = nblocks & 7;
+    __shared__ int s_abort;
+    if (t == 0) s_abort = 0;
+    for (int layer = 0; layer < (STAGE ? a.nlayers : 1); ++layer) {
+    // ---- this block's operands (STAGE: block `layer` of the stage, between the two ping-pong tensors) ----
+    // (STAGE reads the record's fields where they are used — scalar loads — instead of holding nine pointers across the phases)
+    const BneckLayer* const L = STAGE ? a.layers + layer : nullptr;
+#define BN_L(F) (STAGE ? L->F : a.F)
+    const _Float16* const Lx = STAGE ? a.pp[layer & 1] : a.x;
+    _Float16* const Ly = STAGE ? a.pp[(layer + 1) & 1] : a.y;
+    // tables of phases A / B (the previous tile's last readers passed the barrier that ends a tile)
+    {
+        const float *Ls1 = BN_L(s1), *Lh1 = BN_L(h1), *Ls2 = BN_L(s2), *Lh2 = BN_L(h2);
+        for (int i = t; i < 4 * C; i += 512) {
+            const int w = i / C, c = i - w * C;
+            const float* src = w == 0 ? Ls1 : w == 1 ? Lh1 : w == 2 ? Ls2 : Lh2;
+            tabAB[i] = src ? src[c] : ((w & 1) ? 0.0f : 1.0f);
+        }
+    }
     __syncthreads();
     for (int v = blockIdx.x; v < nblocks; v += gridDim.x) {
         // XCD-aware bijective walk: the blocks of one XCD (blockIdx & 7) own a contiguous run of tiles (neighbours share halo rows and L2)
@@ -210,8 +253,8 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
         const int b = tile / per_img, tr = tile - b * per_img;
         const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
         const int y0 = ty * K::TH, x0 = tx * K::TW;
-        const _Float16* const ximg = a.x + (size_t)b * a.H * a.W * CIN;
-        _Float16* const yimg = a.y + (size_t)b * a.H * a.W * 4 * C;
+        const _Float16* const ximg = Lx + (size_t)b * a.H * a.W * CIN;
+        _Float16* const yimg = Ly + (size_t)b * a.H * a.W * 4 * C;
         srdX = mk(ximg, img_bytes);
 
         // x rows of this thread's phase-A DMAs: halo pixel r -> image pixel (y0 - 1 + r / 18, x0 - 1 + r % 18)
@@ -251,18 +294,40 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
             xvo[m] = ok ? (int)(((size_t)gy * a.W + gx) * 4 * C * 2 + c * 16) : (int)OOB;
             xls[m] = (unsigned)(r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
         }
-        const uint4* const wp1 = a.w1f + (size_t)wave * KG1 * 64 + lane;
+        const uint4* const wp1 = BN_L(w1f) + (size_t)wave * KG1 * 64 + lane;
         uint4 wq1[D1];
 #pragma unroll
         for (int d = 0; d < D1; ++d) wq1[d] = wp1[d * 64];
+        if constexpr (STAGE) {
+            // the neighbours' previous block: lanes 0..8 of wave 0 poll one tile each (device-scope atomic loads), everybody waits at the barrier
+            if (layer > 0) {
+                if (t < 9) {
+                    const int ny = ty + t / 3 - 1, nx = tx + t % 3 - 1;
+                    if ((unsigned)ny < (unsigned)a.tiles_y && (unsigned)nx < (unsigned)a.tiles_x) {
+                        const unsigned* const f = a.done + (b * per_img + ny * a.tiles_x + nx);
+                        unsigned spins = 0;
+                        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)layer) {
+                            __builtin_amdgcn_s_sleep(2);
+                            if (++spins > (1u << 16) || ((spins & 255u) == 0 && (__hip_atomic_load(a.range_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2))) {
+                                atomicOr(a.range_flag, 2);      // no progress (a grid that is not resident as a whole?): end the launch, the host fails the call
+                                s_abort = 1;
+                                break;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                if (s_abort) return;
+            }
+        }
         bn_u32x4 xr[3];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) xr[m] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvo[m], 0, 0);
+        for (int m = 0; m < 3; ++m) xr[m] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvo[m], 0, DEV);
         __syncthreads();                               // (the previous tile's phase C has read the last of its LDS tile)
 #pragma unroll
         for (int m = 0; m < 3; ++m) *reinterpret_cast<bn_u32x4*>(smem + xls[m]) = xr[m];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) xr[m] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvo[m], 128, 0);
+        for (int m = 0; m < 3; ++m) xr[m] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvo[m], 128, DEV);
         __syncthreads();
         const unsigned xfr = (unsigned)(l31 * 128);    // fragment rows i*32 + l31 of a stage
         for (int ks = 0; ks < ((a.dbg & 1) ? 1 : NS1); ks += 2) {
@@ -291,7 +356,7 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
                     int kn = ks + h + 2;
                     kn = kn < NS1 ? kn : NS1 - 1;
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) xr[m] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvo[m], kn * 128, 0);
+                    for (int m = 0; m < 3; ++m) xr[m] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvo[m], kn * 128, DEV);
                 }
                 __syncthreads();
             }
@@ -408,7 +473,7 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
-        const uint4* const wp2 = a.w2f + (size_t)wave * KG2 * 64 + lane;
+        const uint4* const wp2 = BN_L(w2f) + (size_t)wave * KG2 * 64 + lane;
         uint4 wq[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) wq[d] = wp2[d * 64];
@@ -448,13 +513,13 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
             }
         }
         // W3's first fragments ride under the epilogue; round r: output columns (8 r + wave) * 32 ..
-        const uint4* const wp3 = a.w3f + (size_t)wave * KG3 * 64 + lane;
+        const uint4* const wp3 = BN_L(w3f) + (size_t)wave * KG3 * 64 + lane;
 #pragma unroll
         for (int d = 0; d < D; ++d) wq[d] = wp3[d * 64];
         __syncthreads();                               // every wave is done with t1: t2 and phase C's table may overwrite it
         for (int i = t; i < 8 * C; i += 512) {
             const int w = i / (4 * C), c = i - w * 4 * C;
-            const float* src = w == 0 ? a.s3 : a.h3;
+            const float* src = w == 0 ? BN_L(s3) : BN_L(h3);
             tabC[i] = src ? src[c] : (w ? 0.0f : 1.0f);
         }
         // epilogue B -> t2: channels 32 wave + 16 p + 8 kk .. of pixel i*32 + l31
@@ -494,7 +559,8 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
 #define BN_RES_DMA(R)                                                                                          \
     {                                                                                                          \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                        \
-            BN_BLDS(yv ^ (unsigned)(j << 5), srdX, yrow + (unsigned)(j * 2 * 4 * C * 2 + (R) * 512), ybuf + j * 1024) \
+            if constexpr (STAGE) { BN_BLDS_DEV(yv ^ (unsigned)(j << 5), srdX, yrow + (unsigned)(j * 2 * 4 * C * 2 + (R) * 512), ybuf + j * 1024) } \
+            else { BN_BLDS(yv ^ (unsigned)(j << 5), srdX, yrow + (unsigned)(j * 2 * 4 * C * 2 + (R) * 512), ybuf + j * 1024) } \
         }                                                                                                      \
     }
         const __amdgpu_buffer_rsrc_t srdY = __builtin_amdgcn_make_buffer_rsrc(yimg, 0, (int)img_bytes, 0x00020000);
@@ -553,7 +619,7 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
             for (int j = 0; j < 8; ++j) {
                 typedef unsigned bn_u32x4 __attribute__((ext_vector_type(4)));
                 const bn_u32x4 v = *reinterpret_cast<const bn_u32x4*>(smem + (wave * 8 + j) * 1024 + lane * 16);
-                __builtin_amdgcn_raw_buffer_store_b128(v, srdY, (int)(yv ^ (unsigned)(j << 5)), (int)(yrow + (unsigned)(j * 2 * 4 * C * 2 + r * 512)), 0);
+                __builtin_amdgcn_raw_buffer_store_b128(v, srdY, (int)(yv ^ (unsigned)(j << 5)), (int)(yrow + (unsigned)(j * 2 * 4 * C * 2 + r * 512)), DEV);
             }
             __syncthreads();                            // ... and read out: the next round's shortcut may land
             if (r + 1 < 4) BN_RES_DMA(r + 1)
@@ -609,7 +675,7 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
         // phase C's table: scale | shift of the 4C output columns
         for (int i = t; i < 8 * C; i += 512) {
             const int w = i / (4 * C), c = i - w * 4 * C;
-            const float* src = w == 0 ? a.s3 : a.h3;
+            const float* src = w == 0 ? BN_L(s3) : BN_L(h3);
             tabC[i] = src ? src[c] : (w ? 0.0f : 1.0f);
         }
         // the first W3 step rides under the epilogue (the ring is free: the barrier above retired phase B's last reads)
@@ -872,8 +938,14 @@ __global__ __launch_bounds__(512) void k_bneck_h(const BneckArgs a)
             }
 #undef BN_ISSUE_W
         }
-        __syncthreads();                               // the next tile's phase A restarts the ring at stage 0
+        if constexpr (STAGE) BN_VMCNT0                 // this thread's output stores have completed ...
+        __syncthreads();                               // the next tile's phase A restarts the ring at stage 0 (STAGE: ... and everybody's)
+        if constexpr (STAGE) {
+            if (t == 0) __hip_atomic_store(a.done + tile, (unsigned)(layer + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
+    }
+#undef BN_L
     if (a.range_flag && range_trip) atomicOr(a.range_flag, 1);
 }
 
@@ -935,12 +1007,46 @@ void bneck_launch(hipStream_t s, int C, const void* x, void* y, int B, int H, in
     int grid = n_cus > 0 ? n_cus / 8 * 8 : 256;
     if (grid <= 0) grid = 8;
     if (a.ntiles < grid) grid = a.ntiles;
+    a.layers = nullptr; a.nlayers = 1; a.pp[0] = a.pp[1] = nullptr; a.done = nullptr;
     if (C == 256 && w1f && w2f && w3f) hipLaunchKernelGGL((k_bneck_h<256, true>), dim3(grid), dim3(512), 0, s, a);
     else if (C == 256) hipLaunchKernelGGL((k_bneck_h<256, false>), dim3(grid), dim3(512), 0, s, a);
     else if (C == 128) hipLaunchKernelGGL((k_bneck_h<128, false>), dim3(grid), dim3(512), 0, s, a);
     else if (first) hipLaunchKernelGGL((k_bneck_h<64, false, true>), dim3(grid), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((k_bneck_h<64, false>), dim3(grid), dim3(512), 0, s, a);
     HIP_CHECK(hipGetLastError());
+}
+
+// The identity blocks of a C = 256 stage as ONE launch (STAGE form).  layers: nlayers BneckLayer records on the device; pp0 holds the stage's
+// input and, with pp1, the two tensors the blocks ping-pong between (the result is in pp[nlayers & 1]); done: one counter per tile, zeroed here
+// on the stream (a memset node: the launch stays graph-capturable).  Needs the whole grid resident: at most one block per CU.
+void bneck_stage_launch(hipStream_t s, const void* layers_dev, int nlayers, void* pp0, void* pp1, int B, int H, int W, unsigned* done, int* range_flag, int n_cus)
+{
+    MRCNN_REQUIRE(bneck_geometry_ok(256, H, W), MRCNN_ERR_SHAPE, "bneck stage: C 256 at %dx%d", H, W);
+    MRCNN_REQUIRE(layers_dev && nlayers >= 1 && pp0 && pp1 && pp0 != pp1 && done && range_flag, MRCNN_ERR_INVALID, "bneck stage: bad argument");
+    MRCNN_REQUIRE((size_t)H * W * 1024 * 2 < 0x80000000ull, MRCNN_ERR_SHAPE, "bneck stage: image of %dx%dx1024 exceeds the 2-GB offset range", H, W);
+    BneckArgs a{};
+    a.B = B; a.H = H; a.W = W;
+    a.tiles_x = W / 16; a.tiles_y = H / 8; a.ntiles = B * a.tiles_x * a.tiles_y;
+    a.range_flag = range_flag;
+    a.dbg = 0;
+    a.layers = static_cast<const BneckLayer*>(layers_dev); a.nlayers = nlayers;
+    a.pp[0] = static_cast<_Float16*>(pp0); a.pp[1] = static_cast<_Float16*>(pp1);
+    a.done = done;
+    int grid = n_cus > 0 ? n_cus / 8 * 8 : 256;
+    if (grid <= 0) grid = 8;
+    if (a.ntiles < grid) grid = a.ntiles;
+    HIP_CHECK(hipMemsetAsync(done, 0, (size_t)a.ntiles * sizeof(unsigned), s));
+    hipLaunchKernelGGL((k_bneck_h<256, true, false, true>), dim3(grid), dim3(512), 0, s, a);
+    HIP_CHECK(hipGetLastError());
+}
+size_t bneck_layer_record_bytes() { return sizeof(BneckLayer); }
+void bneck_layer_record(void* dst, const void* w1f, const void* w2f, const void* w3f, const float* s1, const float* h1, const float* s2, const float* h2,
+                        const float* s3, const float* h3)
+{
+    BneckLayer L;
+    L.w1f = static_cast<const uint4*>(w1f); L.w2f = static_cast<const uint4*>(w2f); L.w3f = static_cast<const uint4*>(w3f);
+    L.s1 = s1; L.h1 = h1; L.s2 = s2; L.h2 = h2; L.s3 = s3; L.h3 = h3;
+    memcpy(dst, &L, sizeof(L));
 }
 
 }  // namespace mrcnn

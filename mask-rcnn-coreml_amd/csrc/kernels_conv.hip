@@ -583,6 +583,11 @@ static int g_tail = env_int("MRCNN_TAIL", 0);
 // fp16 mode: identity bottleneck blocks (branch2a + branch2b + branch2c + shortcut) as ONE persistent launch with the two mid tensors on chip
 // (kernels_bneck.hip; bit-identical to the three launches).  MRCNN_BNECK=0 / mrcnn_debug_set("conv_bneck", 0): the three launches.
 static int g_bneck = env_int("MRCNN_BNECK", 1);
+// ... and (round 6) the consecutive identity blocks of a C = 256 stage — C4: 22 of ResNet-101's blocks — as ONE launch whose tiles wait for their
+// neighbours' previous block instead of for a launch boundary (kernels_bneck.hip, STAGE form; bit-identical).  Measured EQUAL to one launch per
+// block (profiles/r06_bneck_stage_ab.txt) and dependent on the whole grid being resident, so OFF by default: MRCNN_BNECK_STAGE=1 /
+// mrcnn_debug_set("conv_bneck_stage", 1) switch it on.
+static int g_bneck_stage = env_int("MRCNN_BNECK_STAGE", 0);
 // fp16 mode: 3x3 stride-1 layers with 256 | 512 output columns on the halo-tile / fragment-streaming kernel (kernels_conv3x3_h.hip; its own K order)
 // 0: never; 1 (default): where the RPN's heads ride in its epilogue (the engine's P2..P4 levels) — as a plain 3x3 layer it equals the ping-pong kernel
 // on the large levels and loses on under-filled grids (profiles/r05_c3h_ab.txt); 2: every eligible layer (tests, A/B); 3: as 1, heads as their own launch (A/B)
@@ -681,6 +686,7 @@ bool conv_debug_set(const char* key, int value)
     else if (k == "conv_stem") g_stem = value;
     else if (k == "conv_tail_dbg") g_tail_dbg = value;
     else if (k == "conv_bneck") g_bneck = value;
+    else if (k == "conv_bneck_stage") g_bneck_stage = value;
     else if (k == "conv_c3h") g_c3h = value;
     else return conv_halo_debug_set(key, value);
     return true;
@@ -1026,6 +1032,37 @@ void conv_bneck_forward(hipStream_t s, const ConvDesc& da, const ConvDesc& db, c
         const double M = (double)da.B * da.H * da.W, C = da.Cout;
         const double fl = 2.0 * M * (4 * C * C + 9 * C * C + 4 * C * C);      // algorithmic flops of the three layers (the halo recompute is not work)
         prof->pending.push_back({7, fl, e0, e1, {(int)M, 4 * da.Cout, 17 * da.Cout, 7}, da.group});
+    }
+}
+
+void conv_bneck_stage_forward(hipStream_t s, const BneckTriple* blocks, int n, const void* layers_dev, unsigned* done)
+{
+    static int n_cus = [] { int dev = 0; hipDeviceProp_t p; (void)hipGetDevice(&dev); return hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }();
+    bool stage = n >= 2 && g_bneck == 1 && g_bneck_stage && layers_dev && done && g_range_flag;
+    if (stage) {
+        const ConvDesc& a0 = blocks[0].a;
+        const long ntiles = (long)a0.B * (a0.H / 8) * (a0.W / 16);
+        stage = a0.Cout == 256 && ntiles * 8 >= (long)n_cus * 7;           // the per-block rule: an under-filled grid runs the three launches
+        for (int i = 0; i < n && stage; ++i) {
+            const BneckTriple& t = blocks[i];
+            stage = conv_bneck_fusable(t.a, t.b, t.c) && t.a.wgt_frag && t.b.wgt_frag && t.c.wgt_frag && t.a.Cout == 256 && t.a.B == a0.B && t.a.H == a0.H && t.a.W == a0.W;
+            if (i > 0) stage = stage && t.a.in == blocks[i - 1].c.out && (i < 2 || t.c.out == blocks[i - 2].c.out);      // a chain between two tensors
+        }
+        stage = stage && blocks[1].c.out == a0.in;
+    }
+    if (!stage) {
+        for (int i = 0; i < n; ++i) conv_bneck_forward(s, blocks[i].a, blocks[i].b, blocks[i].c);
+        return;
+    }
+    const ConvDesc& a0 = blocks[0].a;
+    ConvProfile* prof = (g_prof && g_prof->active) ? g_prof : nullptr;
+    const int e0 = prof ? prof_event(prof, s) : 0;
+    bneck_stage_launch(s, layers_dev, n, const_cast<void*>(a0.in), blocks[0].c.out, a0.B, a0.H, a0.W, done, g_range_flag, n_cus);
+    if (prof) {
+        const int e1 = prof_event(prof, s);
+        const double M = (double)a0.B * a0.H * a0.W, C = a0.Cout;
+        const double fl = 2.0 * M * (4 * C * C + 9 * C * C + 4 * C * C) * n;      // algorithmic flops of the n blocks
+        prof->pending.push_back({7, fl, e0, e1, {(int)M, 4 * a0.Cout, 17 * a0.Cout * n, 7}, a0.group});
     }
 }
 

@@ -149,3 +149,62 @@ def test_fused_stage_entry_block_equals_the_four_launches_bitwise(B, H, W):
     y = F.relu(F.conv2d(t2, h(w3).reshape(256, 64, 1, 1)) * v(bn[4]) + v(bn[5]) + sc).permute(0, 2, 3, 1).numpy()
     bad = np.abs(fused - y) > 2e-3 * np.maximum(1.0, np.abs(y))
     assert bad.mean() < 1e-3
+
+
+# ---- round 6: the consecutive identity blocks of a C = 256 stage as ONE launch (STAGE form) ----------------------------------------------
+def bneck_stage(x, w1, w2, w3, bn6, form, iters=0):
+    import ctypes as C
+    B, H, W, C4 = x.shape
+    n = w1.shape[0]
+    out = np.empty((B, H, W, C4), np.float32)
+    ms = np.zeros(1, np.float32)
+    flag = np.zeros(1, np.int32)
+    keep = [np.ascontiguousarray(a, np.float32) for a in (x, w1, w2, w3) + tuple(bn6)]
+    arr = (C.c_void_p * 6)(*[k.ctypes.data for k in keep[4:]])
+    L.check(L.lib().mrcnn_bottleneck_stage_nhwc(keep[0].ctypes.data, B, H, W, n, *[k.ctypes.data for k in keep[1:4]], arr, int(form), iters,
+                                                 out.ctypes.data, ms.ctypes.data, flag.ctypes.data))
+    return out, float(ms[0]), int(flag[0])
+
+
+def make_stage(n, B, H, W, seed=0):
+    """n blocks whose residual chain stays inside the fp16 range (a damped branch: BatchNorm scale 0.25 on branch2c)."""
+    rng = np.random.default_rng(seed)
+    C = 256
+    x = np.maximum(rng.standard_normal((B, H, W, 4 * C)), 0).astype(np.float32)
+    w1 = (rng.standard_normal((n, C, 4 * C)) * np.sqrt(2.0 / (4 * C))).astype(np.float32)
+    w2 = (rng.standard_normal((n, C, 3, 3, C)) * np.sqrt(2.0 / (9 * C))).astype(np.float32)
+    w3 = (rng.standard_normal((n, 4 * C, C)) * np.sqrt(2.0 / C)).astype(np.float32)
+    bn = []
+    for width, gain in ((C, 1.0), (C, 1.0), (4 * C, 0.25)):
+        bn.append((gain * (1.0 + 0.1 * rng.standard_normal((n, width)))).astype(np.float32))
+        bn.append((0.05 * rng.standard_normal((n, width))).astype(np.float32))
+    return x, w1, w2, w3, bn
+
+
+@pytest.mark.parametrize("n,B,H,W", [(2, 1, 8, 16), (3, 1, 16, 32), (5, 2, 64, 64), (22, 8, 64, 64), (4, 9, 64, 64), (3, 1, 24, 48)])
+def test_whole_stage_launch_equals_one_launch_per_block_bitwise(n, B, H, W):
+    """res4b..res4w of the fp16 mode (Conversion/task.py:69-92) as ONE launch whose tiles wait for their neighbours' previous block
+    (per-tile counters, device-scope stores / loads) against 22 fused launches: same tile arithmetic, so every bit agrees; (4, 9, 64, 64):
+    288 tiles on 256 blocks (a block owns more than one tile); (3, 1, 24, 48): a 3 x 3 tile grid (a centre tile with all eight neighbours)."""
+    x, w1, w2, w3, bn = make_stage(n, B, H, W, seed=n + H)
+    one, _, flag1 = bneck_stage(x, w1, w2, w3, bn, 1)
+    per, _, flag0 = bneck_stage(x, w1, w2, w3, bn, 0)
+    assert flag1 == 0 and flag0 == 0, f"flag words {flag1} / {flag0} (bit 0: fp16 range, bit 1: no progress)"
+    assert np.isfinite(one).all() and one.max() > 0
+    nz = np.flatnonzero(one.view(np.uint32) != per.view(np.uint32))
+    assert nz.size == 0, f"{nz.size} of {one.size} outputs differ, first at {np.unravel_index(nz[0], one.shape)}: {one.flat[nz[0]]} vs {per.flat[nz[0]]}"
+
+
+def test_whole_stage_launch_is_repeatable_and_chains_the_single_block_form():
+    """200 launches of a 6-block stage give the same bits (a missed neighbour wait or a stale line would show as a changed halo row),
+    and the result equals chaining the single-block entry the other tests pin against the three launches and fp64."""
+    n, B, H, W = 6, 2, 64, 64
+    x, w1, w2, w3, bn = make_stage(n, B, H, W, seed=11)
+    ref, _, _ = bneck_stage(x, w1, w2, w3, bn, 1)
+    cur = x
+    for l in range(n):
+        cur, _ = bneck(cur, w1[l], w2[l], w3[l], [b[l] for b in bn], True)
+    assert np.array_equal(cur.view(np.uint32), ref.view(np.uint32))
+    for _ in range(4):
+        again, _, flag = bneck_stage(x, w1, w2, w3, bn, 1, iters=50)
+        assert flag == 0 and np.array_equal(again.view(np.uint32), ref.view(np.uint32))
