@@ -12,7 +12,11 @@ the fixed-size detection records.  Weak scaling: every GPU proc
 Weights are seeded synthetic weights of the exact architecture ("forced full load": 1000 proposals and
 100 detections per image, so no data-dependent stage idles); there is no network for checkpoints.
 
-Default compute mode: f32x3 — fp32 tensors, fp32 accumulation, products formed on the fp16 matrix cores from a three-part
+Default compute mode: the one a drop-in host gets (round 6).  Rank 0 writes the synthetic artefacts, calibrates them once the way
+`convert --calibrate` does (convert.calibrate_artefact: the split exponents of the tensor groups stored in MaskRCNN.mrcw) and every rank
+loads the model WITHOUT naming a precision (MRCNN_DEFAULT, as `MaskRCNN()` in ViewController.swift:37): an artefact that carries stored
+exponents resolves to f32x3 (`config.model_loaded_by`, `dtype` in the line).  `--dtype f32x3` etc. load explicitly as before.
+f32x3 — fp32 tensors, fp32 accumulation, products formed on the fp16 matrix cores from a three-part
 fp16 split of the activation × the fp16-stored filter: an activation with 0.5 <= |a| < 65504 is carried EXACTLY (all 24
 significand bits, so a*w is the exact product), a smaller one to 2^-25 ABSOLUTE (rounded to nearest: the third part
 reaches the fp16 subnormal step) — so the engine stores every tensor a split convolution reads as 2^e * value, with a power-of-two
@@ -36,8 +40,11 @@ only.  Rank 0 writes the synthetic model directory once; `per_rank_ms_per_step` 
 Rank 0 prints ONE JSON line with, besides the contract fields:
   roofline     — dominant conv kernel (the tile class with the largest share of the step): its ALGORITHMIC flops per
                  launch ÷ its average launch duration, both measured live with HIP events on the launching stream
-                 inside the timed region (the first --event-steps steps of it: bracketing every launch drains the
-                 queue between kernels); peak = dense fp16 MFMA 2500 TFLOP/s ÷ the MFMA passes per product
+                 in --event-steps further steps of the same batch run RIGHT BEHIND the timed region (round 6: every timed
+                 step is uninstrumented — bracketing every launch drains the queue between kernels and cost ~2 % of an
+                 fp32 step, ~13 % of an fp16 one; shares are taken against those instrumented steps' own wall time); every
+                 tile class carries its bound (mfma | hbm: the larger of flops / MFMA peak and ALGORITHMIC bytes / 8 TB/s),
+                 GB/s and frac_of_hbm beside TFLOP/s — the 1x1 layers of the fp32-tensor modes are HBM-bound; peak = dense fp16 MFMA 2500 TFLOP/s ÷ the MFMA passes per product
                  (f32x3: 3, f32s: 2, f16: 1) or 157.3 TFLOP/s for the fp32-MFMA mode
   cpu_baseline — the oracle (torch-CPU fp32 network + the C restatement of the custom layers) timed on this
                  box's host cores on a bounded sample of the same workload (rank 0, N = 1 only), to the reference's
@@ -85,8 +92,9 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--num-classes", type=int, default=81, help="BASELINE configs[4] uses 2")
     ap.add_argument("--pre-nms", type=int, default=6000, help="preNMSMaxProposals (BASELINE configs[4]: 12000)")
-    ap.add_argument("--dtype", default="f32x3", choices=["f32", "f16", "f32s", "f32x3"],
-                    help="compute mode of the convolutions.  f32x3 (default): fp32 tensors, products a*w formed on the "
+    ap.add_argument("--dtype", default="default", choices=["default", "f32", "f16", "f32s", "f32x3"],
+                    help="compute mode of the convolutions.  default: the artefact is calibrated once (convert.calibrate_artefact = `convert --calibrate`) and loaded with "
+                         "MRCNN_DEFAULT, which resolves to f32x3 — what a drop-in host gets.  f32x3: fp32 tensors, products a*w formed on the "
                          "fp16 matrix cores from a three-part split of the fp32 activation against the fp16-stored filter "
                          "(task.py:90; exact for 0.5 <= |a| < 65504, the activation carried to 2^-25 absolute below), fp32 accumulate — measured closer to an fp64 evaluation than the fp32-MFMA engine "
                          "(profiles/r03_fp64_trunk_parity.json), 99.97 %% of 25 600 detections matched end to end with the CPU oracle (profiles/r03_parity_e2e_256.json); "
@@ -107,8 +115,8 @@ def main():
     ap.add_argument("--no-other-modes", action="store_true",
                     help="skip the short extra timed loops of the other compute modes (reported under other_modes, N = 1 only)")
     ap.add_argument("--event-steps", type=int, default=3,
-                    help="conv launches are bracketed by HIP events during the first N steps of the timed region "
-                         "(the events cost ~2 %% of an fp32 step, ~13 %% of an fp16 one); 0 = all steps")
+                    help="conv launches are bracketed by HIP events during N further steps behind the timed region "
+                         "(the events cost ~2 %% of an fp32 step, ~13 %% of an fp16 one: kept out of `value`); 0 = as many as --steps")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -154,16 +162,35 @@ def main():
     cfg = pkg.ModelConfig(architecture=args.arch, input_image_shape=(args.size, args.size, 3), num_classes=args.num_classes,
                           pre_nms_max_proposals=args.pre_nms)
     # rank 0 writes the 250 MB synthetic model directory ONCE; the other ranks of the node load the same files
-    model_dir = shared_model_dir(rank, use_dist, lambda d: weights.save_synthetic_models(d, cfg, seed=0, forced_load=True))
-    m = models.load_maskrcnn(model_dir, max_batch=args.batch, compute_dtype=args.dtype)
     B = args.batch
+    # (the calibration images: their OWN stream, seed 7 — disjoint from the timed batch and from the end-to-end images, which come from the seed-1 stream)
+    calib_np = np.random.default_rng(7).integers(0, 256, (min(B, 2), args.size, args.size, 3), dtype=np.uint8)
+    by_default = args.dtype == "default"
+    stored_info = {}
+
+    def write_artefacts(d):
+        weights.save_synthetic_models(d, cfg, seed=0, forced_load=True)
+        if by_default and not args.no_calibrate:
+            # what `python -m mask-rcnn-coreml_amd.convert ... --calibrate images` does behind the conversion: one calibration predict on the GPU,
+            # the exponent vector stored in MaskRCNN.mrcw ("split_exp.<group>")
+            convert = importlib.import_module("mask-rcnn-coreml_amd.convert")
+            stored_info.update(convert.calibrate_artefact(d, calib_np, verbose=False))
+
+    model_dir = shared_model_dir(rank, use_dist, write_artefacts)
+    # by default NO precision is named (MRCNN_DEFAULT): the library resolves it from the artefact — stored exponents -> f32x3
+    m = models.load_maskrcnn(model_dir, max_batch=args.batch) if by_default else models.load_maskrcnn(model_dir, max_batch=args.batch, compute_dtype=args.dtype)
+    args.dtype = m.compute_dtype
+    loaded_by = (f"MRCNN_DEFAULT (no precision named, as MaskRCNN() in ViewController.swift:37) -> {m.compute_dtype}: "
+                 + ("the artefact carries stored split exponents (convert.calibrate_artefact = convert --calibrate)" if m.get_int("split_exponents_from_artefact")
+                    else "the artefact carries no stored split exponents")) if by_default else f"explicit compute_dtype {args.dtype}"
     # Scale-aware split (include/maskrcnn_hip.h: mrcnn_model_calibrate_split): the split modes run with a power-of-two pre-scale
     # per tensor group, chosen from ONE calibration predict on a canonical batch — two images of a separate seeded stream, the
     # same on every rank, so every rank holds the same exponent vector (per-image results do not depend on the rank).
     split_info = None
-    # (its OWN stream, seed 7: disjoint from the timed batch and from the end-to-end images, which come from the seed-1 stream)
-    calib = torch.from_numpy(np.random.default_rng(7).integers(0, 256, (min(B, 2), args.size, args.size, 3), dtype=np.uint8)).to(dev)
-    if args.dtype in ("f32x3", "f32s") and not args.no_calibrate:
+    calib = torch.from_numpy(calib_np).to(dev)
+    if by_default:
+        split_info = dict(stored_info, source="stored in MaskRCNN.mrcw by convert.calibrate_artefact, applied by mrcnn_model_load") if stored_info else None
+    elif args.dtype in ("f32x3", "f32s") and not args.no_calibrate:
         split_info = m.calibrate_split(calib)
     # synthetic batch, uint8 uniform[0,255], seed 1; a different slice of the stream per rank
     rng = np.random.default_rng(1)
@@ -194,9 +221,6 @@ def main():
     for _ in range(args.warmup):
         step()
     drain()
-    if not args.no_kernel_events:
-        m.conv_profile_enable(True)
-    m.enable_timing(True)
 
     def fence():
         torch.cuda.synchronize()
@@ -207,24 +231,37 @@ def main():
     fence()
     busy0, calls0 = m.get_int("gpu_busy_us"), m.get_int("predict_calls")
     t0 = time.perf_counter()
-    ev_steps = 0 if args.no_kernel_events else (min(args.event_steps, args.steps) if args.event_steps > 0 else args.steps)
-    for i in range(args.steps):
-        if i == ev_steps and not args.no_kernel_events:
-            m.conv_profile_enable(False)               # window closed, totals kept
+    for i in range(args.steps):                        # EXACTLY K uninstrumented steps: no stage timer, no event around any launch
         step()
     drain()                                            # the last exchange belongs to the timed region
     fence()
     elapsed = time.perf_counter() - t0
-    if not args.no_kernel_events and ev_steps >= args.steps:
-        m.conv_profile_enable(False)                   # (a window as long as the timed region: closed here, totals kept)
     busy_s = (m.get_int("gpu_busy_us") - busy0) * 1e-6
     busy_calls = m.get_int("predict_calls") - calls0
+    # The instrumented steps: the SAME step a few more times right behind the timed region, with every conv launch
+    # bracketed by HIP events and the stage timer on — `roofline` and `stage_ms_last_step` come from these, `value` from none of them.
+    ev_steps = 0 if args.no_kernel_events else (args.event_steps if args.event_steps > 0 else args.steps)
+    m.enable_timing(True)
+    if not args.no_kernel_events:
+        m.conv_profile_enable(True)
+    torch.cuda.synchronize()
+    t_ev = time.perf_counter()
+    for i in range(max(ev_steps, 1)):
+        step()
+    drain()
+    torch.cuda.synchronize()
+    ev_elapsed = time.perf_counter() - t_ev            # wall time of the instrumented steps: what the shares below are taken against
+    if not args.no_kernel_events:
+        m.conv_profile_enable(False)                   # window closed, totals kept
+    if use_dist:
+        dist.barrier()
     every = gather_elapsed(elapsed, world) if use_dist else [elapsed]
     per_rank_ms = [1e3 * e / args.steps for e in every]
     elapsed = max(every)                                        # the job is as slow as its slowest rank
 
     prof = m.conv_profile() if not args.no_kernel_events else None
     prof_groups = m.conv_profile_groups() if not args.no_kernel_events else None
+    prof_bytes = m.conv_profile_bytes() if not args.no_kernel_events else None
     stages = m.stage_ms()
     n_prop = int(m.read_tensor("keep_count", 0)[0])
     n_det = int((det[0, :, 5] > 0).sum().item())
@@ -261,6 +298,7 @@ def main():
                                    + f"{args.arch}+FPN {args.size}x{args.size}, batch {B} per GPU, "
                                    f"{args.num_classes} classes, pre_nms {args.pre_nms}, max_proposals 1000, max_detections 100; "
                                    f"synthetic seeded weights (forced full load)",
+                       "model_loaded_by": loaded_by,
                        "global_batch": n_gpus * B, "parallelism": f"dp{n_gpus}" if n_gpus > 1 else "single",
                        "proposals_kept_image0": n_prop, "detections_image0": n_det},
             "stage_ms_last_step": {k: round(v, 3) for k, v in stages.items()},
@@ -306,15 +344,15 @@ def main():
                     "launches_per_step": launches // ev_steps, "event_steps": ev_steps,
                     "avg_launch_ms": round(ms / launches, 4),
                     "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
-                    "share_of_step_time": round(ms / (1e3 * elapsed * ev_steps / args.steps), 4),
-                    "by_tile_class": {k: {"launches_per_step": v[0] // ev_steps, "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1),
-                                          "share_of_step_time": round(v[1] / (1e3 * elapsed * ev_steps / args.steps), 4)}
-                                      for k, v in prof.items() if v[0]},
+                    "share_of_step_time": round(ms / (1e3 * ev_elapsed), 4),
+                    "instrumented": {"steps": ev_steps, "ms_per_step": round(1e3 * ev_elapsed / max(ev_steps, 1), 3),
+                                     "note": "run right behind the timed region; `value` / `ms_per_step` above come from uninstrumented steps only"},
+                    "by_tile_class": {k: tile_class_entry(v, prof_bytes[k], ev_steps, ev_elapsed, peak) for k, v in prof.items() if v[0]},
                     "all_conv_kernels": {"tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2),
                                          "frac": round(all_fl / (all_ms * 1e-3) / 1e12 / peak, 4),
                                          "gflop_per_image": round(all_fl / (B * ev_steps) / 1e9, 2),
                                          "survey_gflop_per_image": GFLOP_PER_IMAGE_SURVEY,
-                                         "share_of_step_time": round(all_ms / (1e3 * elapsed * ev_steps / args.steps), 4)},
+                                         "share_of_step_time": round(all_ms / (1e3 * ev_elapsed), 4)},
                 }
                 if prof_groups and prof_groups["backbone"][0]:
                     # the subset north_star's ">= 50 % MFMA roofline for the backbone convs" is worded on: conv1 + res2..res5 (C1-C5)
@@ -322,7 +360,7 @@ def main():
                     out["roofline"]["backbone_convs"] = {
                         "tflops": round(bfl / (bms * 1e-3) / 1e12, 2), "frac": round(bfl / (bms * 1e-3) / 1e12 / peak, 4),
                         "gflop_per_image": round(bfl / (B * ev_steps) / 1e9, 2), "survey_gflop_per_image": GFLOP_BACKBONE_SURVEY.get(args.arch),
-                        "launches_per_step": bl // ev_steps, "share_of_step_time": round(bms / (1e3 * elapsed * ev_steps / args.steps), 4),
+                        "launches_per_step": bl // ev_steps, "share_of_step_time": round(bms / (1e3 * ev_elapsed), 4),
                         "what": "conv1 + the res2..res5 stages (SURVEY.md section 8d 'backbone convs'); every other convolution (FPN, RPN, heads) is in all_conv_kernels only"}
                 if live_probe:
                     # held against what THIS box's matrix cores sustain in this process, the figure is comparable across boxes of the pool
@@ -377,7 +415,24 @@ def main():
                     mm.predict_into(images, det, mask, sync=True)
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t0) / n_om
+                # ... and two instrumented steps behind its timed loop: the backbone subset of THIS mode against its own MFMA roof
+                bb = None
+                if not args.no_kernel_events:
+                    mm.conv_profile_enable(True)
+                    for _ in range(2):
+                        mm.predict_into(images, det, mask, sync=True)
+                    mm.conv_profile_enable(False)
+                    g_ = mm.conv_profile_groups()
+                    p_ = mm.conv_profile()
+                    parts_ = {"f32": 1, "f16": 1, "f32s": 2, "f32x3": 3}[mode]
+                    peak_ = PEAK_FP32_MFMA_TFLOPS if mode == "f32" else PEAK_FP16_MFMA_TFLOPS / parts_
+                    if g_["backbone"][0]:
+                        bt = g_["backbone"][2] / (g_["backbone"][1] * 1e-3) / 1e12
+                        at = sum(v[2] for v in p_.values()) / (sum(v[1] for v in p_.values()) * 1e-3) / 1e12
+                        bb = {"backbone_convs": {"tflops": round(bt, 1), "frac": round(bt / peak_, 4)},
+                              "all_conv_kernels": {"tflops": round(at, 1), "frac": round(at / peak_, 4)}, "peak_tflops": round(peak_, 1)}
                 out["other_modes"][mode] = {"value": round(B / dt, 1), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3), "steps": n_om,
+                                            "roofline": bb,
                                             "note": {"f32": "exact-fp32 MFMA", "f16": "fp16 tensors + fp16 MFMA (BASELINE configs[3])",
                                                      "f32s": "fp32 tensors, two fp16 MFMA passes over a hi/lo split of the activations "
                                                              "(fp32-grade: parity-tested at the fp32 tolerances)",
@@ -439,6 +494,24 @@ def host_group_init(rank, world):
         dist.init_process_group("gloo")
     else:
         dist.init_process_group("gloo", rank=0, world_size=1)
+
+
+PEAK_HBM_GBPS = 8000.0                 # MI355X_MICROARCH.md: HBM3E spec
+HBM_MEASURED_GBPS = 6290.0             # the streaming rate this engine's kernels have measured on the pool (profiles/r05_pmc_kernels_f32x3.txt: ROIAlign 6.28 TB/s)
+
+
+def tile_class_entry(v, nbytes, ev_steps, ev_elapsed, peak_tflops):
+    """One tile class of the conv family: its rate against BOTH roofs and which one bounds it.  ALGORITHMIC bytes (every operand across HBM once:
+    conv_algorithmic_bytes in kernels_conv.hip) over the class's summed launch time; bound = whichever of flops / MFMA peak and bytes / 8 TB/s is larger."""
+    launches, ms, flops = v
+    tflops = flops / (ms * 1e-3) / 1e12
+    gbps = nbytes / (ms * 1e-3) / 1e9
+    t_mfma, t_hbm = flops / (peak_tflops * 1e12), nbytes / (PEAK_HBM_GBPS * 1e9)
+    return {"launches_per_step": launches // max(ev_steps, 1), "share_of_step_time": round(ms / (1e3 * ev_elapsed), 4),
+            "bound": "hbm" if t_hbm > t_mfma else "mfma",
+            "tflops": round(tflops, 1), "frac_of_mfma": round(tflops / peak_tflops, 4),
+            "algorithmic_bytes_per_launch": int(nbytes / launches), "gbps": round(gbps, 1),
+            "frac_of_hbm": round(gbps / PEAK_HBM_GBPS, 4), "frac_of_hbm_measured": round(gbps / HBM_MEASURED_GBPS, 4)}
 
 
 def shared_model_dir(rank, use_dist, write):
@@ -686,7 +759,8 @@ def cpu_baseline(model_dir, cfg, args, imgs):
         dets.append(d[0]); masks.append(k[0])
     med = float(np.median(ts))
     rec = {"value": round(1.0 / med, 4), "unit": "images/s", "cores": int(torch.get_num_threads()), "physical_cores": physical,
-           "logical_cores": logical, "kind": "port",
+           "logical_cores": logical, "kind": "port", "images": len(ts), "ms_per_image": {"median": round(med * 1e3, 1), "min": round(min(ts) * 1e3, 1), "max": round(max(ts) * 1e3, 1)},
+           "note": "context only: the figure swings 0.14-0.24 images/s across boxes / rounds on 5 images — no GPU/CPU ratio should be quoted from it",
            "sample": f"{len(ts)} images of the same workload after 1 warm-up, batch 1, median {round(med * 1e3, 1)} ms/image "
                      f"(min {round(min(ts) * 1e3, 1)}, max {round(max(ts) * 1e3, 1)}); torch-CPU fp32 network (oneDNN, "
                      f"{int(torch.get_num_threads())} threads = physical cores) + C restatement of the custom layers (1 thread)"}

@@ -9,7 +9,7 @@
  *
  *   cc -std=c99 -Iinclude examples/maskrcnn_predict.c -Lmask-rcnn-coreml_amd -lmaskrcnn_hip \
  *      -Wl,-rpath,$PWD/mask-rcnn-coreml_amd -Wl,-rpath-link,/opt/rocm/lib -o maskrcnn_predict
- *   ./maskrcnn_predict <artefact dir> <image.rgb> <height> <width> [f32|f16|f32s|f32x3]
+ *   ./maskrcnn_predict <artefact dir> <image.rgb> <height> <width> [default|f32|f16|f32s|f32x3]
  *
  * <artefact dir> holds MaskRCNN.mrcw, Classifier.mrcw, Mask.mrcw, anchors.bin; <image.rgb> is raw
  * interleaved RGB8 of height×width.  Exit status 0 on success; on failure the mrcnn_last_error()
@@ -42,12 +42,14 @@ static double now_s(void)
 int main(int argc, char** argv)
 {
     if (argc < 5) {
-        fprintf(stderr, "usage: %s <artefact dir> <image.rgb> <height> <width> [f32|f16|f32s|f32x3]\n", argv[0]);
+        fprintf(stderr, "usage: %s <artefact dir> <image.rgb> <height> <width> [default|f32|f16|f32s|f32x3]\n", argv[0]);
         return 64;
     }
     const char* dir = argv[1];
     const int h = atoi(argv[3]), w = atoi(argv[4]);
-    const int dtype = argc <= 5 ? MRCNN_F32 : strcmp(argv[5], "f16") == 0 ? MRCNN_F16 : strcmp(argv[5], "f32s") == 0 ? MRCNN_F32S : strcmp(argv[5], "f32x3") == 0 ? MRCNN_F32X3 : MRCNN_F32;
+    /* no precision named (as `MaskRCNN()` in ViewController.swift:37): MRCNN_DEFAULT = the mode the artefact is prepared for */
+    const int dtype = argc <= 5 || strcmp(argv[5], "default") == 0 ? MRCNN_DEFAULT : strcmp(argv[5], "f16") == 0 ? MRCNN_F16 : strcmp(argv[5], "f32s") == 0 ? MRCNN_F32S
+                    : strcmp(argv[5], "f32x3") == 0 ? MRCNN_F32X3 : MRCNN_F32;
     char path[4][4096];
     snprintf(path[0], sizeof path[0], "%s/anchors.bin", dir);
     snprintf(path[1], sizeof path[1], "%s/Classifier.mrcw", dir);

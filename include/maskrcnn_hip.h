@@ -53,7 +53,9 @@ MRCNN_API int mrcnn_device_count(void);
 typedef enum {
     MRCNN_F32 = 0, MRCNN_F64 = 1, MRCNN_F16 = 2, MRCNN_U8 = 3, MRCNN_I32 = 4,
     MRCNN_F32S = 5,  /* compute mode only (mrcnn_model_load): fp32 tensors, fp16 filters, split-fp16 MFMA — see there */
-    MRCNN_F32X3 = 6  /* compute mode only: as MRCNN_F32S with a three-part split (all 24 significand bits for |a| >= 0.5) */
+    MRCNN_F32X3 = 6, /* compute mode only: as MRCNN_F32S with a three-part split (all 24 significand bits for |a| >= 0.5) */
+    MRCNN_DEFAULT = -1 /* compute mode only (mrcnn_model_load): what the ARTEFACT is prepared for — MRCNN_F32X3 when MaskRCNN.mrcw carries
+                        * stored split exponents (convert.py --calibrate), MRCNN_F32 otherwise; see mrcnn_model_load */
 } mrcnn_dtype;
 typedef enum { MRCNN_HOST = 0, MRCNN_DEVICE = 1 } mrcnn_memspace;
 
@@ -147,8 +149,12 @@ typedef struct mrcnn_model mrcnn_model;
  * config singleton at load time (like ProposalLayer.init, ProposalLayer.swift:68), and loaded ONCE
  * (the reference re-loads the sub-models on every evaluate, TimeDistributedClassifierLayer.swift:41 —
  * deliberately not reproduced).  max_batch sizes the activation arena (images per predict call).
- * compute_dtype: MRCNN_F32 (exact-fp32 MFMA, fp32 activations — the default and the parity
- * baseline), MRCNN_F16 (fp16 activations and filters, fp32 accumulate, fp32 box path and outputs:
+ * compute_dtype: MRCNN_DEFAULT — what a drop-in host passes (`MaskRCNN()` of ViewController.swift:37 names no precision): a MaskRCNN
+ * artefact that carries stored split exponents ("split_exp.<group>" metadata, written by `convert --calibrate`) loads as MRCNN_F32X3
+ * — fp32 tensors, every product exact, the mode bench.py's `value` is measured in — with those exponents applied; any other artefact
+ * (no calibration stored; the stand-alone Classifier / Mask models) loads as MRCNN_F32.  mrcnn_model_get_int "compute_dtype" returns
+ * the resolved mode, "compute_dtype_defaulted" 1 when it was chosen this way.  Explicit modes: MRCNN_F32 (exact-fp32 MFMA, fp32
+ * activations — the parity baseline), MRCNN_F16 (fp16 activations and filters, fp32 accumulate, fp32 box path and outputs:
  * BASELINE configs[3]) or MRCNN_F32S (everything stays fp32 in memory; each convolution runs as TWO fp16
  * MFMA passes over a hi/lo split of its fp32 activations against the fp16 filters the artefact stores
  * (task.py:90), fp32 accumulate: products are exact, the split carries 22 of the 24 significand bits —
@@ -252,7 +258,10 @@ MRCNN_API int mrcnn_maskrcnn_predict_async(mrcnn_model* model, const uint8_t* rg
  *   mrcnn_dist_simulate_host  the pack -> concatenate (what ncclAllGather does) -> unpack code of the device path run on
  *                          host buffers for all `world` ranks in one process (detections[r] / masks[r] = rank r's local
  *                          results, status[r] optional): the seam through which the layout is tested at world sizes the
- *                          build machine does not have */
+ *                          build machine does not have.  status[r] == MRCNN_DIST_ABORTED models a rank that could not even
+ *                          enqueue a zeroed slot and tore the communicator down (ncclCommAbort): the call fails with
+ *                          MRCNN_ERR_HIP — what every peer's ncclAllGather does then — and writes nothing */
+#define MRCNN_DIST_ABORTED (-1)
 typedef struct mrcnn_dist mrcnn_dist;
 MRCNN_API int mrcnn_dist_unique_id(uint8_t* id128);
 MRCNN_API int mrcnn_dist_init(int rank, int world, const uint8_t* id128, mrcnn_dist** out);

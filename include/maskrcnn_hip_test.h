@@ -35,7 +35,11 @@ typedef struct mrcnn_conv_shape_stat {
     int32_t M, N, K, tile;
     int64_t launches;
     double total_ms, total_flops;
+    double total_bytes;      /* ALGORITHMIC bytes: every operand of the layer across HBM once (inputs read, filters, residual, outputs stored) */
 } mrcnn_conv_shape_stat;
+/* ALGORITHMIC bytes of the launches counted in tile class `tile` (as mrcnn_model_conv_profile_get's totals): what a memory-bound class is priced
+ * against (bench.py: roofline.by_tile_class[*].bound / frac_of_hbm). */
+MRCNN_API int mrcnn_model_conv_profile_bytes(mrcnn_model* model, int tile, double* total_bytes);
 MRCNN_API int mrcnn_model_conv_profile_shapes(mrcnn_model* model, mrcnn_conv_shape_stat* out, int capacity, int* count);
 
 /* ---------------------------------------------------------------------------------------------

@@ -14,6 +14,7 @@ SO_PATH = os.environ.get("MRCNN_HIP_LIB") or os.path.join(_HERE, "libmaskrcnn_hi
 
 MRCNN_OK = 0
 F32, F64, F16, U8, I32, F32S, F32X3 = 0, 1, 2, 3, 4, 5, 6
+DEFAULT = -1          # MRCNN_DEFAULT of mrcnn_model_load: the mode the artefact is prepared for (stored split exponents -> F32X3, else F32)
 HOST, DEVICE = 0, 1
 PARAM_INT, PARAM_DOUBLE, PARAM_STRING = 0, 1, 2
 MODEL_MASKRCNN, MODEL_CLASSIFIER, MODEL_MASK = 0, 1, 2
@@ -38,7 +39,7 @@ EXPORTED_SYMBOLS = [
 # declared in include/maskrcnn_hip_test.h (test / measurement entry points of the same library)
 TEST_SYMBOLS = [
     "mrcnn_bench_conv", "mrcnn_bench_conv_dtype", "mrcnn_model_conv_profile_enable", "mrcnn_model_conv_profile_get",
-    "mrcnn_model_conv_profile_shapes", "mrcnn_conv2d_nhwc", "mrcnn_debug_set", "mrcnn_bottleneck_nhwc", "mrcnn_bench_mfma_probe", "mrcnn_model_conv_profile_group", "mrcnn_bottleneck_first_nhwc", "mrcnn_bottleneck_stage_nhwc",
+    "mrcnn_model_conv_profile_shapes", "mrcnn_conv2d_nhwc", "mrcnn_debug_set", "mrcnn_bottleneck_nhwc", "mrcnn_bench_mfma_probe", "mrcnn_model_conv_profile_group", "mrcnn_bottleneck_first_nhwc", "mrcnn_bottleneck_stage_nhwc", "mrcnn_model_conv_profile_bytes",
 ]
 
 
@@ -76,7 +77,7 @@ _lib = None
 
 class ConvShapeStat(C.Structure):    # mrcnn_conv_shape_stat
     _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("tile", C.c_int32),
-                ("launches", C.c_int64), ("total_ms", C.c_double), ("total_flops", C.c_double)]
+                ("launches", C.c_int64), ("total_ms", C.c_double), ("total_flops", C.c_double), ("total_bytes", C.c_double)]
 
 
 def lib():
@@ -132,6 +133,7 @@ def lib():
     L.mrcnn_model_conv_profile_get.argtypes = [vp, C.c_int, i64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.mrcnn_model_conv_profile_group.argtypes = [vp, C.c_int, i64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.mrcnn_model_enable_graph.argtypes = [vp, C.c_int]
+    L.mrcnn_model_conv_profile_bytes.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.mrcnn_model_conv_profile_shapes.argtypes = [vp, C.POINTER(ConvShapeStat), C.c_int, C.POINTER(C.c_int)]
     L.mrcnn_bench_conv.argtypes = [C.c_int] * 8 + [f32p, C.POINTER(C.c_double)]
     L.mrcnn_bench_conv_dtype.argtypes = [C.c_int] * 9 + [f32p, C.POINTER(C.c_double)]

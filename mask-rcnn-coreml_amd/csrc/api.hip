@@ -501,8 +501,8 @@ extern "C" int mrcnn_model_load(int kind, const char* path, int max_batch, int c
     return guarded([&] {
         MRCNN_REQUIRE(path && out_model, MRCNN_ERR_INVALID, "null argument");
         MRCNN_REQUIRE(kind >= 0 && kind <= 2, MRCNN_ERR_INVALID, "unknown model kind %d", kind);
-        MRCNN_REQUIRE(compute_dtype == MRCNN_F32 || compute_dtype == MRCNN_F16 || compute_dtype == MRCNN_F32S || compute_dtype == MRCNN_F32X3,
-                      MRCNN_ERR_UNSUPPORTED, "compute dtype %d not available (MRCNN_F32, MRCNN_F16, MRCNN_F32S or MRCNN_F32X3)", compute_dtype);
+        MRCNN_REQUIRE(compute_dtype == MRCNN_DEFAULT || compute_dtype == MRCNN_F32 || compute_dtype == MRCNN_F16 || compute_dtype == MRCNN_F32S || compute_dtype == MRCNN_F32X3,
+                      MRCNN_ERR_UNSUPPORTED, "compute dtype %d not available (MRCNN_DEFAULT, MRCNN_F32, MRCNN_F16, MRCNN_F32S or MRCNN_F32X3)", compute_dtype);
         std::unique_ptr<mrcnn_model> h(new mrcnn_model);
         h->m.load(kind, path, max_batch, compute_dtype);
         *out_model = h.release();
@@ -651,6 +651,7 @@ extern "C" int mrcnn_model_get_int(mrcnn_model* model, const char* key, int64_t*
         if (k == "num_classes") *value = m.nc;
         else if (k == "max_batch") *value = m.max_batch;
         else if (k == "compute_dtype") *value = m.mode;
+        else if (k == "compute_dtype_defaulted") *value = m.mode_defaulted ? 1 : 0;
         else if (m.kind != MRCNN_MODEL_MASKRCNN) *value = m.file.get_int(k);
         else if (k == "image_height") *value = m.H;
         else if (k == "image_width") *value = m.W;
@@ -847,10 +848,23 @@ extern "C" int mrcnn_model_conv_profile_get(mrcnn_model* model, int tile, int64_
     });
 }
 
+extern "C" int mrcnn_model_conv_profile_bytes(mrcnn_model* model, int tile, double* total_bytes)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(model && total_bytes && tile >= 0 && tile < 9, MRCNN_ERR_INVALID, "bad argument");
+        HIP_CHECK(hipStreamSynchronize(model->m.stream));
+        model->m.conv_profile.collect();
+        *total_bytes = model->m.conv_profile.by_tile[tile].bytes;
+    });
+}
+
 extern "C" int mrcnn_model_conv_profile_group(mrcnn_model* model, int group, int64_t* launches, double* total_ms, double* total_flops)
 {
     return guarded([&] {
         MRCNN_REQUIRE(model && launches && total_ms && total_flops && (group == 0 || group == 1), MRCNN_ERR_INVALID, "bad argument");
+        // (the totals are complete only once the pending launches' events have been read — as in _get)
+        HIP_CHECK(hipStreamSynchronize(model->m.stream));
+        model->m.conv_profile.collect();
         const auto& sl = model->m.conv_profile.by_group[group];
         *launches = sl.launches; *total_ms = sl.ms; *total_flops = sl.flops;
     });
@@ -866,7 +880,7 @@ extern "C" int mrcnn_model_conv_profile_shapes(mrcnn_model* model, mrcnn_conv_sh
         int i = 0;
         for (const auto& kv : shapes) {
             if (i >= capacity) break;
-            out[i++] = {kv.first.M, kv.first.N, kv.first.K, kv.first.tile, (int64_t)kv.second.launches, kv.second.ms, kv.second.flops};
+            out[i++] = {kv.first.M, kv.first.N, kv.first.K, kv.first.tile, (int64_t)kv.second.launches, kv.second.ms, kv.second.flops, kv.second.bytes};
         }
     });
 }

@@ -233,6 +233,10 @@ extern "C" int mrcnn_dist_simulate_host(int world, int global_batch, int max_det
         HostCopy c;
         for (int r = 0; r < world; ++r) {
             const int n = plan[r].end - plan[r].begin;
+            // status MRCNN_DIST_ABORTED: a rank that could not even enqueue a zeroed slot and tore the communicator down (release_peers) —
+            // its peers' ncclAllGather then FAILS (nccl_check raises on each of them) instead of blocking; nothing is unpacked
+            MRCNN_REQUIRE(!(status && status[r] == MRCNN_DIST_ABORTED), MRCNN_ERR_HIP,
+                          "ncclAllGather failed: rank %d aborted the communicator (it could not take part in the all-gather)", r);
             MRCNN_REQUIRE(n == 0 || (detections[r] && masks[r]), MRCNN_ERR_INVALID, "rank %d: null local results", r);
             const int32_t tr[TRAILER] = {status ? status[r] : 0, n, 0, 0};
             pack_slot(c, g, n, detections[r], masks[r], tr, gathered.data() + plan[r].recv_off);      // = rank r's ncclAllGather contribution

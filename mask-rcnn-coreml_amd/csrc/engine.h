@@ -155,6 +155,7 @@ struct StageTimer {
 struct Model {
     int kind = 0;
     int max_batch = 1;
+    bool mode_defaulted = false;   // loaded with MRCNN_DEFAULT: `mode` was chosen from the artefact (stored split exponents -> MRCNN_F32X3)
     int mode = MRCNN_F32;       // compute mode: MRCNN_F32 | MRCNN_F16 | MRCNN_F32S
     int dtype = MRCNN_F32;      // element type of the activations = mode_act(mode)
     MrcwFile file;

@@ -642,10 +642,18 @@ void Model::load(int kind_, const std::string& path, int max_batch_, int dtype_)
 {
     require_gpu();
     kind = kind_;
-    mode = dtype_;
-    dtype = mode_act(mode);
     max_batch = max_batch_ > 0 ? max_batch_ : 1;
     file.load(path);
+    mode = dtype_;
+    if (dtype_ == MRCNN_DEFAULT) {
+        // the mode the artefact is prepared for (include/maskrcnn_hip.h): stored split exponents -> the three-part split, else exact fp32
+        bool stored = false;
+        if (kind == MRCNN_MODEL_MASKRCNN)
+            for (auto& kv : file.ints) stored = stored || kv.first.compare(0, 10, "split_exp.") == 0;
+        mode = stored ? MRCNN_F32X3 : MRCNN_F32;
+        mode_defaulted = true;
+    }
+    dtype = mode_act(mode);
     const char* want = kind == MRCNN_MODEL_MASKRCNN ? "MaskRCNN" : kind == MRCNN_MODEL_CLASSIFIER ? "Classifier" : "Mask";
     MRCNN_REQUIRE(file.get_string("kind") == want, MRCNN_ERR_IO, "'%s' holds a %s model, expected %s", path.c_str(),
                   file.get_string("kind").c_str(), want);

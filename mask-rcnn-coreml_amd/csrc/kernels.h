@@ -158,13 +158,13 @@ struct ConvDesc {
 // conv_forward launch is bracketed by HIP events on its own stream; collect() (after the stream
 // has been synchronised) folds the elapsed times into per-tile-shape totals.
 struct ConvProfile {
-    struct Slot { long launches = 0; double ms = 0, flops = 0; };
+    struct Slot { long launches = 0; double ms = 0, flops = 0, bytes = 0; };       // bytes: ALGORITHMIC bytes (conv_algorithmic_bytes: every operand once)
     Slot by_tile[9];                 // 8: 16 x 16 halo tiles x 256 columns of the fp16 mode's 3x3 layers (kernels_conv3x3_h.hip); 7: a whole identity bottleneck of the fp16 mode in one launch (kernels_bneck.hip; flops of its three layers); 0: 128x128, 1: 128x64, 2: 128x32, 3: 128x128 run by 4 waves of 32x128 (split modes, long K), 4: 256x256 ping-pong,
                                      // 5: persistent halo tiles (3x3 stride 1, split modes), 6: halo tiles with the fused bottleneck tail (3x3 + 1x1)
     std::vector<hipEvent_t> pool;
     struct Shape { int M, N, K, tile; bool operator<(const Shape& o) const { return std::tie(M, N, K, tile) < std::tie(o.M, o.N, o.K, o.tile); } };
     std::map<Shape, Slot> by_shape;  // per GEMM shape (M = images·OH·OW, N = output columns, K = taps·Cin)
-    struct Pending { int tile; double flops; int e0, e1; Shape shape; int group = 0; };
+    struct Pending { int tile; double flops; int e0, e1; Shape shape; int group = 0; double bytes = 0; };
     Slot by_group[2];                // ConvDesc::group: 0 = everything else, 1 = the backbone convolutions (C1..C5: north_star's roofline target is worded on them)
     std::vector<Pending> pending;
     int used = 0;

@@ -533,10 +533,11 @@ void ConvProfile::collect()
         by_tile[pd.tile].launches += 1;
         by_tile[pd.tile].ms += ms;
         by_tile[pd.tile].flops += pd.flops;
+        by_tile[pd.tile].bytes += pd.bytes;
         Slot& sh = by_shape[pd.shape];
-        sh.launches += 1; sh.ms += ms; sh.flops += pd.flops;
+        sh.launches += 1; sh.ms += ms; sh.flops += pd.flops; sh.bytes += pd.bytes;
         Slot& gr = by_group[pd.group == 1 ? 1 : 0];
-        gr.launches += 1; gr.ms += ms; gr.flops += pd.flops;
+        gr.launches += 1; gr.ms += ms; gr.flops += pd.flops; gr.bytes += pd.bytes;
     }
     pending.clear();
     used = 0;
@@ -544,6 +545,26 @@ void ConvProfile::collect()
 ConvProfile::~ConvProfile()
 {
     for (auto e : pool) (void)hipEventDestroy(e);
+}
+// ALGORITHMIC bytes of a layer: every operand crosses HBM once — the input pixels the layer reads (a strided 1x1 layer: the sampled ones),
+// the filters, the residual / the fused shortcut's input, the outputs it stores (fused heads: their fp32 columns instead of the feature
+// tensor; selected-class mode: nothing).  What a memory-bound layer is priced against (bench.py: roofline.by_tile_class[*].frac_of_hbm).
+static double conv_algorithmic_bytes(const ConvDesc& d, const ConvDesc* sc = nullptr)
+{
+    const double es = d.dtype == MRCNN_F16 ? 2.0 : 4.0;
+    const int wdt = d.wdtype < 0 ? d.dtype : d.wdtype;
+    const double ws = wdt == MRCNN_F32 ? 4.0 : 2.0;
+    const double M = (double)d.B * d.OH * d.OW;
+    const double ncols = d.deconv2 ? 4.0 * d.Cout : d.Cout;
+    double b = 0;
+    if (d.algo_k > 0) b += (double)d.B * d.H * d.W * 16.0;                               // the stem's staging tensor: 16 B per padded pixel
+    else b += (d.KH * d.KW == 1 ? M : (double)d.B * d.H * d.W) * d.Cin * es;
+    b += ncols * d.KH * d.KW * (d.algo_k > 0 ? (double)d.algo_k / (d.KH * d.KW) : (double)d.Cin) * ws;
+    if (d.res) b += M * d.Cout * es / (d.res_shift ? 4.0 : 1.0);
+    if (sc) b += M * sc->Cin * es + (double)d.Cout * sc->Cin * ws;
+    if (d.head_w) b += M * d.head_cols * 4.0;
+    else if (!d.sel_partial) b += M * ncols * (d.out_f32 ? 4.0 : es);
+    return b;
 }
 static int prof_event(ConvProfile* p, hipStream_t s)
 {
@@ -806,7 +827,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d_in, const ConvDesc* sc)
         if (prof) {
             const int e1 = prof_event(prof, s);
             const double M = (double)d.B * d.OH * d.OW;
-            prof->pending.push_back({8, 2.0 * M * d.Cout * 9.0 * d.Cin, e0, e1, {(int)M, d.Cout, 9 * d.Cin, 8}, d.group});
+            prof->pending.push_back({8, 2.0 * M * d.Cout * 9.0 * d.Cin, e0, e1, {(int)M, d.Cout, 9 * d.Cin, 8}, d.group, conv_algorithmic_bytes(d)});
         }
         return;
     }
@@ -899,7 +920,7 @@ void conv_forward(hipStream_t s, const ConvDesc& d_in, const ConvDesc* sc)
         const int e1 = prof_event(prof, s);
         const double k = (d.algo_k > 0 ? d.algo_k : a.Ktot) + (fuse ? sc->Cin : 0);          // (a fused shortcut: both K loops)
         const int tile = halo ? 5 : pp_bn == 256 ? 4 : (wide_waves ? 3 : (bn == 128 ? 0 : (bn == 64 ? 1 : 2)));
-        prof->pending.push_back({tile, 2.0 * (double)a.M * (double)a.ncols * k, e0, e1, {a.M, a.ncols, a.Ktot, tile}, d.group});
+        prof->pending.push_back({tile, 2.0 * (double)a.M * (double)a.ncols * k, e0, e1, {a.M, a.ncols, a.Ktot, tile}, d.group, conv_algorithmic_bytes(d, fuse ? sc : nullptr)});
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -933,7 +954,9 @@ void conv_stem_forward(hipStream_t s, const ConvDesc& d, void* pooled, int PH, i
         const long M = (long)d.B * d.OH * d.OW;
         const double k = d.algo_k > 0 ? d.algo_k : d.KH * d.KW * d.Cin;
         // (the 64-column class of the table: the layer it replaces ran there; the pool rides in the same launch)
-        prof->pending.push_back({1, 2.0 * (double)M * 64.0 * k, e0, e1, {(int)M, 64, d.KH * d.KW * d.Cin, 1}, d.group});
+        // algorithmic bytes: the staging tensor in, the POOLED tensor out (conv1's own output never exists)
+        const double by = (double)d.B * d.H * d.W * 16.0 + 64.0 * k * 2.0 + (double)d.B * PH * PW * 64.0 * (d.dtype == MRCNN_F16 ? 2.0 : 4.0);
+        prof->pending.push_back({1, 2.0 * (double)M * 64.0 * k, e0, e1, {(int)M, 64, d.KH * d.KW * d.Cin, 1}, d.group, by});
     }
 }
 
@@ -983,7 +1006,8 @@ void conv_forward_tail(hipStream_t s, const ConvDesc& d3, const ConvDesc& d1, co
         const int e1 = prof_event(prof, s);
         // one launch, two layers: algorithmic flops of both; the shape key is the 3x3 layer's M and K with the 1x1's N (tile class 6)
         const double fl = 2.0 * (double)a3.M * ((double)a3.ncols * a3.Ktot + (double)a1.ncols * a1.Ktot);
-        prof->pending.push_back({6, fl, e0, e1, {a3.M, a1.ncols, a3.Ktot + a1.Ktot, 6}, d3.group});
+        ConvDesc d3n = d3; d3n.sel_partial = (float*)1;          // (the tensor between the two layers is not stored: count d3 without its output)
+        prof->pending.push_back({6, fl, e0, e1, {a3.M, a1.ncols, a3.Ktot + a1.Ktot, 6}, d3.group, conv_algorithmic_bytes(d3n) + conv_algorithmic_bytes(d1) - (double)a3.M * d1.Cin * 4.0});
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -1031,7 +1055,7 @@ void conv_bneck_forward(hipStream_t s, const ConvDesc& da, const ConvDesc& db, c
         const int e1 = prof_event(prof, s);
         const double M = (double)da.B * da.H * da.W, C = da.Cout;
         const double fl = 2.0 * M * (4 * C * C + 9 * C * C + 4 * C * C);      // algorithmic flops of the three layers (the halo recompute is not work)
-        prof->pending.push_back({7, fl, e0, e1, {(int)M, 4 * da.Cout, 17 * da.Cout, 7}, da.group});
+        prof->pending.push_back({7, fl, e0, e1, {(int)M, 4 * da.Cout, 17 * da.Cout, 7}, da.group, 2.0 * M * 4 * C * 2.0 + 17.0 * C * C * 2.0});      // x in + y out + the filters
     }
 }
 
@@ -1062,7 +1086,7 @@ void conv_bneck_stage_forward(hipStream_t s, const BneckTriple* blocks, int n, c
         const int e1 = prof_event(prof, s);
         const double M = (double)a0.B * a0.H * a0.W, C = a0.Cout;
         const double fl = 2.0 * M * (4 * C * C + 9 * C * C + 4 * C * C) * n;      // algorithmic flops of the n blocks
-        prof->pending.push_back({7, fl, e0, e1, {(int)M, 4 * a0.Cout, 17 * a0.Cout * n, 7}, a0.group});
+        prof->pending.push_back({7, fl, e0, e1, {(int)M, 4 * a0.Cout, 17 * a0.Cout * n, 7}, a0.group, (2.0 * M * 4 * C * 2.0 + 17.0 * C * C * 2.0) * n});
     }
 }
 
@@ -1103,7 +1127,7 @@ void conv_bneck_first_forward(hipStream_t s, const ConvDesc& da, const ConvDesc&
         const int e1 = prof_event(prof, s);
         const double M = (double)da.B * da.H * da.W, C = da.Cout;
         const double fl = 2.0 * M * (C * C + 9 * C * C + 4 * C * C + 4 * C * C);       // branch2a, 2b, 2c and branch1
-        prof->pending.push_back({7, fl, e0, e1, {(int)M, 4 * da.Cout, 18 * da.Cout, 7}, da.group});
+        prof->pending.push_back({7, fl, e0, e1, {(int)M, 4 * da.Cout, 18 * da.Cout, 7}, da.group, M * C * 2.0 + M * 4 * C * 2.0 + 18.0 * C * C * 2.0});
     }
 }
 

@@ -61,16 +61,35 @@ class DetectionGather:
         return unpack_records(self.recv, self.D, self.S)
 
 
-def gather_uneven(rec: torch.Tensor, global_batch: int) -> torch.Tensor:
-    """All-gather for shards that differ by one image: pad to the largest shard, gather, drop padding."""
+class RemoteRankError(RuntimeError):
+    """A rank of the sharded call failed its local predict: raised on EVERY rank after the exchange (csrc/dist.hip: raise_remote_status)."""
+
+    def __init__(self, statuses: List[int], rank: int):
+        self.statuses = list(statuses)
+        bad = [(r, s) for r, s in enumerate(statuses) if s]
+        super().__init__(f"rank(s) {[r for r, _ in bad]} of {len(statuses)} failed their local predict (status {[s for _, s in bad]}); "
+                         f"the records of this batch are not valid on any rank" + (": see this rank's earlier message" if statuses[rank] else ""))
+
+
+def gather_uneven(rec: torch.Tensor, global_batch: int, status=None):
+    """All-gather for shards that differ by one image: pad to the largest shard, gather, drop padding.
+    status (int, optional): this rank's status word rides behind its padded records (the slot's trailer of csrc/dist.hip); the call then
+    returns (records, [status of every rank])."""
     world, rank = dist.get_world_size(), dist.get_rank()
     sizes = [shard_bounds(global_batch, world, r) for r in range(world)]
     mx = max(hi - lo for lo, hi in sizes)
-    pad = torch.zeros((mx, rec.shape[1]), dtype=rec.dtype, device=rec.device)
+    trailer = 0 if status is None else 1
+    pad = torch.zeros((mx + trailer, rec.shape[1]), dtype=rec.dtype, device=rec.device)
     pad[: rec.shape[0]] = rec
+    if trailer:
+        pad[mx, 0] = float(status)
+        pad[mx, 1] = float(rec.shape[0])
     parts: List[torch.Tensor] = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad)
-    return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)
+    out = torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)
+    if status is None:
+        return out
+    return out, [int(p[mx, 0].item()) for p in parts]
 
 
 def predict_sharded(predict_fn, images, max_det: int, mask_size: int):
@@ -79,12 +98,25 @@ def predict_sharded(predict_fn, images, max_det: int, mask_size: int):
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     lo, hi = shard_bounds(images.shape[0], world, rank)
-    det, mask = predict_fn(images[lo:hi])
-    det = torch.as_tensor(det)
-    mask = torch.as_tensor(mask)
+    # The contract of csrc/dist.hip (issue_exchange): a rank-LOCAL failure — a HIP error, the data-dependent fp16-range watchdog — must not
+    # keep this rank out of the collective, or every other rank blocks in it.  It becomes the status word of a zeroed slot; every rank
+    # raises after the gather.
+    status, local = 0, None
+    try:
+        det, mask = predict_fn(images[lo:hi])
+        det = torch.as_tensor(det)
+        mask = torch.as_tensor(mask)
+    except Exception as e:
+        status, local = int(getattr(e, "code", 0) or 2), e
+        det = torch.zeros((hi - lo, max_det, 6), dtype=torch.float32)
+        mask = torch.zeros((hi - lo, max_det, mask_size, mask_size), dtype=torch.float32)
     rec = pack_records(det, mask)
     if world > 1:
-        rec = gather_uneven(rec, images.shape[0])
+        rec, statuses = gather_uneven(rec, images.shape[0], status)
+        if any(statuses):
+            raise RemoteRankError(statuses, rank) from local
+    elif local is not None:
+        raise local
     return unpack_records(rec, max_det, mask_size)
 
 

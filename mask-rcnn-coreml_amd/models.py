@@ -19,7 +19,11 @@ import numpy as np
 from . import _lib
 from .config import MaskRCNNConfig
 
-DTYPES = {"f32": _lib.F32, "f16": _lib.F16, "f32s": _lib.F32S, "f32x3": _lib.F32X3}   # f32s / f32x3: fp32 tensors, 2- / 3-part split-fp16 MFMA
+# f32s / f32x3: fp32 tensors, 2- / 3-part split-fp16 MFMA.  "default" = MRCNN_DEFAULT (include/maskrcnn_hip.h): what the artefact is prepared
+# for — f32x3 with the stored exponents when `convert --calibrate` wrote them into MaskRCNN.mrcw, f32 otherwise — the mode a host that names no
+# precision gets (`MaskRCNN()` of ViewController.swift:37).
+DTYPES = {"default": _lib.DEFAULT, "f32": _lib.F32, "f16": _lib.F16, "f32s": _lib.F32S, "f32x3": _lib.F32X3}
+DTYPE_NAMES = {v: k for k, v in DTYPES.items() if k != "default"}
 STAGES = ["Trunk", "Proposal-Eval", "PyramidROIAlign-Eval", "TimeDistributedClassifierLayer-Eval", "Detection-Eval",
           "PyramidROIAlign-Eval-Mask", "TimeDistributedMask-Eval"]
 
@@ -27,7 +31,7 @@ STAGES = ["Trunk", "Proposal-Eval", "PyramidROIAlign-Eval", "TimeDistributedClas
 class _Model:
     KIND = -1
 
-    def __init__(self, path: str, max_batch: int, compute_dtype: int = _lib.F32):
+    def __init__(self, path: str, max_batch: int, compute_dtype: int = _lib.DEFAULT):
         self._h = C.c_void_p()
         _lib.check(_lib.lib().mrcnn_model_load(self.KIND, os.fspath(path).encode(), int(max_batch), compute_dtype,
                                                C.byref(self._h)))
@@ -59,14 +63,15 @@ class MaskRCNN(_Model):
     ``MaskRCNNConfig.defaultConfig()`` which must be set first (AppDelegate.swift:18-20)."""
     KIND = _lib.MODEL_MASKRCNN
 
-    def __init__(self, path: str, max_batch: int = 1, compute_dtype: str = "f32"):
+    def __init__(self, path: str, max_batch: int = 1, compute_dtype: str = "default"):
         cfg = MaskRCNNConfig.defaultConfig()
         for name in ("anchorsURL", "compiledClassifierModelURL", "compiledMaskModelURL"):
             if getattr(cfg, name) is None:
                 # the reference force-unwraps and crashes (ProposalLayer.swift:68); we raise
                 raise _lib.MrcnnError(6, f"MaskRCNNConfig.defaultConfig().{name} must be set before loading MaskRCNN")
         super().__init__(path, max_batch, DTYPES[compute_dtype])
-        self.compute_dtype = compute_dtype
+        self.compute_dtype = DTYPE_NAMES[self.get_int("compute_dtype")]      # the RESOLVED mode ("default" never stays)
+        self.compute_dtype_defaulted = bool(self.get_int("compute_dtype_defaulted"))
         self.max_batch = max_batch
         self.image_height = self.get_int("image_height")
         self.image_width = self.get_int("image_width")
@@ -206,6 +211,15 @@ class MaskRCNN(_Model):
             out[name] = (int(n.value), float(ms.value), float(fl.value))
         return out
 
+    def conv_profile_bytes(self):
+        """{tile: total ALGORITHMIC bytes} of the launches conv_profile() counts (every operand across HBM once)."""
+        out = {}
+        for tile, name in enumerate(("128x128", "128x64", "128x32", "128x128w4", "256x256pp", "128xNhalo", "128x256tail", "bneck", "c3h")):
+            b = C.c_double(0)
+            _lib.check(_lib.lib().mrcnn_model_conv_profile_bytes(self._h, tile, C.byref(b)))
+            out[name] = float(b.value)
+        return out
+
     def conv_profile_groups(self):
         """{"backbone" | "other": (launches, total_ms, total_algorithmic_flops)} — conv1 + res2..res5 against everything else."""
         out = {}
@@ -216,13 +230,13 @@ class MaskRCNN(_Model):
         return out
 
     def conv_profile_shapes(self):
-        """[(M, N, K, tile, launches, total_ms, total_algorithmic_flops)] per distinct GEMM shape."""
+        """[(M, N, K, tile, launches, total_ms, total_algorithmic_flops, total_algorithmic_bytes)] per distinct GEMM shape."""
         L = _lib.lib()
         n = C.c_int(0)
         _lib.check(L.mrcnn_model_conv_profile_shapes(self._h, None, 0, C.byref(n)))
         buf = (_lib.ConvShapeStat * max(n.value, 1))()
         _lib.check(L.mrcnn_model_conv_profile_shapes(self._h, buf, n.value, C.byref(n)))
-        return [(r.M, r.N, r.K, r.tile, r.launches, r.total_ms, r.total_flops) for r in buf[:n.value]]
+        return [(r.M, r.N, r.K, r.tile, r.launches, r.total_ms, r.total_flops, r.total_bytes) for r in buf[:n.value]]
 
     def enable_timing(self, on: bool = True):
         _lib.check(_lib.lib().mrcnn_model_enable_timing(self._h, int(on)))
@@ -239,7 +253,7 @@ class MaskRCNN(_Model):
 class Classifier(_Model):
     KIND = _lib.MODEL_CLASSIFIER
 
-    def __init__(self, path: str, max_rows: int = 1000, compute_dtype: str = "f32"):
+    def __init__(self, path: str, max_rows: int = 1000, compute_dtype: str = "default"):
         super().__init__(path, max_rows, DTYPES[compute_dtype])
         self.num_classes = self.get_int("num_classes")
 
@@ -261,7 +275,7 @@ class Classifier(_Model):
 class Mask(_Model):
     KIND = _lib.MODEL_MASK
 
-    def __init__(self, path: str, max_rows: int = 100, compute_dtype: str = "f32"):
+    def __init__(self, path: str, max_rows: int = 100, compute_dtype: str = "default"):
         super().__init__(path, max_rows, DTYPES[compute_dtype])
         self.num_classes = self.get_int("num_classes")
 
@@ -277,7 +291,7 @@ class Mask(_Model):
         return {"masks": masks[0] if single else masks}
 
 
-def load_maskrcnn(model_dir: str, max_batch: int = 1, compute_dtype: str = "f32") -> MaskRCNN:
+def load_maskrcnn(model_dir: str, max_batch: int = 1, compute_dtype: str = "default") -> MaskRCNN:
     """Sets MaskRCNNConfig from a directory holding MaskRCNN.mrcw / Classifier.mrcw / Mask.mrcw /
     anchors.bin (the four artefacts of DownloadCommand.swift:10-32) and loads the main model —
     the sequence of EvaluateCommand.swift:144-153."""

@@ -19,6 +19,9 @@ public final class MaskRCNNConfig {
 
 /// Compute mode of the convolutions (`compute_dtype` of mrcnn_model_load; include/maskrcnn_hip.h).
 public enum ComputeMode {
+    /// MRCNN_DEFAULT: the mode the artefact is prepared for — `.f32x3` with the stored exponents when `convert --calibrate` wrote them
+    /// into MaskRCNN.mrcw, `.f32` otherwise.  What `MaskRCNN()` (ViewController.swift:37), which names no precision, gets.
+    case artefact
     /// fp32 tensors, exact-fp32 MFMA (`v_mfma_f32_32x32x2_f32`): the scale-invariant baseline.
     case f32
     /// fp32 tensors; products on the fp16 matrix cores from a THREE-part split of the activation (exact for 0.5 <= |a| < 65504,
@@ -30,6 +33,7 @@ public enum ComputeMode {
     case f16
     var raw: Int32 {
         switch self {
+        case .artefact: return Int32(MRCNN_DEFAULT.rawValue)
         case .f32: return Int32(MRCNN_F32.rawValue)
         case .f32x3: return Int32(MRCNN_F32X3.rawValue)
         case .f32s: return Int32(MRCNN_F32S.rawValue)
@@ -45,20 +49,23 @@ public final class MaskRCNN {
     public let maskSide: Int
     public let width: Int32
     public let height: Int32
+    /// The mode the handle runs in (`.artefact` resolved by the library: mrcnn_model_get_int "compute_dtype").
+    public let computeMode: ComputeMode
 
-    /// `computeMode` defaults to `.f32x3`: fp32 tensors whose products are formed on the fp16 matrix cores from a three-part split
-    /// (2.5x the exact-fp32 mode).  Two things differ from `.f32` and a host must know them: (1) the mode carries activations
-    /// below 0.5 to 2^-25 ABSOLUTE rather than 2^-24 relative — call `calibrateSplit` once (a power-of-two pre-scale per tensor,
-    /// folded into the layers at no run-time cost) to make it fp32-grade at any activation scale; (2) an activation that leaves
-    /// the fp16 range (|v| >= 65504) fails the predict with MRCNN_ERR_UNSUPPORTED ("load the model with MRCNN_F32") instead of
-    /// returning a wrong result.  `.f32` has neither property.
-    public init(contentsOf url: URL, maxBatch: Int32 = 1, computeMode: ComputeMode = .f32x3) throws {
+    /// `computeMode` defaults to `.artefact` (MRCNN_DEFAULT): an artefact written by `convert --calibrate` carries the split exponents of
+    /// its tensor groups and loads as `.f32x3` — fp32 tensors whose products are formed exactly on the fp16 matrix cores from a three-part
+    /// split (2.6x the exact-fp32 mode; the mode `bench.py` measures), fp32-grade at any activation scale with those exponents, and a batch
+    /// that leaves the calibrated range is recovered inside the call (INTEGRATION.md §2.4c); an artefact without them loads as `.f32`.
+    /// `computeMode` (read-only) says which one it became.
+    public init(contentsOf url: URL, maxBatch: Int32 = 1, computeMode: ComputeMode = .artefact) throws {
         try check(mrcnn_model_load(Int32(MRCNN_MODEL_MASKRCNN.rawValue), url.path, maxBatch, computeMode.raw, &handle))
         var v: Int64 = 0
         try check(mrcnn_model_get_int(handle, "max_detections", &v)); maxDetections = Int(v)
         try check(mrcnn_model_get_int(handle, "mask_size", &v)); maskSide = Int(v)
         try check(mrcnn_model_get_int(handle, "image_width", &v)); width = Int32(v)
         try check(mrcnn_model_get_int(handle, "image_height", &v)); height = Int32(v)
+        try check(mrcnn_model_get_int(handle, "compute_dtype", &v))
+        self.computeMode = v == Int64(MRCNN_F32X3.rawValue) ? .f32x3 : v == Int64(MRCNN_F32S.rawValue) ? .f32s : v == Int64(MRCNN_F16.rawValue) ? .f16 : .f32
     }
     /// Source compatibility with the first version of this shim (`halfPrecision: Bool`): `true` = `.f16`, `false` = `.f32`
     /// (the exact-fp32 engine that initialiser used to select — NOT the new `.f32x3` default).

@@ -79,6 +79,22 @@ def test_headline_batch8_full_size(pkg, orc, full_model, full_images, full_oracl
         m.predict(full_images)
         for k, b in enumerate((0, 7)):
             np.testing.assert_array_equal(m.read_tensor("P5", b), p5[k])
+    if mode == "f16":
+        # round 6: C4's 22 identity blocks as ONE launch whose tiles wait for their neighbours' previous block (kernels_bneck.hip, STAGE form;
+        # opt-in: measured equal, profiles/r06_bneck_stage_ab.txt) — the same tile arithmetic, so the whole predict agrees bit for bit, twice
+        L = __import__("importlib").import_module("mask-rcnn-coreml_amd._lib")
+        try:
+            L.check(L.lib().mrcnn_debug_set(b"conv_bneck_stage", 1))
+            for _ in range(2):
+                det_s, mask_s = m.predict(full_images)
+                np.testing.assert_array_equal(det_s, det)
+                np.testing.assert_array_equal(mask_s, mask)
+            p4 = [m.read_tensor("P4", b) for b in (0, 7)]
+        finally:
+            L.check(L.lib().mrcnn_debug_set(b"conv_bneck_stage", 0))
+        m.predict(full_images)
+        for k, b in enumerate((0, 7)):
+            np.testing.assert_array_equal(m.read_tensor("P4", b), p4[k])
     pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None
 
 

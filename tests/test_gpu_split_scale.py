@@ -281,6 +281,45 @@ def test_exponents_stored_in_the_artefact_make_the_drop_in_load_calibrated(pkg, 
         assert m2.get_int("range_recoveries") == 0
     m16 = _models().load_maskrcnn(d, max_batch=1, compute_dtype="f16")      # modes without a split ignore the stored vector
     assert m16.get_int("split_exponents_from_artefact") == 0
+    del m16, m2
+    # Round 6: a host that names NO precision — `MaskRCNN()` in ViewController.swift:37; here load_maskrcnn(d) / MRCNN_DEFAULT —
+    # gets the mode the artefact is prepared for: the stored exponents make it f32x3, and the handle agrees bit for bit with the explicitly
+    # loaded and explicitly calibrated one above, and with the CPU oracle's staged parity
+    L = importlib.import_module("mask-rcnn-coreml_amd._lib")
+    md = _models().load_maskrcnn(d, max_batch=3)
+    assert md.compute_dtype == "f32x3" and md.compute_dtype_defaulted and md.get_int("compute_dtype") == L.F32X3
+    assert md.get_int("split_exponents_from_artefact") == 1 and md.get_int("split_calibrated") == 1
+    np.testing.assert_array_equal(md.split_exponents, want_e)
+    dd, kd = md.predict(images)
+    np.testing.assert_array_equal(dd, det)
+    np.testing.assert_array_equal(kd, mask)
+    assert max(_trunk_errors(md, om, cfg, images[:1])) < 2e-5
+    del md
+
+
+def test_a_default_load_of_an_uncalibrated_artefact_is_the_exact_fp32_mode(pkg, orc, small_model):
+    """MRCNN_DEFAULT on an artefact WITHOUT stored exponents (and on the stand-alone Classifier / Mask models) resolves to MRCNN_F32 —
+    the scale-invariant engine — and is the same handle an explicit "f32" load gives; staged oracle parity holds as for that mode."""
+    from test_gpu_engine import _check_stages
+    from oracle.network import load_oracle_model
+    L = importlib.import_module("mask-rcnn-coreml_amd._lib")
+    d, cfg = small_model
+    images = rand_images(2, cfg.image_height, cfg.image_width, seed=9)
+    m0 = _models().load_maskrcnn(d, max_batch=2)
+    assert m0.compute_dtype == "f32" and m0.compute_dtype_defaulted and m0.get_int("compute_dtype") == L.F32
+    m1 = _models().load_maskrcnn(d, max_batch=2, compute_dtype="f32")
+    assert not m1.compute_dtype_defaulted
+    d0, k0 = m0.predict(images)
+    d1, k1 = m1.predict(images)
+    np.testing.assert_array_equal(d0, d1)
+    np.testing.assert_array_equal(k0, k1)
+    om = load_oracle_model(d)
+    _check_stages(pkg, orc, om, m0, cfg, images, 1, True, om.trunk(images[1:2]), tb=0)
+    c = _models().Classifier(os.path.join(d, "Classifier.mrcw"), max_rows=4)
+    assert c.get_int("compute_dtype") == L.F32 and c.get_int("compute_dtype_defaulted") == 1
+    import ctypes as C
+    h = C.c_void_p()
+    assert L.lib().mrcnn_model_load(1, os.path.join(d, "Classifier.mrcw").encode(), 4, 7, C.byref(h)) != 0 and not h.value      # an unknown compute dtype is still refused
 
 
 def test_split_counters_mean_what_the_header_says(small_model):

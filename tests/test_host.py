@@ -270,6 +270,92 @@ def test_sharded_predict_gloo(world, global_batch):
         np.testing.assert_array_equal(gm, wm.numpy())
 
 
+def _rank_main_failing(rank, world, port, global_batch, mode, q):
+    """mode "status": rank 1's local predict raises — it still joins the exchange with a zeroed slot and its status word.
+    mode "gone": rank 1 cannot reach the collective at all and tears its end down (the gloo stand-in for release_peers' ncclCommAbort)."""
+    import datetime
+    import time
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    dmod = importlib.import_module("mask-rcnn-coreml_amd.dist")
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=20))
+    imgs = torch.arange(global_batch * 2 * 2 * 3, dtype=torch.float32).reshape(global_batch, 2, 2, 3)
+
+    class WatchdogError(RuntimeError):
+        code = 5                                   # MRCNN_ERR_UNSUPPORTED: the fp16-range watchdog
+
+    def predict(x):
+        if rank == 1:
+            raise WatchdogError("an activation left the fp16 range")
+        return _fake_predict(x)
+
+    def report(*rec):
+        q.put(rec)
+        q.close()
+        q.join_thread()                            # (flushed before the process goes away without the interpreter's own shutdown)
+
+    t0 = time.monotonic()
+    try:
+        if mode == "gone" and rank == 1:
+            report(rank, "gone", "", 0.0)
+            os._exit(0)                            # never reaches the collective: its sockets close, as an aborted communicator's would
+        dmod.predict_sharded(predict, imgs, 4, 3)
+        report(rank, "returned", "", time.monotonic() - t0)
+    except dmod.RemoteRankError as e:
+        report(rank, "remote", f"{e.statuses}|{e}|{type(e.__cause__).__name__}", time.monotonic() - t0)
+    except Exception as e:                         # the peers of a rank that is gone: their collective FAILS instead of blocking
+        report(rank, "failed", f"{type(e).__name__}: {e}"[:300], time.monotonic() - t0)
+    os._exit(0)
+
+
+@pytest.mark.parametrize("mode", ["status", "gone"])
+def test_a_rank_that_fails_before_the_collective_does_not_hang_its_peers(mode):
+    """world 2 over gloo, rank 1 fails BEFORE the all-gather.
+    "status": its local predict raises — the twin of csrc/dist.hip's issue_exchange sends a zeroed slot with the status word, and BOTH
+    ranks raise RemoteRankError naming rank 1 (rank 1's chained to its own exception).  "gone": rank 1 cannot take part at all and tears
+    its end down (release_peers: ncclCommAbort) — rank 0's collective fails within the group's timeout instead of blocking for ever."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main_failing, args=(r, 2, port, 5, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, kind, text, secs = q.get(timeout=90)
+        res[rank] = (kind, text, secs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if mode == "status":
+        assert res[0][0] == "remote" and res[1][0] == "remote", res
+        assert res[0][1].startswith("[0, 5]|") and "rank(s) [1] of 2 failed" in res[0][1] and res[0][1].endswith("|NoneType")
+        assert res[1][1].startswith("[0, 5]|") and "see this rank's earlier message" in res[1][1] and res[1][1].endswith("|WatchdogError")
+        assert res[0][2] < 15 and res[1][2] < 15
+    else:
+        assert res[1][0] == "gone"
+        assert res[0][0] == "failed", res           # an error, not a hang (and not a silently short result)
+        assert res[0][2] < 45, res
+
+
+def test_native_dist_aborted_rank_fails_the_exchange_on_its_peers():
+    """csrc/dist.hip release_peers: a rank that cannot even enqueue a zeroed slot aborts the communicator, so that its peers'
+    ncclAllGather fails (nccl_check raises) instead of blocking.  Through the host seam: status MRCNN_DIST_ABORTED for rank 1 makes
+    the exchange fail with MRCNN_ERR_HIP naming the rank, and no output word is written."""
+    dmod = importlib.import_module("mask-rcnn-coreml_amd.dist")
+    L = importlib.import_module("mask-rcnn-coreml_amd._lib")
+    D, S, world, gb = 3, 2, 2, 5
+    rng = np.random.default_rng(6)
+    det = rng.standard_normal((gb, D, 6)).astype(np.float32)
+    mask = rng.standard_normal((gb, D, S, S)).astype(np.float32)
+    bounds = [dmod.shard_bounds(gb, world, r) for r in range(world)]
+    with pytest.raises(L.MrcnnError) as ei:
+        dmod.NativeDist.simulate_host([det[b:e] for b, e in bounds], [mask[b:e] for b, e in bounds], gb, D, S, np.array([0, -1], np.int32))
+    assert ei.value.code == 3 and "rank 1 aborted the communicator" in str(ei.value)          # MRCNN_ERR_HIP
+
+
 def test_unletterbox_boxes_follow_the_norm_boxes_convention(pkg):
     """normalized coordinates are Matterport's norm_boxes (pixel = n*(size-1), far edge +1) — the convention
     of anchors.py and the mask paste — so a box covering exactly the letterboxed content maps back to the full
