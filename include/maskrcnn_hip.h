@@ -275,6 +275,13 @@ MRCNN_API int mrcnn_maskrcnn_predict_sharded(mrcnn_dist* dist, mrcnn_model* mode
 MRCNN_API int mrcnn_dist_all_gather_records_async(mrcnn_dist* dist, mrcnn_model* model, const float* detections, const float* masks,
                                                   int global_batch, float* out_detections, float* out_masks);
 MRCNN_API int mrcnn_dist_wait(mrcnn_dist* dist);
+/* Range recoveries seen by the LAST completed exchange of mrcnn_maskrcnn_predict_sharded (split modes; §"scale-aware split" below): every rank's
+ * slot carries, beside its status word, how many times its local predict lowered its split exponents in that call.  *ranks = how many ranks
+ * did (0: every rank still holds the exponent vector it was given), per_rank[r] (optional, `world` entries) = rank r's count.  A rank that
+ * recovered computes later images with other exponents than its peers: a job that wants per-image results independent of the rank then takes
+ * the vector with the LOWEST exponents (mrcnn_model_get_split_exponents on the ranks that recovered, element-wise minimum — the host's own
+ * all-reduce or the same record exchange) and gives it to every rank (mrcnn_model_set_split_exponents).  Identical on every rank, no GPU work. */
+MRCNN_API int mrcnn_dist_recovered(mrcnn_dist* dist, int32_t* per_rank, int* ranks);
 /* Which RCCL this library bound (dist.hip binds it at run time): 1 = the copy the process had already mapped (e.g. the one
  * PyTorch ships under the soname librccl.so.1 — taken first, so that a process holds ONE RCCL), 0 = its own dlopen of
  * librccl.so.1, -1 = RCCL could not be loaded.  Loads RCCL when it is not bound yet; needs no GPU. */

@@ -95,7 +95,13 @@ MRCNN_API int mrcnn_bench_mfma_probe(double seconds, int kind, double* tflops, d
  * chunk's own alive candidates of the class, classes at the limit dropping out (default 1).
  * Measurement-only environment variable read by mrcnn_model_load: MRCNN_CU_MASK_PROBE="w0,...,w7" (hexadecimal) creates the handle's stream on that subset of the
  * CUs (hipExtStreamCreateWithCUMask) — tools/dual_stream_probe.py's question whether two half batches on disjoint halves of the chip beat one batch on all of it (no).
- * The switches are PROCESS-WIDE test / measurement knobs: not thread-safe; a choice captured in a hipGraph stays captured. */
+ * The switches are PROCESS-WIDE test / measurement knobs: not thread-safe; a choice captured in a hipGraph stays captured.
+ * ARMING (round 6): mrcnn_debug_set, the MRCNN_* environment overrides of the switches' defaults and the measurement hooks (MRCNN_CU_MASK_PROBE,
+ * MRCNN_BNECK_DBG, MRCNN_SPLIT_EXP, MRCNN_BENCH_RESIDUAL) work only in a process started with MRCNN_TEST_KNOBS=1 in its environment (tests/conftest.py
+ * and the tools set it; read once, at the library's first use).  Anywhere else — every production host — mrcnn_debug_set returns MRCNN_ERR_UNSUPPORTED
+ * and the overrides are ignored: the alternative forms stay in the library as the tests' bit-identity anchors, out of a host's reach
+ * (tests/test_host.py::test_the_knobs_are_out_of_a_production_hosts_reach).  Forms that lost their A/B and anchor nothing are removed instead
+ * (round 6: the level-parallel FPN / RPN region of round 5). */
 MRCNN_API int mrcnn_conv2d_nhwc(const float* in, int batch, int h, int w, int cin, const float* filters, int cout,
                                 int ksize, int stride, const float* scale, const float* shift, const float* residual,
                                 int act, int dtype, float* out);

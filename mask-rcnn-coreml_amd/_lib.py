@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "mrcnn_model_get_split_exponents", "mrcnn_model_set_split_exponents", "mrcnn_roi_align_nhwc",
     "mrcnn_dist_unique_id", "mrcnn_dist_init", "mrcnn_dist_destroy", "mrcnn_dist_shard", "mrcnn_dist_record_floats",
     "mrcnn_dist_all_gather_records", "mrcnn_maskrcnn_predict_sharded", "mrcnn_mask_to_u8_f64",
-    "mrcnn_dist_all_gather_records_async", "mrcnn_dist_wait", "mrcnn_dist_rccl_shared", "mrcnn_dist_plan", "mrcnn_dist_simulate_host",
+    "mrcnn_dist_all_gather_records_async", "mrcnn_dist_wait", "mrcnn_dist_recovered", "mrcnn_dist_rccl_shared", "mrcnn_dist_plan", "mrcnn_dist_simulate_host",
     "mrcnn_maskrcnn_predict_scalefit", "mrcnn_unletterbox_boxes",
 ]
 # declared in include/maskrcnn_hip_test.h (test / measurement entry points of the same library)
@@ -169,6 +169,7 @@ def lib():
     L.mrcnn_maskrcnn_predict_sharded.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     L.mrcnn_dist_all_gather_records_async.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp]
     L.mrcnn_dist_wait.argtypes = [vp]
+    L.mrcnn_dist_recovered.argtypes = [vp, vp, C.POINTER(C.c_int)]
     L.mrcnn_dist_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, i64p, i64p]
     L.mrcnn_dist_simulate_host.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp]
     L.mrcnn_roi_align_nhwc.argtypes = [C.POINTER(vp), ip, ip, C.c_int, C.c_int, vp, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double,

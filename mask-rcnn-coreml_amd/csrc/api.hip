@@ -940,7 +940,7 @@ extern "C" int mrcnn_bench_conv_dtype(int batch, int h, int w, int cin, int cout
         d.OH = oh; d.OW = ow; d.Cout = cout; d.Npad = npad;
         d.out = dout.p; d.out_sP = cout; d.out_sB = (long)oh * ow * cout; d.act = ACT_RELU;
         DevBuf dres;
-        if (getenv("MRCNN_BENCH_RESIDUAL") && atoi(getenv("MRCNN_BENCH_RESIDUAL"))) {        // the bottleneck blocks' branch2c shape
+        if (knob_env("MRCNN_BENCH_RESIDUAL") && atoi(knob_env("MRCNN_BENCH_RESIDUAL"))) {        // the bottleneck blocks' branch2c shape
             dres.alloc(n_out * es);
             HIP_CHECK(hipMemset(dres.p, 0, n_out * es));
             d.res = dres.p; d.res_sB = d.out_sB; d.res_sW = cout; d.res_sH = (long)ow * cout;
@@ -984,6 +984,8 @@ extern "C" int mrcnn_debug_set(const char* key, int value)
 {
     return guarded([&] {
         MRCNN_REQUIRE(key, MRCNN_ERR_INVALID, "null key");
+        MRCNN_REQUIRE(test_knobs_armed(), MRCNN_ERR_UNSUPPORTED, "mrcnn_debug_set('%s'): the test / measurement knobs are armed only in a process started with "
+                      "MRCNN_TEST_KNOBS=1 (include/maskrcnn_hip_test.h); a production host runs the shipped policy", key);
         if (strcmp(key, "conv2d_alias_res") == 0) { g_conv2d_alias_res = value; return; }
         MRCNN_REQUIRE(conv_debug_set(key, value) || boxes_debug_set(key, value) || engine_debug_set(key, value), MRCNN_ERR_INVALID, "unknown debug key '%s'", key);
     });

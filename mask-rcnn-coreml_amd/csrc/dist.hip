@@ -104,7 +104,7 @@ void shard(int total, int world, int rank, int* lo, int* hi)
 }
 
 // ---- the layout of one exchange --------------------------------------------------------------------------------------
-constexpr int TRAILER = 4;        // floats: [status, images in the shard, 0, 0] (int32 bit patterns)
+constexpr int TRAILER = 4;        // floats: [status, images in the shard, range recoveries of the rank's predict, 0] (int32 bit patterns)
 struct Geometry {
     size_t det_len, mask_len, rec;   // floats per image
     int n_max;                       // images of the largest shard
@@ -229,6 +229,7 @@ extern "C" int mrcnn_dist_simulate_host(int world, int global_batch, int max_det
                       "bad dist_simulate_host argument");
         const Geometry g = geometry(global_batch, world, max_detections, mask_size);
         const auto plan = plan_entries(global_batch, world, g);
+        static_assert(TRAILER >= 3, "status | records | range recoveries of the rank's predict");
         std::vector<float> gathered((size_t)world * g.slot, -1.0f);       // poisoned: every word must come from a pack
         HostCopy c;
         for (int r = 0; r < world; ++r) {
@@ -336,7 +337,7 @@ static void release_peers(mrcnn_dist* d)
 // word of a zeroed slot; only when even that cannot be enqueued is the communicator aborted (ncclCommAbort: the peers' collective
 // then fails instead of blocking for ever) and the error raised.  *enqueued is set as soon as work targets d's buffers.
 static void issue_exchange(mrcnn_dist* d, Model& m, hipStream_t s, const float* det, const float* masks, int in_space, int global_batch,
-                           int out_space, float* out_det, float* out_masks, int status, bool* enqueued = nullptr)
+                           int out_space, float* out_det, float* out_masks, int status, bool* enqueued = nullptr, int recovered = 0)
 {
     MRCNN_REQUIRE(m.kind == MRCNN_MODEL_MASKRCNN, MRCNN_ERR_INVALID, "all_gather_records needs the MaskRCNN model (record geometry)");
     d->g = geometry(global_batch, d->world, m.max_det, 2 * m.mask_pool);
@@ -354,7 +355,9 @@ static void issue_exchange(mrcnn_dist* d, Model& m, hipStream_t s, const float* 
                  out_space != MRCNN_DEVICE ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice};
     if (enqueued) *enqueued = true;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        d->trailer[0] = status; d->trailer[1] = n_local; d->trailer[2] = d->trailer[3] = 0;
+        // word 2 (round 6): this rank's predict lowered its split exponents (range recovery) — from then on its bits for a given
+        // image differ from its peers', which is what a sharded job that wants rank-independent results must know: mrcnn_dist_recovered
+        d->trailer[0] = status; d->trailer[1] = n_local; d->trailer[2] = recovered; d->trailer[3] = 0;
         try {
             pack_slot(c, g, n_local, det, masks, d->trailer, d->send.as<float>());
             break;
@@ -385,6 +388,21 @@ static void issue_exchange(mrcnn_dist* d, Model& m, hipStream_t s, const float* 
     HIP_CHECK(hipMemcpy2DAsync(d->statuses.data(), TRAILER * 4, d->recv.as<float>() + (size_t)g.n_max * g.rec, g.slot * 4, TRAILER * 4,
                                (size_t)d->world, hipMemcpyDeviceToHost, s));
     if (!local_msg.empty()) set_error("rank %d: %s (sent as the status word of this rank's slot)", d->rank, local_msg.c_str());
+}
+
+extern "C" int mrcnn_dist_recovered(mrcnn_dist* d, int32_t* per_rank, int* ranks)
+{
+    return guarded([&] {
+        MRCNN_REQUIRE(d && ranks, MRCNN_ERR_INVALID, "null argument");
+        MRCNN_REQUIRE(!d->pending, MRCNN_ERR_INVALID, "an exchange is still pending: call mrcnn_dist_wait first");
+        int n = 0;
+        for (int r = 0; r < d->world; ++r) {
+            const int v = d->statuses.size() == (size_t)d->world * TRAILER ? d->statuses[(size_t)r * TRAILER + 2] : 0;
+            if (per_rank) per_rank[r] = v;
+            n += v != 0;
+        }
+        *ranks = n;
+    });
 }
 
 extern "C" int mrcnn_dist_wait(mrcnn_dist* d)
@@ -456,6 +474,7 @@ extern "C" int mrcnn_maskrcnn_predict_sharded(mrcnn_dist* d, mrcnn_model* model,
         // of the collective.  It becomes the status word of this rank's slot, and every rank raises after the gather.
         int status = 0;
         std::string local_msg;
+        const long recoveries_before = m.range_recoveries;
         try {
             const size_t nd = (size_t)(n > 0 ? n : 1) * D * 6 * 4, nm = (size_t)(n > 0 ? n : 1) * D * S * S * 4;
             if (d->stage_det.bytes < nd) d->stage_det.alloc(nd);
@@ -479,7 +498,7 @@ extern "C" int mrcnn_maskrcnn_predict_sharded(mrcnn_dist* d, mrcnn_model* model,
             local_msg = e.what();
         }
         issue_exchange(d, m, m.stream, d->stage_det.as<float>(), d->stage_mask.as<float>(), MRCNN_DEVICE, global_batch, memspace, detections, masks,
-                       status);
+                       status, nullptr, (int)(m.range_recoveries - recoveries_before));
         HIP_CHECK(hipStreamSynchronize(m.stream));
         if (status != 0) fail(status, "rank %d: %s (the other ranks were told through the status word of this rank's slot)", d->rank, local_msg.c_str());
         raise_remote_status(d);

@@ -179,18 +179,6 @@ struct Model {
     DevBuf arena;
     std::vector<Op> trunk_ops;
     std::vector<std::unique_ptr<DevBuf>> stage_tabs;   // fp16 mode: per-block operand tables + tile counters of the whole-stage bottleneck launches (kernels.h: bneck_stage_launch)
-    // Level-parallel region of the trunk (round 5): once the FPN's lateral chain is done, level l's output 3x3 layer and its RPN launches
-    // depend on nothing but that level (P6 on P5) — on a single image most of these launches cover a fraction of the chip, so the levels
-    // P3.. run on side streams beside P2 (fork behind the laterals, join in front of the soft-max).  trunk_branch[i]: stream of op i
-    // (0 = the model's); ops [fork_at, join_at) form the region.  MEASURED SLOWER at every batch (single image: 4.18 -> 4.36 ms in f32x3, 2.69 ->
-    // 2.83 ms in fp16; batch 8: -0.9 %, profiles/r05_level_parallel_ab.txt): the persistent kernels of P2 own every CU, so the side streams'
-    // blocks queue behind them and the cross-stream events add gaps — OFF by default (`branch_max_batch` 0), opt-in: mrcnn_debug_set("level_parallel", n).
-    std::vector<int> trunk_branch;
-    size_t fork_at = 0, join_at = 0;
-    static constexpr int N_SIDE = 3;
-    hipStream_t side[N_SIDE] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[N_SIDE] = {nullptr, nullptr, nullptr};
-    int branch_max_batch = 0;
     struct Tap { void* base; long per_image; int dtype; int group = -1; };     // group >= 0: stored as 2^e * value (read_tensor undoes it)
     std::map<std::string, Tap> taps;    // name → (base, per-image elements, element type)
     uint8_t* d_rgb = nullptr;

@@ -509,13 +509,9 @@ void MaskHead::load(const MrcwFile& f, int capacity_rows, int dtype_)
 
 // process-wide A/B switch of the fused mask tail (tests, tools/e2e_ab.py): mrcnn_debug_set("mask_fused", 0 | 1)
 static int g_fuse_mask_tail = 1;
-// level-parallel region of the trunk (engine.h; measured slower, off by default): -1 = the model's own limit (0: never), n >= 0 = batches up to n.
-// MRCNN_LEVEL_PARALLEL / mrcnn_debug_set("level_parallel", n).  Results do not depend on it (the same launches, other streams).
-static int g_level_parallel = getenv("MRCNN_LEVEL_PARALLEL") ? atoi(getenv("MRCNN_LEVEL_PARALLEL")) : -1;
 bool engine_debug_set(const char* key, int value)
 {
     if (std::string(key) == "mask_fused") { g_fuse_mask_tail = value; return true; }
-    if (std::string(key) == "level_parallel") { g_level_parallel = value; return true; }
     return false;
 }
 
@@ -621,11 +617,6 @@ Model::~Model()
     if (pipe_out) (void)hipStreamDestroy(pipe_out);
     if (ev_p0) (void)hipEventDestroy(ev_p0);
     if (ev_p1) (void)hipEventDestroy(ev_p1);
-    for (int b = 0; b < N_SIDE; ++b) {
-        if (ev_join[b]) (void)hipEventDestroy(ev_join[b]);
-        if (side[b]) (void)hipStreamDestroy(side[b]);
-    }
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
 
@@ -657,7 +648,8 @@ void Model::load(int kind_, const std::string& path, int max_batch_, int dtype_)
     const char* want = kind == MRCNN_MODEL_MASKRCNN ? "MaskRCNN" : kind == MRCNN_MODEL_CLASSIFIER ? "Classifier" : "Mask";
     MRCNN_REQUIRE(file.get_string("kind") == want, MRCNN_ERR_IO, "'%s' holds a %s model, expected %s", path.c_str(),
                   file.get_string("kind").c_str(), want);
-    if (const char* cm = getenv("MRCNN_CU_MASK_PROBE")) {
+    if (const char* cm = knob_env("MRCNN_CU_MASK_PROBE")) {
+        fprintf(stderr, "libmaskrcnn_hip: MRCNN_CU_MASK_PROBE — this handle's stream runs on a subset of the CUs (measurement only)\n");
         // measurement only (tools/dual_stream_probe.py): the handle's stream on a subset of the CUs — 8 hexadecimal words, "w0,w1,...,w7"
         uint32_t words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int n = 0;
@@ -667,7 +659,7 @@ void Model::load(int kind_, const std::string& path, int max_batch_, int dtype_)
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     own_stream = true;
     if (const char* e = getenv("MRCNN_GRAPH")) use_graph = atoi(e) != 0;
-    if (const char* e = getenv("MRCNN_FUSE_MASK_TAIL")) fuse_mask_tail = atoi(e) != 0;
+    if (const char* e = knob_env("MRCNN_FUSE_MASK_TAIL")) fuse_mask_tail = atoi(e) != 0;
     boxes_one_time_init();
     range_flag.alloc(sizeof(int));
     HIP_CHECK(hipMemset(range_flag.p, 0, sizeof(int)));
@@ -678,12 +670,6 @@ void Model::load(int kind_, const std::string& path, int max_batch_, int dtype_)
     if (kind == MRCNN_MODEL_CLASSIFIER) { cls_head.load(file, max_batch, mode); return; }
     if (kind == MRCNN_MODEL_MASK) { mask_head.load(file, max_batch, mode); return; }
     build_maskrcnn();
-    // the side streams of the level-parallel region (engine.h): created here, never inside a launch (a caller may be capturing)
-    for (int b = 0; b < N_SIDE; ++b) {
-        HIP_CHECK(hipStreamCreateWithFlags(&side[b], hipStreamNonBlocking));
-        HIP_CHECK(hipEventCreateWithFlags(&ev_join[b], hipEventDisableTiming));
-    }
-    HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
 }
 
 void Model::build_maskrcnn()
@@ -786,7 +772,6 @@ void Model::build_maskrcnn()
     for (int pass = 0; pass < 2; ++pass) {
         ar.off = 0;
         trunk_ops.clear();
-        trunk_branch.clear();
         taps.clear();
         sgroups.clear();
         sops.clear();
@@ -794,8 +779,7 @@ void Model::build_maskrcnn()
         const bool real = pass == 1;
         const int dt = dtype;
         auto T = [&](int h, int w, int c) { Tensor4 t; t.H = h; t.W = w; t.C = c; t.p = ar.alloc_e((size_t)Bm * h * w * c, dt); return t; };
-        int cur_branch = 0;          // stream of the ops being recorded (Model::trunk_branch)
-        auto add = [&](Op op) { if (real) { trunk_ops.push_back(std::move(op)); trunk_branch.push_back(cur_branch); } };
+        auto add = [&](Op op) { if (real) trunk_ops.push_back(std::move(op)); };
         // split groups (engine.h: SplitGroup): g_in / g_out of every convolution; a residual rides in the output's group
         const int g_img = new_split_group("image", true);        // pixel - mean: written by the pre-processing kernel, exponent 0
         const int g_zero = new_split_group("outputs", true);      // logits, box deltas, probabilities: consumed by fp32 arithmetic
@@ -1024,13 +1008,10 @@ void Model::build_maskrcnn()
         const Tensor4 Ls[4] = {L2, L3, L4, L5};
         const char* pn[4] = {"fpn_p2", "fpn_p3", "fpn_p4", "fpn_p5"};
         const char* tn[4] = {"P2", "P3", "P4", "P5"};
-        fork_at = trunk_ops.size();                               // the laterals are done: from here the levels are independent
         for (int l = 0; l < 4; ++l) {
             P[l] = T(Ls[l].H, Ls[l].W, 256);
             g_P[l] = new_split_group(tn[l]);
-            cur_branch = l;
             conv_op(pn[l], Ls[l], P[l], 1, 1, ACT_NONE, nullptr, 0, g_L, g_P[l]);
-            cur_branch = 0;
             taps[tn[l]] = {P[l].p, P[l].sB(), dt, g_P[l]};
             MRCNN_REQUIRE(P[l].H == fh[l] && P[l].W == fw[l], MRCNN_ERR_SHAPE, "pyramid level %d shape mismatch", l + 2);
         }
@@ -1040,12 +1021,10 @@ void Model::build_maskrcnn()
         rpn_deltas = ar.alloc_f((size_t)Bm * A * 4);
         taps["rpn_probs"] = {rpn_probs, (long)A * 2, MRCNN_F32};
         taps["rpn_deltas"] = {rpn_deltas, (long)A * 4, MRCNN_F32};
-        // the shared layer's 512-channel tensor, one per branch of the level-parallel region: P2 | P3 | P4 | P5 and P6 (same stream)
-        void* rpn_feat_l[5];
-        for (int l = 0; l < 5; ++l) rpn_feat_l[l] = l == 4 ? rpn_feat_l[3] : ar.alloc_e((size_t)Bm * fh[l] * fw[l] * 512, dt);
+        // the shared layer's 512-channel tensor: ONE buffer, sized for the largest level, reused level after level on the model's stream
+        // (round 5's per-level copies served the level-parallel region, measured slower and removed in round 6: profiles/r05_level_parallel_ab.txt)
+        void* const rpn_feat = ar.alloc_e((size_t)Bm * fh[0] * fw[0] * 512, dt);
         for (int l = 0; l < 5; ++l) {
-            void* const rpn_feat = rpn_feat_l[l];
-            cur_branch = l < 4 ? l : 3;
             const Tensor4& src = P[l < 4 ? l : 3];
             const int sub = l < 4 ? 1 : 2;
             const PackedConv* pc = &convs.at("rpn_conv_shared");
@@ -1104,8 +1083,6 @@ void Model::build_maskrcnn()
                 ConvDesc y = e; y.B = batch; conv_forward(s, y);
             });
         }
-        cur_branch = 0;
-        join_at = trunk_ops.size();
         {
             float* lg = rpn_logits; float* pr = rpn_probs; const long per = A;
             add([=](hipStream_t s, int batch) { softmax_pairs_forward(s, lg, pr, per * batch); });
@@ -1162,7 +1139,7 @@ void Model::build_maskrcnn()
         }
         if (found) { apply_split_exponents(); split_calibrated = true; exponents_from_artefact = true; }
     }
-    if (const char* e = getenv("MRCNN_SPLIT_EXP")) {          // measurement / tests: one exponent for every non-fixed group (split modes only)
+    if (const char* e = knob_env("MRCNN_SPLIT_EXP")) {          // measurement / tests: one exponent for every non-fixed group (split modes only)
         if (split_mode) {
             for (auto& g : sgroups) if (!g.fixed) g.exp = atoi(e);
             apply_split_exponents();
@@ -1298,7 +1275,9 @@ void Model::measure_split_groups(const uint8_t* rgb, int batch, int h, int w, in
         memcpy(&mx, &raw[g * 8], 4);
         mx = ldexpf(mx, -sgroups[g].exp);               // stored = 2^e * value
         sgroups[g].absmax = mx;
-        MRCNN_REQUIRE(mx == mx && mx < 3.0e38f, MRCNN_ERR_UNSUPPORTED, "calibrate_split: tensor group '%s' holds inf / NaN", sgroups[g].name.c_str());
+        MRCNN_REQUIRE(mx == mx && mx < 3.0e38f, MRCNN_ERR_UNSUPPORTED, "%s: tensor group '%s' holds inf / NaN on this batch (an fp32 engine would produce them too)",
+                      resident ? "range recovery of a predict (the batch was measured where it sits, after an activation left the fp16 range)" : "calibrate_split",
+                      sgroups[g].name.c_str());
     }
 }
 
@@ -1357,6 +1336,12 @@ bool Model::recover_range(int batch, int h, int w, bool fit)
     for (size_t g = 0; g < G; ++g) before[g] = sgroups[g].exp;
     try {
         measure_split_groups(nullptr, batch, h, w, MRCNN_DEVICE, fit, true);
+    } catch (const Error& e) {
+        for (size_t g = 0; g < G; ++g) sgroups[g].exp = before[g];
+        apply_split_exponents();
+        // (the caller asked for a predict, not for a calibration: say what happened in ITS terms — ADVICE r5)
+        fail(e.code, "predict: an activation left the calibrated fp16 range and the batch could not be measured for a range recovery (%s); the split "
+             "exponents are unchanged, the results of this call are not valid", e.msg.c_str());
     } catch (...) {
         for (size_t g = 0; g < G; ++g) sgroups[g].exp = before[g];
         apply_split_exponents();
@@ -1561,6 +1546,11 @@ void Model::enqueue_pipeline(hipStream_t s, int batch, const int* fit)
 {
     int* const rflag = mode != MRCNN_F32 ? range_flag.as<int>() : nullptr;
     if (rflag) HIP_CHECK(hipMemsetAsync(rflag, 0, sizeof(int), s));
+    // the thread-local hand-overs of the convolution family (range flag, scratch, profiler) point into THIS model: whatever way the
+    // function is left — a launch may throw — they are cleared, so that nothing dangles once the handle is destroyed
+    struct LaunchContext {
+        ~LaunchContext() { conv_set_profiler(nullptr); conv_set_range_flag(nullptr); conv_set_scratch(nullptr); }
+    } launch_context;
     conv_set_range_flag(rflag);
     conv_set_scratch(conv_scratch.ks_buf.p ? &conv_scratch : nullptr);
     timer.begin(s);
@@ -1572,22 +1562,7 @@ void Model::enqueue_pipeline(hipStream_t s, int batch, const int* fit)
             preprocess_scalefit_forward(s, fit_src.as<uint8_t>(), batch, fit[0], fit[1], H, W, fit[2], fit[3], fit[4], fit[5], 3, mean, stem_in, dtype);
             first = 1;
         }
-        // (a calibration pass observes tensors on the model's stream, the stage timer and the conv profile bracket launches on it: those run serially)
-        const int pmax = g_level_parallel >= 0 ? g_level_parallel : branch_max_batch;
-        const bool parallel = side[0] && batch <= pmax && fork_at < join_at && !calib_phase && !conv_profile.active && !timer.enabled;
-        for (size_t i = first; i < trunk_ops.size(); ++i) {
-            if (parallel && i == fork_at) {
-                HIP_CHECK(hipEventRecord(ev_fork, s));
-                for (int b = 0; b < N_SIDE; ++b) HIP_CHECK(hipStreamWaitEvent(side[b], ev_fork, 0));
-            }
-            if (parallel && i == join_at)
-                for (int b = 0; b < N_SIDE; ++b) {
-                    HIP_CHECK(hipEventRecord(ev_join[b], side[b]));
-                    HIP_CHECK(hipStreamWaitEvent(s, ev_join[b], 0));
-                }
-            const int br = parallel && i >= fork_at && i < join_at ? trunk_branch[i] : 0;
-            trunk_ops[i](br > 0 ? side[br - 1] : s, batch);
-        }
+        for (size_t i = first; i < trunk_ops.size(); ++i) trunk_ops[i](s, batch);
     }
     timer.mark(s, "Trunk");
     // ProposalLayer
@@ -1659,9 +1634,6 @@ void Model::enqueue_pipeline(hipStream_t s, int batch, const int* fit)
                             batch, msel_ws, mask_out, (long)max_det * HW, HW, dtype);
     }
     timer.mark(s, "TimeDistributedMask-Eval");
-    conv_set_profiler(nullptr);
-    conv_set_range_flag(nullptr);
-    conv_set_scratch(nullptr);
 }
 
 void Model::read_tensor(const std::string& name, int image, float* dst, int64_t cap, int64_t* count)

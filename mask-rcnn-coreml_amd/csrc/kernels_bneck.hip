@@ -1002,7 +1002,13 @@ void bneck_launch(hipStream_t s, int C, const void* x, void* y, int B, int H, in
     const int th = C == 256 ? 8 : 16;
     a.tiles_x = W / 16; a.tiles_y = H / th; a.ntiles = B * a.tiles_x * a.tiles_y;
     a.range_flag = range_flag;
-    static const int dbg = getenv("MRCNN_BNECK_DBG") ? atoi(getenv("MRCNN_BNECK_DBG")) : 0;      // measurement only: 1 / 2 / 4 = phase A / B / C cut to one step (results invalid)
+    // measurement only (tools/bneck_phases.sh; needs MRCNN_TEST_KNOBS=1): 1 / 2 / 4 = phase A / B / C cut to one step — RESULTS INVALID, said once on stderr
+    static const int dbg = [] {
+        const char* e = knob_env("MRCNN_BNECK_DBG");
+        const int v = e ? atoi(e) : 0;
+        if (v) fprintf(stderr, "libmaskrcnn_hip: MRCNN_BNECK_DBG=%d — the fused bottleneck blocks skip work: results are NOT valid (measurement only)\n", v);
+        return v;
+    }();
     a.dbg = dbg;
     int grid = n_cus > 0 ? n_cus / 8 * 8 : 256;
     if (grid <= 0) grid = 8;

@@ -28,7 +28,7 @@ namespace mrcnn {
 static constexpr int CHUNK = 1024;   // scores per block in the select passes (256 threads × 4)
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
-static int boxes_env_int(const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; }
+static int boxes_env_int(const char* name, int dflt) { const char* e = knob_env(name); return e && *e ? atoi(e) : dflt; }      // (honoured only with MRCNN_TEST_KNOBS=1)
 // Run-time switches (A/B and bit-identity tests; mrcnn_debug_set): none of them changes an output bit
 static int g_rank_sort = boxes_env_int("MRCNN_RANK_SORT", 1);       // "proposal_rank_sort": 1 rank counting over the chip (k_rank_decode), 0 the one-block bitonic sort
 static int g_nms_splits = boxes_env_int("MRCNN_NMS_SPLITS", 0);     // "nms_col_splits": column splits of k_nms_mask's grid; 0 = by policy (nms_col_splits)

@@ -670,7 +670,7 @@ void conv_pp_launch(hipStream_t s, const ConvArgs& a, int mode);   // kernels_co
 // Run-time switches of the tile choice (A/B measurements through the micro-benchmark hook; defaults = the shipped policy)
 static int env_int(const char* name, int dflt)
 {
-    const char* e = getenv(name);
+    const char* e = knob_env(name);          // (honoured only with MRCNN_TEST_KNOBS=1: common.h)
     return e && *e ? atoi(e) : dflt;
 }
 struct PpPolicy { int on, min_tiles, min_kt, dbg, min_fill_pct, split; };

@@ -43,7 +43,7 @@ namespace mrcnn {
 
 ConvScratch* conv_current_scratch();      // kernels_conv.hip: the calling thread's scratch (conv_set_scratch)
 
-static int env_int_halo(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static int env_int_halo(const char* name, int dflt) { const char* e = knob_env(name); return e ? atoi(e) : dflt; }      // (honoured only with MRCNN_TEST_KNOBS=1)
 
 static constexpr int HALO_MAX_SLOT = 640;        // LDS pixel slots of one plane (region rows x LDS pitch <= this)
 static constexpr unsigned HALO_OOB = 0xC0000000u;

@@ -184,6 +184,15 @@ class NativeDist:
     def wait(self):
         self._lib.check(self._lib.lib().mrcnn_dist_wait(self._h))
 
+    def recovered(self):
+        """[range recoveries of rank r's predict] of the last completed sharded predict (mrcnn_dist_recovered): any non-zero entry means that
+        rank lowered its split exponents — redistribute the element-wise minimum of the vectors for rank-independent per-image results."""
+        C = self._C
+        per = (C.c_int32 * self.world)()
+        n = C.c_int(0)
+        self._lib.check(self._lib.lib().mrcnn_dist_recovered(self._h, per, C.byref(n)))
+        return list(per)
+
     @staticmethod
     def plan(global_batch: int, world: int, max_det: int, mask_size: int):
         """[(begin, end, slot offset in floats, record floats)] per rank and the slot size — host arithmetic of dist.hip."""

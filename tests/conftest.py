@@ -8,6 +8,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The bit-identity tests switch between forms of the kernels through mrcnn_debug_set: those knobs (and the MRCNN_* overrides of their
+# defaults) exist only in a process started with MRCNN_TEST_KNOBS=1 (csrc/common.h) — set before the library is loaded.  A production
+# host never sets it: tests/test_host.py::test_the_knobs_are_out_of_a_production_hosts_reach pins that.
+os.environ.setdefault("MRCNN_TEST_KNOBS", "1")
 
 
 def pytest_configure(config):

@@ -793,45 +793,3 @@ def test_fp16_fused_rpn_heads_equal_the_separate_head_launches(pkg, weights_mod,
     d1, m1 = m.predict(images[1:2])
     np.testing.assert_array_equal(d1[0], det[1])
     assert np.isfinite(probs[0]).all() and (det[..., 5] > 0).sum() > 0
-
-
-@pytest.mark.parametrize("dtype", ["f32x3", "f16"])
-def test_level_parallel_region_leaves_predict_bit_identical(pkg, weights_mod, tmp_path_factory, dtype):
-    """Round 5 (opt-in; measured slower, off by default): the FPN output layers and the RPN launches of the levels P3.. on side streams beside
-    P2's (fork behind the lateral chain, join in front of the soft-max; each level its own 512-channel scratch).  The same launches on
-    other streams: with mrcnn_debug_set("level_parallel", 2) nothing may change by one bit against the serial default, run after run, and
-    a batch above the limit (serial) must equal its images' single-image (parallel) results."""
-    import importlib
-    L = importlib.import_module("mask-rcnn-coreml_amd._lib")
-    models = importlib.import_module("mask-rcnn-coreml_amd.models")
-    d, cfg = make_model_dir(tmp_path_factory, pkg, weights_mod, "lvlpar" + dtype, architecture="resnet50", input_image_shape=(512, 512, 3),
-                            num_classes=21, pre_nms_max_proposals=1000, max_proposals=128, max_detections=32)
-    m = models.load_maskrcnn(d, max_batch=3, compute_dtype=dtype)
-    images = rand_images(3, 512, 512, seed=17)
-    if dtype == "f32x3":
-        m.calibrate_split(images[:2])
-    names = ("P2", "P3", "P4", "P5", "rpn_probs", "rpn_deltas")
-    try:
-        L.check(L.lib().mrcnn_debug_set(b"level_parallel", 0))
-        want = []
-        for b in range(3):
-            det, mask = m.predict(images[b:b + 1])
-            want.append((det.copy(), mask.copy(), {n: m.read_tensor(n, 0).copy() for n in names}))
-    finally:
-        L.check(L.lib().mrcnn_debug_set(b"level_parallel", 2))     # batches of up to two images: level-parallel
-    try:
-      for rep in range(5):
-        for b in range(3):
-            det, mask = m.predict(images[b:b + 1])                # parallel (batch 1)
-            np.testing.assert_array_equal(det, want[b][0])
-            np.testing.assert_array_equal(mask, want[b][1])
-            for n in names:
-                np.testing.assert_array_equal(m.read_tensor(n, 0), want[b][2][n], err_msg=f"{n} image {b} repeat {rep}")
-      det2, _ = m.predict(images[:2])                               # parallel (batch 2)
-      det3, _ = m.predict(images)                                   # serial (batch 3)
-      for b in range(3):
-        np.testing.assert_array_equal(det3[b], want[b][0][0])
-        if b < 2:
-            np.testing.assert_array_equal(det2[b], want[b][0][0])
-    finally:
-        L.check(L.lib().mrcnn_debug_set(b"level_parallel", -1))

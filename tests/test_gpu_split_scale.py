@@ -246,6 +246,33 @@ def test_an_input_far_above_the_calibrated_range_recovers_and_matches_the_oracle
         assert m.get_int("range_recoveries") == 1
 
 
+def test_a_sharded_predict_tells_every_rank_that_a_rank_recovered(pkg, weights_mod, tmp_path_factory):
+    """a range recovery lowers the split exponents of ONE rank's handle for good — from then on its bits for an image differ from
+    its peers'.  The exchange therefore carries, beside the status word, how often the rank's predict recovered (word 2 of the slot's
+    trailer): mrcnn_dist_recovered reports it on every rank, so that the host can redistribute the lowered vector.  World 1 through RCCL:
+    the call that recovers reports [1] and returns the recovered (oracle-grade) results, the next call reports [0]."""
+    dmod = importlib.import_module("mask-rcnn-coreml_amd.dist")
+    d, cfg = _rescaled_model(tmp_path_factory, pkg, weights_mod, "recover_dist", 0, 0)
+    flat = np.empty((1, 128, 128, 3), np.uint8)
+    flat[...] = np.array([124, 117, 104], np.uint8)
+    images = rand_images(2, 128, 128, seed=9)
+    m = _models().load_maskrcnn(d, max_batch=2, compute_dtype="f32x3")
+    m.calibrate_split(flat)
+    nd = dmod.NativeDist(0, 1, dmod.NativeDist.unique_id())
+    try:
+        assert nd.recovered() == [0]
+        det, mask = nd.predict_sharded(m, images)
+        assert nd.recovered() == [1] and m.get_int("range_recoveries") == 1
+        want_d, want_m = m.predict(images)                                  # (the handle now holds the lowered exponents: same bits)
+        np.testing.assert_array_equal(det, want_d)
+        np.testing.assert_array_equal(mask, want_m)
+        nd.predict_sharded(m, images)
+        assert nd.recovered() == [0] and m.get_int("range_recoveries") == 1
+    finally:
+        nd.close()
+    pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None
+
+
 def test_exponents_stored_in_the_artefact_make_the_drop_in_load_calibrated(pkg, weights_mod, tmp_path_factory):
     """`convert --calibrate` stores the exponent vector in MaskRCNN.mrcw; mrcnn_model_load applies it, so
     MaskRCNN().prediction(image) (ViewController.swift:37) needs no extra call.  The reloaded model reproduces the calibrated one

@@ -1,5 +1,6 @@
 """A/B of the fp16 3x3 kernel (kernels_conv3x3_h.hip, "conv_c3h" 1) against the 128-row / ping-pong kernels ("conv_c3h" 0) through the
 micro-benchmark hook, interleaved rounds in one process.   usage: python tools/c3h_ab.py [rounds] [iters]"""
+import os as _os; _os.environ.setdefault("MRCNN_TEST_KNOBS", "1")      # arm the test / measurement knobs (csrc/common.h) before the library loads
 import ctypes as C
 import importlib
 import os

@@ -2,6 +2,7 @@
 """A/B of the fp16 conv kernels on the trunk's big layer shapes: the 128-row kernel vs the 256-row ping-pong kernel,
 interleaved rounds in one process (cdna guide §5.4 rule 24).  usage: conv_ab.py [rounds] [iters] [min_tiles] [dtype] [pp_dbg]
 (pp_dbg: a third column with the ping-pong kernel under that conv_pp_dbg value, e.g. 512 = the other DMA addressing form)"""
+import os as _os; _os.environ.setdefault("MRCNN_TEST_KNOBS", "1")      # arm the test / measurement knobs (csrc/common.h) before the library loads
 import ctypes as C
 import importlib
 import os

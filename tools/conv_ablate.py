@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Ablations of the 128-row kernels on one shape (measurement build: make -C mask-rcnn-coreml_amd/csrc ablate; results are wrong
 under the switches).  usage: MRCNN_HIP_LIB=.../libmaskrcnn_hip_ablate.so [MRCNN_BENCH_RESIDUAL=1] conv_ablate.py dtype b h w cin cout k stride"""
+import os as _os; _os.environ.setdefault("MRCNN_TEST_KNOBS", "1")      # arm the test / measurement knobs (csrc/common.h) before the library loads
 import ctypes as C, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 L = importlib.import_module("mask-rcnn-coreml_amd._lib")

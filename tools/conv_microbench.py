@@ -1,5 +1,6 @@
 #!/usr/bin/env python
 """Micro-benchmark of the conv kernel family on the trunk's layer shapes (through the C ABI)."""
+import os as _os; _os.environ.setdefault("MRCNN_TEST_KNOBS", "1")      # arm the test / measurement knobs (csrc/common.h) before the library loads
 import ctypes as C
 import importlib
 import os

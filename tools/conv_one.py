@@ -1,5 +1,6 @@
 #!/usr/bin/env python
 """One conv shape through mrcnn_bench_conv_dtype: conv_one.py batch h w cin cout k stride [iters] [f32|f16|f32s]"""
+import os as _os; _os.environ.setdefault("MRCNN_TEST_KNOBS", "1")      # arm the test / measurement knobs (csrc/common.h) before the library loads
 import ctypes as C, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 L = importlib.import_module("mask-rcnn-coreml_amd._lib")

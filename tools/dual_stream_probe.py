@@ -2,6 +2,7 @@
 """Does the chip run two half batches on two streams faster than one whole batch on one?  (memory-bound 1x1 layers of one half under the
    power-bound 3x3 layers of the other).  Two model handles (own arena + stream each), one host thread per handle, free-running.
    dual_stream_probe.py <dtype> [batch] [steps]"""
+import os as _os; _os.environ.setdefault("MRCNN_TEST_KNOBS", "1")      # arm the test / measurement knobs (csrc/common.h) before the library loads
 import importlib, os, sys, tempfile, threading, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

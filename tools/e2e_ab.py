@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Whole-model A/B of a kernel-policy knob, interleaved rounds in one process (cdna guide rule 24):
    e2e_ab.py <dtype> <key> <value A> <value B> [rounds] [steps]      e.g.  e2e_ab.py f32x3 conv_tn4 0 -1"""
+import os as _os; _os.environ.setdefault("MRCNN_TEST_KNOBS", "1")      # arm the test / measurement knobs (csrc/common.h) before the library loads
 import importlib, os, sys, tempfile, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -6,6 +6,7 @@ outputs of the HIP engine in modes f32 / f32x3 / f32s / f16 are compared with or
 float64 — fp16-exact weights widened), next to the torch-CPU fp32 network itself.  Error = max |x - x64| / max |x64|
 per tensor.  Writes JSON (default gpurun_out/fp64_trunk_parity.json; the committed copy lives under profiles/).
 """
+import os as _os; _os.environ.setdefault("MRCNN_TEST_KNOBS", "1")      # arm the test / measurement knobs (csrc/common.h) before the library loads
 import argparse
 import importlib
 import json

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
 """hipGraph replay vs plain stream launches for predict: graph_probe.py [iters]  (R101 1024², synthetic weights)."""
+import os as _os; _os.environ.setdefault("MRCNN_TEST_KNOBS", "1")      # arm the test / measurement knobs (csrc/common.h) before the library loads
 import importlib
 import os
 import sys

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """A/B of the 3x3 layers of the split modes: the 128-row kernel family vs the persistent halo kernel (kernels_conv_halo.hip),
 interleaved rounds in one process.  usage: halo_ab.py [rounds] [iters] [dtype]"""
+import os as _os; _os.environ.setdefault("MRCNN_TEST_KNOBS", "1")      # arm the test / measurement knobs (csrc/common.h) before the library loads
 import ctypes as C
 import importlib
 import os

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Ablations of the halo kernel on one shape (measurement only: results are wrong under most of them).
 usage: halo_ablate.py [dtype] [shape...]"""
+import os as _os; _os.environ.setdefault("MRCNN_TEST_KNOBS", "1")      # arm the test / measurement knobs (csrc/common.h) before the library loads
 import ctypes as C, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 L = importlib.import_module("mask-rcnn-coreml_amd._lib")

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Instruction-order digest of the conv kernels' K loop (M = MFMA, R = ds_read, G = global→LDS DMA, W = s_waitcnt):
    tools/isa_stream.py   — compiles kernels_conv.hip to gfx950 assembly and prints the stream after the first barrier."""
+import os as _os; _os.environ.setdefault("MRCNN_TEST_KNOBS", "1")      # arm the test / measurement knobs (csrc/common.h) before the library loads
 import os
 import subprocess
 import sys

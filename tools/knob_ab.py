@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """A/B of one policy knob (mrcnn_debug_set) on single layers through the micro-benchmark hook, interleaved rounds in one process.
 usage: knob_ab.py <knob> <v0> <v1> <dtype> [rounds] [iters] [shape-set]      shape-set: pw (the long-K 1x1 layers; default) | all"""
+import os as _os; _os.environ.setdefault("MRCNN_TEST_KNOBS", "1")      # arm the test / measurement knobs (csrc/common.h) before the library loads
 import ctypes as C
 import importlib
 import os

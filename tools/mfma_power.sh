@@ -1,4 +1,5 @@
 #!/bin/bash
+export MRCNN_TEST_KNOBS=1      # arm the test / measurement knobs (csrc/common.h)
 # The board's sustained matrix rate with no data movement (tools/probes/mfma_probe.hip) with rocm-smi power / clock samples beside it.
 R=$(cd "$(dirname "$0")/.." && pwd)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $R/tools/probes/mfma_probe $R/tools/probes/mfma_probe.hip

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MRCNN_TEST_KNOBS=1      # arm the test / measurement knobs (csrc/common.h)
 # PMC digest of the conv kernels on one shape, 128-row vs ping-pong:
 #   pmc_conv_probe.sh <dtype> "<b h w cin cout k stride>" "<counter set 1>" "<counter set 2>" ...
 # (each set is its own rocprofv3 --pmc pass, kernel-trace only; both kernels: MRCNN_PP=0 / 1 with the size gate off)

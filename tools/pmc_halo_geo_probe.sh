@@ -1,4 +1,5 @@
 #!/bin/bash
+export MRCNN_TEST_KNOBS=1      # arm the test / measurement knobs (csrc/common.h)
 # LDS bank conflicts (and VALU / LDS instruction counts) of the halo kernel per layer shape, round-3 tile geometries
 # (MRCNN_HALO_GEO=0) vs round 4 (=1):   pmc_halo_geo_probe.sh <dtype> "<b h w cin cout k stride>" ...
 # Each shape is its own rocprofv3 --pmc pass (kernel-trace only), per MI355X_MICROARCH.md.

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MRCNN_TEST_KNOBS=1      # arm the test / measurement knobs (csrc/common.h)
 # PMC digest of one 3x3 shape in a split mode, 128-row kernel (MRCNN_HALO=0) vs halo kernel (MRCNN_HALO=1):
 #   pmc_halo_probe.sh <dtype> "<b h w cin cout k stride>" "<counter set 1>" "<counter set 2>" ...
 # (each set is its own rocprofv3 --pmc pass, kernel-trace only)

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MRCNN_TEST_KNOBS=1      # arm the test / measurement knobs (csrc/common.h)
 # Board power and shader clock while ONE convolution shape runs back to back for a few seconds, per compute mode:
 # is the sustained clock under matrix load (1.45-1.7 GHz against 2.4 GHz nominal) a power limit?
 #   power_probe.sh [modes...]      (default: f32 f32x3 f32s f16), RPN 3x3 256->512 at 256^2, batch 8

@@ -2,6 +2,7 @@
 """Ablations of the ping-pong conv kernel on one shape (measurement-only switches, see kernels_conv_pp.hip a.dbg):
 usage: pp_ablate.py [shape index] — prints us / TF for: 128-row kernel, ping-pong, and the ping-pong kernel with
 1 no setprio, 2 no stagger, 4 no DMA in the main loop, 8 no fragment reads, 16 no MFMAs (and combinations)."""
+import os as _os; _os.environ.setdefault("MRCNN_TEST_KNOBS", "1")      # arm the test / measurement knobs (csrc/common.h) before the library loads
 import ctypes as C, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 L = importlib.import_module("mask-rcnn-coreml_amd._lib")

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MRCNN_TEST_KNOBS=1      # arm the test / measurement knobs (csrc/common.h)
 # Sustained clock and MFMA-busy of the ping-pong kernel and its ablations on the largest layer (RPN 3x3 256->512 at 256², batch 8):
 #   pp_clock_probe.sh <f16|f32s|f32x3> ["<dbg bits> ..."]   dbg: 0 shipped, 4 no DMA in the main loop, 8 no fragment reads, 256 every activation DMA from the same 128 bytes (L1-hot)
 # clock = GRBM_GUI_ACTIVE / 8 XCDs / duration; util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles)

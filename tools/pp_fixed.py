@@ -1,5 +1,6 @@
 #!/usr/bin/env python
 """Where the per-tile fixed cost of the ping-pong kernel goes: 1x1 conv M = 8*256*256, N = 512, Cin = 128 (KT = 2), fp16."""
+import os as _os; _os.environ.setdefault("MRCNN_TEST_KNOBS", "1")      # arm the test / measurement knobs (csrc/common.h) before the library loads
 import ctypes as C, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 L = importlib.import_module("mask-rcnn-coreml_amd._lib")

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
 """Fixed cost vs per-K-tile cost of the conv kernels: 1x1 convs M = 8*256*256, N = 512, Cin = 256..2048 (KT = 4..32)."""
+import os as _os; _os.environ.setdefault("MRCNN_TEST_KNOBS", "1")      # arm the test / measurement knobs (csrc/common.h) before the library loads
 import ctypes as C, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 L = importlib.import_module("mask-rcnn-coreml_amd._lib")

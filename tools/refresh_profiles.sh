@@ -1,4 +1,5 @@
 #!/bin/bash
+export MRCNN_TEST_KNOBS=1      # arm the test / measurement knobs (csrc/common.h)
 # Regenerates everything under profiles/ for round $1 (default r02) on a GPU box:
 #   gpurun --timeout 3300 -- 'bash tools/refresh_profiles.sh r04'
 # Outputs land in gpurun_out/profiles_<round>/ (merged back by gpurun); copy them into profiles/ and commit.

@@ -2,6 +2,7 @@
 """Soak: the same batch of 8 (the headline batch: the fp16 mode then runs its large layers on the ping-pong kernel) through predict N times per compute mode; every output must be bit-identical to the first
 (races in the DMA ring / barriers / atomics would show up as run-to-run differences).  soak_determinism.py [iters] [batch] [modes]
 batch 1 exercises the single-image forms: shared-tile K chunks (whichever block arrives last folds the partial sums), the halo kernel's latency form."""
+import os as _os; _os.environ.setdefault("MRCNN_TEST_KNOBS", "1")      # arm the test / measurement knobs (csrc/common.h) before the library loads
 import importlib
 import os
 import sys

@@ -2,6 +2,7 @@
 """The scale-aware split's calibration report on the headline model (R101+FPN 1024^2, synthetic weights): per tensor group the
 maximum |a| of the calibration batch, the exponent chosen (max |a| * 2^e in [2^11, 2^12)) and the diagnostic counters
 (include/maskrcnn_hip.h: mrcnn_model_calibrate_split).  usage: split_report.py [dtype] [images]"""
+import os as _os; _os.environ.setdefault("MRCNN_TEST_KNOBS", "1")      # arm the test / measurement knobs (csrc/common.h) before the library loads
 import importlib
 import os
 import sys

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
 """Probe: batch 8 as two half-batches on two model instances / streams vs one batch-8 predict."""
+import os as _os; _os.environ.setdefault("MRCNN_TEST_KNOBS", "1")      # arm the test / measurement knobs (csrc/common.h) before the library loads
 import importlib, os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
