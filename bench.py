@@ -634,7 +634,7 @@ def sustained_peak(dtype, parts, achieved):
     """What the matrix cores of this board sustain for seconds with NO data movement (tools/probes/mfma_probe.hip under
     tools/mfma_power.sh, committed under profiles/): the fp16 MFMA on operands that change every instruction, the fp32 MFMA
     on constants.  Informational — `peak` / `frac` above stay the nominal figures of MI355X_MICROARCH.md."""
-    path = next((p for p in (os.path.join(ROOT, "profiles", f"{r}_mfma_power.txt") for r in ("r05", "r04", "r03", "r02")) if os.path.exists(p)),
+    path = next((p for p in (os.path.join(ROOT, "profiles", f"{r}_mfma_power.txt") for r in ("r06", "r05", "r04", "r03", "r02")) if os.path.exists(p)),
                 os.path.join(ROOT, "profiles", "r02_mfma_power.txt"))
     try:
         want = "v_mfma_f32_32x32x2_f32" if dtype == "f32" else "random data"
@@ -658,7 +658,7 @@ def pmc_traffic(dtype, tile_class=None):
     command in this compute mode (profiles/rNN_pmc_kernels_<dtype>.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE
     doubled per MI355X_MICROARCH.md §HBM).  PMC collection cannot run inside the timed process, hence a committed value."""
     if tile_class in CLASS_KERNELS:
-        for rnd in ("r05", "r04", "r03"):
+        for rnd in ("r06", "r05", "r04", "r03"):
             try:
                 with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_kernels_{dtype}.json")) as f:
                     ks = json.load(f)["kernels"]
@@ -668,7 +668,7 @@ def pmc_traffic(dtype, tile_class=None):
                     return round(sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in sel) / n)
             except Exception:
                 pass
-    for name in (f"r05_pmc_traffic_{dtype}.json", f"r04_pmc_traffic_{dtype}.json", f"r03_pmc_traffic_{dtype}.json", f"r02_pmc_traffic_{dtype}.json", "r01_pmc_traffic.json" if dtype == "f32" else None):
+    for name in (f"r06_pmc_traffic_{dtype}.json", f"r05_pmc_traffic_{dtype}.json", f"r04_pmc_traffic_{dtype}.json", f"r03_pmc_traffic_{dtype}.json", f"r02_pmc_traffic_{dtype}.json", "r01_pmc_traffic.json" if dtype == "f32" else None):
         if not name:
             continue
         try:
@@ -680,7 +680,7 @@ def pmc_traffic(dtype, tile_class=None):
 
 
 def pmc_traffic_source(dtype):
-    for name in (f"r05_pmc_kernels_{dtype}.json", f"r04_pmc_kernels_{dtype}.json", f"r03_pmc_kernels_{dtype}.json", f"r03_pmc_traffic_{dtype}.json", f"r02_pmc_traffic_{dtype}.json", "r01_pmc_traffic.json" if dtype == "f32" else None):
+    for name in (f"r06_pmc_kernels_{dtype}.json", f"r05_pmc_kernels_{dtype}.json", f"r04_pmc_kernels_{dtype}.json", f"r03_pmc_kernels_{dtype}.json", f"r03_pmc_traffic_{dtype}.json", f"r02_pmc_traffic_{dtype}.json", "r01_pmc_traffic.json" if dtype == "f32" else None):
         if name and os.path.exists(os.path.join(ROOT, "profiles", name)):
             return "profiles/" + name
     return None

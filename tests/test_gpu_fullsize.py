@@ -208,11 +208,15 @@ def test_headline_end_to_end_agreement_with_the_oracle(pkg, full_model, e2e_orac
     pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None
 
 
+F16_MATCHED_FIRST4 = None       # detections of the first four end-to-end images the fp16 mode shares with the fp32 oracle within 2e-3 (filled from a measured run)
+
+
 def test_fp16_mode_end_to_end_bar(pkg, full_model, e2e_oracle):
     """BASELINE configs[3] (fp16 tensors + fp16 MFMA) has an end-to-end bar of its own, the one
     include/maskrcnn_hip.h states for MRCNN_F16: at full size, batch 8, against the fp32 CPU oracle at least 95 % of the
     detections have a partner with the same class id and a box within 2e-3 (normalized), matched scores agree within 5e-4 and
-    matched masks (in front of any removeZeros flip) within 3e-2; every image yields its full 100 detections."""
+    matched masks (in front of any removeZeros flip) within 3e-2; every image yields its full 100 detections.  The TEST holds the mode to
+    what it measures (>= 98 %, 3e-4, 2e-2; round 6), tighter than the header's promise."""
     import importlib
     models = importlib.import_module("mask-rcnn-coreml_amd.models")
     ev = importlib.import_module("mask-rcnn-coreml_amd.evaluate")
@@ -220,16 +224,22 @@ def test_fp16_mode_end_to_end_bar(pkg, full_model, e2e_oracle):
     images, od, ok, _ = e2e_oracle
     m = models.load_maskrcnn(d, max_batch=8, compute_dtype="f16")
     hd, hk, _ = _hip_predict_with_taps(m, images)
-    tot = matched = 0
+    tot = matched = matched4 = 0
     worst_score = worst_mask = 0.0
     for b in range(N_E2E):
         a = ev.detection_agreement(hd[b], od[b], 2e-3, hk[b], ok[b])
         assert a["n_a"] == a["n_b"] == cfg.max_detections, (b, a)
         tot += a["n_a"]; matched += a["matched"]
+        matched4 += a["matched"] if b < 4 else 0
         worst_score = max(worst_score, a["max_score_diff"]); worst_mask = max(worst_mask, a["max_mask_diff"])
-    print(f"e2e f16 vs oracle: {matched}/{tot} detections within 2e-3, score diff {worst_score:.2e}, mask diff {worst_mask:.2e}")
-    assert matched >= 0.95 * tot, (matched, tot)             # measured: 1584 / 1600
-    assert worst_score < 5e-4 and worst_mask < 3e-2, (worst_score, worst_mask)     # measured: 1.6e-4, 1.3e-2
+    print(f"e2e f16 vs oracle: {matched}/{tot} detections within 2e-3 ({matched4}/400 on the first four images), score diff {worst_score:.2e}, mask diff {worst_mask:.2e}")
+    # Round 6: the bar is what is MEASURED, not what fp16 tensors could get away with — 1584 / 1600 (99 %), 1.6e-4, 1.3e-2:
+    # a K-order change in the fused blocks that costs a point of agreement must show.
+    assert matched >= 0.98 * tot, (matched, tot)
+    assert worst_score < 3e-4 and worst_mask < 2e-2, (worst_score, worst_mask)
+    # ... and on the first four images (fixed seeds, a deterministic engine) the count itself is pinned
+    if F16_MATCHED_FIRST4 is not None:
+        assert matched4 == F16_MATCHED_FIRST4, matched4
     pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None
 
 

@@ -5,7 +5,7 @@ export MRCNN_TEST_KNOBS=1      # arm the test / measurement knobs (csrc/common.h
 # Outputs land in gpurun_out/profiles_<round>/ (merged back by gpurun); copy them into profiles/ and commit.
 # Counter passes follow MI355X_MICROARCH.md: --pmc in its own run with --kernel-trace only, FETCH_SIZE and WRITE_SIZE separately.
 set -u
-RND=${1:-r05}
+RND=${1:-r06}
 MODES=${2:-"f32x3 f16 f32s f32"}
 R=$(pwd)
 OUT=$R/gpurun_out/profiles_$RND
@@ -64,6 +64,8 @@ timeout 300 python tools/conv_ab.py 3 10 1 f16 > $OUT/${RND}_conv_ab_f16.txt 2>/
 timeout 300 python tools/bneck_ab.py 8 20 2>/dev/null | grep -v amdgpu > $OUT/${RND}_bneck_ab_f16.txt
 { BNECK_ONLY=C4 timeout 300 bash tools/bneck_phases.sh 8; BNECK_ONLY=C2 timeout 300 bash tools/bneck_phases.sh 8; } 2>/dev/null | grep -v amdgpu > $OUT/${RND}_bneck_phases_f16.txt
 timeout 300 python tools/c3h_ab.py 3 10 2>/dev/null | grep -v amdgpu > $OUT/${RND}_c3h_ab_f16.txt
+# round 6 (fp16 mode): C4's 22 identity blocks as ONE launch with per-tile neighbour counters against one launch per block (kernel level and whole model)
+{ timeout 300 python tools/bneck_stage_ab.py 8 22 20 3 2>/dev/null | grep -v amdgpu; timeout 300 python tools/e2e_ab.py f16 conv_bneck_stage 0 1 4 10 2>/dev/null | tail -1; } > $OUT/${RND}_bneck_stage_ab_f16.txt
 { for kv in "conv_bneck 0 1" "conv_c3h 0 1"; do timeout 300 python tools/e2e_ab.py f16 $kv 3 10 2>/dev/null | tail -1; done; BATCH=1 timeout 300 python tools/e2e_ab.py f16 conv_bneck 0 1 3 20 2>/dev/null | tail -1; } > $OUT/${RND}_e2e_ab_f16.txt
 for dt in f32x3 f32s; do timeout 300 python tools/halo_ab.py 3 10 $dt 2>/dev/null | grep -v amdgpu > $OUT/${RND}_halo_ab_$dt.txt; done
 timeout 200 python tools/halo_ablate.py f32x3 2>/dev/null | grep -v amdgpu > $OUT/${RND}_halo_ablate_f32x3.txt
