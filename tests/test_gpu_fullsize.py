@@ -208,7 +208,7 @@ def test_headline_end_to_end_agreement_with_the_oracle(pkg, full_model, e2e_orac
     pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None
 
 
-F16_MATCHED_FIRST4 = None       # detections of the first four end-to-end images the fp16 mode shares with the fp32 oracle within 2e-3 (filled from a measured run)
+F16_MATCHED_FIRST4 = 397        # detections of the first four end-to-end images the fp16 mode shares with the fp32 oracle within 2e-3 (measured on two boxes, round 6: 397 / 400, 1575 / 1600 over all sixteen)
 
 
 def test_fp16_mode_end_to_end_bar(pkg, full_model, e2e_oracle):
@@ -233,8 +233,8 @@ def test_fp16_mode_end_to_end_bar(pkg, full_model, e2e_oracle):
         matched4 += a["matched"] if b < 4 else 0
         worst_score = max(worst_score, a["max_score_diff"]); worst_mask = max(worst_mask, a["max_mask_diff"])
     print(f"e2e f16 vs oracle: {matched}/{tot} detections within 2e-3 ({matched4}/400 on the first four images), score diff {worst_score:.2e}, mask diff {worst_mask:.2e}")
-    # Round 6: the bar is what is MEASURED, not what fp16 tensors could get away with — 1584 / 1600 (99 %), 1.6e-4, 1.3e-2:
-    # a K-order change in the fused blocks that costs a point of agreement must show.
+    # Round 6: the bar is what is MEASURED, not what fp16 tensors could get away with — 1575 / 1600 (98.4 %), 1.0e-4, 1.4e-2 at this
+    # round's kernels (round 3's 1584 predates the compact stem and the fused blocks): a K-order change that costs a point of agreement must show.
     assert matched >= 0.98 * tot, (matched, tot)
     assert worst_score < 3e-4 and worst_mask < 2e-2, (worst_score, worst_mask)
     # ... and on the first four images (fixed seeds, a deterministic engine) the count itself is pinned
