@@ -70,12 +70,10 @@ SHAPES = [  # B, H, W, Cin, Cout, k, stride, residual
 ]
 
 
-@pytest.mark.parametrize("dtype", ["f16", "f32s", "f32x3"])
-@pytest.mark.parametrize("shape", SHAPES)
+# (the fp16 kernels step K by 64 channels: a shape whose channel count does not divide is not a case of that mode — not generated, rather than skipped)
+@pytest.mark.parametrize("shape,dtype", [(sh, dt) for sh in SHAPES for dt in ("f16", "f32s", "f32x3") if not (dt == "f16" and sh[3] % 64)])
 def test_pingpong_kernel_equals_128row_kernel_bitwise(shape, dtype):
     B, H, W, Ci, Co, k, stride, with_res = shape
-    if dtype == "f16" and Ci % 64:
-        pytest.skip("the fp16 kernels step K by 64 channels")
     rng = np.random.default_rng(sum(shape))
     x = rng.standard_normal((B, H, W, Ci), np.float32)
     w = (rng.standard_normal((Co, k, k, Ci), np.float32) * np.float32(1.0 / np.sqrt(k * k * Ci)))
