@@ -88,6 +88,44 @@ def test_c_host_matches_python_mirror(pkg, small_model, tmp_path, dtype):
 
 
 
+@pytest.mark.gpu
+def test_c_host_that_names_no_precision_runs_the_mode_the_artefact_is_prepared_for(pkg, weights_mod, tmp_path_factory, tmp_path):
+    """Round 6: `maskrcnn_predict <dir> <image> <h> <w>` — no fifth argument, as `MaskRCNN()` in ViewController.swift:37 names
+    no precision — passes MRCNN_DEFAULT.  On an artefact calibrated the way `convert --calibrate` does the plain-C host must print the numbers
+    of the Python mirror's f32x3 handle (stored exponents applied), on an uncalibrated one those of the exact-fp32 handle; the host runs as a
+    PRODUCTION process: without MRCNN_TEST_KNOBS in its environment (and with a stray MRCNN_HALO=0, which it must ignore)."""
+    from conftest import make_model_dir
+    models = importlib.import_module("mask-rcnn-coreml_amd.models")
+    ev = importlib.import_module("mask-rcnn-coreml_amd.evaluate")
+    convert = importlib.import_module("mask-rcnn-coreml_amd.convert")
+    exe = _build_example(tmp_path)
+    img = np.random.default_rng(23).integers(0, 256, (90, 120, 3), dtype=np.uint8)
+    (tmp_path / "img.rgb").write_bytes(img.tobytes())
+    env = {k: v for k, v in os.environ.items() if k != "MRCNN_TEST_KNOBS"}
+    env["MRCNN_HALO"] = "0"
+    for calibrated, want_mode in ((False, "f32"), (True, "f32x3")):
+        d, cfg = make_model_dir(tmp_path_factory, pkg, weights_mod, "chost_default" + str(int(calibrated)), architecture="resnet50",
+                                input_image_shape=(128, 128, 3), num_classes=21, pre_nms_max_proposals=300, max_proposals=64, max_detections=16)
+        if calibrated:
+            convert.calibrate_artefact(d, np.random.default_rng(7).integers(0, 256, (2, 128, 128, 3), dtype=np.uint8), verbose=False)
+        r = subprocess.run([exe, d, str(tmp_path / "img.rgb"), "90", "120"], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr
+        lines = r.stdout.strip().splitlines()
+        n = int(lines[1].split()[1])
+        rows = [l.split() for l in lines[2:]]
+        m = models.load_maskrcnn(d, max_batch=1)                      # the mirror names no precision either
+        assert m.compute_dtype == want_mode and m.compute_dtype_defaulted
+        out = m.prediction(ev.letterbox(img, m.image_height, m.image_width))
+        dets = pkg.Detection.detectionsFromFeatureValue(out["detections"], out["mask"])
+        assert n == len(dets) == len(rows) and n > 0
+        for row, dd in zip(rows, dets):
+            assert (int(row[0]), int(row[1])) == (dd.index, dd.classId) and float(row[2]) == float(dd.score)
+            assert tuple(float(v) for v in row[3:7]) == tuple(float(v) for v in dd.boundingBox)
+            assert float(row[7]) == float(np.asarray(out["mask"][int(row[0])], dtype=np.float64).sum())
+        del m
+    pkg.MaskRCNNConfig.defaultConfig().anchorsURL = None
+
+
 def test_mgpu_c_host_builds_and_fails_loudly_without_gpu(tmp_path):
     exe = _build_example(tmp_path, "maskrcnn_predict_mgpu")
     if HAS_GPU:
