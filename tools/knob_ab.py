@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """A/B of one policy knob (mrcnn_debug_set) on single layers through the micro-benchmark hook, interleaved rounds in one process.
-usage: knob_ab.py <knob> <v0> <v1> <dtype> [rounds] [iters] [shape-set]      shape-set: pw (the long-K 1x1 layers; default) | all"""
+usage: knob_ab.py <knob> <v0> <v1> <dtype> [rounds] [iters] [shape-set]      shape-set: pw (the long-K 1x1 layers; default) | all | hbm (the short-K 1x1 layers)"""
 import os as _os; _os.environ.setdefault("MRCNN_TEST_KNOBS", "1")      # arm the test / measurement knobs (csrc/common.h) before the library loads
 import ctypes as C
 import importlib
@@ -40,11 +40,21 @@ ALL = PW + [
     ("C2 3x3 64->64 @256 b8", 8, 256, 256, 64, 64, 3, 1),
     ("C2 3x3 64->64 @256 b1", 1, 256, 256, 64, 64, 3, 1),
 ]
+HBM = [  # the short-K 1x1 layers whose roof is HBM in the fp32-tensor modes (round 6: roofline.by_tile_class[*].bound)
+    ("C2 2a 256->64 @256 b8", 8, 256, 256, 256, 64, 1, 1),
+    ("C2 2c 64->256 @256 b8", 8, 256, 256, 64, 256, 1, 1),
+    ("P2 lat 256->256 @256 b8", 8, 256, 256, 256, 256, 1, 1),
+    ("C3 2a 512->128 @128 b8", 8, 128, 128, 512, 128, 1, 1),
+    ("C3 2c 128->512 @128 b8", 8, 128, 128, 128, 512, 1, 1),
+    ("P3 lat 512->256 @128 b8", 8, 128, 128, 512, 256, 1, 1),
+    ("C4 2a 1024->256 @64 b8", 8, 64, 64, 1024, 256, 1, 1),
+    ("C4 2c 256->1024 @64 b8", 8, 64, 64, 256, 1024, 1, 1),
+]
 knob, v0, v1 = sys.argv[1].encode(), int(sys.argv[2]), int(sys.argv[3])
 DT = {"f32": L.F32, "f16": L.F16, "f32s": L.F32S, "f32x3": L.F32X3}[sys.argv[4]]
 rounds = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 20
-shapes = ALL if (sys.argv[7] if len(sys.argv) > 7 else "pw") == "all" else PW
+shapes = {"all": ALL, "hbm": HBM}.get(sys.argv[7] if len(sys.argv) > 7 else "pw", PW)
 
 
 def run(shape, v):
