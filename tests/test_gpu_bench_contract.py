@@ -157,4 +157,13 @@ def test_mfma_probe_and_profile_groups_behind_the_test_header():
         # BASELINE.md section 2's 189.8 adds the box head's 28.62 by mistake); at 256^2 a sixteenth of it
         per_image = groups["backbone"][2] / 2 / 1e9
         assert abs(per_image - 161.16 / 16) < 0.005 * 161.16 / 16, per_image
+        # round 6: ALGORITHMIC bytes ride with every launch (what the hbm roofs of bench.py's by_tile_class are priced against): the per-class and
+        # per-shape totals agree, and one layer by hand — the FPN's 3x3 output layer on P2 (2 images x 64 x 64 pixels, 256 -> 256): its input
+        # pixels once, its fp16 filters, its output
+        by_tile, shapes = m.conv_profile_bytes(), m.conv_profile_shapes()
+        assert sum(by_tile.values()) > 0 and abs(sum(by_tile.values()) - sum(r[7] for r in shapes)) < 1e-6 * sum(by_tile.values())
+        es = 2 if mode == "f16" else 4
+        p2 = [r for r in shapes if (r[0], r[1], r[2]) == (2 * 64 * 64, 256, 2304)]
+        assert len(p2) == 1 and p2[0][4] == 1, p2
+        assert p2[0][7] == 2 * 64 * 64 * 256 * es + 256 * 2304 * 2 + 2 * 64 * 64 * 256 * es, p2
         del m

@@ -463,6 +463,20 @@ def test_bench_sustained_peak_reads_the_committed_probe():
     assert 140 < bench.sustained_peak("f32", 1, 100.0)["value"] < 160
 
 
+def test_bench_tile_class_entry_names_the_roof_that_bounds_a_class():
+    """bench.py's per-class record (round 6): a class is hbm-bound when its ALGORITHMIC bytes at 8 TB/s take longer than its flops at the MFMA peak;
+    both rates and both fractions are carried either way."""
+    import bench
+    # 62 launches, 4.67 ms, 1.115e12 flop and 1.83e10 B in total: the 1x1 class of the headline mode — 239 TFLOP/s, 3.9 TB/s
+    e = bench.tile_class_entry((62, 4.67, 1.115e12), 1.83e10, 1, 18.0e-3, 2500.0 / 3)
+    assert e["bound"] == "hbm" and e["launches_per_step"] == 62
+    assert abs(e["tflops"] - 238.8) < 0.5 and abs(e["gbps"] - 3918.6) < 2 and abs(e["frac_of_hbm"] - 0.4898) < 1e-3 and abs(e["frac_of_hbm_measured"] - 0.623) < 1e-3
+    assert abs(e["share_of_step_time"] - 4.67 / 18.0) < 1e-4 and e["algorithmic_bytes_per_launch"] == int(1.83e10 / 62)
+    # the 3x3 class: 46 launches, 9.46 ms, 4.48e12 flop, 6.5e9 B — far on the matrix side
+    e = bench.tile_class_entry((46, 9.46, 4.48e12), 6.5e9, 1, 18.0e-3, 2500.0 / 3)
+    assert e["bound"] == "mfma" and abs(e["frac_of_mfma"] - 0.5683) < 1e-3 and e["frac_of_hbm"] < 0.1
+
+
 def test_bench_host_core_count():
     import bench
     physical, logical = bench.host_cores()
